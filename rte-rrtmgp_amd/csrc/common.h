@@ -1,0 +1,77 @@
+// common.h -- shared declarations of the HIP kernel library (gfx950 only).
+//
+// Layout conventions used by every kernel in this library:
+//   * all arrays are the caller's dense column-major Fortran arrays, column index fastest;
+//     a wavefront's 64 lanes always span 64 CONSECUTIVE COLUMNS, so every access to an
+//     (ncol, ...) array is a unit-stride 512-byte (fp64) request per wave;
+//   * index values stored in integer arrays are 1-based, exactly as the frontend passes them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "rte_rrtmgp_kernels.h"
+
+#define RTE_WAVE 64
+
+#define HIP_CHECK(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      fprintf(stderr, "rte_rrtmgp_hip: %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__,  \
+              hipGetErrorString(e_));                                                         \
+      abort(); /* the reference kernel interface has no error channel */                     \
+    }                                                                                         \
+  } while (0)
+
+namespace rte {
+
+// ---- runtime (runtime.hip) ---------------------------------------------------------------
+hipStream_t stream();
+// device scratch that lives until the end of the current API call (bump allocator; grows)
+void* scratch(size_t bytes);
+// persistent named device buffers (LUT re-layouts etc.), keyed by a caller-chosen id
+void* persistent(int slot, size_t bytes, bool* fresh);
+
+// Scope object of one API call: serialises calls, resets the scratch arena, and stages host
+// arrays.  in()/out()/inout() return a device pointer for `p`: `p` itself when it already is a
+// device (or managed/registered) pointer, otherwise a scratch copy (copied back on destruction
+// for out/inout, after a stream synchronise).
+class Call {
+ public:
+  explicit Call(const char* name);
+  ~Call();
+  template <class T> const T* in(const T* p, size_t n) { return (const T*)stage((void*)p, n * sizeof(T), true, false); }
+  template <class T> T* out(T* p, size_t n) { return (T*)stage((void*)p, n * sizeof(T), false, true); }
+  template <class T> T* inout(T* p, size_t n) { return (T*)stage((void*)p, n * sizeof(T), true, true); }
+  // small host-side copy of an input array that may live on the device (index tables etc.)
+  template <class T> const T* host(const T* p, size_t n) { return (const T*)to_host((const void*)p, n * sizeof(T)); }
+  bool any_host() const { return n_back_ > 0 || staged_in_; }
+  const char* name;
+
+ private:
+  void* stage(void* p, size_t bytes, bool copy_in, bool copy_out);
+  const void* to_host(const void* p, size_t bytes);
+  struct Back { void* host; void* dev; size_t bytes; };
+  Back back_[16];
+  int n_back_ = 0;
+  bool staged_in_ = false;
+  void* host_tmp_[16];
+  int n_host_tmp_ = 0;
+};
+
+bool is_device_pointer(const void* p);
+
+// kernel-level timing hooks (rte_hip_profile_*): record(name) brackets a launch with events
+void prof_begin(const char* kernel);
+void prof_end();
+struct ProfScope {
+  explicit ProfScope(const char* k) { prof_begin(k); }
+  ~ProfScope() { prof_end(); }
+};
+
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace rte

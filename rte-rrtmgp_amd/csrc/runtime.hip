@@ -1,0 +1,226 @@
+// runtime.hip -- stream, scratch arena, host-pointer staging and kernel timing hooks.
+//
+// Drop-in semantics: the reference kernels own nothing -- every buffer is
+// the caller's -- and take host arrays from the unchanged Fortran frontend.  This library accepts
+// BOTH kinds of pointer on every array argument:
+//   device pointer -> the kernel is launched in place, asynchronously, on the library stream;
+//   host pointer   -> the array is staged through the scratch arena (H2D before, D2H after) and
+//                     the call returns only after the stream has drained (functional mode).
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace rte {
+
+static std::recursive_mutex g_mutex;  // entry points are serialised: stateless for the caller
+static hipStream_t g_stream = nullptr;
+
+hipStream_t stream() { return g_stream; }
+
+// ---- scratch arena -----------------------------------------------------------------------
+struct Block { char* base; size_t size; size_t used; };
+static std::vector<Block> g_blocks;
+static size_t g_call_total = 0;
+
+void* scratch(size_t bytes) {
+  bytes = (bytes + 255) & ~size_t(255);
+  g_call_total += bytes;
+  for (auto& b : g_blocks)
+    if (b.size - b.used >= bytes) {
+      void* p = b.base + b.used;
+      b.used += bytes;
+      return p;
+    }
+  size_t sz = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
+  Block nb{nullptr, sz, bytes};
+  HIP_CHECK(hipMalloc((void**)&nb.base, sz));
+  g_blocks.push_back(nb);
+  return nb.base;
+}
+
+static void scratch_reset() {
+  // keep one block big enough for the largest call seen so far; drop fragmentation
+  if (g_blocks.size() > 1) {
+    HIP_CHECK(hipStreamSynchronize(g_stream));
+    size_t total = 0;
+    for (auto& b : g_blocks) { total += b.size; HIP_CHECK(hipFree(b.base)); }
+    g_blocks.clear();
+    Block nb{nullptr, total, 0};
+    HIP_CHECK(hipMalloc((void**)&nb.base, total));
+    g_blocks.push_back(nb);
+  }
+  for (auto& b : g_blocks) b.used = 0;
+  g_call_total = 0;
+}
+
+// ---- persistent slots ----------------------------------------------------------------------
+struct Slot { void* p = nullptr; size_t bytes = 0; };
+static Slot g_slots[16];
+void* persistent(int slot, size_t bytes, bool* fresh) {
+  Slot& s = g_slots[slot];
+  if (fresh) *fresh = false;
+  if (s.bytes < bytes) {
+    if (s.p) { HIP_CHECK(hipStreamSynchronize(g_stream)); HIP_CHECK(hipFree(s.p)); }
+    HIP_CHECK(hipMalloc(&s.p, bytes));
+    s.bytes = bytes;
+    if (fresh) *fresh = true;
+  }
+  return s.p;
+}
+
+// ---- pointer classification ------------------------------------------------------------------
+bool is_device_pointer(const void* p) {
+  if (!p) return true;
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc'ed host memory: "invalid value"
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged ||
+         (a.type == hipMemoryTypeHost && a.devicePointer != nullptr);
+}
+
+// ---- Call ---------------------------------------------------------------------------------------
+Call::Call(const char* n) : name(n) {
+  g_mutex.lock();
+  scratch_reset();
+}
+
+void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out) {
+  if (!p || bytes == 0 || is_device_pointer(p)) return p;
+  void* d = scratch(bytes);
+  if (copy_in) {
+    HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, g_stream));
+    staged_in_ = true;
+  }
+  if (copy_out) {
+    if (n_back_ >= 16) { fprintf(stderr, "rte_rrtmgp_hip: too many staged outputs\n"); abort(); }
+    back_[n_back_++] = Back{p, d, bytes};
+  }
+  return d;
+}
+
+const void* Call::to_host(const void* p, size_t bytes) {
+  if (!p || bytes == 0 || !is_device_pointer(p)) return p;
+  void* h = malloc(bytes);
+  HIP_CHECK(hipMemcpyAsync(h, p, bytes, hipMemcpyDeviceToHost, g_stream));
+  HIP_CHECK(hipStreamSynchronize(g_stream));
+  host_tmp_[n_host_tmp_++] = h;
+  return h;
+}
+
+Call::~Call() {
+  for (int i = 0; i < n_back_; ++i)
+    HIP_CHECK(hipMemcpyAsync(back_[i].host, back_[i].dev, back_[i].bytes, hipMemcpyDeviceToHost, g_stream));
+  if (n_back_ > 0 || staged_in_) HIP_CHECK(hipStreamSynchronize(g_stream));
+  for (int i = 0; i < n_host_tmp_; ++i) free(host_tmp_[i]);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "rte_rrtmgp_hip: %s: launch error: %s\n", name, hipGetErrorString(e));
+    abort();
+  }
+  g_mutex.unlock();
+}
+
+// ---- kernel timing ------------------------------------------------------------------------------
+struct ProfEntry { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms = 0; long n = 0; };
+static bool g_prof_on = false;
+static std::vector<ProfEntry> g_prof;
+static ProfEntry* g_cur = nullptr;
+static hipEvent_t g_cur_start;
+
+void prof_begin(const char* kernel) {
+  if (!g_prof_on) return;
+  g_cur = nullptr;
+  for (auto& e : g_prof)
+    if (e.name == kernel) g_cur = &e;
+  if (!g_cur) {
+    g_prof.push_back(ProfEntry{kernel});
+    g_cur = &g_prof.back();
+  }
+  HIP_CHECK(hipEventCreate(&g_cur_start));
+  HIP_CHECK(hipEventRecord(g_cur_start, g_stream));
+}
+void prof_end() {
+  if (!g_prof_on || !g_cur) return;
+  hipEvent_t stop;
+  HIP_CHECK(hipEventCreate(&stop));
+  HIP_CHECK(hipEventRecord(stop, g_stream));
+  g_cur->ev.emplace_back(g_cur_start, stop);
+  g_cur = nullptr;
+}
+static void prof_resolve() {
+  for (auto& e : g_prof) {
+    for (auto& p : e.ev) {
+      HIP_CHECK(hipEventSynchronize(p.second));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, p.first, p.second));
+      e.ms += ms;
+      e.n += 1;
+      HIP_CHECK(hipEventDestroy(p.first));
+      HIP_CHECK(hipEventDestroy(p.second));
+    }
+    e.ev.clear();
+  }
+}
+
+}  // namespace rte
+
+// ---- library-extension entry points (not part of the reference interface) ------------------------
+extern "C" {
+
+int rte_hip_set_stream(void* s) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::g_stream = (hipStream_t)s;
+  return 0;
+}
+int rte_hip_sync(void) {
+  HIP_CHECK(hipStreamSynchronize(rte::g_stream));
+  return 0;
+}
+int rte_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+int rte_hip_profile_enable(int on) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::g_prof_on = on != 0;
+  return 0;
+}
+int rte_hip_profile_reset(void) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::prof_resolve();
+  rte::g_prof.clear();
+  return 0;
+}
+int rte_hip_profile_count(void) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::prof_resolve();
+  return (int)rte::g_prof.size();
+}
+// i-th timed kernel: name copied into buf, launches and total milliseconds returned
+int rte_hip_profile_get(int i, char* buf, int buflen, long long* launches, double* total_ms) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  if (i < 0 || i >= (int)rte::g_prof.size()) return -1;
+  snprintf(buf, buflen, "%s", rte::g_prof[i].name.c_str());
+  *launches = rte::g_prof[i].n;
+  *total_ms = rte::g_prof[i].ms;
+  return 0;
+}
+// release every device buffer held by the library (arena + persistent slots)
+int rte_hip_release(void) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  HIP_CHECK(hipStreamSynchronize(rte::g_stream));
+  for (auto& b : rte::g_blocks) HIP_CHECK(hipFree(b.base));
+  rte::g_blocks.clear();
+  for (auto& s : rte::g_slots) {
+    if (s.p) HIP_CHECK(hipFree(s.p));
+    s = rte::Slot{};
+  }
+  return 0;
+}
+}

@@ -1,0 +1,847 @@
+// solvers.hip -- RTE solver kernels for gfx950 (MI355X), hand-written HIP.
+//
+// Entry points (C ABI = reference rte/kernels/api/mo_rte_solver_kernels.F90):
+//   rte_lw_solver_noscat, rte_lw_solver_2stream, rte_sw_solver_noscat, rte_sw_solver_2stream
+// Arithmetic follows the reference `default` CPU kernels (rte/kernels/mo_rte_solver_kernels.F90)
+// expression by expression.  Mapping: one thread per (column, g-point); wave lanes = 64
+// consecutive columns, blockIdx.y = g-point; the vertical recurrences run sequentially inside
+// the thread.
+//
+// Two families of kernels live here:
+//   * lw_noscat_seg_kernel -- the production path for the no-scattering LW solver without
+//     rescaling: the column is cut into vertical segments owned by different waves of a block;
+//     transmissivities and sources live in registers, segment composites are exchanged through
+//     LDS, and broadband sums are accumulated in registers over the block's g-points
+//     ("K4").
+//   * the *_generic kernels -- every other solver/flag combination; per-layer intermediates that
+//     a second sweep needs are parked in a device scratch slab, g-points processed in chunks.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+using rte::cdiv;
+
+#ifdef RTE_USE_SP
+#define RTE_EPS 1.1920929e-07f
+#else
+#define RTE_EPS 2.220446049250313e-16
+#endif
+__device__ constexpr Float kPi = (Float)3.14159265358979323846264338327950288;
+
+// ---------------------------------------------------------------------------------------------
+// shared pieces
+// ---------------------------------------------------------------------------------------------
+// lw_source_noscat for one layer: reference :652-663.  lev_dec / lev_inc are the Planck sources
+// at level ilay and ilay+1 (array order); returns the sources emitted toward increasing / decreasing index
+__device__ __forceinline__ void lw_source_layer(Float tau_loc, Float trans, Float lay, Float lev_lo, Float lev_hi,
+                                                Float& src_inc, Float& src_dec) {
+  const Float tau_thresh = sqrt(sqrt((Float)RTE_EPS));
+  Float fact;
+  if (tau_loc > tau_thresh)
+    fact = ((Float)1 - trans) / tau_loc - trans;
+  else
+    fact = tau_loc * ((Float)0.5 + tau_loc * (-(Float)1 / (Float)3 + tau_loc * (Float)1 / (Float)8));
+  src_inc = ((Float)1 - trans) * lev_hi + (Float)2 * fact * (lay - lev_hi);
+  src_dec = ((Float)1 - trans) * lev_lo + (Float)2 * fact * (lay - lev_lo);
+}
+
+// broadband(c,l) = [prev +] scale * sum_g spectral(c,l,g)   (sequential over g like the reference)
+__global__ void __launch_bounds__(256)
+sum_gpt_kernel(size_t n2, int ngpt, const Float* __restrict__ spectral, Float* __restrict__ out, Float scale,
+               int mode /*0: out = s ; 1: out += s ; 2: out = scale*(out + s) ; 3: out = scale*s*/) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  Float s = (mode == 1 || mode == 2) ? out[i] : (Float)0;
+  for (int g = 0; g < ngpt; ++g) s = s + spectral[i + n2 * (size_t)g];
+  out[i] = (mode >= 2) ? scale * s : s;
+}
+
+__global__ void __launch_bounds__(256)
+axpy_kernel(size_t n, const Float* __restrict__ x, Float* __restrict__ y, int first) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = first ? x[i] : y[i] + x[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// LW no-scattering, generic: reference lw_solver_noscat_oneangle :51-240
+// radn_up / radn_dn: (ncol, nlay+1, gchunk) intensities for this chunk of g-points (either the
+// caller's spectral flux arrays or scratch).  jac: (ncol, nlay+1, gchunk) scratch or null.
+// ---------------------------------------------------------------------------------------------
+struct LwArgs {
+  int ncol, nlay, ngpt, g_begin, gchunk;
+  bool top_at_1, do_jac, do_rescaling, scale_out, accumulate;
+  Float weight;
+  const Float *D, *tau, *lay_source, *lev_source, *sfc_emis, *sfc_src, *inc_flux, *sfc_srcJac, *ssa, *g;
+  Float *radn_up, *radn_dn, *jac;
+};
+
+__global__ void __launch_bounds__(256) lw_noscat_generic_kernel(LwArgs a) {
+  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gl = blockIdx.y;  // g-point within the chunk
+  if (icol >= a.ncol) return;
+  const int igpt = a.g_begin + gl;
+  const int ncol = a.ncol, nlay = a.nlay, nlev = nlay + 1;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev;
+  const size_t cg = icol + (size_t)ncol * igpt;
+  const Float* tau = a.tau + icol + ncl * igpt;
+  const Float* lay_source = a.lay_source + icol + ncl * igpt;
+  const Float* lev_source = a.lev_source + icol + nclv * igpt;
+  const Float* ssa = a.do_rescaling ? a.ssa + icol + ncl * igpt : nullptr;
+  const Float* gg = a.do_rescaling ? a.g + icol + ncl * igpt : nullptr;
+  Float* up = a.radn_up + icol + nclv * gl;
+  Float* dn = a.radn_dn + icol + nclv * gl;
+  Float* jac = a.do_jac ? a.jac + icol + nclv * gl : nullptr;
+  const Float D = a.D[cg];
+  const Float piw = kPi * a.weight;
+  const int top_level = a.top_at_1 ? 0 : nlay, sfc_level = a.top_at_1 ? nlay : 0;
+
+  // per-layer quantities recomputed by every sweep (no cross-sweep storage besides the radiances)
+  auto layer = [&](int ilay, Float& trans, Float& src_dn, Float& src_up, Float& An, Float& Cn) {
+    const Float t = tau[(size_t)ncol * ilay];
+    Float tau_loc;
+    if (a.do_rescaling) {  // :154-178
+      const Float ssal = ssa[(size_t)ncol * ilay];
+      const Float wb = ssal * ((Float)1 - gg[(size_t)ncol * ilay]) * (Float)0.5;
+      const Float scaleTau = ((Float)1 - ssal + wb);
+      Cn = (Float)0.4 * wb / scaleTau;
+      tau_loc = t * D * scaleTau;
+      trans = exp(-tau_loc);
+      An = ((Float)1 - trans * trans);
+    } else {  // :180-183
+      tau_loc = t * D;
+      trans = exp(-tau_loc);
+      An = Cn = 0;
+    }
+    Float s_inc, s_dec;
+    lw_source_layer(tau_loc, trans, lay_source[(size_t)ncol * ilay], lev_source[(size_t)ncol * ilay],
+                    lev_source[(size_t)ncol * (ilay + 1)], s_inc, s_dec);
+    src_dn = a.top_at_1 ? s_inc : s_dec;
+    src_up = a.top_at_1 ? s_dec : s_inc;
+  };
+
+  Float trans, src_dn, src_up, An, Cn;
+  // ---- transport down :681-708
+  Float r = a.inc_flux[cg] / piw;  // :144
+  dn[(size_t)ncol * top_level] = r;
+  if (a.top_at_1) {
+    for (int ilev = 1; ilev < nlev; ++ilev) {
+      layer(ilev - 1, trans, src_dn, src_up, An, Cn);
+      r = trans * r + src_dn;
+      dn[(size_t)ncol * ilev] = r;
+    }
+  } else {
+    for (int ilev = nlay - 1; ilev >= 0; --ilev) {
+      layer(ilev, trans, src_dn, src_up, An, Cn);
+      r = trans * r + src_dn;
+      dn[(size_t)ncol * ilev] = r;
+    }
+  }
+  // ---- surface :198-202
+  const Float emis = a.sfc_emis[cg];
+  const Float sfc_albedo = (Float)1 - emis;
+  Float u = r * sfc_albedo + emis * a.sfc_src[cg];
+  up[(size_t)ncol * sfc_level] = u;
+  Float j = 0;
+  if (a.do_jac) {
+    j = emis * a.sfc_srcJac[cg];
+    jac[(size_t)ncol * sfc_level] = j;
+  }
+  // ---- transport up (:710-745) or up + second down with rescaling (:753-844)
+  if (a.top_at_1) {
+    for (int ilev = nlay - 1; ilev >= 0; --ilev) {
+      layer(ilev, trans, src_dn, src_up, An, Cn);
+      if (a.do_rescaling) {
+        const Float adj = Cn * (An * dn[(size_t)ncol * ilev] - trans * src_dn - src_up);
+        u = trans * u + src_up + adj;
+      } else {
+        u = trans * u + src_up;
+      }
+      up[(size_t)ncol * ilev] = u;
+      if (a.do_jac) { j = trans * j; jac[(size_t)ncol * ilev] = j; }
+    }
+    if (a.do_rescaling) {
+      r = dn[0];
+      for (int ilev = 0; ilev < nlay; ++ilev) {
+        layer(ilev, trans, src_dn, src_up, An, Cn);
+        const Float adj = Cn * (An * up[(size_t)ncol * ilev] - trans * src_up - src_dn);
+        r = trans * r + src_dn + adj;
+        dn[(size_t)ncol * (ilev + 1)] = r;
+      }
+    }
+  } else {
+    for (int ilev = 0; ilev < nlay; ++ilev) {
+      layer(ilev, trans, src_dn, src_up, An, Cn);
+      if (a.do_rescaling) {
+        const Float adj = Cn * (An * dn[(size_t)ncol * (ilev + 1)] - trans * src_dn - src_up);
+        u = trans * u + src_up + adj;
+      } else {
+        u = trans * u + src_up;
+      }
+      up[(size_t)ncol * (ilev + 1)] = u;
+      if (a.do_jac) { j = trans * j; jac[(size_t)ncol * (ilev + 1)] = j; }
+    }
+    if (a.do_rescaling) {
+      r = dn[(size_t)ncol * nlay];
+      for (int ilev = nlay - 1; ilev >= 0; --ilev) {
+        layer(ilev, trans, src_dn, src_up, An, Cn);
+        const Float adj = Cn * (An * up[(size_t)ncol * ilev] - trans * src_up - src_dn);
+        r = trans * r + src_dn + adj;
+        dn[(size_t)ncol * ilev] = r;
+      }
+    }
+  }
+  // ---- spectral output: intensity -> flux (:223-224)
+  if (a.scale_out)
+    for (int ilev = 0; ilev < nlev; ++ilev) {
+      dn[(size_t)ncol * ilev] = piw * dn[(size_t)ncol * ilev];
+      up[(size_t)ncol * ilev] = piw * up[(size_t)ncol * ilev];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LW no-scattering, segmented production kernel (broadband, no rescaling).
+//
+// block = S waves x 64 columns; wave s owns layers [s*L, (s+1)*L) counted FROM THE TOP of the
+// atmosphere ("position" p; array layer index = p if top_at_1 else nlay-1-p).  Per g-point:
+//   pass 1  each thread loads tau / lay / lev of its L layers, computes trans, src_dn, src_up
+//           (kept in registers) and the segment composites  Td = prod t,  Sd, Su  (the radiance
+//           leaving the segment for zero radiance entering it);
+//   exchange composites through LDS, chain them: radiance entering every segment from above
+//           (down) and from below (up, after the surface reflection);
+//   pass 2  re-sweep the segment from registers with the correct entering radiances and add the
+//           level radiances to register accumulators (levels p = s*L .. s*L+L-1, the last
+//           segment also owns the surface level).
+// Within a segment the recurrence is the reference's; across segments the entering radiance is
+// formed from composites (same mathematics, different rounding: ~1e-16 relative).
+// After the block's g-points: acc * pi * weight -> partial broadband slab for this g-group.
+// ---------------------------------------------------------------------------------------------
+template <int L, bool do_jac>
+__global__ void __launch_bounds__(64 * 8)
+lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
+                     const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
+                     const Float* __restrict__ lay_source_, const Float* __restrict__ lev_source_,
+                     const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
+                     const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
+                     Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac) {
+  extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][S][64]
+  const int lane = threadIdx.x & 63;
+  const int s = threadIdx.x >> 6;
+  const int icol = blockIdx.x * 64 + lane;
+  const bool active = icol < ncol;
+  const int c = active ? icol : ncol - 1;  // clamp: inactive lanes compute on a valid column, never store
+  const int nlev = nlay + 1;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev;
+  const int p0 = s * L;
+  const int np = min(L, nlay - p0);  // layers in this segment (>= 1 by construction)
+  const bool last = (s == S - 1);
+  const Float piw = kPi * weight;
+  const int g_begin = blockIdx.y * g_per_block;
+  const int g_end = min(ngpt, g_begin + g_per_block);
+
+  Float acc_dn[L + 1], acc_up[L + 1], acc_j[do_jac ? L + 1 : 1];
+#pragma unroll
+  for (int i = 0; i <= L; ++i) { acc_dn[i] = 0; acc_up[i] = 0; if (do_jac) acc_j[i] = 0; }
+
+  int buf = 0;
+  for (int igpt = g_begin; igpt < g_end; ++igpt, buf ^= 1) {
+    const size_t cg = c + (size_t)ncol * igpt;
+    const Float D = Dsec[cg];
+    const Float* tau = tau_ + c + ncl * igpt;
+    const Float* lay_source = lay_source_ + c + ncl * igpt;
+    const Float* lev_source = lev_source_ + c + nclv * igpt;
+    Float t[L], sd[L], su[L];
+    // ---- pass 1
+    Float Td = 1, Sd = 0;
+    // level source at the top of the segment's first layer
+    Float lev_top = lev_source[(size_t)ncol * (top_at_1 ? p0 : nlay - p0)];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (i < np) {
+        const int p = p0 + i;
+        const int ilay = top_at_1 ? p : nlay - 1 - p;
+        const Float lev_bot = lev_source[(size_t)ncol * (top_at_1 ? p + 1 : nlay - 1 - p)];
+        const Float tau_loc = tau[(size_t)ncol * ilay] * D;
+        const Float tr = exp(-tau_loc);
+        Float s_toward_bot, s_toward_top;
+        // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo); choose so that
+        // "toward bottom" uses the bottom level source and "toward top" the top level source
+        lw_source_layer(tau_loc, tr, lay_source[(size_t)ncol * ilay], lev_top, lev_bot, s_toward_bot, s_toward_top);
+        t[i] = tr;
+        sd[i] = s_toward_bot;
+        su[i] = s_toward_top;
+        Sd = tr * Sd + s_toward_bot;
+        Td = Td * tr;
+        lev_top = lev_bot;
+      } else {
+        t[i] = 1; sd[i] = 0; su[i] = 0;
+      }
+    }
+    Float Su = 0;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i)
+      if (i < np) Su = t[i] * Su + su[i];
+    // ---- exchange
+    Float* X = lds + (size_t)buf * 3 * S * 64;
+    X[(0 * S + s) * 64 + lane] = Td;
+    X[(1 * S + s) * 64 + lane] = Sd;
+    X[(2 * S + s) * 64 + lane] = Su;
+    __syncthreads();
+    Float r = inc_flux[cg] / piw;  // radiance entering segment 0 from above (:144)
+    Float r_in = r;
+    for (int q = 0; q < S; ++q) {
+      if (q == s) r_in = r;
+      r = X[(0 * S + q) * 64 + lane] * r + X[(1 * S + q) * 64 + lane];
+    }
+    const Float emis = sfc_emis[cg];
+    const Float u_sfc = r * ((Float)1 - emis) + emis * sfc_src[cg];  // :198-200
+    Float u = u_sfc, u_in = u_sfc;
+    Float jv = do_jac ? emis * sfc_srcJac[cg] : (Float)0, j_in = jv;
+    for (int q = S - 1; q > s; --q) {
+      const Float Tq = X[(0 * S + q) * 64 + lane];
+      u = Tq * u + X[(2 * S + q) * 64 + lane];
+      jv = Tq * jv;
+    }
+    u_in = u;
+    j_in = jv;
+    // ---- pass 2: down
+    r = r_in;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (i < np) {
+        acc_dn[i] += r;
+        r = t[i] * r + sd[i];
+      }
+    }
+    // ---- pass 2: up (+ Jacobian, :729-743)
+    if (last) {
+      // surface level is slot np of the last segment
+#pragma unroll
+      for (int i = 0; i <= L; ++i)
+        if (i == np) { acc_dn[i] += r; acc_up[i] += u_sfc; if (do_jac) acc_j[i] += j_in; }
+    }
+    u = u_in;
+    jv = j_in;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      if (i < np) {
+        u = t[i] * u + su[i];
+        acc_up[i] += u;
+        if (do_jac) { jv = t[i] * jv; acc_j[i] += jv; }
+      }
+    }
+  }
+  // ---- partial broadband for this g-group: (ncol, nlev, ngroups)
+  if (active) {
+    const size_t base = icol + nclv * blockIdx.y;
+#pragma unroll
+    for (int i = 0; i <= L; ++i) {
+      if (i < np || (last && i == np)) {
+        const int p = p0 + i;  // level position from the top
+        const int ilev = top_at_1 ? p : nlay - p;
+        part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
+        part_up[base + (size_t)ncol * ilev] = acc_up[i];
+        if (do_jac) part_jac[base + (size_t)ncol * ilev] = acc_j[i];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LW two-stream, generic: reference :377-440 (lw_two_stream :854-909, lw_source_2str :917-967,
+// adding :1135-1245).  ws: 4 layer slabs (ncol, nlay, gchunk): Rdif, Tdif, src_dn, denom.
+// flux_up temporarily holds `src`, flux_dn holds `albedo` (each level is read before it is
+// overwritten in the final downward pass).
+// ---------------------------------------------------------------------------------------------
+struct Lw2Args {
+  int ncol, nlay, ngpt, g_begin;
+  bool top_at_1, lev_gpt1;
+  const Float *tau, *ssa, *g, *lay_source, *lev_source, *sfc_emis, *sfc_src, *inc_flux;
+  Float *flux_up, *flux_dn, *ws;
+};
+
+__global__ void __launch_bounds__(256) lw_2stream_generic_kernel(Lw2Args a) {
+  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gl = blockIdx.y;
+  if (icol >= a.ncol) return;
+  const int igpt = a.g_begin + gl;
+  const int ncol = a.ncol, nlay = a.nlay, nlev = nlay + 1;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev;
+  const size_t cg = icol + (size_t)ncol * igpt;
+  const Float* tau = a.tau + icol + ncl * igpt;
+  const Float* ssa = a.ssa + icol + ncl * igpt;
+  const Float* gg = a.g + icol + ncl * igpt;
+  const Float* lev_source = a.lev_source + icol + nclv * (a.lev_gpt1 ? 0 : igpt);
+  Float* fup = a.flux_up + icol + nclv * igpt;
+  Float* fdn = a.flux_dn + icol + nclv * igpt;
+  const size_t slab = ncl * gridDim.y;
+  Float* wR = a.ws + icol + ncl * gl;
+  Float* wT = wR + slab;
+  Float* wSd = wT + slab;
+  Float* wDen = wSd + slab;
+  const Float LW_diff_sec = (Float)1.66f;  // :870: default-real literal widened to wp
+  const Float emis = a.sfc_emis[cg];
+  Float albedo = (Float)1 - emis;                 // :428
+  Float src = kPi * emis * a.sfc_src[cg];         // :965
+  const int sfc_level = a.top_at_1 ? nlay : 0, top_level = a.top_at_1 ? 0 : nlay;
+  fdn[(size_t)ncol * sfc_level] = albedo;
+  fup[(size_t)ncol * sfc_level] = src;
+  // ---- bottom -> top: layer properties, sources, albedo / source recurrences (adding :1174-1186 / :1214-1226)
+  for (int k = 0; k < nlay; ++k) {
+    const int ilay = a.top_at_1 ? nlay - 1 - k : k;
+    const size_t o = (size_t)ncol * ilay;
+    const Float t = tau[o], w0 = ssa[o], g = gg[o];
+    const Float gamma1 = LW_diff_sec * ((Float)1 - (Float)0.5 * w0 * ((Float)1 + g));
+    const Float gamma2 = LW_diff_sec * (Float)0.5 * w0 * ((Float)1 - g);
+    const Float kk = sqrt(fmax((gamma1 - gamma2) * (gamma1 + gamma2), (Float)1.e-12));
+    const Float e1 = exp(-t * kk);
+    const Float e2 = e1 * e1;
+    const Float RT = (Float)1 / (kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
+    const Float Rdif = RT * gamma2 * ((Float)1 - e2);
+    const Float Tdif = RT * (Float)2 * kk * e1;
+    const Float lev_a = lev_source[(size_t)ncol * ilay], lev_b = lev_source[(size_t)ncol * (ilay + 1)];
+    const Float lev_top = a.top_at_1 ? lev_a : lev_b, lev_bot = a.top_at_1 ? lev_b : lev_a;
+    Float s_up, s_dn;
+    if (t > (Float)1.0e-8) {
+      const Float Z = (lev_bot - lev_top) / (t * (gamma1 + gamma2));
+      const Float Zup_top = Z + lev_top, Zup_bottom = Z + lev_bot;
+      const Float Zdn_top = -Z + lev_top, Zdn_bottom = -Z + lev_bot;
+      s_up = kPi * (Zup_top - Rdif * Zdn_top - Tdif * Zup_bottom);
+      s_dn = kPi * (Zdn_bottom - Rdif * Zup_bottom - Tdif * Zdn_top);
+    } else {
+      s_up = 0;
+      s_dn = 0;
+    }
+    const Float denom = (Float)1 / ((Float)1 - Rdif * albedo);
+    const Float src_new = s_up + Tdif * denom * (src + albedo * s_dn);
+    const Float alb_new = Rdif + Tdif * Tdif * albedo * denom;
+    albedo = alb_new;
+    src = src_new;
+    const int lev_above = a.top_at_1 ? ilay : ilay + 1;
+    fdn[(size_t)ncol * lev_above] = albedo;
+    fup[(size_t)ncol * lev_above] = src;
+    wR[o] = Rdif; wT[o] = Tdif; wSd[o] = s_dn; wDen[o] = denom;
+  }
+  // ---- top boundary and top -> bottom fluxes (:1188-1202 / :1228-1243)
+  Float fd = a.inc_flux[cg];  // :432
+  fdn[(size_t)ncol * top_level] = fd;
+  fup[(size_t)ncol * top_level] = fd * albedo + src;
+  for (int k = 0; k < nlay; ++k) {
+    const int ilay = a.top_at_1 ? k : nlay - 1 - k;
+    const int lev_below = a.top_at_1 ? ilay + 1 : ilay;
+    const size_t o = (size_t)ncol * ilay, ol = (size_t)ncol * lev_below;
+    const Float alb = fdn[ol], sr = fup[ol];
+    fd = (wT[o] * fd + wR[o] * sr + wSd[o]) * wDen[o];
+    fdn[ol] = fd;
+    fup[ol] = fd * alb + sr;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SW direct beam only: reference :450-494
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sw_noscat_kernel(int ncol, int nlay, int ngpt, bool top_at_1, const Float* __restrict__ tau,
+                 const Float* __restrict__ mu0, const Float* __restrict__ inc_flux_dir, Float* __restrict__ flux_dir) {
+  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+  const int igpt = blockIdx.y;
+  if (icol >= ncol) return;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const Float* t = tau + icol + ncl * igpt;
+  Float* f = flux_dir + icol + nclv * igpt;
+  if (top_at_1) {
+    Float v = inc_flux_dir[icol + (size_t)ncol * igpt] * mu0[icol];
+    f[0] = v;
+    for (int ilev = 1; ilev <= nlay; ++ilev) {
+      v = v * exp(-t[(size_t)ncol * (ilev - 1)] / mu0[icol + (size_t)ncol * (ilev - 1)]);
+      f[(size_t)ncol * ilev] = v;
+    }
+  } else {
+    Float v = inc_flux_dir[icol + (size_t)ncol * igpt] * mu0[icol + (size_t)ncol * (nlay - 1)];
+    f[(size_t)ncol * nlay] = v;
+    for (int ilev = nlay - 1; ilev >= 0; --ilev) {
+      v = v * exp(-t[(size_t)ncol * ilev] / mu0[icol + (size_t)ncol * ilev]);
+      f[(size_t)ncol * ilev] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SW two-stream, generic: reference :503-609 (sw_dif_and_source :985-1127, adding :1135-1245)
+// up/dn/dir: (ncol, nlay+1, gchunk) slabs (the caller's spectral arrays, or scratch when
+// broadband).  ws: 5 layer slabs (ncol, nlay, gchunk): Rdif, Tdif, src_up, src_dn, denom.
+// `up` temporarily holds src, `dn` holds albedo (as in the LW two-stream kernel).
+// ---------------------------------------------------------------------------------------------
+struct Sw2Args {
+  int ncol, nlay, ngpt, g_begin;
+  bool top_at_1, has_dif_bc, add_dir_to_dn;
+  const Float *tau, *ssa, *g, *mu0, *sfc_alb_dir, *sfc_alb_dif, *inc_flux_dir, *inc_flux_dif;
+  Float *up, *dn, *dir, *ws;
+};
+
+__global__ void __launch_bounds__(256) sw_2stream_generic_kernel(Sw2Args a) {
+  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gl = blockIdx.y;
+  if (icol >= a.ncol) return;
+  const int igpt = a.g_begin + gl;
+  const int ncol = a.ncol, nlay = a.nlay, nlev = nlay + 1;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev;
+  const size_t cg = icol + (size_t)ncol * igpt;
+  const Float* tau = a.tau + icol + ncl * igpt;
+  const Float* ssa = a.ssa + icol + ncl * igpt;
+  const Float* gg = a.g + icol + ncl * igpt;
+  const Float* mu0 = a.mu0 + icol;
+  Float* fup = a.up + icol + nclv * gl;
+  Float* fdn = a.dn + icol + nclv * gl;
+  Float* fdir = a.dir + icol + nclv * gl;
+  const size_t slab = ncl * gridDim.y;
+  Float* wR = a.ws + icol + ncl * gl;
+  Float* wT = wR + slab;
+  Float* wSu = wT + slab;
+  Float* wSd = wSu + slab;
+  Float* wDen = wSd + slab;
+  const Float min_k = (Float)1.e4 * (Float)RTE_EPS;
+  const Float min_mu0 = sqrt((Float)RTE_EPS);
+  const int top_level = a.top_at_1 ? 0 : nlay, top_layer = a.top_at_1 ? 0 : nlay - 1;
+  const int sfc_level = a.top_at_1 ? nlay : 0, sfc_layer = a.top_at_1 ? nlay - 1 : 0;
+
+  // ---- top -> bottom: layer R/T, direct beam, sources (:1015-1114)
+  Float dir = a.inc_flux_dir[cg] * mu0[(size_t)ncol * top_layer];  // :575
+  fdir[(size_t)ncol * top_level] = dir;
+  for (int k = 0; k < nlay; ++k) {
+    const int ilay = a.top_at_1 ? k : nlay - 1 - k;
+    const size_t o = (size_t)ncol * ilay;
+    const Float tau_s = tau[o], w0_s = ssa[o], g_s = gg[o];
+    const Float gamma1 = ((Float)8 - w0_s * ((Float)5 + (Float)3 * g_s)) * (Float).25;
+    const Float gamma2 = (Float)3 * (w0_s * ((Float)1 - g_s)) * (Float).25;
+    const Float kk = sqrt(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
+    const Float e1 = exp(-tau_s * kk);
+    const Float e2 = e1 * e1;
+    Float RT = (Float)1 / (kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
+    const Float Rdif = RT * gamma2 * ((Float)1 - e2);
+    const Float Tdif = RT * (Float)2 * kk * e1;
+    const Float mu0_raw = mu0[o];
+    const Float mu0_s = fmax(min_mu0, mu0_raw);
+    const Float k_mu = kk * mu0_s;
+    const Float om = (Float)1 - k_mu * k_mu;
+    RT = w0_s * RT / (fabs(om) >= (Float)RTE_EPS ? om : (Float)RTE_EPS);
+    const Float gamma3 = ((Float)2 - (Float)3 * mu0_s * g_s) * (Float).25;
+    const Float gamma4 = (Float)1 - gamma3;
+    const Float alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
+    const Float alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
+    const Float k_gamma3 = kk * gamma3, k_gamma4 = kk * gamma4;
+    const Float Tnoscat = exp(-tau_s / mu0_s);
+    Float Rdir = RT * (((Float)1 - k_mu) * (alpha2 + k_gamma3) - ((Float)1 + k_mu) * (alpha2 - k_gamma3) * e2 -
+                       (Float)2.0 * (k_gamma3 - alpha2 * k_mu) * e1 * Tnoscat);
+    Float Tdir = -RT * (((Float)1 + k_mu) * (alpha1 + k_gamma4) * Tnoscat -
+                        ((Float)1 - k_mu) * (alpha1 - k_gamma4) * e2 * Tnoscat -
+                        (Float)2.0 * (k_gamma4 + alpha1 * k_mu) * e1);
+    Rdir = fmax((Float)0, fmin(Rdir, ((Float)1 - Tnoscat)));
+    Tdir = fmax((Float)0, fmin(Tdir, ((Float)1 - Tnoscat - Rdir)));
+    Float s_up = Rdir * dir, s_dn = Tdir * dir;
+    dir = Tnoscat * dir;
+    if (mu0_raw <= (Float)0) { s_up = 0; s_dn = 0; }  // :1122-1125
+    fdir[(size_t)ncol * (a.top_at_1 ? ilay + 1 : ilay)] = dir;
+    wR[o] = Rdif; wT[o] = Tdif; wSu[o] = s_up; wSd[o] = s_dn;
+  }
+  // :1120-1121
+  Float src = (mu0[(size_t)ncol * sfc_layer] > (Float)0) ? dir * a.sfc_alb_dir[cg] : (Float)0;
+  Float albedo = a.sfc_alb_dif[cg];
+  fdn[(size_t)ncol * sfc_level] = albedo;
+  fup[(size_t)ncol * sfc_level] = src;
+  // ---- bottom -> top: adding recurrences (:1174-1186 / :1214-1226)
+  for (int k = 0; k < nlay; ++k) {
+    const int ilay = a.top_at_1 ? nlay - 1 - k : k;
+    const size_t o = (size_t)ncol * ilay;
+    const Float Rdif = wR[o], Tdif = wT[o];
+    const Float denom = (Float)1 / ((Float)1 - Rdif * albedo);
+    const Float src_new = wSu[o] + Tdif * denom * (src + albedo * wSd[o]);
+    const Float alb_new = Rdif + Tdif * Tdif * albedo * denom;
+    albedo = alb_new;
+    src = src_new;
+    const int lev_above = a.top_at_1 ? ilay : ilay + 1;
+    fdn[(size_t)ncol * lev_above] = albedo;
+    fup[(size_t)ncol * lev_above] = src;
+    wDen[o] = denom;
+  }
+  // ---- top boundary, top -> bottom fluxes (:1188-1202 / :1228-1243); dn gets direct added (:603,:606)
+  Float fd = a.has_dif_bc ? a.inc_flux_dif[cg] : (Float)0;  // :579-583
+  {
+    const size_t ol = (size_t)ncol * top_level;
+    fup[ol] = fd * albedo + src;
+    fdn[ol] = a.add_dir_to_dn ? fd + fdir[ol] : fd;
+  }
+  for (int k = 0; k < nlay; ++k) {
+    const int ilay = a.top_at_1 ? k : nlay - 1 - k;
+    const int lev_below = a.top_at_1 ? ilay + 1 : ilay;
+    const size_t o = (size_t)ncol * ilay, ol = (size_t)ncol * lev_below;
+    const Float alb = fdn[ol], sr = fup[ol];
+    fd = (wT[o] * fd + wR[o] * sr + wSd[o]) * wDen[o];
+    fup[ol] = fd * alb + sr;
+    fdn[ol] = a.add_dir_to_dn ? fd + fdir[ol] : fd;
+  }
+}
+
+// out(c,l) = sum over the ngroups partial slabs (in order), times scale; optionally accumulate
+__global__ void __launch_bounds__(256)
+reduce_parts_kernel(size_t n2, int ngroups, const Float* __restrict__ parts, Float* __restrict__ out, Float scale,
+                    int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  Float s = 0;
+  for (int q = 0; q < ngroups; ++q) s = s + parts[i + n2 * (size_t)q];
+  s = scale * s;
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+size_t pick_gchunk(size_t bytes_per_g, int ngpt) {
+  const size_t budget = (size_t)3 << 30;  // scratch budget for the generic solvers
+  size_t c = budget / (bytes_per_g ? bytes_per_g : 1);
+  if (c < 1) c = 1;
+  if (c > (size_t)ngpt) c = ngpt;
+  return c;
+}
+
+}  // namespace
+
+// bug-compat switch for rte_lw_solver_2stream (see DESIGN.md / SURVEY.md section 9-1):
+// 0 (default) = each g-point uses its own level source (what the reference accel kernel and
+// the physics intend); 1 = replicate the reference default CPU kernel, which passes the 3-D
+// lev_source to a 2-D dummy and therefore uses g-point 1's level source everywhere.
+static int g_lw2str_gpt1_levsource = 0;
+static int g_lw_force_generic = 0;
+
+extern "C" {
+
+int rte_hip_set_lw2str_bugcompat(int on) { g_lw2str_gpt1_levsource = on; return 0; }
+int rte_hip_force_generic_lw(int on) { g_lw_force_generic = on; return 0; }
+
+void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
+                          const int* nmus_, const Float* Ds, const Float* weights, const Float* tau,
+                          const Float* lay_source, const Float* lev_source, const Float* sfc_emis,
+                          const Float* sfc_src, const Float* inc_flux, Float* flux_up,
+                          Float* flux_dn, const Bool* do_broadband_, Float* broadband_up,
+                          Float* broadband_dn, const Bool* do_Jacobians_, const Float* sfc_srcJac,
+                          Float* flux_upJac, const Bool* do_rescaling_, const Float* ssa,
+                          const Float* g) {
+  const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_, nmus = *nmus_, nlev = nlay + 1;
+  const bool do_broadband = *do_broadband_, do_jac = *do_Jacobians_, do_rescaling = *do_rescaling_;
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0 || nmus <= 0) return;
+  rte::Call c("rte_lw_solver_noscat");
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev, ncg = (size_t)ncol * ngpt;
+  const Float* w_h = c.host(weights, (size_t)nmus);
+  const Float* d_Ds = c.in(Ds, ncg * nmus);
+  const Float* d_tau = c.in(tau, ncl * ngpt);
+  const Float* d_lay = c.in(lay_source, ncl * ngpt);
+  const Float* d_lev = c.in(lev_source, nclv * ngpt);
+  const Float* d_emis = c.in(sfc_emis, ncg);
+  const Float* d_sfc = c.in(sfc_src, ncg);
+  const Float* d_inc = c.in(inc_flux, ncg);
+  const Float* d_srcJac = do_jac ? c.in(sfc_srcJac, ncg) : nullptr;
+  const Float* d_ssa = do_rescaling ? c.in(ssa, ncl * ngpt) : nullptr;
+  const Float* d_g = do_rescaling ? c.in(g, ncl * ngpt) : nullptr;
+  Float* d_flux_up = do_broadband ? nullptr : c.out(flux_up, nclv * ngpt);
+  Float* d_flux_dn = do_broadband ? nullptr : c.out(flux_dn, nclv * ngpt);
+  Float* d_bb_up = do_broadband ? c.out(broadband_up, nclv) : nullptr;
+  Float* d_bb_dn = do_broadband ? c.out(broadband_dn, nclv) : nullptr;
+  Float* d_jac = do_jac ? c.out(flux_upJac, nclv) : nullptr;
+  hipStream_t st = rte::stream();
+
+  // ------------------------------------------------------------------ production path
+  const int L = nlay <= 64 ? 8 : 16;  // layers per segment; 8 waves per block at most
+  const int S = (nlay + L - 1) / L;
+  if (do_broadband && !do_rescaling && S <= 8 && !g_lw_force_generic) {
+    // g-points per block: enough blocks to fill the chip several times over, few enough partial slabs
+    const int col_tiles = cdiv(ncol, 64);
+    int ngroups = 1;
+    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    const int g_per_block = (ngpt + ngroups - 1) / ngroups;
+    ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    Float* part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
+    Float* part_dn = part_up + nclv * ngroups;
+    Float* part_jac = do_jac ? part_dn + nclv * ngroups : nullptr;
+    const size_t lds_bytes = sizeof(Float) * 2 * 3 * S * 64;
+    for (int imu = 0; imu < nmus; ++imu) {
+      {
+        rte::ProfScope p("lw_noscat_seg_kernel");
+#define RTE_LAUNCH_SEG(LL, JJ)                                                                                  \
+  hipLaunchKernelGGL((lw_noscat_seg_kernel<LL, JJ>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st, ncol, \
+                     nlay, ngpt, S, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev, \
+                     d_emis, d_sfc, d_inc, d_srcJac, part_up, part_dn, part_jac)
+        if (L == 8) { if (do_jac) RTE_LAUNCH_SEG(8, true); else RTE_LAUNCH_SEG(8, false); }
+        else        { if (do_jac) RTE_LAUNCH_SEG(16, true); else RTE_LAUNCH_SEG(16, false); }
+#undef RTE_LAUNCH_SEG
+      }
+      rte::ProfScope p("lw_reduce_parts");
+      const Float piw = (Float)3.14159265358979323846264338327950288 * w_h[imu];
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_up,
+                         d_bb_up, piw, imu > 0);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_dn,
+                         d_bb_dn, piw, imu > 0);
+      if (do_jac)
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_jac,
+                           d_jac, piw, imu > 0);
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ generic path
+  // spectral intensities for a chunk of g-points: in the caller's arrays (single angle, spectral
+  // output) or in scratch; then reduce / accumulate.
+  const bool direct = !do_broadband && nmus == 1;
+  const int nslab = (direct ? 0 : 2) + (do_jac ? 1 : 0);
+  const size_t gchunk = direct && !do_jac ? (size_t)ngpt : pick_gchunk(sizeof(Float) * nclv * (nslab ? nslab : 1), ngpt);
+  Float* ws = nslab ? (Float*)rte::scratch(sizeof(Float) * nclv * gchunk * nslab) : nullptr;
+  Float* bb_tmp = (do_broadband || do_jac) ? (Float*)rte::scratch(sizeof(Float) * nclv * 3) : nullptr;
+  for (int imu = 0; imu < nmus; ++imu) {
+    const Float piw = (Float)3.14159265358979323846264338327950288 * w_h[imu];
+    for (int g0 = 0; g0 < ngpt; g0 += (int)gchunk) {
+      const int gc = (int)((size_t)(ngpt - g0) < gchunk ? (size_t)(ngpt - g0) : gchunk);
+      LwArgs a;
+      a.ncol = ncol; a.nlay = nlay; a.ngpt = ngpt; a.g_begin = g0; a.gchunk = gc;
+      a.top_at_1 = *top_at_1; a.do_jac = do_jac; a.do_rescaling = do_rescaling;
+      a.scale_out = !do_broadband; a.accumulate = false; a.weight = w_h[imu];
+      a.D = d_Ds + ncg * imu; a.tau = d_tau; a.lay_source = d_lay; a.lev_source = d_lev;
+      a.sfc_emis = d_emis; a.sfc_src = d_sfc; a.inc_flux = d_inc; a.sfc_srcJac = d_srcJac;
+      a.ssa = d_ssa; a.g = d_g;
+      Float* w = ws;
+      if (direct) {
+        a.radn_up = d_flux_up + nclv * g0;
+        a.radn_dn = d_flux_dn + nclv * g0;
+      } else {
+        a.radn_up = w; w += nclv * gchunk;
+        a.radn_dn = w; w += nclv * gchunk;
+      }
+      a.jac = do_jac ? w : nullptr;
+      {
+        rte::ProfScope p("lw_noscat_generic_kernel");
+        hipLaunchKernelGGL(lw_noscat_generic_kernel, dim3(cdiv(ncol, 256), gc), dim3(256), 0, st, a);
+      }
+      rte::ProfScope p("lw_generic_reduce");
+      const bool first_chunk = g0 == 0, last_chunk = g0 + gc >= ngpt;
+      if (do_broadband) {
+        // per-angle unscaled sums in bb_tmp, scaled and added to the outputs after the last chunk
+        hipLaunchKernelGGL(sum_gpt_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, gc, a.radn_up, bb_tmp,
+                           (Float)1, first_chunk ? 0 : 1);
+        hipLaunchKernelGGL(sum_gpt_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, gc, a.radn_dn,
+                           bb_tmp + nclv, (Float)1, first_chunk ? 0 : 1);
+        if (last_chunk) {
+          hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, 1, bb_tmp, d_bb_up,
+                             piw, imu > 0);
+          hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, 1, bb_tmp + nclv,
+                             d_bb_dn, piw, imu > 0);
+        }
+      } else if (!direct) {
+        // spectral output with several angles: flux(:,:,g) (+)= this angle's flux
+        hipLaunchKernelGGL(axpy_kernel, dim3(cdiv(nclv * gc, 256)), dim3(256), 0, st, nclv * gc, a.radn_up,
+                           d_flux_up + nclv * g0, imu == 0);
+        hipLaunchKernelGGL(axpy_kernel, dim3(cdiv(nclv * gc, 256)), dim3(256), 0, st, nclv * gc, a.radn_dn,
+                           d_flux_dn + nclv * g0, imu == 0);
+      }
+      if (do_jac) {
+        hipLaunchKernelGGL(sum_gpt_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, gc, a.jac,
+                           bb_tmp + 2 * nclv, (Float)1, first_chunk ? 0 : 1);
+        if (last_chunk)
+          hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, 1,
+                             bb_tmp + 2 * nclv, d_jac, piw, imu > 0);
+      }
+    }
+  }
+}
+
+void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
+                           const Float* tau, const Float* ssa, const Float* g,
+                           const Float* lay_source, const Float* lev_source, const Float* sfc_emis,
+                           const Float* sfc_src, const Float* inc_flux, Float* flux_up,
+                           Float* flux_dn) {
+  const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_, nlev = nlay + 1;
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  rte::Call c("rte_lw_solver_2stream");
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev, ncg = (size_t)ncol * ngpt;
+  Lw2Args a;
+  a.ncol = ncol; a.nlay = nlay; a.ngpt = ngpt; a.top_at_1 = *top_at_1; a.lev_gpt1 = g_lw2str_gpt1_levsource != 0;
+  a.tau = c.in(tau, ncl * ngpt); a.ssa = c.in(ssa, ncl * ngpt); a.g = c.in(g, ncl * ngpt);
+  a.lay_source = c.in(lay_source, ncl * ngpt); a.lev_source = c.in(lev_source, nclv * ngpt);
+  a.sfc_emis = c.in(sfc_emis, ncg); a.sfc_src = c.in(sfc_src, ncg); a.inc_flux = c.in(inc_flux, ncg);
+  a.flux_up = c.out(flux_up, nclv * ngpt); a.flux_dn = c.out(flux_dn, nclv * ngpt);
+  const size_t gchunk = pick_gchunk(sizeof(Float) * ncl * 4, ngpt);
+  a.ws = (Float*)rte::scratch(sizeof(Float) * ncl * 4 * gchunk);
+  rte::ProfScope p("lw_2stream_generic_kernel");
+  for (int g0 = 0; g0 < ngpt; g0 += (int)gchunk) {
+    const int gc = (int)((size_t)(ngpt - g0) < gchunk ? (size_t)(ngpt - g0) : gchunk);
+    a.g_begin = g0;
+    hipLaunchKernelGGL(lw_2stream_generic_kernel, dim3(cdiv(ncol, 256), gc), dim3(256), 0, rte::stream(), a);
+  }
+}
+
+void rte_sw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
+                          const Float* tau, const Float* mu0, const Float* inc_flux_dir,
+                          Float* flux_dir) {
+  const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_;
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  rte::Call c("rte_sw_solver_noscat");
+  const size_t ncl = (size_t)ncol * nlay;
+  const Float* d_tau = c.in(tau, ncl * ngpt);
+  const Float* d_mu0 = c.in(mu0, ncl);
+  const Float* d_inc = c.in(inc_flux_dir, (size_t)ncol * ngpt);
+  Float* d_dir = c.out(flux_dir, (size_t)ncol * (nlay + 1) * ngpt);
+  rte::ProfScope p("sw_noscat_kernel");
+  hipLaunchKernelGGL(sw_noscat_kernel, dim3(cdiv(ncol, 256), ngpt), dim3(256), 0, rte::stream(), ncol, nlay, ngpt,
+                     (bool)*top_at_1, d_tau, d_mu0, d_inc, d_dir);
+}
+
+void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
+                           const Float* tau, const Float* ssa, const Float* g, const Float* mu0,
+                           const Float* sfc_alb_dir, const Float* sfc_alb_dif,
+                           const Float* inc_flux_dir, Float* flux_up, Float* flux_dn,
+                           Float* flux_dir, const Bool* has_dif_bc, const Float* inc_flux_dif,
+                           const Bool* do_broadband_, Float* broadband_up, Float* broadband_dn,
+                           Float* broadband_dir) {
+  const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_, nlev = nlay + 1;
+  const bool do_broadband = *do_broadband_;
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  rte::Call c("rte_sw_solver_2stream");
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev, ncg = (size_t)ncol * ngpt;
+  Sw2Args a;
+  a.ncol = ncol; a.nlay = nlay; a.ngpt = ngpt; a.top_at_1 = *top_at_1; a.has_dif_bc = *has_dif_bc;
+  a.add_dir_to_dn = true;
+  a.tau = c.in(tau, ncl * ngpt); a.ssa = c.in(ssa, ncl * ngpt); a.g = c.in(g, ncl * ngpt);
+  a.mu0 = c.in(mu0, ncl);
+  a.sfc_alb_dir = c.in(sfc_alb_dir, ncg); a.sfc_alb_dif = c.in(sfc_alb_dif, ncg);
+  a.inc_flux_dir = c.in(inc_flux_dir, ncg);
+  a.inc_flux_dif = *has_dif_bc ? c.in(inc_flux_dif, ncg) : nullptr;
+  Float *d_up = nullptr, *d_dn = nullptr, *d_dir = nullptr, *d_bu = nullptr, *d_bd = nullptr, *d_bdir = nullptr;
+  if (do_broadband) {
+    d_bu = c.out(broadband_up, nclv); d_bd = c.out(broadband_dn, nclv); d_bdir = c.out(broadband_dir, nclv);
+  } else {
+    d_up = c.out(flux_up, nclv * ngpt); d_dn = c.out(flux_dn, nclv * ngpt); d_dir = c.out(flux_dir, nclv * ngpt);
+  }
+  const size_t per_g = sizeof(Float) * (ncl * 5 + (do_broadband ? nclv * 3 : 0));
+  const size_t gchunk = pick_gchunk(per_g, ngpt);
+  a.ws = (Float*)rte::scratch(sizeof(Float) * ncl * 5 * gchunk);
+  Float* slabs = do_broadband ? (Float*)rte::scratch(sizeof(Float) * nclv * 3 * gchunk) : nullptr;
+  hipStream_t st = rte::stream();
+  for (int g0 = 0; g0 < ngpt; g0 += (int)gchunk) {
+    const int gc = (int)((size_t)(ngpt - g0) < gchunk ? (size_t)(ngpt - g0) : gchunk);
+    a.g_begin = g0;
+    if (do_broadband) {
+      a.up = slabs; a.dn = slabs + nclv * gchunk; a.dir = slabs + 2 * nclv * gchunk;
+    } else {
+      a.up = d_up + nclv * g0; a.dn = d_dn + nclv * g0; a.dir = d_dir + nclv * g0;
+    }
+    {
+      rte::ProfScope p("sw_2stream_generic_kernel");
+      hipLaunchKernelGGL(sw_2stream_generic_kernel, dim3(cdiv(ncol, 256), gc), dim3(256), 0, st, a);
+    }
+    if (do_broadband) {
+      rte::ProfScope p("sw_generic_reduce");
+      const int mode = g0 == 0 ? 0 : 1;
+      hipLaunchKernelGGL(sum_gpt_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, gc, a.up, d_bu, (Float)1, mode);
+      hipLaunchKernelGGL(sum_gpt_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, gc, a.dn, d_bd, (Float)1, mode);
+      hipLaunchKernelGGL(sum_gpt_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, gc, a.dir, d_bdir, (Float)1, mode);
+    }
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+// util.hip -- array utilities, flux reductions and frontend-glue kernels (gfx950).
+//
+// C ABI: zero_array_*, set_to_scalar_* (reference rte/kernels/mo_rte_util_array.F90:32-132),
+//        rte_sum_broadband, rte_net_broadband_full, rte_net_broadband_precalc
+//        (reference rte/kernels/mo_fluxes_broadband_kernels.F90:32-128).
+// Extension symbols (rte_hip_*): device versions of frontend glue loops that are not behind the
+// reference's C API but must run on the device in a device-resident driver.
+#include "common.h"
+
+namespace {
+using rte::cdiv;
+
+__global__ void __launch_bounds__(256) fill_kernel(Float* __restrict__ a, size_t n, Float v) {
+  // 2 elements per thread, grid-stride: wide coalesced stores
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) a[i] = v;
+}
+
+void fill(const char* name, Float* a, size_t n, Float v) {
+  if (n == 0) return;
+  rte::Call c(name);
+  Float* d = c.out(a, n);
+  rte::ProfScope p("fill_kernel");
+  if (v == (Float)0) {
+    HIP_CHECK(hipMemsetAsync(d, 0, n * sizeof(Float), rte::stream()));
+  } else {
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, rte::stream(), d, n, v);
+  }
+}
+
+// sequential sum over g-points, exactly the reference's order
+__global__ void __launch_bounds__(256)
+sum_broadband_kernel(size_t n2, int ngpt, const Float* __restrict__ spectral, Float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  Float s = 0;
+  for (int g = 0; g < ngpt; ++g) s = s + spectral[i + n2 * (size_t)g];
+  out[i] = s;
+}
+__global__ void __launch_bounds__(256)
+net_broadband_full_kernel(size_t n2, int ngpt, const Float* __restrict__ dn, const Float* __restrict__ up,
+                          Float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  Float s = dn[i] - up[i];
+  for (int g = 1; g < ngpt; ++g) s = s + (dn[i + n2 * (size_t)g] - up[i + n2 * (size_t)g]);
+  out[i] = s;
+}
+__global__ void __launch_bounds__(256)
+net_precalc_kernel(size_t n2, const Float* __restrict__ dn, const Float* __restrict__ up, Float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n2) out[i] = dn[i] - up[i];
+}
+
+// combine_abs_and_rayleigh, 2-stream branch: reference rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:1983-2002
+__global__ void __launch_bounds__(256)
+combine_2str_kernel(size_t n, const Float* __restrict__ tau_abs, const Float* __restrict__ tau_ray,
+                    Float* __restrict__ tau, Float* __restrict__ ssa, Float* __restrict__ g) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Float tr = tau_ray[i];
+  const Float t = tau_abs[i] + tr;
+#ifdef RTE_USE_SP
+  const Float tiny2 = (Float)2 * (Float)1.17549435e-38f;
+#else
+  const Float tiny2 = (Float)2 * (Float)2.2250738585072014e-308;
+#endif
+  ssa[i] = (t > tiny2) ? tr / t : (Float)0;
+  tau[i] = t;
+  g[i] = 0;
+}
+// out(icol, igpt) = per_gpt(igpt): toa_src broadcast, reference mo_gas_optics_rrtmgp.F90:405-411
+__global__ void __launch_bounds__(256)
+broadcast_gpt_kernel(int ncol, int ngpt, const Float* __restrict__ per_gpt, Float* __restrict__ out) {
+  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (icol < ncol) out[icol + (size_t)ncol * g] = per_gpt[g];
+}
+}  // namespace
+
+extern "C" {
+void zero_array_1D(const int* ni, Float* a) { fill("zero_array_1D", a, (size_t)*ni, 0); }
+void zero_array_2D(const int* ni, const int* nj, Float* a) { fill("zero_array_2D", a, (size_t)*ni * *nj, 0); }
+void zero_array_3D(const int* ni, const int* nj, const int* nk, Float* a) {
+  fill("zero_array_3D", a, (size_t)*ni * *nj * *nk, 0);
+}
+void zero_array_4D(const int* ni, const int* nj, const int* nk, const int* nl, Float* a) {
+  fill("zero_array_4D", a, (size_t)*ni * *nj * *nk * *nl, 0);
+}
+void set_to_scalar_1D(const int* ni, Float* a, const Float* v) { fill("set_to_scalar_1D", a, (size_t)*ni, *v); }
+void set_to_scalar_2D(const int* ni, const int* nj, Float* a, const Float* v) {
+  fill("set_to_scalar_2D", a, (size_t)*ni * *nj, *v);
+}
+void set_to_scalar_3D(const int* ni, const int* nj, const int* nk, Float* a, const Float* v) {
+  fill("set_to_scalar_3D", a, (size_t)*ni * *nj * *nk, *v);
+}
+void set_to_scalar_4D(const int* ni, const int* nj, const int* nk, const int* nl, Float* a, const Float* v) {
+  fill("set_to_scalar_4D", a, (size_t)*ni * *nj * *nk * *nl, *v);
+}
+
+void rte_sum_broadband(const int* ncol, const int* nlev, const int* ngpt, const Float* spectral_flux,
+                       Float* broadband_flux) {
+  const size_t n2 = (size_t)*ncol * *nlev;
+  if (n2 == 0) return;
+  rte::Call c("rte_sum_broadband");
+  const Float* s = c.in(spectral_flux, n2 * *ngpt);
+  Float* o = c.out(broadband_flux, n2);
+  rte::ProfScope p("sum_broadband_kernel");
+  hipLaunchKernelGGL(sum_broadband_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, rte::stream(), n2, *ngpt, s, o);
+}
+void rte_net_broadband_full(const int* ncol, const int* nlev, const int* ngpt, const Float* spectral_flux_dn,
+                            const Float* spectral_flux_up, Float* broadband_flux_net) {
+  const size_t n2 = (size_t)*ncol * *nlev;
+  if (n2 == 0) return;
+  rte::Call c("rte_net_broadband_full");
+  const Float* d = c.in(spectral_flux_dn, n2 * *ngpt);
+  const Float* u = c.in(spectral_flux_up, n2 * *ngpt);
+  Float* o = c.out(broadband_flux_net, n2);
+  rte::ProfScope p("net_broadband_full_kernel");
+  hipLaunchKernelGGL(net_broadband_full_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, rte::stream(), n2, *ngpt, d, u, o);
+}
+void rte_net_broadband_precalc(const int* ncol, const int* nlev, const Float* flux_dn, const Float* flux_up,
+                               Float* broadband_flux_net) {
+  const size_t n2 = (size_t)*ncol * *nlev;
+  if (n2 == 0) return;
+  rte::Call c("rte_net_broadband_precalc");
+  const Float* d = c.in(flux_dn, n2);
+  const Float* u = c.in(flux_up, n2);
+  Float* o = c.out(broadband_flux_net, n2);
+  rte::ProfScope p("net_precalc_kernel");
+  hipLaunchKernelGGL(net_precalc_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, rte::stream(), n2, d, u, o);
+}
+
+// ---- extension symbols (scalars by value) ---------------------------------------------------
+int rte_hip_combine_abs_and_rayleigh_2str(int ncol, int nlay, int ngpt, const Float* tau_abs, const Float* tau_ray,
+                                          Float* tau, Float* ssa, Float* g) {
+  const size_t n = (size_t)ncol * nlay * ngpt;
+  if (n == 0) return 0;
+  rte::Call c("rte_hip_combine_abs_and_rayleigh_2str");
+  const Float* a = c.in(tau_abs, n);
+  const Float* r = c.in(tau_ray, n);
+  Float *t = c.out(tau, n), *s = c.out(ssa, n), *gg = c.out(g, n);
+  rte::ProfScope p("combine_2str_kernel");
+  hipLaunchKernelGGL(combine_2str_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, a, r, t, s, gg);
+  return 0;
+}
+int rte_hip_broadcast_gpt(int ncol, int ngpt, const Float* per_gpt, Float* out) {
+  if (ncol <= 0 || ngpt <= 0) return 0;
+  rte::Call c("rte_hip_broadcast_gpt");
+  const Float* pg = c.in(per_gpt, (size_t)ngpt);
+  Float* o = c.out(out, (size_t)ncol * ngpt);
+  rte::ProfScope p("broadcast_gpt_kernel");
+  hipLaunchKernelGGL(broadcast_gpt_kernel, dim3(cdiv(ncol, 256), ngpt), dim3(256), 0, rte::stream(), ncol, ngpt, pg, o);
+  return 0;
+}
+}

@@ -1,0 +1,392 @@
+"""Host-side mirror of the reference frontend's calls on the hot path, over the kernel C ABI.
+
+This is NOT a re-implementation of the reference's Fortran classes; it is the thin sequence of
+kernel calls (plus the few frontend "glue" loops that sit between them) that
+``ty_gas_optics_rrtmgp%gas_optics`` , ``rte_lw`` and ``rte_sw`` perform, so that a device-resident
+driver can chain the same ``bind(C)`` symbols the unchanged Fortran frontend would call:
+
+  GasOptics.gas_optics_lw   <- gas_optics_int   rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:220-331
+  GasOptics.gas_optics_sw   <- gas_optics_ext   :337-414
+  GasOptics.compute_gas_taus<- compute_gas_taus :419-745   (interpolation, zero, tau_absorption
+                                                            [, tau_rayleigh, combine])
+  GasOptics.source          <- source           :840-928   (compute_Planck_source)
+  rte_lw                    <- rte_lw           rte/frontend/mo_rte_lw.F90:79-473 (lw_solver_noscat /
+                                                            lw_solver_2stream)
+  rte_sw                    <- rte_sw_mu0_full  rte/frontend/mo_rte_sw.F90:103-394 (sw_solver_2stream /
+                                                            sw_solver_noscat)
+
+It works with any library exporting the ABI (``cabi.KernelLib``) and any array container through
+an ``Arrays`` backend: ``NumpyArrays`` (host arrays; the HIP library stages them, the oracles use
+them directly) or ``TorchArrays`` (device-resident tensors; the HIP library launches in place).
+A Fortran array of shape (n1,n2,n3) (n1 fastest) is a torch tensor of shape (n3,n2,n1).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+
+# Gauss-Jacobi-5 quadrature secants / weights for 1..4 angles, reference
+# rte/frontend/mo_rte_lw.F90:146-160 (row n-1 holds the n-angle rule)
+GAUSS_DS = [
+    [1.0 / 0.6096748751],
+    [1.0 / 0.2509907356, 1.0 / 0.7908473988],
+    [1.0 / 0.1024922169, 1.0 / 0.4417960320, 1.0 / 0.8633751621],
+    [1.0 / 0.0454586727, 1.0 / 0.2322334416, 1.0 / 0.5740198775, 1.0 / 0.9030775973],
+]
+GAUSS_WTS = [
+    [1.0],
+    [0.2300253764, 0.7699746236],
+    [0.0437820218, 0.3875796738, 0.5686383044],
+    [0.0092068785, 0.1285704278, 0.4323381850, 0.4298845087],
+]
+
+
+# --------------------------------------------------------------------------------------
+# array backends
+# --------------------------------------------------------------------------------------
+class NumpyArrays:
+    """Host arrays in Fortran order (what the unchanged Fortran frontend would pass)."""
+
+    def __init__(self, precision: str = "dp"):
+        self.ftype = np.float64 if precision == "dp" else np.float32
+        self._dt = {"f": self.ftype, "i": np.int32, "b": np.bool_}
+
+    def empty(self, shape, kind="f"):
+        return np.empty(shape, dtype=self._dt[kind], order="F")
+
+    def zeros(self, shape, kind="f"):
+        return np.zeros(shape, dtype=self._dt[kind], order="F")
+
+    def full(self, shape, value, kind="f"):
+        return np.full(shape, value, dtype=self._dt[kind], order="F")
+
+    def asarray(self, a):
+        a = np.asarray(a)
+        if a.dtype.kind == "f":
+            a = a.astype(self.ftype)
+        return np.asfortranarray(a)
+
+    def to_numpy(self, a):
+        return np.asarray(a)
+
+    def sync(self):
+        pass
+
+
+class TorchArrays:
+    """Device-resident tensors; Fortran shape (n1,..,nk) is stored as a C-contiguous tensor of
+    shape (nk,..,n1), which is byte-identical to the column-major array."""
+
+    def __init__(self, device="cuda:0", precision: str = "dp"):
+        import torch
+
+        self.torch = torch
+        self.device = torch.device(device)
+        self.ftype = np.float64 if precision == "dp" else np.float32
+        self._dt = {"f": torch.float64 if precision == "dp" else torch.float32, "i": torch.int32,
+                    "b": torch.bool}
+
+    def empty(self, shape, kind="f"):
+        return self.torch.empty(tuple(reversed(tuple(shape))), dtype=self._dt[kind], device=self.device)
+
+    def zeros(self, shape, kind="f"):
+        return self.torch.zeros(tuple(reversed(tuple(shape))), dtype=self._dt[kind], device=self.device)
+
+    def full(self, shape, value, kind="f"):
+        return self.torch.full(tuple(reversed(tuple(shape))), value, dtype=self._dt[kind],
+                               device=self.device)
+
+    def asarray(self, a):
+        a = np.asarray(a)
+        if a.dtype.kind == "f":
+            a = a.astype(self.ftype)
+        t = self.torch.from_numpy(np.ascontiguousarray(a.T))
+        return t.to(self.device)
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy().T
+
+    def sync(self):
+        if self.device.type == "cuda":
+            self.torch.cuda.synchronize(self.device)
+
+
+@dataclass
+class InterpState:
+    """Outputs of ``interpolation`` (the reference keeps them as locals of compute_gas_taus and
+    hands them on to ``source``: mo_gas_optics_rrtmgp.F90:264-273,310-315)."""
+
+    jtemp: object
+    jpress: object
+    tropo: object
+    jeta: object
+    col_mix: object
+    fmajor: object
+    fminor: object
+
+
+# --------------------------------------------------------------------------------------
+# gas optics
+# --------------------------------------------------------------------------------------
+class GasOptics:
+    """The kernel-facing part of ``ty_gas_optics_rrtmgp`` for one k-distribution."""
+
+    LUT_NAMES = ["flavor", "press_ref_log", "temp_ref", "vmr_ref", "gpoint_flavor", "band_lims_gpt",
+                 "gpoint_bands", "kmajor", "kminor_lower", "kminor_upper", "minor_limits_gpt_lower",
+                 "minor_limits_gpt_upper", "minor_scales_with_density_lower",
+                 "minor_scales_with_density_upper", "scale_by_complement_lower",
+                 "scale_by_complement_upper", "idx_minor_lower", "idx_minor_upper",
+                 "idx_minor_scaling_lower", "idx_minor_scaling_upper", "kminor_start_lower",
+                 "kminor_start_upper", "planck_frac", "totplnk", "krayl", "solar_source",
+                 "optimal_angle_fit"]
+
+    def __init__(self, lib, kdist, arrays):
+        self.lib = lib
+        self.kd = kdist
+        self.xp = arrays
+        self.t = {n: arrays.asarray(kdist.arrays[n]) for n in self.LUT_NAMES if n in kdist.arrays}
+        self.ngas, self.nflav, self.neta = kdist.ngas, kdist.nflav, kdist.neta
+        self.npres, self.ntemp = kdist.npres, kdist.ntemp
+        self.nbnd, self.ngpt = kdist.nbnd, kdist.ngpt
+        self.nminorlower = kdist.arrays["idx_minor_lower"].shape[0]
+        self.nminorupper = kdist.arrays["idx_minor_upper"].shape[0]
+        self.nminorklower = kdist.arrays["kminor_lower"].shape[2]
+        self.nminorkupper = kdist.arrays["kminor_upper"].shape[2]
+        self.is_lw = "totplnk" in kdist.arrays
+
+    # -- interpolation (mo_gas_optics_rrtmgp.F90:615-635)
+    def interpolation(self, ncol, nlay, play, tlay, col_gas, out: Optional[InterpState] = None):
+        xp, kd, t = self.xp, self.kd, self.t
+        if out is None:
+            out = InterpState(
+                jtemp=xp.empty((ncol, nlay), "i"), jpress=xp.empty((ncol, nlay), "i"),
+                tropo=xp.empty((ncol, nlay), "b"), jeta=xp.empty((2, ncol, nlay, self.nflav), "i"),
+                col_mix=xp.empty((2, ncol, nlay, self.nflav)),
+                fmajor=xp.empty((2, 2, 2, ncol, nlay, self.nflav)),
+                fminor=xp.empty((2, 2, ncol, nlay, self.nflav)))
+        self.lib.rrtmgp_interpolation(
+            ncol, nlay, self.ngas, self.nflav, self.neta, self.npres, self.ntemp, t["flavor"],
+            t["press_ref_log"], t["temp_ref"], kd.press_ref_log_delta, kd.temp_ref_min,
+            kd.temp_ref_delta, kd.press_ref_trop_log, t["vmr_ref"], play, tlay, col_gas, out.jtemp,
+            out.fmajor, out.fminor, out.col_mix, out.tropo, out.jeta, out.jpress)
+        return out
+
+    # -- compute_tau_absorption (mo_gas_optics_rrtmgp.F90:638-665 / 680-707); tau is ACCUMULATED
+    def compute_tau_absorption(self, ncol, nlay, st: InterpState, play, tlay, col_gas, tau):
+        t = self.t
+        self.lib.rrtmgp_compute_tau_absorption(
+            ncol, nlay, self.nbnd, self.ngpt, self.ngas, self.nflav, self.neta, self.npres,
+            self.ntemp, self.nminorlower, self.nminorklower, self.nminorupper, self.nminorkupper,
+            self.kd.idx_h2o, t["gpoint_flavor"], t["band_lims_gpt"], t["kmajor"], t["kminor_lower"],
+            t["kminor_upper"], t["minor_limits_gpt_lower"], t["minor_limits_gpt_upper"],
+            t["minor_scales_with_density_lower"], t["minor_scales_with_density_upper"],
+            t["scale_by_complement_lower"], t["scale_by_complement_upper"], t["idx_minor_lower"],
+            t["idx_minor_upper"], t["idx_minor_scaling_lower"], t["idx_minor_scaling_upper"],
+            t["kminor_start_lower"], t["kminor_start_upper"], st.tropo, st.col_mix, st.fmajor,
+            st.fminor, play, tlay, col_gas, st.jeta, st.jtemp, st.jpress, tau)
+
+    def compute_tau_rayleigh(self, ncol, nlay, st: InterpState, col_dry, col_gas, tau_rayleigh):
+        t = self.t
+        self.lib.rrtmgp_compute_tau_rayleigh(
+            ncol, nlay, self.nbnd, self.ngpt, self.ngas, self.nflav, self.neta, self.npres,
+            self.ntemp, t["gpoint_flavor"], t["band_lims_gpt"], t["krayl"], self.kd.idx_h2o, col_dry,
+            col_gas, st.fminor, st.jeta, st.tropo, st.jtemp, tau_rayleigh)
+
+    # -- source (mo_gas_optics_rrtmgp.F90:840-928)
+    def source(self, ncol, nlay, st: InterpState, tlay, tlev, tsfc, top_at_1, sfc_src, lay_src,
+               lev_src, sfc_src_jac):
+        t, kd = self.t, self.kd
+        sfc_lay = nlay if top_at_1 else 1  # :920
+        self.lib.rrtmgp_compute_Planck_source(
+            ncol, nlay, self.nbnd, self.ngpt, self.nflav, self.neta, self.npres, self.ntemp,
+            int(kd.nPlanckTemp), tlay, tlev, tsfc, sfc_lay, st.fmajor, st.jeta, st.tropo, st.jtemp,
+            st.jpress, t["gpoint_bands"], t["band_lims_gpt"], t["planck_frac"], kd.temp_ref_min,
+            kd.totplnk_delta, t["totplnk"], t["gpoint_flavor"], sfc_src, lay_src, lev_src, sfc_src_jac)
+
+    # -- gas_optics_int: LW, returns 1scl optical props + sources
+    def gas_optics_lw(self, ncol, nlay, play, plev, tlay, tsfc, col_gas, tlev, top_at_1,
+                      buffers: Optional[Dict[str, object]] = None):
+        xp = self.xp
+        b = buffers if buffers is not None else {}
+
+        def buf(name, shape, kind="f"):
+            if name not in b:
+                b[name] = xp.empty(shape, kind)
+            return b[name]
+
+        st = self.interpolation(ncol, nlay, play, tlay, col_gas, b.get("interp"))
+        b["interp"] = st
+        tau = buf("tau", (ncol, nlay, self.ngpt))
+        self.lib.zero_array_3D(ncol, nlay, self.ngpt, tau)  # :679
+        self.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau)
+        lay_src = buf("lay_src", (ncol, nlay, self.ngpt))
+        lev_src = buf("lev_src", (ncol, nlay + 1, self.ngpt))
+        sfc_src = buf("sfc_src", (ncol, self.ngpt))
+        sfc_src_jac = buf("sfc_src_jac", (ncol, self.ngpt))
+        self.source(ncol, nlay, st, tlay, tlev, tsfc, top_at_1, sfc_src, lay_src, lev_src, sfc_src_jac)
+        return b
+
+    # -- gas_optics_ext: SW, returns 2str optical props + toa source
+    def gas_optics_sw(self, ncol, nlay, play, plev, tlay, col_gas, col_dry,
+                      buffers: Optional[Dict[str, object]] = None, glue=None):
+        xp = self.xp
+        b = buffers if buffers is not None else {}
+
+        def buf(name, shape, kind="f"):
+            if name not in b:
+                b[name] = xp.empty(shape, kind)
+            return b[name]
+
+        st = self.interpolation(ncol, nlay, play, tlay, col_gas, b.get("interp"))
+        b["interp"] = st
+        tau_abs = buf("tau_abs", (ncol, nlay, self.ngpt))
+        tau_ray = buf("tau_rayleigh", (ncol, nlay, self.ngpt))
+        self.lib.zero_array_3D(ncol, nlay, self.ngpt, tau_abs)  # :637
+        self.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau_abs)
+        self.compute_tau_rayleigh(ncol, nlay, st, col_dry, col_gas, tau_ray)
+        tau, ssa, g = (buf(n, (ncol, nlay, self.ngpt)) for n in ("tau", "ssa", "g"))
+        (glue or default_glue(self.lib, xp)).combine_abs_and_rayleigh_2str(
+            ncol, nlay, self.ngpt, tau_abs, tau_ray, tau, ssa, g)
+        toa = buf("toa_src", (ncol, self.ngpt))
+        (glue or default_glue(self.lib, xp)).broadcast_gpt(ncol, self.ngpt, self.t["solar_source"], toa)
+        return b
+
+
+# --------------------------------------------------------------------------------------
+# frontend glue loops (not behind the reference's C API)
+# --------------------------------------------------------------------------------------
+class NumpyGlue:
+    """Host glue for host arrays (numpy restatements of the frontend's elementwise loops)."""
+
+    # combine_abs_and_rayleigh, 2-stream branch: mo_gas_optics_rrtmgp.F90:1983-2002
+    def combine_abs_and_rayleigh_2str(self, ncol, nlay, ngpt, tau_abs, tau_ray, tau, ssa, g):
+        t = tau_abs + tau_ray
+        tiny2 = 2.0 * np.finfo(t.dtype).tiny
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ssa[...] = np.where(t > tiny2, tau_ray / t, 0.0)
+        tau[...] = t
+        g[...] = 0.0
+
+    # toa_src(icol,igpt) = solar_source(igpt): mo_gas_optics_rrtmgp.F90:405-411
+    def broadcast_gpt(self, ncol, ngpt, per_gpt, out):
+        out[...] = np.asarray(per_gpt)[None, :]
+
+
+class HipGlue:
+    """Device glue: extension entry points of the HIP library (names ``rte_hip_*``)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def combine_abs_and_rayleigh_2str(self, ncol, nlay, ngpt, tau_abs, tau_ray, tau, ssa, g):
+        from .hiplib import ext_call
+
+        ext_call(self.lib, "rte_hip_combine_abs_and_rayleigh_2str", ["i", "i", "i", "a", "a", "a", "a", "a"],
+                 ncol, nlay, ngpt, tau_abs, tau_ray, tau, ssa, g)
+
+    def broadcast_gpt(self, ncol, ngpt, per_gpt, out):
+        from .hiplib import ext_call
+
+        ext_call(self.lib, "rte_hip_broadcast_gpt", ["i", "i", "a", "a"], ncol, ngpt, per_gpt, out)
+
+
+def default_glue(lib, arrays):
+    return NumpyGlue() if isinstance(arrays, NumpyArrays) else HipGlue(lib)
+
+
+# --------------------------------------------------------------------------------------
+# RTE solvers
+# --------------------------------------------------------------------------------------
+def rte_lw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, lay_src, lev_src, sfc_emis_gpt, sfc_src,
+           n_gauss_angles: int = 1, inc_flux=None, sfc_src_jac=None, do_jacobians=False,
+           lw_Ds=None, ssa=None, g=None, use_2stream=False, do_broadband=True,
+           buffers: Optional[Dict[str, object]] = None):
+    """Mirror of ``rte_lw`` (rte/frontend/mo_rte_lw.F90:79-473) for 1scl / 2str optical props.
+
+    Returns the dict of output buffers: ``flux_up``/``flux_dn`` are broadband (ncol,nlay+1) when
+    ``do_broadband`` else spectral (ncol,nlay+1,ngpt); ``flux_up_jac`` when requested."""
+    b = buffers if buffers is not None else {}
+
+    def buf(name, shape, kind="f"):
+        if name not in b:
+            b[name] = xp.empty(shape, kind)
+        return b[name]
+
+    if inc_flux is None:
+        if "inc_flux_zero" not in b:
+            b["inc_flux_zero"] = xp.zeros((ncol, ngpt))
+        inc_flux = b["inc_flux_zero"]  # :297-305
+    if use_2stream:
+        # lw_solver_2stream path :388-409 (spectral fluxes, then reduce)
+        gfu, gfd = buf("gpt_flux_up", (ncol, nlay + 1, ngpt)), buf("gpt_flux_dn", (ncol, nlay + 1, ngpt))
+        lib.rte_lw_solver_2stream(ncol, nlay, ngpt, top_at_1, tau, ssa, g, lay_src, lev_src,
+                                  sfc_emis_gpt, sfc_src, inc_flux, gfu, gfd)
+        if do_broadband:
+            fu, fd = buf("flux_up", (ncol, nlay + 1)), buf("flux_dn", (ncol, nlay + 1))
+            lib.rte_sum_broadband(ncol, nlay + 1, ngpt, gfu, fu)
+            lib.rte_sum_broadband(ncol, nlay + 1, ngpt, gfd, fd)
+        return b
+    nmus = n_gauss_angles
+    key = ("secants", nmus, id(lw_Ds))
+    if key not in b:
+        if lw_Ds is not None:  # :346-356 user-provided secants (ncol,ngpt)
+            b[key] = lw_Ds
+        else:  # :357-365
+            sec = np.empty((ncol, ngpt, nmus), order="F")
+            for imu in range(nmus):
+                sec[:, :, imu] = GAUSS_DS[nmus - 1][imu]
+            b[key] = xp.asarray(sec)
+        b[("weights", nmus)] = xp.asarray(np.array(GAUSS_WTS[nmus - 1] if lw_Ds is None else [1.0]))
+    secants, weights = b[key], b[("weights", nmus)]
+    do_rescaling = ssa is not None and g is not None
+    decoy2 = buf("decoy2D", (ncol, nlay + 1))
+    if do_broadband:
+        fu, fd = buf("flux_up", (ncol, nlay + 1)), buf("flux_dn", (ncol, nlay + 1))
+        gfu = gfd = buf("decoy3D", (1,))  # never written in broadband mode
+    else:
+        gfu, gfd = buf("gpt_flux_up", (ncol, nlay + 1, ngpt)), buf("gpt_flux_dn", (ncol, nlay + 1, ngpt))
+        fu = fd = decoy2
+    jac = buf("flux_up_jac", (ncol, nlay + 1)) if do_jacobians else decoy2
+    lib.rte_lw_solver_noscat(
+        ncol, nlay, ngpt, top_at_1, nmus if lw_Ds is None else 1, secants, weights, tau, lay_src,
+        lev_src, sfc_emis_gpt, sfc_src, inc_flux, gfu, gfd, do_broadband, fu, fd, do_jacobians,
+        sfc_src_jac if do_jacobians else sfc_src, jac, do_rescaling, ssa if do_rescaling else tau,
+        g if do_rescaling else tau)
+    return b
+
+
+def rte_sw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, inc_flux_dir, sfc_alb_dir_gpt,
+           sfc_alb_dif_gpt, inc_flux_dif=None, do_broadband=True, noscat=False,
+           buffers: Optional[Dict[str, object]] = None):
+    """Mirror of ``rte_sw_mu0_full`` (rte/frontend/mo_rte_sw.F90:103-394); ``mu0`` is (ncol,nlay)."""
+    b = buffers if buffers is not None else {}
+
+    def buf(name, shape, kind="f"):
+        if name not in b:
+            b[name] = xp.empty(shape, kind)
+        return b[name]
+
+    if noscat:  # 1scl branch :283-302: direct beam only
+        fdir = buf("gpt_flux_dir", (ncol, nlay + 1, ngpt))
+        lib.rte_sw_solver_noscat(ncol, nlay, ngpt, top_at_1, tau, mu0, inc_flux_dir, fdir)
+        if do_broadband:
+            lib.rte_sum_broadband(ncol, nlay + 1, ngpt, fdir, buf("flux_dir", (ncol, nlay + 1)))
+        return b
+    has_dif_bc = inc_flux_dif is not None
+    if not has_dif_bc:
+        if "inc_flux_zero" not in b:
+            b["inc_flux_zero"] = xp.zeros((ncol, ngpt))
+        inc_flux_dif = b["inc_flux_zero"]
+    if do_broadband:
+        d3 = buf("decoy3D", (1,))  # one aliased decoy, never written (mo_rte_sw.F90:204-207)
+        gfu = gfd = gfdir = d3
+        fu, fd, fdir = (buf(n, (ncol, nlay + 1)) for n in ("flux_up", "flux_dn", "flux_dir"))
+    else:
+        gfu, gfd, gfdir = (buf(n, (ncol, nlay + 1, ngpt)) for n in ("gpt_flux_up", "gpt_flux_dn", "gpt_flux_dir"))
+        fu = fd = fdir = buf("decoy2D", (ncol, nlay + 1))
+    lib.rte_sw_solver_2stream(ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, sfc_alb_dir_gpt,
+                              sfc_alb_dif_gpt, inc_flux_dir, gfu, gfd, gfdir, has_dif_bc,
+                              inc_flux_dif, do_broadband, fu, fd, fdir)
+    return b

@@ -1,0 +1,97 @@
+"""Builder / loader of the product library ``librte_rrtmgp_hip.so`` (hand-written HIP, gfx950).
+
+``build()`` compiles rte-rrtmgp_amd/csrc/*.hip with hipcc (cross-compiles without a GPU) into
+rte-rrtmgp_amd/librte_rrtmgp_hip.so (in-tree so it travels with the repo snapshot; git-ignored).
+``load()`` returns a ``cabi.KernelLib`` on it and FAILS LOUDLY when the library is missing or a
+symbol is absent -- there is no CPU fallback anywhere in the product path.
+"""
+from __future__ import annotations
+
+import ctypes
+import glob
+import os
+import shutil
+import subprocess
+from typing import List, Optional, Sequence
+
+from . import cabi
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+ROOT = os.path.dirname(PKG_DIR)
+LIB_NAMES = {"dp": "librte_rrtmgp_hip.so", "sp": "librte_rrtmgp_hip_sp.so"}
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-Wall", "-Wno-unused-function"]
+
+_loaded = {}
+
+
+def lib_path(precision: str = "dp") -> str:
+    return os.path.join(PKG_DIR, LIB_NAMES[precision])
+
+
+def sources() -> List[str]:
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale(path: str) -> bool:
+    if not os.path.exists(path):
+        return True
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    return any(os.path.getmtime(d) > os.path.getmtime(path) for d in deps)
+
+
+def build(precision: str = "dp", force: bool = False, verbose: bool = False, extra: Sequence[str] = ()) -> str:
+    """Compile the HIP library for gfx950; returns its path."""
+    out = lib_path(precision)
+    if not force and not _stale(out):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build librte_rrtmgp_hip.so")
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    if precision == "sp":
+        cmd.append("-DRTE_USE_SP")
+    cmd += sources() + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
+def load(precision: str = "dp", build_if_missing: bool = True) -> cabi.KernelLib:
+    """Load the HIP library.  Raises (never falls back) when it cannot be built or loaded."""
+    if precision in _loaded:
+        return _loaded[precision]
+    path = lib_path(precision)
+    if _stale(path):
+        if not build_if_missing or not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+            if not os.path.exists(path):
+                raise RuntimeError(f"{path} is missing and cannot be built: the HIP extension is "
+                                   "mandatory (no CPU fallback in the product path)")
+        else:
+            build(precision)
+    hdr = os.path.join(ROOT, "include", "rte_rrtmgp_kernels.h")
+    lib = cabi.KernelLib(path, precision, required=cabi.header_symbols(hdr))
+    _loaded[precision] = lib
+    return lib
+
+
+_KINDS = {"i": ctypes.c_int, "l": ctypes.c_longlong, "d": ctypes.c_double}
+
+
+def ext_call(lib: cabi.KernelLib, name: str, kinds: Sequence[str], *args):
+    """Call a library-extension entry point (``rte_hip_*``).  Extension symbols take scalars BY
+    VALUE ('i' int, 'l' long long, 'd' double) and arrays as pointers ('a')."""
+    fn = lib.raw(name)
+    cargs = []
+    for k, v in zip(kinds, args):
+        cargs.append(cabi.as_pointer(v) if k == "a" else _KINDS[k](v))
+    fn.restype = ctypes.c_int
+    return fn(*cargs)
+
+
+def set_stream(lib: cabi.KernelLib, stream_handle: Optional[int]) -> None:
+    """Make the library launch on the given hipStream_t (0/None = the null stream, which is also
+    torch's default stream on ROCm)."""
+    ext_call(lib, "rte_hip_set_stream", ["a"], int(stream_handle or 0))

@@ -1,0 +1,76 @@
+"""CPU tests of the drop-in boundary (no compute calls): the HIP library builds for gfx950, loads,
+and exports every symbol include/rte_rrtmgp_kernels.h declares; the ctypes signature table agrees
+with the header's argument lists; and the symbol set is the reference's own bind(C) name set."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from rte_rrtmgp_amd import cabi, hiplib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rte_rrtmgp_kernels.h")
+
+
+def _header_decls():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return {m.group(1): [a.strip() for a in m.group(2).split(",")]
+            for m in re.finditer(r"\bvoid\s+(\w+)\s*\((.*?)\)\s*;", txt, flags=re.S)}
+
+
+def test_library_builds_and_exports_every_header_symbol():
+    path = hiplib.build()
+    assert os.path.exists(path)
+    dll = ctypes.CDLL(path)
+    for name in cabi.header_symbols(HEADER):
+        assert hasattr(dll, name), f"{name} declared in the header but not exported"
+    for ext in ("rte_hip_set_stream", "rte_hip_sync", "rte_hip_profile_enable", "rte_hip_profile_get",
+                "rte_hip_combine_abs_and_rayleigh_2str", "rte_hip_broadcast_gpt", "rte_hip_release"):
+        assert hasattr(dll, ext)
+
+
+def test_signature_table_matches_header():
+    decls = _header_decls()
+    assert set(decls) == set(cabi.SIGNATURES), set(decls) ^ set(cabi.SIGNATURES)
+    for name, args in decls.items():
+        sig = cabi.SIGNATURES[name]
+        assert len(args) == len(sig), name
+        for a, (argname, kind) in zip(args, sig):
+            toks = a.replace("*", " * ").split()
+            assert toks[-1] == argname, (name, a, argname)
+            base = [t for t in toks[:-1] if t not in ("const", "*")][0]
+            is_array = kind == "a"
+            if kind == "i":
+                assert base == "int"
+            elif kind == "f":
+                assert base == "Float"
+            elif kind == "b":
+                assert base == "Bool"
+            # scalars are `const T*` (by reference); output arrays are non-const
+            assert "*" in toks
+            if not is_array:
+                assert "const" in toks
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    """No CPU fallback: a missing extension is an error, not a silent eager path."""
+    monkeypatch.setattr(hiplib, "PKG_DIR", str(tmp_path))
+    monkeypatch.setattr(hiplib, "_loaded", {})
+    monkeypatch.setattr(hiplib.shutil, "which", lambda *_: None)
+    monkeypatch.setattr(hiplib.os.path, "exists", lambda p: False if "hipcc" in p or str(tmp_path) in p else os.path.lexists(p))
+    with pytest.raises((RuntimeError, FileNotFoundError)):
+        hiplib.load()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/rte/kernels/api"), reason="reference tree not present")
+def test_names_are_the_reference_bind_c_names():
+    """Every symbol we export under a reference name exists as bind(C) in the reference's api modules."""
+    names = set()
+    for d in ("/root/reference/rte/kernels/api", "/root/reference/rrtmgp/kernels/api"):
+        for f in os.listdir(d):
+            if f.endswith(".F90"):
+                names |= set(re.findall(r'bind\s*\(\s*C\s*,\s*name\s*=\s*"(\w+)"', open(os.path.join(d, f)).read(), flags=re.I))
+    ours = set(cabi.header_symbols(HEADER))
+    assert ours <= names, ours - names
