@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py -- columns/s of the LW hot path on MI355X: RRTMGP gas optics + RTE lw_solver_noscat.
+
+Workload (BASELINE.json configs[1]): RFMIP-like clear-sky LW, 1e5 synthetic columns x 60 layers x
+256 g-points per GPU, double precision, synthetic seeded k-distribution with the g256 shapes.
+One "step" = one pass of the kernel chain the reference frontend executes for this configuration
+(SURVEY.md section 3.1), every call going through the reference's own C ABI symbols:
+
+    rrtmgp_interpolation -> zero_array_3D -> rrtmgp_compute_tau_absorption
+      -> rrtmgp_compute_Planck_source -> rte_lw_solver_noscat (broadband, 1 Gauss angle)
+
+with all inputs (play, plev, tlay, tlev, tsfc, col_gas, sfc_emis, secants, the k-distribution)
+already resident in HBM when the timed region starts.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--ncol C]
+For N > 1 launch under torch.distributed.run (one rank per GPU); columns are sharded across ranks
+(weak scaling: --ncol columns per GPU), and the only collective is the RCCL all-reduce of the
+domain-mean broadband flux profile.
+
+Prints ONE JSON line on rank 0 (see the task contract): value = whole-job columns/s.
+`roofline` is for the dominant kernel: algorithmic bytes per launch / its mean launch duration,
+timed with HIP events on the library's stream inside the timed region (rte_hip_profile_*).
+`cpu_baseline` times the reference's own Fortran kernels (oracle/_ref, kind "reference") or, if
+that binary is absent, the C restatement (kind "port") on the host cores, rank 0, N=1 only, on a
+bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+NLAY, NGPT = 60, 256
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_collay(nflav=10, ngas=8, ngpt=NGPT, nlay=NLAY):
+    """Compulsory HBM traffic at the reference kernel-API boundary per (column, layer), in bytes
+    (every `in` array read once, every `out` array written once; LUTs and
+    private temporaries excluded).  Unlike the survey's table, tau is counted as the API cuts it:
+    zero_array writes it, compute_tau_absorption reads AND writes it (intent(inout))."""
+    F, G, N, r = nflav, ngas, ngpt, (nlay + 1) / nlay
+    k = {
+        "interpolation_kernel": (16 + 8 * (G + 1)) + (9 + 120 * F),
+        "fill_kernel": 8 * N,
+        "tau_absorption_kernel": (25 + 120 * F + 8 * (G + 1)) + 8 * N + 8 * N,
+        "planck_source_kernel": (25 + 72 * F + 8 * r) + (8 * N + 8 * N * r),
+        "lw_noscat_seg_kernel": (16 * N + 8 * N * r + 32 * N / nlay) + 16 * r,
+    }
+    return k
+
+
+def cpu_baseline(ncol_block=32, target_seconds=12.0):
+    """Reference (or port) CPU kernels on the host cores, bounded sample of the same workload."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import oracle as O
+    from rte_rrtmgp_amd import frontend, synth
+
+    lib, kind = None, "reference"
+    try:
+        lib = O.load_ref()
+    except Exception:
+        lib = None
+    if lib is None:
+        lib, kind = O.load_c(), "port"
+    cores = os.cpu_count() or 1
+    kd = synth.make_kdist("lw")
+    xp = frontend.NumpyArrays()
+
+    def one_block(seed):
+        atm = synth.make_atmosphere(ncol_block, NLAY, seed=seed, kdist=kd)
+        go = frontend.GasOptics(lib, kd, xp)
+        emis = xp.full((ncol_block, kd.ngpt), 0.98)
+        bufs, rb = {}, {}
+
+        def run():
+            go.gas_optics_lw(ncol_block, NLAY, atm.play, atm.plev, atm.tlay, atm.tsfc, atm.col_gas, atm.tlev,
+                             atm.top_at_1, buffers=bufs)
+            frontend.rte_lw(lib, xp, ncol_block, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["lay_src"],
+                            bufs["lev_src"], emis, bufs["sfc_src"], buffers=rb)
+
+        return run
+
+    old = threading.stack_size(512 << 20)  # flang keeps automatic arrays on the stack
+    try:
+        runs = [one_block(1000 + i) for i in range(cores)]
+        reps = 1
+
+        def worker(i):
+            for _ in range(reps):
+                runs[i]()
+
+        with ThreadPoolExecutor(cores) as ex:
+            # calibrate with every core busy (memory contention makes one block much slower than alone)
+            t0 = time.perf_counter()
+            list(ex.map(worker, range(cores)))
+            t_cal = time.perf_counter() - t0
+            reps = max(1, min(200, int(target_seconds / max(t_cal, 1e-3))))
+            t0 = time.perf_counter()
+            list(ex.map(worker, range(cores)))
+            dt = time.perf_counter() - t0
+    finally:
+        threading.stack_size(old)
+    ncols = cores * reps * ncol_block
+    return {"value": ncols / dt, "unit": "columns/s", "cores": cores, "kind": kind,
+            "sample": f"{ncols} columns ({cores} threads x {reps} blocks of {ncol_block} columns x {NLAY} lay x "
+                      f"{kd.ngpt} gpt), same kernel chain, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ncol", type=int, default=100000, help="columns per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from rte_rrtmgp_amd import frontend, hiplib, synth
+
+    lib = hiplib.load()  # raises if the HIP extension is missing
+    hiplib.set_stream(lib, torch.cuda.current_stream().cuda_stream)
+    dev = f"cuda:{local_rank}"
+    xp = frontend.TorchArrays(dev)
+    ncol = args.ncol
+    kd = synth.make_kdist("lw")
+    atm = synth.make_atmosphere(ncol, NLAY, seed=42 + rank, kdist=kd)  # each rank owns different columns
+    go = frontend.GasOptics(lib, kd, xp)
+    A = xp.asarray
+    play, plev, tlay, tlev, tsfc, col_gas = (A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas"))
+    emis = xp.full((ncol, kd.ngpt), 0.98)
+    bufs, rb = {}, {}
+    mean_profile = torch.zeros(2, NLAY + 1, dtype=torch.float64, device=dev)
+
+    def step():
+        go.gas_optics_lw(ncol, NLAY, play, plev, tlay, tsfc, col_gas, tlev, atm.top_at_1, buffers=bufs)
+        frontend.rte_lw(lib, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["lay_src"], bufs["lev_src"],
+                        emis, bufs["sfc_src"], buffers=rb)
+        if dist is not None:
+            # the path's only exchange: domain-mean broadband flux profile (RCCL all-reduce)
+            mean_profile[0] = rb["flux_up"].sum(dim=1)
+            mean_profile[1] = rb["flux_dn"].sum(dim=1)
+            dist.all_reduce(mean_profile)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    hiplib.ext_call(lib, "rte_hip_profile_reset", [])
+    hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 0)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(rb["flux_up"]).all() and float(rb["flux_up"].max()) > 0
+
+    # per-kernel HIP-event timings collected inside the timed region
+    kern = {}
+    n = hiplib.ext_call(lib, "rte_hip_profile_count", [])
+    for i in range(n):
+        buf = ctypes.create_string_buffer(128)
+        cnt, ms = ctypes.c_longlong(0), ctypes.c_double(0)
+        lib.raw("rte_hip_profile_get")(ctypes.c_int(i), buf, ctypes.c_int(128), ctypes.byref(cnt), ctypes.byref(ms))
+        kern[buf.value.decode()] = {"launches": int(cnt.value), "avg_ms": ms.value / max(1, cnt.value)}
+
+    if rank == 0:
+        ab = algorithmic_bytes_per_collay(kd.nflav, kd.ngas, kd.ngpt, NLAY)
+        per_kernel = {}
+        for name, bytes_cl in ab.items():
+            if name in kern:
+                gb = bytes_cl * ncol * NLAY / 1e9
+                ms = kern[name]["avg_ms"]
+                per_kernel[name] = {"avg_ms": round(ms, 4), "alg_GB": round(gb, 3),
+                                    "GBps": round(gb / (ms * 1e-3), 1), "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
+        others = {k: round(v["avg_ms"], 4) for k, v in kern.items() if k not in per_kernel}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
+        chain_gb = sum(v["alg_GB"] for v in per_kernel.values())
+        chain_ms = sum(v["avg_ms"] for v in per_kernel.values()) + sum(others.values())
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if dom and os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                if pmc.get("ncol") == ncol and dom in pmc.get("kernels", {}):
+                    traffic = pmc["kernels"][dom]["hbm_GB_per_launch"]
+            except Exception:
+                traffic = None
+        roof = None
+        if dom:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic,
+                    "chain": {"alg_GB_per_step": round(chain_gb, 3), "kernel_ms_per_step": round(chain_ms, 4),
+                              "GBps": round(chain_gb / (chain_ms * 1e-3), 1),
+                              "frac": round(chain_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4)},
+                    "per_kernel": per_kernel, "other_kernels_avg_ms": others}
+        res = {
+            "metric": "columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)",
+            "value": ncol * world * args.steps / dt, "unit": "columns/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"RFMIP-like clear-sky LW, {ncol} synthetic columns per GPU x {NLAY} layers x "
+                                   f"{kd.ngpt} g-points (BASELINE configs[1]), synthetic g256-shaped k-distribution",
+                       "columns_per_gpu": ncol, "nlay": NLAY, "ngpt": kd.ngpt, "sharding": f"columns x{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001
+                res["cpu_baseline"] = {"value": None, "unit": "columns/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

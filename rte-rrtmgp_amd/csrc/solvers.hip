@@ -217,6 +217,43 @@ __global__ void __launch_bounds__(256) lw_noscat_generic_kernel(LwArgs a) {
 // formed from composites (same mathematics, different rounding: ~1e-16 relative).
 // After the block's g-points: acc * pi * weight -> partial broadband slab for this g-group.
 // ---------------------------------------------------------------------------------------------
+template <int L>
+struct SegTile {  // one g-point's inputs for one thread's segment
+  Float tau[L], lay[L], lev[L + 1], D, emis, ssrc, inc, sjac;
+};
+
+template <int L, bool do_jac>
+__device__ __forceinline__ void seg_load(SegTile<L>& t, int igpt, int c, int ncol, int nlay, int p0, int np,
+                                         bool top_at_1, const Float* __restrict__ Dsec,
+                                         const Float* __restrict__ tau_, const Float* __restrict__ lay_source_,
+                                         const Float* __restrict__ lev_source_, const Float* __restrict__ sfc_emis,
+                                         const Float* __restrict__ sfc_src, const Float* __restrict__ inc_flux,
+                                         const Float* __restrict__ sfc_srcJac) {
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const size_t cg = c + (size_t)ncol * igpt;
+  const Float* tau = tau_ + c + ncl * igpt;
+  const Float* lay = lay_source_ + c + ncl * igpt;
+  const Float* lev = lev_source_ + c + nclv * igpt;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    // clamp instead of predicating: out-of-segment slots re-read a valid layer and are never used
+    const int p = p0 + min(i, np - 1);
+    const int ilay = top_at_1 ? p : nlay - 1 - p;
+    t.tau[i] = tau[(size_t)ncol * ilay];
+    t.lay[i] = lay[(size_t)ncol * ilay];
+  }
+#pragma unroll
+  for (int i = 0; i <= L; ++i) {
+    const int p = p0 + min(i, np);
+    t.lev[i] = lev[(size_t)ncol * (top_at_1 ? p : nlay - p)];
+  }
+  t.D = Dsec[cg];
+  t.emis = sfc_emis[cg];
+  t.ssrc = sfc_src[cg];
+  t.inc = inc_flux[cg];
+  t.sjac = do_jac ? sfc_srcJac[cg] : (Float)0;
+}
+
 template <int L, bool do_jac>
 __global__ void __launch_bounds__(64 * 8)
 lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
@@ -232,7 +269,7 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   const bool active = icol < ncol;
   const int c = active ? icol : ncol - 1;  // clamp: inactive lanes compute on a valid column, never store
   const int nlev = nlay + 1;
-  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev;
+  const size_t nclv = (size_t)ncol * nlev;
   const int p0 = s * L;
   const int np = min(L, nlay - p0);  // layers in this segment (>= 1 by construction)
   const bool last = (s == S - 1);
@@ -244,36 +281,32 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 #pragma unroll
   for (int i = 0; i <= L; ++i) { acc_dn[i] = 0; acc_up[i] = 0; if (do_jac) acc_j[i] = 0; }
 
+  SegTile<L> cur;
+  seg_load<L, do_jac>(cur, g_begin, c, ncol, nlay, p0, np, top_at_1, Dsec, tau_, lay_source_, lev_source_, sfc_emis,
+                      sfc_src, inc_flux, sfc_srcJac);
   int buf = 0;
   for (int igpt = g_begin; igpt < g_end; ++igpt, buf ^= 1) {
-    const size_t cg = c + (size_t)ncol * igpt;
-    const Float D = Dsec[cg];
-    const Float* tau = tau_ + c + ncl * igpt;
-    const Float* lay_source = lay_source_ + c + ncl * igpt;
-    const Float* lev_source = lev_source_ + c + nclv * igpt;
+    // software prefetch: the next g-point's loads are in flight while this one is computed
+    SegTile<L> nxt;
+    seg_load<L, do_jac>(nxt, min(igpt + 1, g_end - 1), c, ncol, nlay, p0, np, top_at_1, Dsec, tau_, lay_source_,
+                        lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac);
     Float t[L], sd[L], su[L];
-    // ---- pass 1
+    // ---- pass 1: layer transmissivities and sources (:180-190), segment composites
     Float Td = 1, Sd = 0;
-    // level source at the top of the segment's first layer
-    Float lev_top = lev_source[(size_t)ncol * (top_at_1 ? p0 : nlay - p0)];
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       if (i < np) {
-        const int p = p0 + i;
-        const int ilay = top_at_1 ? p : nlay - 1 - p;
-        const Float lev_bot = lev_source[(size_t)ncol * (top_at_1 ? p + 1 : nlay - 1 - p)];
-        const Float tau_loc = tau[(size_t)ncol * ilay] * D;
+        const Float tau_loc = cur.tau[i] * cur.D;
         const Float tr = exp(-tau_loc);
         Float s_toward_bot, s_toward_top;
-        // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo); choose so that
-        // "toward bottom" uses the bottom level source and "toward top" the top level source
-        lw_source_layer(tau_loc, tr, lay_source[(size_t)ncol * ilay], lev_top, lev_bot, s_toward_bot, s_toward_top);
+        // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo): "toward bottom" uses the
+        // bottom level source, "toward top" the top level source
+        lw_source_layer(tau_loc, tr, cur.lay[i], cur.lev[i], cur.lev[i + 1], s_toward_bot, s_toward_top);
         t[i] = tr;
         sd[i] = s_toward_bot;
         su[i] = s_toward_top;
         Sd = tr * Sd + s_toward_bot;
         Td = Td * tr;
-        lev_top = lev_bot;
       } else {
         t[i] = 1; sd[i] = 0; su[i] = 0;
       }
@@ -282,29 +315,27 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 #pragma unroll
     for (int i = L - 1; i >= 0; --i)
       if (i < np) Su = t[i] * Su + su[i];
-    // ---- exchange
+    // ---- exchange segment composites
     Float* X = lds + (size_t)buf * 3 * S * 64;
     X[(0 * S + s) * 64 + lane] = Td;
     X[(1 * S + s) * 64 + lane] = Sd;
     X[(2 * S + s) * 64 + lane] = Su;
     __syncthreads();
-    Float r = inc_flux[cg] / piw;  // radiance entering segment 0 from above (:144)
+    Float r = cur.inc / piw;  // radiance entering segment 0 from above (:144)
     Float r_in = r;
     for (int q = 0; q < S; ++q) {
       if (q == s) r_in = r;
       r = X[(0 * S + q) * 64 + lane] * r + X[(1 * S + q) * 64 + lane];
     }
-    const Float emis = sfc_emis[cg];
-    const Float u_sfc = r * ((Float)1 - emis) + emis * sfc_src[cg];  // :198-200
-    Float u = u_sfc, u_in = u_sfc;
-    Float jv = do_jac ? emis * sfc_srcJac[cg] : (Float)0, j_in = jv;
+    const Float u_sfc = r * ((Float)1 - cur.emis) + cur.emis * cur.ssrc;  // :198-200
+    Float u = u_sfc;
+    Float jv = do_jac ? cur.emis * cur.sjac : (Float)0;
+    const Float j_sfc = jv;
     for (int q = S - 1; q > s; --q) {
       const Float Tq = X[(0 * S + q) * 64 + lane];
       u = Tq * u + X[(2 * S + q) * 64 + lane];
       jv = Tq * jv;
     }
-    u_in = u;
-    j_in = jv;
     // ---- pass 2: down
     r = r_in;
 #pragma unroll
@@ -314,15 +345,12 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
         r = t[i] * r + sd[i];
       }
     }
-    // ---- pass 2: up (+ Jacobian, :729-743)
-    if (last) {
-      // surface level is slot np of the last segment
+    if (last) {  // the surface level is slot np of the last segment
 #pragma unroll
       for (int i = 0; i <= L; ++i)
-        if (i == np) { acc_dn[i] += r; acc_up[i] += u_sfc; if (do_jac) acc_j[i] += j_in; }
+        if (i == np) { acc_dn[i] += r; acc_up[i] += u_sfc; if (do_jac) acc_j[i] += j_sfc; }
     }
-    u = u_in;
-    jv = j_in;
+    // ---- pass 2: up (+ Jacobian, :729-743)
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) {
       if (i < np) {
@@ -331,6 +359,7 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
         if (do_jac) { jv = t[i] * jv; acc_j[i] += jv; }
       }
     }
+    cur = nxt;
   }
   // ---- partial broadband for this g-group: (ncol, nlev, ngroups)
   if (active) {

@@ -59,10 +59,22 @@ def build(precision: str = "dp", force: bool = False, verbose: bool = False, ext
     return out
 
 
+def _one_hip_runtime() -> None:
+    """torch ships its own libamdhip64; if this library were dlopen'ed first it would pull in
+    /opt/rocm's copy and the process would end up with two HIP runtimes (the second one then
+    reports "no ROCm-capable device").  Import torch first so both share torch's runtime.  A
+    torch-free host program (e.g. the Fortran frontend) simply uses /opt/rocm's."""
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch absent: single runtime anyway
+        pass
+
+
 def load(precision: str = "dp", build_if_missing: bool = True) -> cabi.KernelLib:
     """Load the HIP library.  Raises (never falls back) when it cannot be built or loaded."""
     if precision in _loaded:
         return _loaded[precision]
+    _one_hip_runtime()
     path = lib_path(precision)
     if _stale(path):
         if not build_if_missing or not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):

@@ -23,6 +23,7 @@ def _header_decls():
 def test_library_builds_and_exports_every_header_symbol():
     path = hiplib.build()
     assert os.path.exists(path)
+    hiplib._one_hip_runtime()
     dll = ctypes.CDLL(path)
     for name in cabi.header_symbols(HEADER):
         assert hasattr(dll, name), f"{name} declared in the header but not exported"
