@@ -140,7 +140,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from rte_rrtmgp_amd import frontend, hiplib, synth
+    from rte_rrtmgp_amd import frontend, hiplib, sharding, synth
 
     lib = hiplib.load()  # raises if the HIP extension is missing
     hiplib.set_stream(lib, torch.cuda.current_stream().cuda_stream)
@@ -162,9 +162,7 @@ def main():
                         emis, bufs["sfc_src"], buffers=rb)
         if dist is not None:
             # the path's only exchange: domain-mean broadband flux profile (RCCL all-reduce)
-            mean_profile[0] = rb["flux_up"].sum(dim=1)
-            mean_profile[1] = rb["flux_dn"].sum(dim=1)
-            dist.all_reduce(mean_profile)
+            mean_profile.copy_(sharding.allreduce_mean_profile(rb["flux_up"], rb["flux_dn"], ncol * world))
 
     def fence():
         if dist is not None:

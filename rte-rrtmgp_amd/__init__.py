@@ -10,6 +10,6 @@ Sub-modules
   synth     seeded synthetic k-distribution / atmosphere generators
 """
 from . import cabi, synth  # noqa: F401
-from . import frontend, hiplib  # noqa: F401
+from . import frontend, hiplib, sharding  # noqa: F401
 
-__all__ = ["cabi", "synth", "frontend", "hiplib"]
+__all__ = ["cabi", "synth", "frontend", "hiplib", "sharding"]

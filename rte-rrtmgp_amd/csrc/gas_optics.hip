@@ -218,59 +218,53 @@ __device__ __forceinline__ void minor_chunk(const MinorTables& mt, int flav_row,
 // -------------------------------------------------------------------------------------------
 // compute_tau_absorption: reference :176-338 (driver), :345-396 (major), :402-501 (minor)
 // -------------------------------------------------------------------------------------------
-struct alignas(2 * sizeof(Float)) Float2 { Float x, y; };
-
-struct TauArgs {
-  int ncol, nlay, ngpt, neta, npres, ntemp, idx_h2o, dbg;
-  const int *gpoint_flavor, *band_lims_gpt;
-  const Float *kmajor, *kmajor_g;          // native and g-fastest
-  MinorTables lower, upper;
-  const Float *kminor_lower_g, *kminor_upper_g;
-  int nk_lower, nk_upper;
-  const int* lim;
-  const Bool* tropo;
-  const Float *col_mix, *fmajor, *fminor, *play, *tlay, *col_gas;
-  const int *jeta, *jtemp, *jpress;
-  Float* tau;
-};
-
-// direct-gather version for one (column, layer, band): reads the native tables through L1/L2
-__device__ __forceinline__ void tau_direct_column(const TauArgs& a, int icol, int ilay, int ibnd) {
-  const int ncol = a.ncol, nlay = a.nlay, neta = a.neta, ntemp = a.ntemp;
+__global__ void __launch_bounds__(256)
+tau_absorption_kernel(int ncol, int nlay, int ngpt, int neta, int npres, int ntemp, int idx_h2o,
+                      const int* __restrict__ gpoint_flavor, const int* __restrict__ band_lims_gpt,
+                      const Float* __restrict__ kmajor, MinorTables lower, MinorTables upper,
+                      const int* __restrict__ lim, const Bool* __restrict__ tropo,
+                      const Float* __restrict__ col_mix, const Float* __restrict__ fmajor,
+                      const Float* __restrict__ fminor, const Float* __restrict__ play,
+                      const Float* __restrict__ tlay, const Float* __restrict__ col_gas,
+                      const int* __restrict__ jeta, const int* __restrict__ jtemp,
+                      const int* __restrict__ jpress, Float* __restrict__ tau) {
+  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ilay = blockIdx.y, ibnd = blockIdx.z;
+  if (icol >= ncol) return;
   const size_t ncl = (size_t)ncol * nlay;
   const size_t cl = icol + (size_t)ncol * ilay;
-  const int gptS = a.band_lims_gpt[2 * ibnd] - 1, gptE = a.band_lims_gpt[2 * ibnd + 1] - 1;
-  const int itropo = a.tropo[cl] ? 0 : 1;
-  const int iflav = a.gpoint_flavor[itropo + 2 * gptS] - 1;
+  const int gptS = band_lims_gpt[2 * ibnd] - 1, gptE = band_lims_gpt[2 * ibnd + 1] - 1;
+  const int itropo = tropo[cl] ? 0 : 1;
+  const int iflav = gpoint_flavor[itropo + 2 * gptS] - 1;
   const size_t clf = cl + ncl * iflav;
-  const int jT = a.jtemp[cl];
-  const int jp = a.jpress[cl] + itropo + 1;  // "jpress + itropo": levels jp-1 and jp (1-based)
-  const int je1 = a.jeta[2 * clf], je2 = a.jeta[2 * clf + 1];
-  const Float cm1 = a.col_mix[2 * clf], cm2 = a.col_mix[2 * clf + 1];
+  const int jT = jtemp[cl];
+  const int jp = jpress[cl] + itropo + 1;  // "jpress + itropo": levels jp-1 and jp (1-based)
+  const int je1 = jeta[2 * clf], je2 = jeta[2 * clf + 1];
+  const Float cm1 = col_mix[2 * clf], cm2 = col_mix[2 * clf + 1];
   Float fm[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) fm[i] = a.fmajor[8 * clf + i];
+  for (int i = 0; i < 8; ++i) fm[i] = fmajor[8 * clf + i];
   const size_t tn = (size_t)ntemp * neta;
-  const size_t gstride = tn * (a.npres + 1);
+  const size_t gstride = tn * (npres + 1);
   // corner offsets (without the g-point term) into kmajor(ntemp,neta,npres+1,ngpt)
   const size_t a0 = (size_t)(jT - 1) + (size_t)ntemp * (je1 - 1) + tn * (size_t)(jp - 2);
   const size_t b0 = (size_t)jT + (size_t)ntemp * (je2 - 1) + tn * (size_t)(jp - 2);
-  const Float P = a.play[cl], T = a.tlay[cl];
+  const Float P = play[cl], T = tlay[cl];
   const int lay1 = ilay + 1;
-  const int lo1 = a.lim[icol], lo2 = a.lim[icol + ncol];
-  const int up1 = a.lim[icol + 2 * (size_t)ncol], up2 = a.lim[icol + 3 * (size_t)ncol];
+  const int lo1 = lim[icol], lo2 = lim[icol + ncol];
+  const int up1 = lim[icol + 2 * (size_t)ncol], up2 = lim[icol + 3 * (size_t)ncol];
   const bool in_lower = lo1 > 0 && lay1 >= lo1 && lay1 <= lo2;
   const bool in_upper = up1 > 0 && lay1 >= up1 && lay1 <= up2;
 
   for (int g0 = gptS; g0 <= gptE; g0 += GC) {
     Float acc[GC];
 #pragma unroll
-    for (int j = 0; j < GC; ++j) acc[j] = (g0 + j <= gptE) ? a.tau[cl + ncl * (size_t)(g0 + j)] : (Float)0;
+    for (int j = 0; j < GC; ++j) acc[j] = (g0 + j <= gptE) ? tau[cl + ncl * (size_t)(g0 + j)] : (Float)0;
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
       if (g0 + j <= gptE) {
-        const Float* ka = a.kmajor + gstride * (size_t)(g0 + j) + a0;
-        const Float* kb = a.kmajor + gstride * (size_t)(g0 + j) + b0;
+        const Float* ka = kmajor + gstride * (size_t)(g0 + j) + a0;
+        const Float* kb = kmajor + gstride * (size_t)(g0 + j) + b0;
         // :791-801
         const Float tau_major =
             cm1 * (fm[0] * ka[0] + fm[1] * ka[ntemp] + fm[2] * ka[tn] + fm[3] * ka[tn + ntemp]) +
@@ -279,215 +273,14 @@ __device__ __forceinline__ void tau_direct_column(const TauArgs& a, int icol, in
       }
     }
     if (in_lower)
-      minor_chunk(a.lower, 0, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, a.idx_h2o, P, T, jT, a.col_gas, a.fminor,
-                  a.jeta, a.gpoint_flavor, acc);
+      minor_chunk(lower, 0, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, idx_h2o, P, T, jT, col_gas, fminor,
+                  jeta, gpoint_flavor, acc);
     if (in_upper)
-      minor_chunk(a.upper, 1, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, a.idx_h2o, P, T, jT, a.col_gas, a.fminor,
-                  a.jeta, a.gpoint_flavor, acc);
+      minor_chunk(upper, 1, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, idx_h2o, P, T, jT, col_gas, fminor,
+                  jeta, gpoint_flavor, acc);
 #pragma unroll
     for (int j = 0; j < GC; ++j)
-      if (g0 + j <= gptE) a.tau[cl + ncl * (size_t)(g0 + j)] = acc[j];
-  }
-}
-
-// full-grid direct kernel (small problems)
-__global__ void __launch_bounds__(256) tau_absorption_kernel(TauArgs a) {
-  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
-  if (icol >= a.ncol) return;
-  tau_direct_column(a, icol, blockIdx.y, blockIdx.z);
-}
-
-// -------------------------------------------------------------------------------------------
-// LUT re-layout (per call, into the scratch arena): (TE = ntemp*neta, nouter, ng) with the
-// (temperature, eta) plane fastest  ->  rows of g-points: out[(o*TE + te)*ng + g].
-// A band's g-points of one (T, eta, p) corner become one contiguous 128-byte row, which is what
-// the LDS staging below copies.  ~35 MB moved per call (L2 / Infinity-Cache resident): ~10 us.
-// -------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, Float* __restrict__ out) {
-  extern __shared__ Float tile[];  // [TE][33]
-  const int g0 = blockIdx.x * 32, o = blockIdx.y;
-  const int ngc = min(32, ng - g0);
-  for (int idx = threadIdx.x; idx < TE * ngc; idx += blockDim.x) {
-    const int te = idx % TE, gg = idx / TE;
-    tile[te * 33 + gg] = in[(size_t)te + (size_t)TE * ((size_t)o + (size_t)nouter * (g0 + gg))];
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < TE * ngc; idx += blockDim.x) {
-    const int gg = idx % ngc, te = idx / ngc;
-    out[((size_t)o * TE + te) * ng + g0 + gg] = tile[te * 33 + gg];
-  }
-}
-
-// -------------------------------------------------------------------------------------------
-// compute_tau_absorption, production kernel.
-//
-// thread = (column, layer, band); lanes = consecutive columns.  The tables are read from the
-// g-fastest re-laid-out copies, where the band's 16 g-points of one (T, eta, p) corner are one
-// contiguous 128-byte row: each corner costs 8 back-to-back 16-byte loads of ONE cache line
-// (corner-outer loop order), instead of 16 scattered 8-byte gathers 60 KB apart in the native
-// layout.  Per block, the band's minor-interval metadata (block-uniform, a dependent-load chain
-// in the native kernel) is staged once in LDS, and each thread forms all its minor scalings up
-// front so the column-amount loads are in flight together.
-// Floating-point association is the reference's (:791-801, :757-760): products are summed corner by
-// corner, then scaled, then added to tau -- bit-identical to tau_direct_column().
-// -------------------------------------------------------------------------------------------
-constexpr int MAXM = 8;  // minor intervals per (band, regime) held in LDS; more -> native kernel
-
-struct MinorMeta {  // one minor interval's metadata, staged in LDS once per block
-  int mS, mE, idx_minor, idx_scaling, kstart, flags /*1: scales with density, 2: by complement*/, iflav;
-};
-
-// row[j] (j = 0..15) <- 16 consecutive Floats at p (16-byte aligned when `al`)
-// row[0..W) <- W consecutive Floats at p (16-byte aligned 16-byte loads within one cache line)
-template <int W>
-__device__ __forceinline__ void load_row(const Float* __restrict__ p, Float (&row)[W]) {
-#pragma unroll
-  for (int j = 0; j < W; j += 2) {
-    const Float2 v = *reinterpret_cast<const Float2*>(p + j);
-    row[j] = v.x;
-    row[j + 1] = v.y;
-  }
-}
-
-template <int BS, int MINW, int W>
-__global__ void __launch_bounds__(BS, MINW) tau_absorption_gfast_kernel(TauArgs a) {
-  __shared__ MinorMeta meta[2 * MAXM];  // [0,MAXM): lower-regime list of this band, [MAXM,2*MAXM): upper
-  const int tid = threadIdx.x;
-  const int ilay = blockIdx.y, ibnd = blockIdx.z;
-  const int ncol = a.ncol, nlay = a.nlay, neta = a.neta, ntemp = a.ntemp, ngpt = a.ngpt;
-  const size_t ncl = (size_t)ncol * nlay;
-  const int gptS = a.band_lims_gpt[2 * ibnd] - 1, gptE = a.band_lims_gpt[2 * ibnd + 1] - 1;
-  const int cnt_lo = a.lower.cnt[ibnd], cnt_up = a.upper.cnt[ibnd];
-  if (tid < 2 * MAXM) {
-    const bool up = tid >= MAXM;
-    const int q = up ? tid - MAXM : tid;
-    const MinorTables& mt = up ? a.upper : a.lower;
-    if (q < (up ? cnt_up : cnt_lo)) {
-      const int imnr = mt.list[(size_t)ibnd * mt.nminor + q];
-      MinorMeta m;
-      m.mS = mt.limits[2 * imnr] - 1;
-      m.mE = mt.limits[2 * imnr + 1] - 1;
-      m.idx_minor = mt.idx_minor[imnr];
-      m.idx_scaling = mt.idx_minor_scaling[imnr];
-      m.kstart = mt.kminor_start[imnr] - 1;
-      m.flags = (mt.scales_with_density[imnr] ? 1 : 0) | (mt.scale_by_complement[imnr] ? 2 : 0);
-      m.iflav = a.gpoint_flavor[(up ? 1 : 0) + 2 * m.mS] - 1;
-      meta[tid] = m;
-    }
-  }
-  const int icol = blockIdx.x * BS + tid;
-  const bool valid = icol < ncol;
-  const int ic = min(icol, ncol - 1);
-  const size_t cl = (size_t)ic + (size_t)ncol * ilay;
-  const int itropo = a.tropo[cl] ? 0 : 1;
-  const int jT = a.jtemp[cl];
-  const int jp = a.jpress[cl] + itropo + 1;  // levels jp-1, jp (1-based)
-  const int lay1 = ilay + 1;
-  const int lo1 = a.lim[ic], lo2 = a.lim[ic + ncol];
-  const int up1 = a.lim[ic + 2 * (size_t)ncol], up2 = a.lim[ic + 3 * (size_t)ncol];
-  const bool in_lower = lo1 > 0 && lay1 >= lo1 && lay1 <= lo2;
-  const bool in_upper = up1 > 0 && lay1 >= up1 && lay1 <= up2;
-  const int iflav = a.gpoint_flavor[itropo + 2 * gptS] - 1;
-  const size_t clf = cl + ncl * iflav;
-  const int je1 = a.jeta[2 * clf], je2 = a.jeta[2 * clf + 1];
-  const Float cm1 = a.col_mix[2 * clf], cm2 = a.col_mix[2 * clf + 1];
-  Float fm[8], fn[4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) fm[i] = a.fmajor[8 * clf + i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fn[i] = a.fminor[4 * clf + i];
-  const Float P = a.play[cl], T = a.tlay[cl];
-  const Float cg_dry = a.col_gas[cl], cg_h2o = a.col_gas[cl + ncl * a.idx_h2o];
-  __syncthreads();
-  if (!valid) return;
-  const int n_lo = in_lower ? cnt_lo : 0, n_up = in_upper ? cnt_up : 0;
-  const int TE = ntemp * neta;
-  // g-fastest major table: row(p,e,t) = (p*TE + e*ntemp + t) * ngpt   (0-based p, e, t)
-  const Float* __restrict__ A0 = a.kmajor_g + ((size_t)(jp - 2) * TE + (size_t)(je1 - 1) * ntemp + (jT - 1)) * ngpt; // NOLINT
-  const Float* __restrict__ B0 = a.kmajor_g + ((size_t)(jp - 2) * TE + (size_t)(je2 - 1) * ntemp + jT) * ngpt;
-  size_t dE = (size_t)ntemp * ngpt, dP = (size_t)TE * ngpt;
-  if (a.dbg & 2) { A0 = a.kmajor_g; B0 = a.kmajor_g; dE = 0; dP = 0; }  // all lanes, all corners: one row
-
-  for (int g0 = gptS; g0 <= gptE; g0 += W) {  // host guarantees whole, 16-aligned bands; W divides 16
-    Float acc[W], s[W], u[W], row[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) acc[j] = (a.dbg & 1) ? (Float)0 : a.tau[cl + ncl * (size_t)(g0 + j)];
-    // ---- major species, temperature level jT (:793-796)
-    load_row(A0 + g0, row);
-#pragma unroll
-    for (int j = 0; j < W; ++j) s[j] = fm[0] * row[j];
-    load_row(A0 + dE + g0, row);
-#pragma unroll
-    for (int j = 0; j < W; ++j) s[j] = s[j] + fm[1] * row[j];
-    load_row(A0 + dP + g0, row);
-#pragma unroll
-    for (int j = 0; j < W; ++j) s[j] = s[j] + fm[2] * row[j];
-    load_row(A0 + dP + dE + g0, row);
-#pragma unroll
-    for (int j = 0; j < W; ++j) u[j] = cm1 * (s[j] + fm[3] * row[j]);
-    // ---- temperature level jT+1 (:798-801)
-    load_row(B0 + g0, row);
-#pragma unroll
-    for (int j = 0; j < W; ++j) s[j] = fm[4] * row[j];
-    load_row(B0 + dE + g0, row);
-#pragma unroll
-    for (int j = 0; j < W; ++j) s[j] = s[j] + fm[5] * row[j];
-    load_row(B0 + dP + g0, row);
-#pragma unroll
-    for (int j = 0; j < W; ++j) s[j] = s[j] + fm[6] * row[j];
-    load_row(B0 + dP + dE + g0, row);
-#pragma unroll
-    for (int j = 0; j < W; ++j) acc[j] = acc[j] + (u[j] + cm2 * (s[j] + fm[7] * row[j]));
-    // ---- minor absorbers (:461-494): lower list then upper list, interval order
-#pragma unroll 1
-    for (int kk = 0; kk < ((a.dbg & 8) ? 0 : n_lo + n_up); ++kk) {
-      const int r = kk >= n_lo ? 1 : 0;
-      const MinorMeta m = meta[r * MAXM + (r ? kk - n_lo : kk)];
-      if (m.mE < g0 || m.mS > g0) continue;  // intervals are whole 16-aligned bands
-      Float scaling = a.col_gas[cl + ncl * m.idx_minor];
-      if (m.flags & 1) {
-        scaling = scaling * ((Float)0.01 * P / T);
-        if (m.idx_scaling > 0) {
-          const Float vmr_fact = (Float)1 / cg_dry;
-          const Float dry_fact = (Float)1 / ((Float)1 + cg_h2o * vmr_fact);
-          const Float cgs = a.col_gas[cl + ncl * m.idx_scaling];
-          if (m.flags & 2)
-            scaling = scaling * ((Float)1 - cgs * vmr_fact * dry_fact);
-          else
-            scaling = scaling * (cgs * vmr_fact * dry_fact);
-        }
-      }
-      Float f0 = fn[0], f1 = fn[1], f2 = fn[2], f3 = fn[3];
-      int e1 = je1, e2 = je2;
-      if (m.iflav != iflav) {  // interval whose flavor differs from the band's own (not the usual case)
-        const size_t clm = cl + ncl * m.iflav;
-        f0 = a.fminor[4 * clm]; f1 = a.fminor[4 * clm + 1]; f2 = a.fminor[4 * clm + 2]; f3 = a.fminor[4 * clm + 3];
-        e1 = a.jeta[2 * clm]; e2 = a.jeta[2 * clm + 1];
-      }
-      const Float* kg = r ? a.kminor_upper_g : a.kminor_lower_g;
-      const int nk = r ? a.nk_upper : a.nk_lower;
-      // g-fastest minor table: row(e,t) = (e*ntemp + t) * nk; g-point g of this interval is k = kstart + g - mS
-      const size_t kbase = (size_t)m.kstart + (size_t)(g0 - m.mS);
-      const Float* r1 = kg + ((size_t)(e1 - 1) * ntemp + (jT - 1)) * nk + kbase;
-      const Float* r2 = kg + ((size_t)(e2 - 1) * ntemp + jT) * nk + kbase;
-      const size_t dEm = (size_t)ntemp * nk;
-      load_row(r1, row);
-#pragma unroll
-      for (int j = 0; j < W; ++j) s[j] = f0 * row[j];
-      load_row(r1 + dEm, row);
-#pragma unroll
-      for (int j = 0; j < W; ++j) s[j] = s[j] + f1 * row[j];
-      load_row(r2, row);
-#pragma unroll
-      for (int j = 0; j < W; ++j) s[j] = s[j] + f2 * row[j];
-      load_row(r2 + dEm, row);
-#pragma unroll
-      for (int j = 0; j < W; ++j) acc[j] = acc[j] + scaling * (s[j] + f3 * row[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < W; ++j)
-      if (!(a.dbg & 4) || acc[j] == (Float)-12345.0) a.tau[cl + ncl * (size_t)(g0 + j)] = acc[j];
+      if (g0 + j <= gptE) tau[cl + ncl * (size_t)(g0 + j)] = acc[j];
   }
 }
 
@@ -612,15 +405,7 @@ planck_source_kernel(int ncol, int nlay, int ngpt, int neta, int npres, int ntem
 // ===============================================================================================
 // C ABI
 // ===============================================================================================
-static int g_tau_force_direct = 0;
-static int g_tau_dbg = 0;
-static int g_tau_variant = 308;  // min waves/SIMD the production tau kernel is compiled for (tuning knob)
-
 extern "C" {
-
-int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
-int rte_hip_set_tau_variant(int v) { g_tau_variant = v; return 0; }
-int rte_hip_set_tau_dbg(int v) { g_tau_dbg = v; return 0; }
 
 void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, const int* nflav_,
                           const int* neta_, const int* npres_, const int* ntemp_, const int* flavor,
@@ -722,76 +507,11 @@ void rrtmgp_compute_tau_absorption(
     hipLaunchKernelGGL(plan_minor_kernel, dim3(1), dim3(RTE_WAVE), 0, rte::stream(), nbnd, d_band_lims, nup,
                        up.limits, cnt_up, list_up);
   }
-  TauArgs a;
-  a.ncol = ncol; a.nlay = nlay; a.ngpt = ngpt; a.neta = neta; a.npres = npres; a.ntemp = ntemp;
-  a.idx_h2o = *idx_h2o_;
-  a.gpoint_flavor = d_gpoint_flavor; a.band_lims_gpt = d_band_lims;
-  a.kmajor = d_kmajor; a.kmajor_g = nullptr;
-  a.lower = lo; a.upper = up; a.kminor_lower_g = nullptr; a.kminor_upper_g = nullptr;
-  a.nk_lower = *nminorklower_; a.nk_upper = *nminorkupper_;
-  a.lim = lim; a.tropo = d_tropo; a.col_mix = d_col_mix; a.fmajor = d_fmajor; a.fminor = d_fminor;
-  a.play = d_play; a.tlay = d_tlay; a.col_gas = d_col_gas; a.jeta = d_jeta; a.jtemp = d_jtemp; a.jpress = d_jpress;
-  a.tau = d_tau; a.dbg = g_tau_dbg;
-  // Eligibility of the production kernel (checked on host copies of the small index tables):
-  // every band and every minor interval is made of whole, 16-aligned chunks of 16 g-points (true
-  // for the g256 / g224 k-distributions), k-offsets are even, and no (band, regime) has more than
-  // MAXM minor intervals.  Anything else takes the native-layout kernel.
-  bool fast_ok = (ngpt % GC == 0) && sizeof(Float) == 8;
-  {
-    const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
-    const int* ml[2] = {c.host(minor_limits_gpt_lower, (size_t)2 * nlo), c.host(minor_limits_gpt_upper, (size_t)2 * nup)};
-    const int* ks[2] = {c.host(kminor_start_lower, (size_t)nlo), c.host(kminor_start_upper, (size_t)nup)};
-    const int nn[2] = {nlo, nup};
-    const int nk2[2] = {*nminorklower_, *nminorkupper_};
-    for (int b = 0; b < nbnd; ++b) fast_ok = fast_ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;
-    for (int r = 0; r < 2; ++r) {
-      fast_ok = fast_ok && (nn[r] == 0 || nk2[r] % 2 == 0);
-      for (int i = 0; i < nn[r]; ++i)
-        fast_ok = fast_ok && (ml[r][2 * i] - 1) % GC == 0 && ml[r][2 * i + 1] % GC == 0 && (ks[r][i] - 1) % 2 == 0;
-      for (int b = 0; b < nbnd && fast_ok; ++b) {
-        int n = 0;
-        for (int i = 0; i < nn[r]; ++i) n += ml[r][2 * i] <= bl[2 * b + 1] && ml[r][2 * i + 1] >= bl[2 * b];
-        fast_ok = fast_ok && n <= MAXM;
-      }
-    }
-  }
-  if (ncol < 512 || g_tau_force_direct || !fast_ok) {
-    // small problems: the per-call table re-layout would dominate; gather directly
-    rte::ProfScope p("tau_absorption_kernel");
-    dim3 grid(cdiv(ncol, 256), nlay, nbnd), block(256);
-    hipLaunchKernelGGL(tau_absorption_kernel, grid, block, 0, rte::stream(), a);
-    return;
-  }
-  // g-fastest copies of the three tables (scratch, this call only)
-  const int TE = ntemp * neta, nkl = a.nk_lower, nku = a.nk_upper;
-  Float* kmaj_g = (Float*)rte::scratch(sizeof(Float) * tn * (npres + 1) * ngpt);
-  Float* klo_g = (Float*)rte::scratch(sizeof(Float) * tn * (nkl > 0 ? nkl : 1));
-  Float* kup_g = (Float*)rte::scratch(sizeof(Float) * tn * (nku > 0 ? nku : 1));
-  {
-    rte::ProfScope p("relayout_gfast_kernel");
-    const size_t tile_bytes = sizeof(Float) * TE * 33;
-    hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(ngpt, 32), npres + 1), dim3(256), tile_bytes, rte::stream(),
-                       TE, npres + 1, ngpt, d_kmajor, kmaj_g);
-    if (nkl > 0)
-      hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(nkl, 32), 1), dim3(256), tile_bytes, rte::stream(), TE, 1,
-                         nkl, lo.kminor, klo_g);
-    if (nku > 0)
-      hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(nku, 32), 1), dim3(256), tile_bytes, rte::stream(), TE, 1,
-                         nku, up.kminor, kup_g);
-  }
-  a.kmajor_g = kmaj_g; a.kminor_lower_g = klo_g; a.kminor_upper_g = kup_g;
   rte::ProfScope p("tau_absorption_kernel");
-  constexpr int BS = 256;
-  dim3 grid(cdiv(ncol, BS), nlay, nbnd), block(BS);
-  switch (g_tau_variant) {  // tuning knob: (min waves per SIMD, g-points per register chunk)
-    case 216: hipLaunchKernelGGL((tau_absorption_gfast_kernel<BS, 2, 16>), grid, block, 0, rte::stream(), a); break;
-    case 308: hipLaunchKernelGGL((tau_absorption_gfast_kernel<BS, 3, 8>), grid, block, 0, rte::stream(), a); break;
-    case 408: hipLaunchKernelGGL((tau_absorption_gfast_kernel<BS, 4, 8>), grid, block, 0, rte::stream(), a); break;
-    case 504: hipLaunchKernelGGL((tau_absorption_gfast_kernel<BS, 5, 4>), grid, block, 0, rte::stream(), a); break;
-    case 604: hipLaunchKernelGGL((tau_absorption_gfast_kernel<BS, 6, 4>), grid, block, 0, rte::stream(), a); break;
-    case 804: hipLaunchKernelGGL((tau_absorption_gfast_kernel<BS, 8, 4>), grid, block, 0, rte::stream(), a); break;
-    default: hipLaunchKernelGGL((tau_absorption_gfast_kernel<BS, 4, 8>), grid, block, 0, rte::stream(), a); break;
-  }
+  dim3 grid(cdiv(ncol, 256), nlay, nbnd), block(256);
+  hipLaunchKernelGGL(tau_absorption_kernel, grid, block, 0, rte::stream(), ncol, nlay, ngpt, neta, npres,
+                     ntemp, *idx_h2o_, d_gpoint_flavor, d_band_lims, d_kmajor, lo, up, lim, d_tropo, d_col_mix,
+                     d_fmajor, d_fminor, d_play, d_tlay, d_col_gas, d_jeta, d_jtemp, d_jpress, d_tau);
 }
 
 void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* nbnd_,

@@ -104,41 +104,6 @@ def test_segmented_and_generic_lw_solvers_agree(hip, name):
         assert cases.rel_err(a[k], b[k]) <= 1e-13, k
 
 
-def test_tau_absorption_paths_agree(hip, oracle_c):
-    """The production kernel (g-fastest re-laid-out tables, corner-outer row loads) and the
-    native-layout direct-gather kernel add the same products in the same order: bit-identical
-    results; and both match the oracle."""
-    import torch
-    from rte_rrtmgp_amd import synth
-
-    kd = synth.make_kdist("lw", ngpt=64, nbnd=4, nminor_lower=11, nminor_upper=7)  # 16-wide bands
-    ncol, nlay = 1100, 24
-    atm = synth.make_atmosphere(ncol, nlay, seed=77, kdist=kd)
-    xp = frontend.TorchArrays("cuda:0")
-    A = xp.asarray
-    go = frontend.GasOptics(hip, kd, xp)
-    play, tlay, col_gas = A(atm.play), A(atm.tlay), A(atm.col_gas)
-    st = go.interpolation(ncol, nlay, play, tlay, col_gas)
-
-    def run():
-        tau = xp.full((ncol, nlay, kd.ngpt), 0.125)  # non-zero start: tau is intent(inout)
-        go.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau)
-        return xp.to_numpy(tau).copy()
-
-    t_fast = run()
-    hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 1)
-    t_dir = run()
-    hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 0)
-    assert np.array_equal(t_fast, t_dir)
-    xn = frontend.NumpyArrays()
-    gon = frontend.GasOptics(oracle_c, kd, xn)
-    stn = gon.interpolation(ncol, nlay, atm.play, atm.tlay, atm.col_gas)
-    taun = xn.full((ncol, nlay, kd.ngpt), 0.125)
-    gon.compute_tau_absorption(ncol, nlay, stn, atm.play, atm.tlay, atm.col_gas, taun)
-    assert cases.rel_err(t_fast, taun) <= RTOL_GAS
-    torch.cuda.synchronize()
-
-
 def test_gray_radiative_equilibrium_on_device(hip):
     from test_host_logic import _gray_equilibrium
 
