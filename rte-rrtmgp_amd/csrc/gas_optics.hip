@@ -16,6 +16,8 @@
 //     geometric mean of adjacent layers' Planck fractions needs no second gather.
 #include <math.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -109,7 +111,8 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
 // first extremal location; 0 = no such layer)
 // -------------------------------------------------------------------------------------------
 __global__ void tropo_limits_kernel(int ncol, int nlay, const Float* __restrict__ play,
-                                    const Bool* __restrict__ tropo, int* __restrict__ lim /*(ncol,4)*/) {
+                                    const Bool* __restrict__ tropo, int* __restrict__ lim /*(ncol,4)*/,
+                                    int* __restrict__ overlap) {
   const int icol = blockIdx.x * blockDim.x + threadIdx.x;
   if (icol >= ncol) return;
   const bool top_at_1 = play[0] < play[(size_t)ncol * (nlay - 1)];
@@ -132,6 +135,9 @@ __global__ void tropo_limits_kernel(int ncol, int nlay, const Float* __restrict_
   lim[icol + ncol] = lo2;
   lim[icol + 2 * (size_t)ncol] = up1;
   lim[icol + 3 * (size_t)ncol] = up2;
+  // a layer that lies in BOTH ranges gets both regimes' minor absorbers in the reference (possible
+  // only for non-monotone pressure profiles); the production kernel does not handle that
+  if (lo1 > 0 && up1 > 0 && max(lo1, up1) <= min(lo2, up2)) *overlap = 1;
 }
 
 // Per band, the ordered list of minor intervals whose g-point range intersects the band
@@ -218,53 +224,58 @@ __device__ __forceinline__ void minor_chunk(const MinorTables& mt, int flav_row,
 // -------------------------------------------------------------------------------------------
 // compute_tau_absorption: reference :176-338 (driver), :345-396 (major), :402-501 (minor)
 // -------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-tau_absorption_kernel(int ncol, int nlay, int ngpt, int neta, int npres, int ntemp, int idx_h2o,
-                      const int* __restrict__ gpoint_flavor, const int* __restrict__ band_lims_gpt,
-                      const Float* __restrict__ kmajor, MinorTables lower, MinorTables upper,
-                      const int* __restrict__ lim, const Bool* __restrict__ tropo,
-                      const Float* __restrict__ col_mix, const Float* __restrict__ fmajor,
-                      const Float* __restrict__ fminor, const Float* __restrict__ play,
-                      const Float* __restrict__ tlay, const Float* __restrict__ col_gas,
-                      const int* __restrict__ jeta, const int* __restrict__ jtemp,
-                      const int* __restrict__ jpress, Float* __restrict__ tau) {
-  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ilay = blockIdx.y, ibnd = blockIdx.z;
-  if (icol >= ncol) return;
+struct alignas(2 * sizeof(Float)) Float2 { Float x, y; };
+
+struct TauArgs {
+  int ncol, nlay, ngpt, neta, npres, ntemp, idx_h2o;
+  const int *gpoint_flavor, *band_lims_gpt;
+  const Float* kmajor;
+  MinorTables lower, upper;
+  const int* run_if;  // when non-null the kernel does nothing unless *run_if != 0
+  const int* lim;
+  const Bool* tropo;
+  const Float *col_mix, *fmajor, *fminor, *play, *tlay, *col_gas;
+  const int *jeta, *jtemp, *jpress;
+  Float* tau;
+};
+
+// direct-gather version for one (column, layer, band): reads the native tables through L1/L2
+__device__ __forceinline__ void tau_direct_column(const TauArgs& a, int icol, int ilay, int ibnd) {
+  const int ncol = a.ncol, nlay = a.nlay, neta = a.neta, ntemp = a.ntemp;
   const size_t ncl = (size_t)ncol * nlay;
   const size_t cl = icol + (size_t)ncol * ilay;
-  const int gptS = band_lims_gpt[2 * ibnd] - 1, gptE = band_lims_gpt[2 * ibnd + 1] - 1;
-  const int itropo = tropo[cl] ? 0 : 1;
-  const int iflav = gpoint_flavor[itropo + 2 * gptS] - 1;
+  const int gptS = a.band_lims_gpt[2 * ibnd] - 1, gptE = a.band_lims_gpt[2 * ibnd + 1] - 1;
+  const int itropo = a.tropo[cl] ? 0 : 1;
+  const int iflav = a.gpoint_flavor[itropo + 2 * gptS] - 1;
   const size_t clf = cl + ncl * iflav;
-  const int jT = jtemp[cl];
-  const int jp = jpress[cl] + itropo + 1;  // "jpress + itropo": levels jp-1 and jp (1-based)
-  const int je1 = jeta[2 * clf], je2 = jeta[2 * clf + 1];
-  const Float cm1 = col_mix[2 * clf], cm2 = col_mix[2 * clf + 1];
+  const int jT = a.jtemp[cl];
+  const int jp = a.jpress[cl] + itropo + 1;  // "jpress + itropo": levels jp-1 and jp (1-based)
+  const int je1 = a.jeta[2 * clf], je2 = a.jeta[2 * clf + 1];
+  const Float cm1 = a.col_mix[2 * clf], cm2 = a.col_mix[2 * clf + 1];
   Float fm[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) fm[i] = fmajor[8 * clf + i];
+  for (int i = 0; i < 8; ++i) fm[i] = a.fmajor[8 * clf + i];
   const size_t tn = (size_t)ntemp * neta;
-  const size_t gstride = tn * (npres + 1);
+  const size_t gstride = tn * (a.npres + 1);
   // corner offsets (without the g-point term) into kmajor(ntemp,neta,npres+1,ngpt)
   const size_t a0 = (size_t)(jT - 1) + (size_t)ntemp * (je1 - 1) + tn * (size_t)(jp - 2);
   const size_t b0 = (size_t)jT + (size_t)ntemp * (je2 - 1) + tn * (size_t)(jp - 2);
-  const Float P = play[cl], T = tlay[cl];
+  const Float P = a.play[cl], T = a.tlay[cl];
   const int lay1 = ilay + 1;
-  const int lo1 = lim[icol], lo2 = lim[icol + ncol];
-  const int up1 = lim[icol + 2 * (size_t)ncol], up2 = lim[icol + 3 * (size_t)ncol];
+  const int lo1 = a.lim[icol], lo2 = a.lim[icol + ncol];
+  const int up1 = a.lim[icol + 2 * (size_t)ncol], up2 = a.lim[icol + 3 * (size_t)ncol];
   const bool in_lower = lo1 > 0 && lay1 >= lo1 && lay1 <= lo2;
   const bool in_upper = up1 > 0 && lay1 >= up1 && lay1 <= up2;
 
   for (int g0 = gptS; g0 <= gptE; g0 += GC) {
     Float acc[GC];
 #pragma unroll
-    for (int j = 0; j < GC; ++j) acc[j] = (g0 + j <= gptE) ? tau[cl + ncl * (size_t)(g0 + j)] : (Float)0;
+    for (int j = 0; j < GC; ++j) acc[j] = (g0 + j <= gptE) ? a.tau[cl + ncl * (size_t)(g0 + j)] : (Float)0;
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
       if (g0 + j <= gptE) {
-        const Float* ka = kmajor + gstride * (size_t)(g0 + j) + a0;
-        const Float* kb = kmajor + gstride * (size_t)(g0 + j) + b0;
+        const Float* ka = a.kmajor + gstride * (size_t)(g0 + j) + a0;
+        const Float* kb = a.kmajor + gstride * (size_t)(g0 + j) + b0;
         // :791-801
         const Float tau_major =
             cm1 * (fm[0] * ka[0] + fm[1] * ka[ntemp] + fm[2] * ka[tn] + fm[3] * ka[tn + ntemp]) +
@@ -273,14 +284,333 @@ tau_absorption_kernel(int ncol, int nlay, int ngpt, int neta, int npres, int nte
       }
     }
     if (in_lower)
-      minor_chunk(lower, 0, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, idx_h2o, P, T, jT, col_gas, fminor,
-                  jeta, gpoint_flavor, acc);
+      minor_chunk(a.lower, 0, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, a.idx_h2o, P, T, jT, a.col_gas, a.fminor,
+                  a.jeta, a.gpoint_flavor, acc);
     if (in_upper)
-      minor_chunk(upper, 1, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, idx_h2o, P, T, jT, col_gas, fminor,
-                  jeta, gpoint_flavor, acc);
+      minor_chunk(a.upper, 1, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, a.idx_h2o, P, T, jT, a.col_gas, a.fminor,
+                  a.jeta, a.gpoint_flavor, acc);
 #pragma unroll
     for (int j = 0; j < GC; ++j)
-      if (g0 + j <= gptE) tau[cl + ncl * (size_t)(g0 + j)] = acc[j];
+      if (g0 + j <= gptE) a.tau[cl + ncl * (size_t)(g0 + j)] = acc[j];
+  }
+}
+
+// direct kernel over all (column tile, layer, band) triples, grid-stride
+__global__ void __launch_bounds__(256) tau_absorption_kernel(TauArgs a, int nbnd) {
+  if (a.run_if && *a.run_if == 0) return;
+  const unsigned tiles_x = (a.ncol + 255) / 256;
+  const size_t total = (size_t)tiles_x * a.nlay * nbnd;
+  for (size_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const int tx = (int)(w % tiles_x);
+    const int ilay = (int)((w / tiles_x) % a.nlay);
+    const int ibnd = (int)(w / ((size_t)tiles_x * a.nlay));
+    const int icol = tx * 256 + threadIdx.x;
+    if (icol < a.ncol) tau_direct_column(a, icol, ilay, ibnd);
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// LUT re-layout (per call, into the scratch arena): (TE = ntemp*neta, nouter, ng) with the
+// (temperature, eta) plane fastest  ->  rows of g-points: out[(o*TE + te)*ng + g].
+// A band's g-points of one (T, eta, p) corner become one contiguous 128-byte row, which is what
+// the LDS staging below copies.  ~35 MB moved per call (L2 / Infinity-Cache resident): ~10 us.
+// -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, Float* __restrict__ out) {
+  extern __shared__ Float tile[];  // [TE][33]
+  const int g0 = blockIdx.x * 32, o = blockIdx.y;
+  const int ngc = min(32, ng - g0);
+  for (int idx = threadIdx.x; idx < TE * ngc; idx += blockDim.x) {
+    const int te = idx % TE, gg = idx / TE;
+    tile[te * 33 + gg] = in[(size_t)te + (size_t)TE * ((size_t)o + (size_t)nouter * (g0 + gg))];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < TE * ngc; idx += blockDim.x) {
+    const int gg = idx % ngc, te = idx / ngc;
+    out[((size_t)o * TE + te) * ng + g0 + gg] = tile[te * 33 + gg];
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// compute_tau_absorption, production kernel.
+//
+// What the measurements on MI355X said (profiles/r01_tau_absorption_notes.md): every variant that
+// gathers LUT values with lanes = columns (native layout, g-fastest layout, LDS-staged slab) runs
+// at ~20 ms per 1e5 columns: each lane pulls its own cache line and the vector L1 retires about one
+// distinct line per clock (TCP_TOTAL_CACHE_ACCESSES ~ 1/clk/CU), and the kernels were instruction-
+// bound on 64-bit address arithmetic and SGPR spills from an over-wide argument list.  Hence:
+//
+//   block   = (tile of NC columns, one layer); the block walks the bands.
+//   phase 1 : lanes = columns.  The column's interpolation state for the band is read ONCE,
+//             coalesced and one band ahead of its use; the minor-species scalings (:461-480) are
+//             formed and a compact record {col_mix*fmajor[8], fminor[4], scaling[<=8], row offsets}
+//             is parked in LDS.
+//   phase 2 : lanes = (8 columns) x (8 pairs of g-points).  The 8 lanes of a column read one
+//             128-byte row of the g-fastest table with a single 16-byte load each, i.e. one cache
+//             line per column per corner -- the minimum -- and the per-column weights come from
+//             LDS as broadcasts.  tau is read-modified-written in 64-byte segments.
+// Arithmetic: the same products and sums as the reference (:791-801, :757-760) evaluated with
+// fused multiply-adds and col_mix folded into the major weights; differences from the reference
+// association are a few ulp (tests: 1e-12 relative).
+// -------------------------------------------------------------------------------------------
+constexpr int MAXM = 8;    // minor intervals per (band, regime) handled here; more -> native kernel
+constexpr int MAXB = 32;   // bands
+constexpr int NC = 64;     // columns per block
+
+struct MinorMeta {  // one minor interval
+  int mS, mE, idx_minor, idx_scaling, kstart, flags /*1: scales with density, 2: by complement*/;
+};
+struct BandMeta {  // built on the host from the small index tables, uploaded per call
+  int cnt[2];
+  MinorMeta m[2][MAXM];  // [0]: lower-regime intervals of the band, [1]: upper
+};
+
+struct TauV5 {
+  int ncol, nlay, ngpt, nbnd, ntemp, TE, idx_h2o, nk_lo, nk_up;
+  const int* band_lims;      // (2,nbnd)
+  const int* gpoint_flavor;  // (2,ngpt)
+  const BandMeta* bmeta;     // [nbnd]
+  const Float *kmaj, *klo, *kup;  // g-fastest tables
+  const int *lim, *jeta, *jtemp, *jpress;
+  const Bool* tropo;
+  const Float *col_mix, *fmajor, *fminor, *play, *tlay, *col_gas;
+  Float* tau;
+  const int* skip_if;  // device flag: some column has overlapping regimes -> the fallback kernel does the call
+  int* worklist;       // [0] = count, then (tile, layer, band) triples for tau_absorption_worklist_kernel
+};
+
+struct BandIn {  // flavor-dependent inputs of one band for one column, prefetched one band ahead
+  Float2 fm[4], fn[2], cm;
+  int je1, je2, em1, em2;
+};
+
+constexpr int RS = GC + 1;         // LDS slab row stride in Floats: 17 (odd) spreads lane-private rows over banks
+constexpr int SLAB_FLOATS = 5632;  // 44 KB of LUT slab per block; tiles that need more go to the direct kernel
+
+// lanes = columns; block = (256 columns, one layer), walks the bands.  Per band the block stages the
+// bounding box of LUT rows its columns need (pressure x temperature x eta ranges of the tile) from the
+// g-fastest tables into LDS -- each 128-byte row piece is one coalesced line -- and every thread then
+// gathers its 8 major + 4-per-interval minor corner rows with 8-byte LDS reads (measured on MI355X:
+// lane-private ds_read_b64 sustains ~100 B/clk/CU, lane-private global loads 1 line/clk, see
+// tools/membench.hip).  Inputs of band b+1 are requested before band b is computed.  A tile whose
+// bounding box does not fit the slab is appended to a worklist for tau_absorption_kernel.
+template <int BS>
+__global__ void __launch_bounds__(BS, 3) tau_absorption_v7_kernel(TauV5 a) {
+  __shared__ int rng[6];      // Tmin, Tmax, Pmin, Pmax, has_lower, has_upper
+  __shared__ int erng[2][2];  // eta range of the band (ping-pong between bands)
+  __shared__ Float slab[SLAB_FLOATS];
+  extern __shared__ BandMeta bm[];  // [nbnd]
+  if (*a.skip_if) return;
+  const int tid = threadIdx.x;
+  const unsigned ncol = a.ncol, nlay = a.nlay;
+  const unsigned ilay = blockIdx.y;
+  const unsigned ncl = ncol * nlay;  // host guarantees < 2^31
+  const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nbnd = a.nbnd;
+  if (tid == 0) {
+    rng[0] = 1 << 30; rng[1] = -1; rng[2] = 1 << 30; rng[3] = -1; rng[4] = 0; rng[5] = 0;
+    erng[0][0] = 1 << 30; erng[0][1] = -1; erng[1][0] = 1 << 30; erng[1][1] = -1;
+  }
+  {  // band metadata -> LDS (a few KB, coalesced)
+    const int* src = reinterpret_cast<const int*>(a.bmeta);
+    int* dst = reinterpret_cast<int*>(bm);
+    const int nw = nbnd * (int)(sizeof(BandMeta) / sizeof(int));
+    for (int i = tid; i < nw; i += BS) dst[i] = src[i];
+  }
+  __syncthreads();
+  // ---- band-independent state of this thread's column
+  const unsigned icol = blockIdx.x * BS + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  const unsigned cl = ic + ncol * ilay;
+  const int itropo = a.tropo[cl] ? 0 : 1;
+  const int jT = a.jtemp[cl];
+  const int jp = a.jpress[cl] + itropo + 1;  // levels jp-1, jp (1-based)
+  int regime;
+  {
+    const int lay1 = ilay + 1;
+    const int lo1 = a.lim[ic], lo2 = a.lim[ic + ncol];
+    const int up1 = a.lim[ic + 2 * (size_t)ncol], up2 = a.lim[ic + 3 * (size_t)ncol];
+    regime = ((lo1 > 0 && lay1 >= lo1 && lay1 <= lo2) ? 1 : 0) | ((up1 > 0 && lay1 >= up1 && lay1 <= up2) ? 2 : 0);
+  }
+  const int rsel = regime == 2 ? 1 : 0;
+  const Float P = a.play[cl], T = a.tlay[cl];
+  const Float dens = (Float)0.01 * P / T;                                                             // :469
+  const Float vmr_fact = (Float)1 / a.col_gas[cl];                                                    // :471
+  const Float dry_fact = (Float)1 / ((Float)1 + a.col_gas[cl + (size_t)ncl * a.idx_h2o] * vmr_fact);  // :472
+  if (valid) {
+    atomicMin(&rng[0], jT); atomicMax(&rng[1], jT + 1);
+    atomicMin(&rng[2], jp - 1); atomicMax(&rng[3], jp);
+    if (regime & 1) rng[4] = 1;
+    if (regime & 2) rng[5] = 1;
+  }
+
+  auto load_band = [&](int b, BandIn& in) {
+    const int gptS = a.band_lims[2 * b] - 1;
+    const int iflav = a.gpoint_flavor[itropo + 2 * gptS] - 1;
+    const size_t clf = cl + (size_t)ncl * iflav;
+    const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) in.fm[i] = fmp[i];
+    in.cm = *reinterpret_cast<const Float2*>(a.col_mix + 2 * clf);
+    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
+    in.je1 = je.x; in.je2 = je.y;
+    // minor absorbers interpolate with the flavor of THEIR regime's row (:487)
+    const int iflav_m = a.gpoint_flavor[rsel + 2 * gptS] - 1;
+    const size_t clm = cl + (size_t)ncl * iflav_m;
+    const Float2* fnp = reinterpret_cast<const Float2*>(a.fminor + 4 * clm);
+    in.fn[0] = fnp[0]; in.fn[1] = fnp[1];
+    const int2 em = *reinterpret_cast<const int2*>(a.jeta + 2 * clm);
+    in.em1 = em.x; in.em2 = em.y;
+  };
+
+  BandIn cur;
+  load_band(0, cur);
+
+  for (int ibnd = 0; ibnd < nbnd; ++ibnd) {
+    const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
+    int* er = erng[ibnd & 1];
+    if (valid) {
+      atomicMin(&er[0], min(min(cur.je1, cur.je2), min(cur.em1, cur.em2)));
+      atomicMax(&er[1], max(max(cur.je1, cur.je2), max(cur.em1, cur.em2)) + 1);
+    }
+    __syncthreads();  // ranges complete; previous band's compute finished (slab is free)
+    const int Tmin = rng[0], nT = rng[1] - rng[0] + 1, Pmin = rng[2], nP = rng[3] - rng[2] + 1;
+    const int n_lo = rng[4] ? bm[ibnd].cnt[0] : 0, n_up = rng[5] ? bm[ibnd].cnt[1] : 0;
+    const int emin = er[0], nE = er[1] - er[0] + 1;
+    const int rowsMaj = nP * nT * nE, rowsLo = n_lo * nT * nE, rowsUp = n_up * nT * nE;
+    const bool use_lds = (rowsMaj + rowsLo + rowsUp) * RS <= SLAB_FLOATS && regime != 3;
+    if (tid == 0) {
+      erng[(ibnd + 1) & 1][0] = 1 << 30; erng[(ibnd + 1) & 1][1] = -1;
+      if (!use_lds) {  // hand (tile, layer, band) to the direct kernel
+        const int w = atomicAdd(&a.worklist[0], 1);
+        a.worklist[1 + 3 * w] = blockIdx.x; a.worklist[2 + 3 * w] = ilay; a.worklist[3 + 3 * w] = ibnd;
+      }
+    }
+    // column amounts of this band's minor absorbers: requested now, used after the staging
+    const int n_my = regime > 0 ? bm[ibnd].cnt[rsel] : 0;
+    Float sc[MAXM], cgs[MAXM];
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) {
+      sc[k] = 0; cgs[k] = 0;
+      if (k < n_my) {
+        const MinorMeta& m = bm[ibnd].m[rsel][k];
+        sc[k] = a.col_gas[cl + (size_t)ncl * m.idx_minor];
+        if ((m.flags & 1) && m.idx_scaling > 0) cgs[k] = a.col_gas[cl + (size_t)ncl * m.idx_scaling];
+      }
+    }
+    // weights of this band (col_mix folded into fmajor), then `cur` is free for the prefetch
+    const Float w0 = cur.cm.x * cur.fm[0].x, w1 = cur.cm.x * cur.fm[0].y, w2 = cur.cm.x * cur.fm[1].x,
+                w3 = cur.cm.x * cur.fm[1].y, w4 = cur.cm.y * cur.fm[2].x, w5 = cur.cm.y * cur.fm[2].y,
+                w6 = cur.cm.y * cur.fm[3].x, w7 = cur.cm.y * cur.fm[3].y;
+    const Float f0 = cur.fn[0].x, f1 = cur.fn[0].y, f2 = cur.fn[1].x, f3 = cur.fn[1].y;
+    const int je1 = cur.je1, je2 = cur.je2, em1 = cur.em1, em2 = cur.em2;
+    if (ibnd + 1 < nbnd) load_band(ibnd + 1, cur);
+    if (!use_lds) continue;  // block-uniform
+
+#pragma unroll 1
+    for (int g0 = gptS; g0 <= gptE; g0 += GC) {  // host guarantees whole, 16-aligned chunks
+      if (g0 != gptS) __syncthreads();
+      // ---- stage the slab; rows ordered [p][t][eta] (+ minor: [interval][t][eta]); 16-byte pieces
+      for (int idx = tid; idx < rowsMaj * (GC / 2); idx += BS) {
+        const int j = idx & 7, r = idx >> 3;
+        const int e = r % nE, rest = r / nE, t_l = rest % nT, p_l = rest / nT;
+        const Float2 v = *reinterpret_cast<const Float2*>(
+            a.kmaj + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
+        slab[r * RS + 2 * j] = v.x;
+        slab[r * RS + 2 * j + 1] = v.y;
+      }
+      for (int idx = tid; idx < (rowsLo + rowsUp) * (GC / 2); idx += BS) {
+        const int j = idx & 7;
+        const int r = idx >> 3;
+        const bool up = r >= rowsLo;
+        const int rr = up ? r - rowsLo : r;
+        const int e = rr % nE, rest = rr / nE, t_l = rest % nT, q = rest / nT;
+        const MinorMeta& m = bm[ibnd].m[up ? 1 : 0][q];
+        Float2 v{0, 0};
+        if (m.mS <= g0 && m.mE >= g0) {
+          const Float* kg = up ? a.kup : a.klo;
+          const unsigned nk = up ? a.nk_up : a.nk_lo;
+          v = *reinterpret_cast<const Float2*>(
+              kg + ((size_t)((emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * nk + (unsigned)m.kstart + (g0 - m.mS) + 2 * j));
+        }
+        slab[(rowsMaj + r) * RS + 2 * j] = v.x;
+        slab[(rowsMaj + r) * RS + 2 * j + 1] = v.y;
+      }
+      __syncthreads();
+      if (!valid) continue;
+      if (g0 == gptS) {
+        // minor scalings (:461-480)
+#pragma unroll
+        for (int k = 0; k < MAXM; ++k) {
+          if (k < n_my) {
+            const MinorMeta& m = bm[ibnd].m[rsel][k];
+            if (m.flags & 1) {
+              sc[k] = sc[k] * dens;     // :469
+              if (m.idx_scaling > 0) {  // :470-478
+                if (m.flags & 2)
+                  sc[k] = sc[k] * ((Float)1 - cgs[k] * vmr_fact * dry_fact);
+                else
+                  sc[k] = sc[k] * (cgs[k] * vmr_fact * dry_fact);
+              }
+            }
+          }
+        }
+      }
+      const Float* A0 = slab + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS;
+      const Float* B0 = slab + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
+      const int sP = nT * nE * RS;
+      const Float* M0 = slab + (rowsMaj + (regime == 2 ? rowsLo : 0)) * RS;
+#pragma unroll 1
+      for (int h = 0; h < GC; h += 8) {  // two halves of 8 g-points: bounded register footprint
+        Float acc[8];
+        Float* tp = a.tau + cl + (size_t)ncl * (g0 + h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = tp[(size_t)ncl * j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // :791-801 with col_mix folded into the weights
+          Float m = w0 * A0[h + j];
+          m = fma(w1, A0[RS + h + j], m);
+          m = fma(w2, A0[sP + h + j], m);
+          m = fma(w3, A0[sP + RS + h + j], m);
+          m = fma(w4, B0[h + j], m);
+          m = fma(w5, B0[RS + h + j], m);
+          m = fma(w6, B0[sP + h + j], m);
+          m = fma(w7, B0[sP + RS + h + j], m);
+          acc[j] = acc[j] + m;
+        }
+#pragma unroll 1
+        for (int k = 0; k < n_my; ++k) {
+          const int mS = bm[ibnd].m[rsel][k].mS, mE = bm[ibnd].m[rsel][k].mE;
+          if (mE < g0 || mS > g0) continue;  // intervals are whole 16-aligned chunks inside the band
+          const Float* r1 = M0 + ((k * nT + (jT - Tmin)) * nE + (em1 - emin)) * RS + h;
+          const Float* r2 = M0 + ((k * nT + (jT + 1 - Tmin)) * nE + (em2 - emin)) * RS + h;
+          Float scaling = sc[0];
+#pragma unroll
+          for (int q = 1; q < MAXM; ++q) scaling = (k == q) ? sc[q] : scaling;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            // :757-760, :493
+            Float s_ = f0 * r1[j];
+            s_ = fma(f1, r1[RS + j], s_);
+            s_ = fma(f2, r2[j], s_);
+            s_ = fma(f3, r2[RS + j], s_);
+            acc[j] = fma(scaling, s_, acc[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tp[(size_t)ncl * j] = acc[j];
+      }
+    }
+  }
+}
+
+// (tile, layer, band) triples the slab kernel could not hold, done by the direct-gather code
+__global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a, const int* __restrict__ worklist) {
+  const int n = worklist[0];
+  for (int w = blockIdx.x; w < n; w += gridDim.x) {
+    const int icol = worklist[1 + 3 * w] * 256 + threadIdx.x;
+    if (icol < a.ncol) tau_direct_column(a, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
   }
 }
 
@@ -405,7 +735,37 @@ planck_source_kernel(int ncol, int nlay, int ngpt, int neta, int npres, int ntem
 // ===============================================================================================
 // C ABI
 // ===============================================================================================
+static int g_tau_force_direct = 0;
+static int g_plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget cached host-side plans
+
+namespace {
+struct TauPlanCache {
+  const void* key[12] = {};
+  int dims[6] = {};
+  int epoch = -1;
+  bool fast_ok = false;
+  std::vector<BandMeta> bands;
+  bool matches(const void* const* k, const int* d, int e) const {
+    if (e != epoch) return false;
+    for (int i = 0; i < 12; ++i)
+      if (k[i] != key[i]) return false;
+    for (int i = 0; i < 6; ++i)
+      if (d[i] != dims[i]) return false;
+    return true;
+  }
+  void set(const void* const* k, const int* d, int e) {
+    for (int i = 0; i < 12; ++i) key[i] = k[i];
+    for (int i = 0; i < 6; ++i) dims[i] = d[i];
+    epoch = e;
+  }
+};
+}  // namespace
+
 extern "C" {
+
+int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
+int rte_hip_invalidate_plans(void) { ++g_plan_epoch; return 0; }
+
 
 void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, const int* nflav_,
                           const int* neta_, const int* npres_, const int* ntemp_, const int* flavor,
@@ -489,29 +849,137 @@ void rrtmgp_compute_tau_absorption(
   const int* d_jtemp = c.in(jtemp, ncl);
   const int* d_jpress = c.in(jpress, ncl);
   Float* d_tau = c.inout(tau, ncl * ngpt);
-  // plans and layer limits (device scratch)
-  int* lim = (int*)rte::scratch(sizeof(int) * 4 * (size_t)ncol);
-  int* plan = (int*)rte::scratch(sizeof(int) * ((size_t)2 * nbnd + (size_t)nbnd * (nlo + nup) + 2));
-  int* cnt_lo = plan;
-  int* cnt_up = plan + nbnd;
-  int* list_lo = plan + 2 * nbnd;
-  int* list_up = list_lo + (size_t)nbnd * nlo;
-  lo.cnt = cnt_lo; lo.list = list_lo;
-  up.cnt = cnt_up; up.list = list_up;
+  hipStream_t st = rte::stream();
+  // layer limits of the two regimes per column (:274-285) + "regimes overlap somewhere" flag
+  int* lim = (int*)rte::scratch(sizeof(int) * (4 * (size_t)ncol + 1));
+  int* overlap = lim + 4 * (size_t)ncol;
   {
     rte::ProfScope p("tau_absorption_setup");
-    hipLaunchKernelGGL(tropo_limits_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, rte::stream(), ncol, nlay,
-                       d_play, d_tropo, lim);
-    hipLaunchKernelGGL(plan_minor_kernel, dim3(1), dim3(RTE_WAVE), 0, rte::stream(), nbnd, d_band_lims, nlo,
-                       lo.limits, cnt_lo, list_lo);
-    hipLaunchKernelGGL(plan_minor_kernel, dim3(1), dim3(RTE_WAVE), 0, rte::stream(), nbnd, d_band_lims, nup,
-                       up.limits, cnt_up, list_up);
+    HIP_CHECK(hipMemsetAsync(overlap, 0, sizeof(int), st));
+    hipLaunchKernelGGL(tropo_limits_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, st, ncol, nlay, d_play, d_tropo, lim,
+                       overlap);
   }
-  rte::ProfScope p("tau_absorption_kernel");
-  dim3 grid(cdiv(ncol, 256), nlay, nbnd), block(256);
-  hipLaunchKernelGGL(tau_absorption_kernel, grid, block, 0, rte::stream(), ncol, nlay, ngpt, neta, npres,
-                     ntemp, *idx_h2o_, d_gpoint_flavor, d_band_lims, d_kmajor, lo, up, lim, d_tropo, d_col_mix,
-                     d_fmajor, d_fminor, d_play, d_tlay, d_col_gas, d_jeta, d_jtemp, d_jpress, d_tau);
+  // ---- host-side plan from the small index tables (cached while the caller's table pointers and
+  // dimensions do not change; rte_hip_release() drops the cache)
+  static TauPlanCache cache;
+  const void* key[12] = {band_lims_gpt, minor_limits_gpt_lower, minor_limits_gpt_upper, kminor_start_lower,
+                         kminor_start_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
+                         idx_minor_scaling_upper, minor_scales_with_density_lower, scale_by_complement_lower,
+                         scale_by_complement_upper};
+  const int dims[6] = {nbnd, ngpt, nlo, nup, *nminorklower_, *nminorkupper_};
+  if (!cache.matches(key, dims, g_plan_epoch)) {
+    cache.set(key, dims, g_plan_epoch);
+    const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
+    const int* ml[2] = {c.host(minor_limits_gpt_lower, (size_t)2 * nlo), c.host(minor_limits_gpt_upper, (size_t)2 * nup)};
+    const int* ks[2] = {c.host(kminor_start_lower, (size_t)nlo), c.host(kminor_start_upper, (size_t)nup)};
+    const int* im[2] = {c.host(idx_minor_lower, (size_t)nlo), c.host(idx_minor_upper, (size_t)nup)};
+    const int* is[2] = {c.host(idx_minor_scaling_lower, (size_t)nlo), c.host(idx_minor_scaling_upper, (size_t)nup)};
+    const Bool* sd[2] = {c.host(minor_scales_with_density_lower, (size_t)nlo), c.host(minor_scales_with_density_upper, (size_t)nup)};
+    const Bool* sc[2] = {c.host(scale_by_complement_lower, (size_t)nlo), c.host(scale_by_complement_upper, (size_t)nup)};
+    const int nn[2] = {nlo, nup};
+    const int nk2[2] = {*nminorklower_, *nminorkupper_};
+    // Eligibility of the production kernel: every band and every minor interval is made of whole,
+    // 16-aligned chunks of 16 g-points and lies inside one band (true for the g256 / g224
+    // k-distributions), k-offsets are even, at most MAXM intervals per (band, regime).
+    bool ok = (ngpt % GC == 0) && sizeof(Float) == 8 && nbnd <= MAXB;
+    for (int b = 0; b < nbnd; ++b) ok = ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;
+    cache.bands.assign(nbnd > 0 ? nbnd : 1, BandMeta{});
+    for (int r = 0; r < 2 && ok; ++r) {
+      ok = ok && (nn[r] == 0 || nk2[r] % 2 == 0);
+      for (int i = 0; i < nn[r] && ok; ++i) {
+        ok = ok && (ml[r][2 * i] - 1) % GC == 0 && ml[r][2 * i + 1] % GC == 0 && (ks[r][i] - 1) % 2 == 0;
+        int band = -1;
+        for (int b = 0; b < nbnd; ++b)
+          if (ml[r][2 * i] >= bl[2 * b] && ml[r][2 * i + 1] <= bl[2 * b + 1]) band = b;
+        ok = ok && band >= 0;
+        if (!ok) break;
+        BandMeta& bmh = cache.bands[band];
+        if (bmh.cnt[r] >= MAXM) { ok = false; break; }
+        MinorMeta& m = bmh.m[r][bmh.cnt[r]++];  // interval order is preserved (ascending i)
+        m.mS = ml[r][2 * i] - 1; m.mE = ml[r][2 * i + 1] - 1;
+        m.idx_minor = im[r][i]; m.idx_scaling = is[r][i]; m.kstart = ks[r][i] - 1;
+        m.flags = (sd[r][i] ? 1 : 0) | (sc[r][i] ? 2 : 0);
+      }
+    }
+    cache.fast_ok = ok;
+  }
+  auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
+  const bool fast = cache.fast_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 31) &&
+                    al(d_fmajor, 16) && al(d_fminor, 16) && al(d_col_mix, 16) && al(d_jeta, 8);
+
+  // native-layout direct kernel: always correct; the whole call when the fast path does not apply,
+  // otherwise armed only if some column has overlapping regimes (device-side flag)
+  int* plan = (int*)rte::scratch(sizeof(int) * ((size_t)2 * nbnd + (size_t)nbnd * (nlo + nup) + 2));
+  lo.cnt = plan; up.cnt = plan + nbnd;
+  lo.list = plan + 2 * nbnd; up.list = plan + 2 * nbnd + (size_t)nbnd * nlo;
+  TauArgs a;
+  a.ncol = ncol; a.nlay = nlay; a.ngpt = ngpt; a.neta = neta; a.npres = npres; a.ntemp = ntemp;
+  a.idx_h2o = *idx_h2o_;
+  a.gpoint_flavor = d_gpoint_flavor; a.band_lims_gpt = d_band_lims;
+  a.kmajor = d_kmajor; a.lower = lo; a.upper = up;
+  a.lim = lim; a.tropo = d_tropo; a.col_mix = d_col_mix; a.fmajor = d_fmajor; a.fminor = d_fminor;
+  a.play = d_play; a.tlay = d_tlay; a.col_gas = d_col_gas; a.jeta = d_jeta; a.jtemp = d_jtemp; a.jpress = d_jpress;
+  a.tau = d_tau;
+  a.run_if = fast ? overlap : nullptr;
+  {
+    rte::ProfScope p(fast ? "tau_absorption_fallback" : "tau_absorption_kernel");
+    hipLaunchKernelGGL(plan_minor_kernel, dim3(1), dim3(RTE_WAVE), 0, st, nbnd, d_band_lims, nlo, lo.limits,
+                       (int*)lo.cnt, (int*)lo.list);
+    hipLaunchKernelGGL(plan_minor_kernel, dim3(1), dim3(RTE_WAVE), 0, st, nbnd, d_band_lims, nup, up.limits,
+                       (int*)up.cnt, (int*)up.list);
+  }
+  if (!fast) {
+    rte::ProfScope p("tau_absorption_kernel");
+    const size_t tiles = (size_t)cdiv(ncol, 256) * nlay * nbnd;
+    hipLaunchKernelGGL(tau_absorption_kernel, dim3((unsigned)(tiles < 1048576 ? tiles : 1048576)), dim3(256), 0, st, a,
+                       nbnd);
+    return;
+  }
+  // ---- production path: g-fastest copies of the three tables (scratch, this call only)
+  const int TE = ntemp * neta, nkl = *nminorklower_, nku = *nminorkupper_;
+  Float* kmaj_g = (Float*)rte::scratch(sizeof(Float) * tn * (npres + 1) * ngpt);
+  Float* klo_g = (Float*)rte::scratch(sizeof(Float) * tn * (nkl > 0 ? nkl : 1));
+  Float* kup_g = (Float*)rte::scratch(sizeof(Float) * tn * (nku > 0 ? nku : 1));
+  BandMeta* d_bm = (BandMeta*)rte::scratch(sizeof(BandMeta) * nbnd);
+  {
+    rte::ProfScope p("relayout_gfast_kernel");
+    HIP_CHECK(hipMemcpyAsync(d_bm, cache.bands.data(), sizeof(BandMeta) * nbnd, hipMemcpyHostToDevice, st));
+    const size_t tile_bytes = sizeof(Float) * TE * 33;
+    hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(ngpt, 32), npres + 1), dim3(256), tile_bytes, st, TE,
+                       npres + 1, ngpt, d_kmajor, kmaj_g);
+    if (nkl > 0)
+      hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(nkl, 32), 1), dim3(256), tile_bytes, st, TE, 1, nkl, lo.kminor,
+                         klo_g);
+    if (nku > 0)
+      hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(nku, 32), 1), dim3(256), tile_bytes, st, TE, 1, nku, up.kminor,
+                         kup_g);
+  }
+  TauV5 v;
+  v.ncol = ncol; v.nlay = nlay; v.ngpt = ngpt; v.nbnd = nbnd; v.ntemp = ntemp; v.TE = TE; v.idx_h2o = *idx_h2o_;
+  v.nk_lo = nkl; v.nk_up = nku;
+  v.band_lims = d_band_lims; v.gpoint_flavor = d_gpoint_flavor; v.bmeta = d_bm;
+  v.kmaj = kmaj_g; v.klo = klo_g; v.kup = kup_g;
+  v.lim = lim; v.jeta = d_jeta; v.jtemp = d_jtemp; v.jpress = d_jpress; v.tropo = d_tropo;
+  v.col_mix = d_col_mix; v.fmajor = d_fmajor; v.fminor = d_fminor; v.play = d_play; v.tlay = d_tlay;
+  v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap;
+  constexpr int BS = 256;
+  const size_t wl_cap = (size_t)cdiv(ncol, BS) * nlay * nbnd;
+  v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
+  HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
+  {
+    rte::ProfScope p("tau_absorption_kernel");
+    hipLaunchKernelGGL((tau_absorption_v7_kernel<BS>), dim3(cdiv(ncol, BS), nlay), dim3(BS), sizeof(BandMeta) * nbnd, st,
+                       v);
+  }
+  {
+    // runs only when *overlap != 0 (some column's lower and upper layer ranges intersect)
+    rte::ProfScope p("tau_absorption_fallback");
+    hipLaunchKernelGGL(tau_absorption_kernel, dim3(2048), dim3(256), 0, st, a, nbnd);
+    // tiles whose LUT bounding box exceeded the LDS slab
+    TauArgs aw = a;
+    aw.run_if = nullptr;
+    hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(4096), dim3(256), 0, st, aw, (const int*)v.worklist);
+  }
 }
 
 void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* nbnd_,
