@@ -379,6 +379,18 @@ struct TauV5 {
   int* worklist;       // [0] = count, then (tile, layer, band) triples for tau_absorption_worklist_kernel
 };
 
+// wave-wide min / max by butterfly shuffles (LDS atomics on one address serialise lane by lane)
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
 struct BandIn {  // flavor-dependent inputs of one band for one column, prefetched one band ahead
   Float2 fm[4], fn[2], cm;
   int je1, je2, em1, em2;
@@ -437,11 +449,16 @@ __global__ void __launch_bounds__(BS, 3) tau_absorption_v7_kernel(TauV5 a) {
   const Float dens = (Float)0.01 * P / T;                                                             // :469
   const Float vmr_fact = (Float)1 / a.col_gas[cl];                                                    // :471
   const Float dry_fact = (Float)1 / ((Float)1 + a.col_gas[cl + (size_t)ncl * a.idx_h2o] * vmr_fact);  // :472
-  if (valid) {
-    atomicMin(&rng[0], jT); atomicMax(&rng[1], jT + 1);
-    atomicMin(&rng[2], jp - 1); atomicMax(&rng[3], jp);
-    if (regime & 1) rng[4] = 1;
-    if (regime & 2) rng[5] = 1;
+  {
+    const int big = 1 << 30;
+    const int a0 = wave_min(valid ? jT : big), a1 = wave_max(valid ? jT + 1 : -1);
+    const int a2 = wave_min(valid ? jp - 1 : big), a3 = wave_max(valid ? jp : -1);
+    const int a4 = wave_max(valid ? (regime & 1) : 0), a5 = wave_max(valid ? (regime & 2) : 0);
+    if ((tid & 63) == 0) {
+      atomicMin(&rng[0], a0); atomicMax(&rng[1], a1); atomicMin(&rng[2], a2); atomicMax(&rng[3], a3);
+      if (a4) rng[4] = 1;
+      if (a5) rng[5] = 1;
+    }
   }
 
   auto load_band = [&](int b, BandIn& in) {
@@ -469,9 +486,10 @@ __global__ void __launch_bounds__(BS, 3) tau_absorption_v7_kernel(TauV5 a) {
   for (int ibnd = 0; ibnd < nbnd; ++ibnd) {
     const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
     int* er = erng[ibnd & 1];
-    if (valid) {
-      atomicMin(&er[0], min(min(cur.je1, cur.je2), min(cur.em1, cur.em2)));
-      atomicMax(&er[1], max(max(cur.je1, cur.je2), max(cur.em1, cur.em2)) + 1);
+    {
+      const int e0 = wave_min(valid ? min(min(cur.je1, cur.je2), min(cur.em1, cur.em2)) : (1 << 30));
+      const int e1 = wave_max(valid ? max(max(cur.je1, cur.je2), max(cur.em1, cur.em2)) + 1 : -1);
+      if ((tid & 63) == 0) { atomicMin(&er[0], e0); atomicMax(&er[1], e1); }
     }
     __syncthreads();  // ranges complete; previous band's compute finished (slab is free)
     const int Tmin = rng[0], nT = rng[1] - rng[0] + 1, Pmin = rng[2], nP = rng[3] - rng[2] + 1;
@@ -727,6 +745,167 @@ planck_source_kernel(int ncol, int nlay, int ngpt, int neta, int npres, int ntem
 #pragma unroll
     for (int j = 0; j < GC; ++j)
       if (g0 + j <= gptE) lev_src[icol + (size_t)ncol * nlay + nclv * (size_t)(g0 + j)] = pf_prev[j] * pl_top;  // :705
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// compute_Planck_source, production kernel: same scheme as tau_absorption_v7_kernel.
+// block = (256 columns, one band) and walks the LAYERS, so the previous layer's Planck fractions
+// stay in registers for the geometric mean at the interface (:699).  Per layer the tile's
+// bounding box of pfrac rows is staged in LDS from the g-fastest table; the band's totplnk column
+// sits in LDS for the whole block.  Interpolation state of layer l+1 is requested while layer l
+// is computed (two-deep: indices two layers ahead, flavor-dependent weights one layer ahead).
+// -------------------------------------------------------------------------------------------
+struct PlanckV7 {
+  int ncol, nlay, ngpt, ntemp, TE, nPlanckTemp, sfc_lay;
+  Float temp_ref_min, totplnk_delta_r;
+  const int *band_lims, *gpoint_flavor, *jeta, *jtemp, *jpress;
+  const Bool* tropo;
+  const Float *pf_g, *totplnk, *fmajor, *tlay, *tlev, *tsfc;
+  Float *sfc_src, *lay_src, *lev_src, *sfc_jac;
+};
+
+template <int BS>
+__global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
+  __shared__ int rng[2][6];  // per layer (ping-pong): Tmin, Tmax, Pmin, Pmax, emin, emax
+  __shared__ Float slab[SLAB_FLOATS];
+  extern __shared__ Float tpl[];  // totplnk(:, ibnd)
+  const int tid = threadIdx.x;
+  const int ibnd = blockIdx.y;
+  const unsigned ncol = a.ncol, nlay = a.nlay;
+  const unsigned ncl = ncol * nlay, nclv = ncol * (nlay + 1);  // host guarantees < 2^31
+  const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nPT = a.nPlanckTemp;
+  const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
+  for (int i = tid; i < nPT; i += BS) tpl[i] = a.totplnk[(size_t)nPT * ibnd + i];
+  if (tid < 12) rng[tid / 6][tid % 6] = (tid % 2 == 0) ? (1 << 30) : -1;
+  __syncthreads();
+  const unsigned icol = blockIdx.x * BS + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  auto planck = [&](Float t) {  // interpolate1D :715-737 on the LDS copy of the band's column
+    const Float val0 = (t - a.temp_ref_min) * a.totplnk_delta_r;
+    const Float frac = val0 - trunc(val0);
+    const int index = min(nPT - 1, max(1, (int)val0 + 1));
+    const Float t0 = tpl[index - 1], t1 = tpl[index];
+    return t0 + frac * (t1 - t0);
+  };
+  const Float pl_sfc = planck(a.tsfc[ic]);
+  const Float pl_sfc1 = planck(a.tsfc[ic] + (Float)1);
+
+  struct Idx { int itropo, jT, jp; Float tlay, tlev; };
+  struct Wts { Float2 fm[4]; int je1, je2; };
+  auto load_idx = [&](unsigned l, Idx& x) {
+    const unsigned cl = ic + ncol * l;
+    x.itropo = a.tropo[cl] ? 0 : 1;
+    x.jT = a.jtemp[cl];
+    x.jp = a.jpress[cl] + x.itropo + 1;
+    x.tlay = a.tlay[cl];
+    x.tlev = a.tlev[cl];
+  };
+  auto load_wts = [&](unsigned l, const Idx& x, Wts& w) {
+    const unsigned cl = ic + ncol * l;
+    const int iflav = a.gpoint_flavor[x.itropo + 2 * gptS] - 1;
+    const size_t clf = cl + (size_t)ncl * iflav;
+    const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.fm[i] = fmp[i];
+    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
+    w.je1 = je.x; w.je2 = je.y;
+  };
+  Idx x0, x1;   // layers l and l+1
+  Wts w0;       // layer l
+  load_idx(0, x0);
+  load_idx(min(1u, nlay - 1), x1);
+  load_wts(0, x0, w0);
+
+  for (int g0 = gptS; g0 <= gptE; g0 += GC) {  // host guarantees whole, 16-aligned chunks (one pass per 16 g)
+    if (g0 != gptS) {  // restart the layer walk for the next chunk of a wide band
+      load_idx(0, x0); load_idx(min(1u, nlay - 1), x1); load_wts(0, x0, w0);
+    }
+    Float prev[GC];
+#pragma unroll
+    for (int j = 0; j < GC; ++j) prev[j] = 0;
+    for (unsigned l = 0; l < nlay; ++l) {
+      int* r = rng[l & 1];
+      {
+        const int big = 1 << 30;
+        const int a0 = wave_min(valid ? x0.jT : big), a1 = wave_max(valid ? x0.jT + 1 : -1);
+        const int a2 = wave_min(valid ? x0.jp - 1 : big), a3 = wave_max(valid ? x0.jp : -1);
+        const int a4 = wave_min(valid ? min(w0.je1, w0.je2) : big), a5 = wave_max(valid ? max(w0.je1, w0.je2) + 1 : -1);
+        if ((tid & 63) == 0) {
+          atomicMin(&r[0], a0); atomicMax(&r[1], a1); atomicMin(&r[2], a2); atomicMax(&r[3], a3);
+          atomicMin(&r[4], a4); atomicMax(&r[5], a5);
+        }
+      }
+      __syncthreads();  // ranges complete; previous layer's compute finished (slab is free)
+      const int Tmin = r[0], nT = r[1] - r[0] + 1, Pmin = r[2], nP = r[3] - r[2] + 1, emin = r[4], nE = r[5] - r[4] + 1;
+      const int rows = nP * nT * nE;
+      const bool use_lds = rows * RS <= SLAB_FLOATS;
+      if (tid < 6) rng[(l + 1) & 1][tid] = (tid % 2 == 0) ? (1 << 30) : -1;
+      if (use_lds) {
+        for (int idx = tid; idx < rows * (GC / 2); idx += BS) {
+          const int j = idx & 7, rr = idx >> 3;
+          const int e = rr % nE, rest = rr / nE, t_l = rest % nT, p_l = rest / nT;
+          const Float2 v = *reinterpret_cast<const Float2*>(
+              a.pf_g + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
+          slab[rr * RS + 2 * j] = v.x;
+          slab[rr * RS + 2 * j + 1] = v.y;
+        }
+      }
+      // this layer's values into locals, then request the following layers' inputs
+      const Float f0 = w0.fm[0].x, f1 = w0.fm[0].y, f2 = w0.fm[1].x, f3 = w0.fm[1].y, f4 = w0.fm[2].x, f5 = w0.fm[2].y,
+                  f6 = w0.fm[3].x, f7 = w0.fm[3].y;
+      const int je1 = w0.je1, je2 = w0.je2, jT = x0.jT, jp = x0.jp;
+      const Float tl = x0.tlay, tv = x0.tlev;
+      x0 = x1;
+      if (l + 1 < nlay) load_wts(l + 1, x0, w0);
+      if (l + 2 < nlay) load_idx(l + 2, x1);
+      __syncthreads();
+      if (!valid) continue;
+      const Float pl_lay = planck(tl), pl_lev = planck(tv);
+      const unsigned cl = ic + ncol * l;
+      Float* lay = a.lay_src + cl + (size_t)ncl * g0;
+      Float* lev = a.lev_src + (ic + ncol * l) + (size_t)nclv * g0;
+      const Float* A0;
+      const Float* B0;
+      size_t sE, sP;
+      if (use_lds) {
+        A0 = slab + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS;
+        B0 = slab + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
+        sE = RS; sP = (size_t)nT * nE * RS;
+      } else {  // tile too heterogeneous for the slab: same arithmetic from the g-fastest table
+        A0 = a.pf_g + ((size_t)((jp - 2) * TE + (je1 - 1) * ntemp + (jT - 1)) * ngpt + g0);
+        B0 = a.pf_g + ((size_t)((jp - 2) * TE + (je2 - 1) * ntemp + jT) * ngpt + g0);
+        sE = (size_t)ntemp * ngpt; sP = (size_t)TE * ngpt;
+      }
+      const bool sfc = (int)l == a.sfc_lay - 1;
+#pragma unroll
+      for (int j = 0; j < GC; ++j) {
+        // interpolate3D_byflav with scaling (1,1), :791-801
+        Float pf = f0 * A0[j];
+        pf = fma(f1, A0[sE + j], pf);
+        pf = fma(f2, A0[sP + j], pf);
+        pf = fma(f3, A0[sP + sE + j], pf);
+        Float pg = f4 * B0[j];
+        pg = fma(f5, B0[sE + j], pg);
+        pg = fma(f6, B0[sP + j], pg);
+        pg = fma(f7, B0[sP + sE + j], pg);
+        pf = pf + pg;
+        lay[(size_t)ncl * j] = pf * pl_lay;                                  // :674
+        lev[(size_t)nclv * j] = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;  // :695,:699
+        if (sfc) {                                                           // :651-653
+          a.sfc_src[ic + (size_t)ncol * (g0 + j)] = pf * pl_sfc;
+          a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = pf * (pl_sfc1 - pl_sfc);
+        }
+        prev[j] = pf;
+      }
+    }
+    if (valid) {
+      const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
+#pragma unroll
+      for (int j = 0; j < GC; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
+    }
+    __syncthreads();
   }
 }
 
@@ -1046,12 +1225,47 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   Float* d_lev_src = c.out(lev_src, (size_t)ncol * (nlay + 1) * ngpt);
   Float* d_sfc_jac = c.out(sfc_source_Jac, (size_t)ncol * ngpt);
   const Float totplnk_delta_r = (Float)1 / *totplnk_delta;  // :636
+  hipStream_t st = rte::stream();
+  // production kernel: 16-aligned whole-chunk bands (checked once per table pointer), aligned inputs
+  static const void* bl_key = nullptr;
+  static int bl_n = -1, bl_epoch = -1;
+  static bool bl_ok = false;
+  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch) {
+    const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
+    bl_ok = (ngpt % GC == 0) && sizeof(Float) == 8;
+    for (int b = 0; b < nbnd; ++b) bl_ok = bl_ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;
+    bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = g_plan_epoch;
+  }
+  auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
+  const bool fast = bl_ok && ncol >= 512 && !g_tau_force_direct && (size_t)ncol * (nlay + 1) < ((size_t)1 << 31) &&
+                    al(d_fmajor, 16) && al(d_jeta, 8);
+  if (!fast) {
+    rte::ProfScope p("planck_source_kernel");
+    dim3 grid(cdiv(ncol, 256), nbnd), block(256);
+    hipLaunchKernelGGL(planck_source_kernel, grid, block, 0, st, ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp,
+                       d_tlay, d_tlev, d_tsfc, *sfc_lay_, d_fmajor, d_jeta, d_tropo, d_jtemp, d_jpress, d_band_lims,
+                       d_pfracin, *temp_ref_min, totplnk_delta_r, d_totplnk, d_gpoint_flavor, d_sfc_src, d_lay_src,
+                       d_lev_src, d_sfc_jac);
+    return;
+  }
+  const int TE = ntemp * neta;
+  Float* pf_g = (Float*)rte::scratch(sizeof(Float) * (size_t)TE * (npres + 1) * ngpt);
+  {
+    rte::ProfScope p("relayout_gfast_kernel");
+    hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(ngpt, 32), npres + 1), dim3(256), sizeof(Float) * TE * 33, st,
+                       TE, npres + 1, ngpt, d_pfracin, pf_g);
+  }
+  PlanckV7 v;
+  v.ncol = ncol; v.nlay = nlay; v.ngpt = ngpt; v.ntemp = ntemp; v.TE = TE; v.nPlanckTemp = nPlanckTemp;
+  v.sfc_lay = *sfc_lay_; v.temp_ref_min = *temp_ref_min; v.totplnk_delta_r = totplnk_delta_r;
+  v.band_lims = d_band_lims; v.gpoint_flavor = d_gpoint_flavor; v.jeta = d_jeta; v.jtemp = d_jtemp;
+  v.jpress = d_jpress; v.tropo = d_tropo; v.pf_g = pf_g; v.totplnk = d_totplnk; v.fmajor = d_fmajor;
+  v.tlay = d_tlay; v.tlev = d_tlev; v.tsfc = d_tsfc;
+  v.sfc_src = d_sfc_src; v.lay_src = d_lay_src; v.lev_src = d_lev_src; v.sfc_jac = d_sfc_jac;
   rte::ProfScope p("planck_source_kernel");
-  dim3 grid(cdiv(ncol, 256), nbnd), block(256);
-  hipLaunchKernelGGL(planck_source_kernel, grid, block, 0, rte::stream(), ncol, nlay, ngpt, neta, npres, ntemp,
-                     nPlanckTemp, d_tlay, d_tlev, d_tsfc, *sfc_lay_, d_fmajor, d_jeta, d_tropo, d_jtemp,
-                     d_jpress, d_band_lims, d_pfracin, *temp_ref_min, totplnk_delta_r, d_totplnk,
-                     d_gpoint_flavor, d_sfc_src, d_lay_src, d_lev_src, d_sfc_jac);
+  constexpr int BS = 256;
+  hipLaunchKernelGGL((planck_source_v7_kernel<BS>), dim3(cdiv(ncol, BS), nbnd), dim3(BS), sizeof(Float) * nPlanckTemp, st,
+                     v);
 }
 
 }  // extern "C"
