@@ -407,7 +407,7 @@ constexpr int SLAB_FLOATS = 5632;  // 44 KB of LUT slab per block; tiles that ne
 // tools/membench.hip).  Inputs of band b+1 are requested before band b is computed.  A tile whose
 // bounding box does not fit the slab is appended to a worklist for tau_absorption_kernel.
 template <int BS>
-__global__ void __launch_bounds__(BS, 3) tau_absorption_v7_kernel(TauV5 a) {
+__global__ void __launch_bounds__(BS, 2) tau_absorption_v7_kernel(TauV5 a) {
   __shared__ int rng[6];      // Tmin, Tmax, Pmin, Pmax, has_lower, has_upper
   __shared__ int erng[2][2];  // eta range of the band (ping-pong between bands)
   __shared__ Float slab[SLAB_FLOATS];
@@ -768,7 +768,8 @@ struct PlanckV7 {
 template <int BS>
 __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
   __shared__ int rng[2][6];  // per layer (ping-pong): Tmin, Tmax, Pmin, Pmax, emin, emax
-  __shared__ Float slab[SLAB_FLOATS];
+  constexpr int PSLAB = 8704;  // 68 KB: no minor tables here and 2 blocks per CU, so the slab can be larger
+  __shared__ Float slab[PSLAB];
   extern __shared__ Float tpl[];  // totplnk(:, ibnd)
   const int tid = threadIdx.x;
   const int ibnd = blockIdx.y;
@@ -840,7 +841,7 @@ __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
       __syncthreads();  // ranges complete; previous layer's compute finished (slab is free)
       const int Tmin = r[0], nT = r[1] - r[0] + 1, Pmin = r[2], nP = r[3] - r[2] + 1, emin = r[4], nE = r[5] - r[4] + 1;
       const int rows = nP * nT * nE;
-      const bool use_lds = rows * RS <= SLAB_FLOATS;
+      const bool use_lds = rows * RS <= PSLAB;
       if (tid < 6) rng[(l + 1) & 1][tid] = (tid % 2 == 0) ? (1 << 30) : -1;
       if (use_lds) {
         for (int idx = tid; idx < rows * (GC / 2); idx += BS) {
@@ -866,38 +867,38 @@ __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
       const unsigned cl = ic + ncol * l;
       Float* lay = a.lay_src + cl + (size_t)ncl * g0;
       Float* lev = a.lev_src + (ic + ncol * l) + (size_t)nclv * g0;
-      const Float* A0;
-      const Float* B0;
-      size_t sE, sP;
-      if (use_lds) {
-        A0 = slab + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS;
-        B0 = slab + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
-        sE = RS; sP = (size_t)nT * nE * RS;
-      } else {  // tile too heterogeneous for the slab: same arithmetic from the g-fastest table
-        A0 = a.pf_g + ((size_t)((jp - 2) * TE + (je1 - 1) * ntemp + (jT - 1)) * ngpt + g0);
-        B0 = a.pf_g + ((size_t)((jp - 2) * TE + (je2 - 1) * ntemp + jT) * ngpt + g0);
-        sE = (size_t)ntemp * ngpt; sP = (size_t)TE * ngpt;
-      }
       const bool sfc = (int)l == a.sfc_lay - 1;
+      // one body, instantiated separately for LDS and for global rows (a merged pointer would be a
+      // generic one and every gather a slow flat load)
+      auto body = [&](const Float* __restrict__ A0, const Float* __restrict__ B0, const size_t sE, const size_t sP) {
 #pragma unroll
-      for (int j = 0; j < GC; ++j) {
-        // interpolate3D_byflav with scaling (1,1), :791-801
-        Float pf = f0 * A0[j];
-        pf = fma(f1, A0[sE + j], pf);
-        pf = fma(f2, A0[sP + j], pf);
-        pf = fma(f3, A0[sP + sE + j], pf);
-        Float pg = f4 * B0[j];
-        pg = fma(f5, B0[sE + j], pg);
-        pg = fma(f6, B0[sP + j], pg);
-        pg = fma(f7, B0[sP + sE + j], pg);
-        pf = pf + pg;
-        lay[(size_t)ncl * j] = pf * pl_lay;                                  // :674
-        lev[(size_t)nclv * j] = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;  // :695,:699
-        if (sfc) {                                                           // :651-653
-          a.sfc_src[ic + (size_t)ncol * (g0 + j)] = pf * pl_sfc;
-          a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = pf * (pl_sfc1 - pl_sfc);
+        for (int j = 0; j < GC; ++j) {
+          // interpolate3D_byflav with scaling (1,1), :791-801
+          Float pf = f0 * A0[j];
+          pf = fma(f1, A0[sE + j], pf);
+          pf = fma(f2, A0[sP + j], pf);
+          pf = fma(f3, A0[sP + sE + j], pf);
+          Float pg = f4 * B0[j];
+          pg = fma(f5, B0[sE + j], pg);
+          pg = fma(f6, B0[sP + j], pg);
+          pg = fma(f7, B0[sP + sE + j], pg);
+          pf = pf + pg;
+          lay[(size_t)ncl * j] = pf * pl_lay;                                  // :674
+          lev[(size_t)nclv * j] = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;  // :695,:699
+          if (sfc) {                                                           // :651-653
+            a.sfc_src[ic + (size_t)ncol * (g0 + j)] = pf * pl_sfc;
+            a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = pf * (pl_sfc1 - pl_sfc);
+          }
+          prev[j] = pf;
         }
-        prev[j] = pf;
+      };
+      if (use_lds) {
+        body(slab + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS,
+             slab + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS, (size_t)RS, (size_t)nT * nE * RS);
+      } else {  // tile too heterogeneous for the slab: same arithmetic from the g-fastest table
+        body(a.pf_g + ((size_t)((jp - 2) * TE + (je1 - 1) * ntemp + (jT - 1)) * ngpt + g0),
+             a.pf_g + ((size_t)((jp - 2) * TE + (je2 - 1) * ntemp + jT) * ngpt + g0), (size_t)ntemp * ngpt,
+             (size_t)TE * ngpt);
       }
     }
     if (valid) {
