@@ -17,6 +17,8 @@
 //     a second sweep needs are parked in a device scratch slab, g-points processed in chunks.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -37,6 +39,7 @@ __device__ constexpr Float kPi = (Float)3.14159265358979323846264338327950288;
 // at level ilay and ilay+1 (array order); returns the sources emitted toward increasing / decreasing index
 __device__ __forceinline__ void lw_source_layer(Float tau_loc, Float trans, Float lay, Float lev_lo, Float lev_hi,
                                                 Float& src_inc, Float& src_dec) {
+#pragma clang fp contract(fast)  // well-conditioned sums: a*b+c may fuse (a few ulp from the reference)
   const Float tau_thresh = sqrt(sqrt((Float)RTE_EPS));
   Float fact;
   if (tau_loc > tau_thresh)
@@ -236,16 +239,20 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, int igpt, int c, int nco
   const Float* lev = lev_source_ + c + nclv * igpt;
 #pragma unroll
   for (int i = 0; i < L; ++i) {
-    // clamp instead of predicating: out-of-segment slots re-read a valid layer and are never used
+    // out-of-segment slots (only the last segment can have them) re-read a valid layer and are then
+    // made NEUTRAL: tau = 0, sources = 0  ->  trans = 1, layer sources = 0, so the sweeps need no
+    // predication and the slot after the last real layer naturally receives the surface values
     const int p = p0 + min(i, np - 1);
     const int ilay = top_at_1 ? p : nlay - 1 - p;
-    t.tau[i] = tau[(size_t)ncol * ilay];
-    t.lay[i] = lay[(size_t)ncol * ilay];
+    const Float tv = tau[(size_t)ncol * ilay], lv = lay[(size_t)ncol * ilay];
+    t.tau[i] = i < np ? tv : (Float)0;
+    t.lay[i] = i < np ? lv : (Float)0;
   }
 #pragma unroll
   for (int i = 0; i <= L; ++i) {
     const int p = p0 + min(i, np);
-    t.lev[i] = lev[(size_t)ncol * (top_at_1 ? p : nlay - p)];
+    const Float lv = lev[(size_t)ncol * (top_at_1 ? p : nlay - p)];
+    t.lev[i] = i <= np ? lv : (Float)0;
   }
   t.D = Dsec[cg];
   t.emis = sfc_emis[cg];
@@ -262,9 +269,12 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
                      const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
                      const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
                      Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac) {
+#pragma clang fp contract(fast)  // this kernel is fp64-issue bound: fuse the recurrences' a*b+c
   extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][S][64]
   const int lane = threadIdx.x & 63;
-  const int s = threadIdx.x >> 6;
+  // the wave index is wave-uniform: tell the compiler, so layer offsets live in SGPRs and every load is
+  // (uniform 64-bit base) + (32-bit lane offset) instead of per-lane 64-bit address arithmetic
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int icol = blockIdx.x * 64 + lane;
   const bool active = icol < ncol;
   const int c = active ? icol : ncol - 1;  // clamp: inactive lanes compute on a valid column, never store
@@ -281,40 +291,28 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 #pragma unroll
   for (int i = 0; i <= L; ++i) { acc_dn[i] = 0; acc_up[i] = 0; if (do_jac) acc_j[i] = 0; }
 
-  SegTile<L> cur;
-  seg_load<L, do_jac>(cur, g_begin, c, ncol, nlay, p0, np, top_at_1, Dsec, tau_, lay_source_, lev_source_, sfc_emis,
-                      sfc_src, inc_flux, sfc_srcJac);
-  int buf = 0;
-  for (int igpt = g_begin; igpt < g_end; ++igpt, buf ^= 1) {
-    // software prefetch: the next g-point's loads are in flight while this one is computed
-    SegTile<L> nxt;
-    seg_load<L, do_jac>(nxt, min(igpt + 1, g_end - 1), c, ncol, nlay, p0, np, top_at_1, Dsec, tau_, lay_source_,
-                        lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac);
+  // One g-point of work on tile `cur` (FULL: the segment has all L layers, no predication needed)
+  // One g-point of work on tile `cur` (padded slots are neutral, see seg_load: no predication)
+  auto process = [&](const SegTile<L>& cur, int buf) {
+#pragma clang fp contract(fast)
     Float t[L], sd[L], su[L];
     // ---- pass 1: layer transmissivities and sources (:180-190), segment composites
     Float Td = 1, Sd = 0;
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-      if (i < np) {
-        const Float tau_loc = cur.tau[i] * cur.D;
-        const Float tr = exp(-tau_loc);
-        Float s_toward_bot, s_toward_top;
-        // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo): "toward bottom" uses the
-        // bottom level source, "toward top" the top level source
-        lw_source_layer(tau_loc, tr, cur.lay[i], cur.lev[i], cur.lev[i + 1], s_toward_bot, s_toward_top);
-        t[i] = tr;
-        sd[i] = s_toward_bot;
-        su[i] = s_toward_top;
-        Sd = tr * Sd + s_toward_bot;
-        Td = Td * tr;
-      } else {
-        t[i] = 1; sd[i] = 0; su[i] = 0;
-      }
+      const Float tau_loc = cur.tau[i] * cur.D;
+      const Float tr = exp(-tau_loc);
+      // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo): "toward bottom" uses the
+      // bottom level source, "toward top" the top level source
+      lw_source_layer(tau_loc, tr, cur.lay[i], cur.lev[i], cur.lev[i + 1], sd[i], su[i]);
+      t[i] = tr;
+      Sd = tr * Sd + sd[i];
+      Td = Td * tr;
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (register pressure) to 2 layers
     }
     Float Su = 0;
 #pragma unroll
-    for (int i = L - 1; i >= 0; --i)
-      if (i < np) Su = t[i] * Su + su[i];
+    for (int i = L - 1; i >= 0; --i) Su = t[i] * Su + su[i];
     // ---- exchange segment composites
     Float* X = lds + (size_t)buf * 3 * S * 64;
     X[(0 * S + s) * 64 + lane] = Td;
@@ -330,35 +328,44 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     const Float u_sfc = r * ((Float)1 - cur.emis) + cur.emis * cur.ssrc;  // :198-200
     Float u = u_sfc;
     Float jv = do_jac ? cur.emis * cur.sjac : (Float)0;
-    const Float j_sfc = jv;
     for (int q = S - 1; q > s; --q) {
       const Float Tq = X[(0 * S + q) * 64 + lane];
       u = Tq * u + X[(2 * S + q) * 64 + lane];
       jv = Tq * jv;
     }
-    // ---- pass 2: down
+    // the level below the segment's last slot (used only by a FULL last segment: the surface)
+    acc_up[L] += u;
+    if (do_jac) acc_j[L] += jv;
+    // ---- pass 2: down; slot i is the level at the top of layer i.  In a partial last segment the
+    // neutral slots i >= np all see the surface radiance, so slot np receives the surface value.
     r = r_in;
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-      if (i < np) {
-        acc_dn[i] += r;
-        r = t[i] * r + sd[i];
-      }
+      acc_dn[i] += r;
+      r = t[i] * r + sd[i];
     }
-    if (last) {  // the surface level is slot np of the last segment
-#pragma unroll
-      for (int i = 0; i <= L; ++i)
-        if (i == np) { acc_dn[i] += r; acc_up[i] += u_sfc; if (do_jac) acc_j[i] += j_sfc; }
-    }
-    // ---- pass 2: up (+ Jacobian, :729-743)
+    acc_dn[L] += r;
+    // ---- pass 2: up (+ Jacobian, :729-743); neutral slots leave u at the surface value, which is
+    // exactly what slot np of a partial last segment must accumulate
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) {
-      if (i < np) {
-        u = t[i] * u + su[i];
-        acc_up[i] += u;
-        if (do_jac) { jv = t[i] * jv; acc_j[i] += jv; }
-      }
+      u = t[i] * u + su[i];
+      acc_up[i] += u;
+      if (do_jac) { jv = t[i] * jv; acc_j[i] += jv; }
     }
+  };
+  auto load = [&](SegTile<L>& tile, int igpt) {
+    seg_load<L, do_jac>(tile, min(igpt, g_end - 1), c, ncol, nlay, p0, np, top_at_1, Dsec, tau_, lay_source_, lev_source_,
+                        sfc_emis, sfc_src, inc_flux, sfc_srcJac);
+  };
+  // software prefetch: the next g-point's loads are in flight while this one is computed
+  SegTile<L> cur;
+  load(cur, g_begin);
+  int buf = 0;
+  for (int igpt = g_begin; igpt < g_end; ++igpt, buf ^= 1) {
+    SegTile<L> nxt;
+    load(nxt, igpt + 1);
+    process(cur, buf);
     cur = nxt;
   }
   // ---- partial broadband for this g-group: (ncol, nlev, ngroups)
