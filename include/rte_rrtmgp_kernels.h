@@ -251,6 +251,100 @@ void set_to_scalar_3D(const int* ni, const int* nj, const int* nk, Float* array,
 void set_to_scalar_4D(const int* ni, const int* nj, const int* nk, const int* nl, Float* array,
                       const Float* value);
 
+/* ------------------------------------------------------------------------
+ * Optical-properties arithmetic (reference rte/kernels/api/mo_optical_props_kernels.F90;
+ * default impl rte/kernels/mo_optical_props_kernels.F90:44-778).  Operand 1 is modified in place;
+ * operand 2 is on g-points, or on bands for the *_bybnd variants (gpt_lims = (2,nbnd), 1-based).
+ * ---------------------------------------------------------------------- */
+void rte_delta_scale_2str_f_k(const int* ncol, const int* nlay, const int* ngpt,
+                              Float* tau, Float* ssa, Float* g,   /* (ncol,nlay,ngpt) inout */
+                              const Float* f);                    /* (ncol,nlay,ngpt) */
+void rte_delta_scale_2str_k(const int* ncol, const int* nlay, const int* ngpt,
+                            Float* tau, Float* ssa, Float* g);    /* (ncol,nlay,ngpt) inout */
+void rte_increment_1scalar_by_1scalar(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, const Float* tau2);
+void rte_increment_1scalar_by_2stream(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, const Float* tau2, const Float* ssa2);
+void rte_increment_1scalar_by_nstream(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, const Float* tau2, const Float* ssa2);
+void rte_increment_2stream_by_1scalar(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, Float* ssa1, const Float* tau2);
+void rte_increment_2stream_by_2stream(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, Float* ssa1, Float* g1,
+                                      const Float* tau2, const Float* ssa2, const Float* g2);
+void rte_increment_2stream_by_nstream(const int* ncol, const int* nlay, const int* ngpt, const int* nmom2,
+                                      Float* tau1, Float* ssa1, Float* g1,
+                                      const Float* tau2, const Float* ssa2,
+                                      const Float* p2);           /* (nmom2,ncol,nlay,ngpt) */
+void rte_increment_nstream_by_1scalar(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, Float* ssa1, const Float* tau2);
+void rte_increment_nstream_by_2stream(const int* ncol, const int* nlay, const int* ngpt, const int* nmom1,
+                                      Float* tau1, Float* ssa1,
+                                      Float* p1,                  /* (nmom1,ncol,nlay,ngpt) */
+                                      const Float* tau2, const Float* ssa2, const Float* g2);
+void rte_increment_nstream_by_nstream(const int* ncol, const int* nlay, const int* ngpt,
+                                      const int* nmom1, const int* nmom2,
+                                      Float* tau1, Float* ssa1, Float* p1,
+                                      const Float* tau2, const Float* ssa2, const Float* p2);
+void rte_inc_1scalar_by_1scalar_bybnd(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, const Float* tau2 /* (ncol,nlay,nbnd) */,
+                                      const int* nbnd, const int* gpt_lims);
+void rte_inc_1scalar_by_2stream_bybnd(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, const Float* tau2, const Float* ssa2,
+                                      const int* nbnd, const int* gpt_lims);
+void rte_inc_1scalar_by_nstream_bybnd(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, const Float* tau2, const Float* ssa2,
+                                      const int* nbnd, const int* gpt_lims);
+void rte_inc_2stream_by_1scalar_bybnd(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, Float* ssa1, const Float* tau2,
+                                      const int* nbnd, const int* gpt_lims);
+void rte_inc_2stream_by_2stream_bybnd(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, Float* ssa1, Float* g1,
+                                      const Float* tau2, const Float* ssa2, const Float* g2,
+                                      const int* nbnd, const int* gpt_lims);
+void rte_inc_2stream_by_nstream_bybnd(const int* ncol, const int* nlay, const int* ngpt, const int* nmom2,
+                                      Float* tau1, Float* ssa1, Float* g1,
+                                      const Float* tau2, const Float* ssa2, const Float* p2,
+                                      const int* nbnd, const int* gpt_lims);
+void rte_inc_nstream_by_1scalar_bybnd(const int* ncol, const int* nlay, const int* ngpt,
+                                      Float* tau1, Float* ssa1, const Float* tau2,
+                                      const int* nbnd, const int* gpt_lims);
+void rte_inc_nstream_by_2stream_bybnd(const int* ncol, const int* nlay, const int* ngpt, const int* nmom1,
+                                      Float* tau1, Float* ssa1, Float* p1,
+                                      const Float* tau2, const Float* ssa2, const Float* g2,
+                                      const int* nbnd, const int* gpt_lims);
+void rte_inc_nstream_by_nstream_bybnd(const int* ncol, const int* nlay, const int* ngpt,
+                                      const int* nmom1, const int* nmom2,
+                                      Float* tau1, Float* ssa1, Float* p1,
+                                      const Float* tau2, const Float* ssa2, const Float* p2,
+                                      const int* nbnd, const int* gpt_lims);
+void rte_extract_subset_dim1_3d(const int* ncol, const int* nlay, const int* ngpt,
+                                const Float* array_in,            /* (ncol,nlay,ngpt) */
+                                const int* colS, const int* colE,
+                                Float* array_out);                /* (colE-colS+1,nlay,ngpt) */
+void rte_extract_subset_dim2_4d(const int* nmom, const int* ncol, const int* nlay, const int* ngpt,
+                                const Float* array_in,            /* (nmom,ncol,nlay,ngpt) */
+                                const int* colS, const int* colE,
+                                Float* array_out);                /* (nmom,colE-colS+1,nlay,ngpt) */
+void rte_extract_subset_absorption_tau(const int* ncol, const int* nlay, const int* ngpt,
+                                       const Float* tau_in, const Float* ssa_in,
+                                       const int* colS, const int* colE,
+                                       Float* tau_out);           /* (colE-colS+1,nlay,ngpt) */
+
+/* ------------------------------------------------------------------------
+ * Cloud optics from look-up tables (reference rrtmgp/kernels/api/mo_cloud_optics_rrtmgp_kernels.F90;
+ * default impl rrtmgp/kernels/mo_cloud_optics_rrtmgp_kernels.F90:24-65)
+ * ---------------------------------------------------------------------- */
+void rrtmgp_compute_cld_from_table(const int* ncol, const int* nlay, const int* ngpt,
+                                   const Bool* mask,              /* (ncol,nlay) */
+                                   const Float* lwp,              /* (ncol,nlay) */
+                                   const Float* re,               /* (ncol,nlay) */
+                                   const int* nsteps, const Float* step_size, const Float* offset,
+                                   const Float* tau_table,        /* (nsteps,ngpt) */
+                                   const Float* ssa_table,        /* (nsteps,ngpt) */
+                                   const Float* asy_table,        /* (nsteps,ngpt) */
+                                   Float* tau, Float* taussa, Float* taussag); /* (ncol,nlay,ngpt) */
+
 #ifdef __cplusplus
 }
 #endif

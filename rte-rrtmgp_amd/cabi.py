@@ -84,6 +84,37 @@ SIGNATURES: Dict[str, List[Arg]] = {
     "set_to_scalar_2D": _sig("i:ni i:nj a:array f:value"),
     "set_to_scalar_3D": _sig("i:ni i:nj i:nk a:array f:value"),
     "set_to_scalar_4D": _sig("i:ni i:nj i:nk i:nl a:array f:value"),
+    "rte_delta_scale_2str_f_k": _sig("i:ncol i:nlay i:ngpt a:tau a:ssa a:g a:f"),
+    "rte_delta_scale_2str_k": _sig("i:ncol i:nlay i:ngpt a:tau a:ssa a:g"),
+    "rte_increment_1scalar_by_1scalar": _sig("i:ncol i:nlay i:ngpt a:tau1 a:tau2"),
+    "rte_increment_1scalar_by_2stream": _sig("i:ncol i:nlay i:ngpt a:tau1 a:tau2 a:ssa2"),
+    "rte_increment_1scalar_by_nstream": _sig("i:ncol i:nlay i:ngpt a:tau1 a:tau2 a:ssa2"),
+    "rte_increment_2stream_by_1scalar": _sig("i:ncol i:nlay i:ngpt a:tau1 a:ssa1 a:tau2"),
+    "rte_increment_2stream_by_2stream": _sig("i:ncol i:nlay i:ngpt a:tau1 a:ssa1 a:g1 a:tau2 a:ssa2 a:g2"),
+    "rte_increment_2stream_by_nstream": _sig("i:ncol i:nlay i:ngpt i:nmom2 a:tau1 a:ssa1 a:g1 a:tau2 a:ssa2 a:p2"),
+    "rte_increment_nstream_by_1scalar": _sig("i:ncol i:nlay i:ngpt a:tau1 a:ssa1 a:tau2"),
+    "rte_increment_nstream_by_2stream": _sig("i:ncol i:nlay i:ngpt i:nmom1 a:tau1 a:ssa1 a:p1 a:tau2 a:ssa2 a:g2"),
+    "rte_increment_nstream_by_nstream": _sig(
+        "i:ncol i:nlay i:ngpt i:nmom1 i:nmom2 a:tau1 a:ssa1 a:p1 a:tau2 a:ssa2 a:p2"),
+    "rte_inc_1scalar_by_1scalar_bybnd": _sig("i:ncol i:nlay i:ngpt a:tau1 a:tau2 i:nbnd a:gpt_lims"),
+    "rte_inc_1scalar_by_2stream_bybnd": _sig("i:ncol i:nlay i:ngpt a:tau1 a:tau2 a:ssa2 i:nbnd a:gpt_lims"),
+    "rte_inc_1scalar_by_nstream_bybnd": _sig("i:ncol i:nlay i:ngpt a:tau1 a:tau2 a:ssa2 i:nbnd a:gpt_lims"),
+    "rte_inc_2stream_by_1scalar_bybnd": _sig("i:ncol i:nlay i:ngpt a:tau1 a:ssa1 a:tau2 i:nbnd a:gpt_lims"),
+    "rte_inc_2stream_by_2stream_bybnd": _sig(
+        "i:ncol i:nlay i:ngpt a:tau1 a:ssa1 a:g1 a:tau2 a:ssa2 a:g2 i:nbnd a:gpt_lims"),
+    "rte_inc_2stream_by_nstream_bybnd": _sig(
+        "i:ncol i:nlay i:ngpt i:nmom2 a:tau1 a:ssa1 a:g1 a:tau2 a:ssa2 a:p2 i:nbnd a:gpt_lims"),
+    "rte_inc_nstream_by_1scalar_bybnd": _sig("i:ncol i:nlay i:ngpt a:tau1 a:ssa1 a:tau2 i:nbnd a:gpt_lims"),
+    "rte_inc_nstream_by_2stream_bybnd": _sig(
+        "i:ncol i:nlay i:ngpt i:nmom1 a:tau1 a:ssa1 a:p1 a:tau2 a:ssa2 a:g2 i:nbnd a:gpt_lims"),
+    "rte_inc_nstream_by_nstream_bybnd": _sig(
+        "i:ncol i:nlay i:ngpt i:nmom1 i:nmom2 a:tau1 a:ssa1 a:p1 a:tau2 a:ssa2 a:p2 i:nbnd a:gpt_lims"),
+    "rte_extract_subset_dim1_3d": _sig("i:ncol i:nlay i:ngpt a:array_in i:colS i:colE a:array_out"),
+    "rte_extract_subset_dim2_4d": _sig("i:nmom i:ncol i:nlay i:ngpt a:array_in i:colS i:colE a:array_out"),
+    "rte_extract_subset_absorption_tau": _sig("i:ncol i:nlay i:ngpt a:tau_in a:ssa_in i:colS i:colE a:tau_out"),
+    "rrtmgp_compute_cld_from_table": _sig(
+        "i:ncol i:nlay i:ngpt a:mask a:lwp a:re i:nsteps f:step_size f:offset a:tau_table a:ssa_table "
+        "a:asy_table a:tau a:taussa a:taussag"),
 }
 
 

@@ -355,7 +355,6 @@ relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, 
 // -------------------------------------------------------------------------------------------
 constexpr int MAXM = 8;    // minor intervals per (band, regime) handled here; more -> native kernel
 constexpr int MAXB = 32;   // bands
-constexpr int NC = 64;     // columns per block
 
 struct MinorMeta {  // one minor interval
   int mS, mE, idx_minor, idx_scaling, kstart, flags /*1: scales with density, 2: by complement*/;

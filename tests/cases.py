@@ -164,6 +164,7 @@ def run_suite(lib, xp, case: Case, inputs=None, which="all"):
         r = frontend.rte_sw(lib, xp, ncol, nlay, ngpt, case.top_at_1, b["tau"], None, None, mu0, b["toa_src"],
                             None, None, noscat=True)
         grab("swn.", r, ["gpt_flux_dir", "flux_dir"])
+    run_optprops(lib, xp, case, out)
     # array utilities
     z = xp.full((ncol, 3, 2, 2), 7.0)
     lib.zero_array_4D(ncol, 3, 2, 2, z)
@@ -171,6 +172,73 @@ def run_suite(lib, xp, case: Case, inputs=None, which="all"):
     s = xp.empty((ncol, 7))
     lib.set_to_scalar_2D(ncol, 7, s, 2.5)
     out["set2"] = np.array(xp.to_numpy(s))
+    return out
+
+
+def run_optprops(lib, xp, case: Case, out: dict):
+    """Optical-properties arithmetic, cloud look-up-table optics and column subsetting (elementwise
+    kernels of the all-sky path) on small seeded arrays."""
+    rng = np.random.default_rng(case.seed + 555)
+    ncol, nlay, ngpt, nbnd, nm1, nm2 = case.ncol, min(case.nlay, 9), 12, 3, 3, 4
+    lims = xp.asarray(np.array([[1, 5, 9], [4, 8, 12]], dtype=np.int32))
+    A = xp.asarray
+    F = synth.F
+
+    def r3(n3, lo=0.0, hi=1.0):
+        return F(rng.uniform(lo, hi, size=(ncol, nlay, n3)))
+
+    base = {"tau": r3(ngpt, 0, 3), "ssa": r3(ngpt, 0, 0.99), "g": r3(ngpt, -0.5, 0.9),
+            "p": F(rng.uniform(-0.5, 0.9, size=(nm1, ncol, nlay, ngpt)))}
+    for tag, n3 in (("g", ngpt), ("b", nbnd)):  # operand 2 on g-points / on bands
+        op2 = {"tau": r3(n3, 0, 2), "ssa": r3(n3, 0, 0.99), "g": r3(n3, -0.5, 0.9),
+               "p": F(rng.uniform(-0.5, 0.9, size=(nm2, ncol, nlay, n3)))}
+        sfx, extra = ("", ()) if tag == "g" else ("_bybnd", (nbnd, lims))
+        pre = "increment" if tag == "g" else "inc"
+
+        def call(name, scal, arrs):
+            dev = [A(x) if isinstance(x, np.ndarray) else x for x in arrs]
+            getattr(lib, f"rte_{pre}_{name}{sfx}")(ncol, nlay, ngpt, *scal, *dev, *extra)
+            return dev
+
+        d = call("1scalar_by_1scalar", (), [base["tau"].copy(), op2["tau"]]); out[f"op.{tag}.1s1s"] = np.array(xp.to_numpy(d[0]))
+        d = call("1scalar_by_2stream", (), [base["tau"].copy(), op2["tau"], op2["ssa"]]); out[f"op.{tag}.1s2s"] = np.array(xp.to_numpy(d[0]))
+        d = call("1scalar_by_nstream", (), [base["tau"].copy(), op2["tau"], op2["ssa"]]); out[f"op.{tag}.1sns"] = np.array(xp.to_numpy(d[0]))
+        d = call("2stream_by_1scalar", (), [base["tau"].copy(), base["ssa"].copy(), op2["tau"]])
+        out[f"op.{tag}.2s1s.tau"], out[f"op.{tag}.2s1s.ssa"] = (np.array(xp.to_numpy(x)) for x in d[:2])
+        d = call("2stream_by_2stream", (), [base["tau"].copy(), base["ssa"].copy(), base["g"].copy(), op2["tau"], op2["ssa"], op2["g"]])
+        out[f"op.{tag}.2s2s.tau"], out[f"op.{tag}.2s2s.ssa"], out[f"op.{tag}.2s2s.g"] = (np.array(xp.to_numpy(x)) for x in d[:3])
+        d = call("2stream_by_nstream", (nm2,), [base["tau"].copy(), base["ssa"].copy(), base["g"].copy(), op2["tau"], op2["ssa"], op2["p"]])
+        out[f"op.{tag}.2sns.g"] = np.array(xp.to_numpy(d[2]))
+        d = call("nstream_by_1scalar", (), [base["tau"].copy(), base["ssa"].copy(), op2["tau"]])
+        out[f"op.{tag}.ns1s.ssa"] = np.array(xp.to_numpy(d[1]))
+        d = call("nstream_by_2stream", (nm1,), [base["tau"].copy(), base["ssa"].copy(), base["p"].copy(), op2["tau"], op2["ssa"], op2["g"]])
+        out[f"op.{tag}.ns2s.p"], out[f"op.{tag}.ns2s.ssa"] = np.array(xp.to_numpy(d[2])), np.array(xp.to_numpy(d[1]))
+        d = call("nstream_by_nstream", (nm1, nm2), [base["tau"].copy(), base["ssa"].copy(), base["p"].copy(), op2["tau"], op2["ssa"], op2["p"]])
+        out[f"op.{tag}.nsns.p"], out[f"op.{tag}.nsns.tau"] = np.array(xp.to_numpy(d[2])), np.array(xp.to_numpy(d[0]))
+    # delta scaling
+    t, s_, g_ = A(base["tau"].copy()), A(base["ssa"].copy()), A(base["g"].copy())
+    lib.rte_delta_scale_2str_k(ncol, nlay, ngpt, t, s_, g_)
+    out["ds.tau"], out["ds.ssa"], out["ds.g"] = (np.array(xp.to_numpy(x)) for x in (t, s_, g_))
+    t, s_, g_ = A(base["tau"].copy()), A(base["ssa"].copy()), A(base["g"].copy())
+    lib.rte_delta_scale_2str_f_k(ncol, nlay, ngpt, t, s_, g_, A(r3(ngpt, 0, 0.8)))
+    out["dsf.tau"], out["dsf.ssa"], out["dsf.g"] = (np.array(xp.to_numpy(x)) for x in (t, s_, g_))
+    # column subsets (colS..colE, 1-based inclusive)
+    cS, cE = 2, max(2, ncol - 1)
+    nc = cE - cS + 1
+    o = xp.empty((nc, nlay, ngpt)); lib.rte_extract_subset_dim1_3d(ncol, nlay, ngpt, A(base["tau"]), cS, cE, o)
+    out["sub.3d"] = np.array(xp.to_numpy(o))
+    o = xp.empty((nm1, nc, nlay, ngpt)); lib.rte_extract_subset_dim2_4d(nm1, ncol, nlay, ngpt, A(base["p"]), cS, cE, o)
+    out["sub.4d"] = np.array(xp.to_numpy(o))
+    o = xp.empty((nc, nlay, ngpt)); lib.rte_extract_subset_absorption_tau(ncol, nlay, ngpt, A(base["tau"]), A(base["ssa"]), cS, cE, o)
+    out["sub.abs"] = np.array(xp.to_numpy(o))
+    # cloud optics from tables
+    nsteps = 20
+    mask = F(rng.random((ncol, nlay)) < 0.6, np.bool_)
+    lwp, re = F(rng.uniform(0, 80, (ncol, nlay))), F(rng.uniform(2.5, 21.0, (ncol, nlay)))
+    tabs = [F(rng.uniform(0.01, 1.0, (nsteps, ngpt))) for _ in range(3)]
+    outs = [xp.empty((ncol, nlay, ngpt)) for _ in range(3)]
+    lib.rrtmgp_compute_cld_from_table(ncol, nlay, ngpt, A(mask), A(lwp), A(re), nsteps, 1.0, 2.5, *[A(x) for x in tabs], *outs)
+    out["cld.tau"], out["cld.taussa"], out["cld.taussag"] = (np.array(xp.to_numpy(x)) for x in outs)
     return out
 
 

@@ -6,7 +6,7 @@ Run in the build container (needs /root/reference and flang):  python tests/gold
 For every seeded case of tests/cases.py the reference's own `default` Fortran kernels
 (compiled in place by oracle/build_ref.sh into oracle/_ref/librefkernels.so -- binary only, never
 committed) are driven through the kernel C ABI, and the outputs are stored:
-  * small arrays (<= 20000 elements) in full;
+  * small arrays (<= 6000 elements) in full;
   * large arrays as a strided sample (every k-th element in Fortran order) plus
     [sum, sum of squares, min, max];
   * a SHA-256 of all inputs, so a fixture can never be compared against different inputs.
@@ -30,7 +30,7 @@ import cases  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from rte_rrtmgp_amd import frontend  # noqa: E402
 
-FULL_LIMIT = 20000
+FULL_LIMIT = 6000
 
 
 def summarize(arr):
