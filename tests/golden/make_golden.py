@@ -38,7 +38,7 @@ def summarize(arr):
     if arr.size <= FULL_LIMIT:
         return {"full": arr}
     flat = arr.ravel(order="F")
-    stride = max(1, arr.size // 4096)
+    stride = max(1, -(-arr.size // 1024))
     d = {"sample": flat[::stride].copy(), "stride": np.array(stride), "shape": np.array(arr.shape)}
     if arr.dtype.kind == "f":
         d["stats"] = np.array([flat.sum(), (flat * flat).sum(), flat.min(), flat.max()])
