@@ -39,9 +39,10 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
                      int* __restrict__ jtemp, Float* __restrict__ fmajor, Float* __restrict__ fminor,
                      Float* __restrict__ col_mix, Bool* __restrict__ tropo, int* __restrict__ jeta,
                      int* __restrict__ jpress) {
-  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+  const int icol_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const int ilay = blockIdx.y, iflav = blockIdx.z;
-  if (icol >= ncol) return;
+  const bool in_range = icol_raw < ncol;
+  const int icol = in_range ? icol_raw : ncol - 1;  // ragged last block: compute on a valid column, store nothing
   const size_t ncl = (size_t)ncol * nlay;
   const size_t cl = icol + (size_t)ncol * ilay;
   const Float T = tlay[cl], P = play[cl];
@@ -55,7 +56,7 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
   const Float jpress_aint = fmin((Float)(npres - 1), fmax((Float)1, trunc(locpress)));
   const Float fpress = locpress - jpress_aint;
   const bool trop = P > press_ref_trop;  // :117
-  if (iflav == 0) {
+  if (iflav == 0 && in_range) {
     jtemp[cl] = jt;
     jpress[cl] = (int)jpress_aint;
     tropo[cl] = trop;
@@ -96,14 +97,40 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
     fmj[2 + 4 * itemp] = fpress * f1;
     fmj[3 + 4 * itemp] = fpress * f2;
   }
-  jeta[2 * clf] = je[0];
-  jeta[2 * clf + 1] = je[1];
-  col_mix[2 * clf] = cm[0];
-  col_mix[2 * clf + 1] = cm[1];
+  // The outputs are interleaved records per column (8, 4, 2, 2 values): written straight from the
+  // registers every store instruction would scatter 8-16 bytes per lane over kilobytes.  Transpose
+  // through LDS instead, so each store instruction of the block writes one contiguous 2-4 KB run.
+  __shared__ Float s_fmj[256 * 9], s_fmn[256 * 5], s_cm[256 * 3];
+  __shared__ int s_je[256 * 3];
+  const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fminor[4 * clf + i] = fmn[i];
+  for (int i = 0; i < 8; ++i) s_fmj[t * 9 + i] = fmj[i];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) fmajor[8 * clf + i] = fmj[i];
+  for (int i = 0; i < 4; ++i) s_fmn[t * 5 + i] = fmn[i];
+  s_cm[t * 3] = cm[0]; s_cm[t * 3 + 1] = cm[1];
+  s_je[t * 3] = je[0]; s_je[t * 3 + 1] = je[1];
+  __syncthreads();
+  const int c0 = blockIdx.x * blockDim.x;
+  const int nc = min((int)blockDim.x, ncol - c0);  // columns of this block
+  const size_t rec0 = (size_t)c0 + (size_t)ncol * ilay + ncl * iflav;  // record index of the block's first column
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int e = t + 256 * k;
+    if (e < 8 * nc) fmajor[8 * rec0 + e] = s_fmj[(e >> 3) * 9 + (e & 7)];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = t + 256 * k;
+    if (e < 4 * nc) fminor[4 * rec0 + e] = s_fmn[(e >> 2) * 5 + (e & 3)];
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = t + 256 * k;
+    if (e < 2 * nc) {
+      col_mix[2 * rec0 + e] = s_cm[(e >> 1) * 3 + (e & 1)];
+      jeta[2 * rec0 + e] = s_je[(e >> 1) * 3 + (e & 1)];
+    }
+  }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -396,7 +423,7 @@ struct BandIn {  // flavor-dependent inputs of one band for one column, prefetch
 };
 
 constexpr int RS = GC + 1;         // LDS slab row stride in Floats: 17 (odd) spreads lane-private rows over banks
-constexpr int SLAB_FLOATS = 5632;  // 44 KB of LUT slab per block; tiles that need more go to the direct kernel
+constexpr int SLAB_FLOATS = 8704;  // 68 KB of LUT slab per block (2 blocks per CU); tiles that need more go to the direct kernel
 
 // lanes = columns; block = (256 columns, one layer), walks the bands.  Per band the block stages the
 // bounding box of LUT rows its columns need (pressure x temperature x eta ranges of the tile) from the
