@@ -432,8 +432,8 @@ constexpr int SLAB_FLOATS = 8704;  // 68 KB of LUT slab per block (2 blocks per 
 // lane-private ds_read_b64 sustains ~100 B/clk/CU, lane-private global loads 1 line/clk, see
 // tools/membench.hip).  Inputs of band b+1 are requested before band b is computed.  A tile whose
 // bounding box does not fit the slab is appended to a worklist for tau_absorption_kernel.
-template <int BS>
-__global__ void __launch_bounds__(BS, 2) tau_absorption_v7_kernel(TauV5 a) {
+template <int BS, int MINW, int HW>
+__global__ void __launch_bounds__(BS, MINW) tau_absorption_v7_kernel(TauV5 a) {
   __shared__ int rng[6];      // Tmin, Tmax, Pmin, Pmax, has_lower, has_upper
   __shared__ int erng[2][2];  // eta range of the band (ping-pong between bands)
   __shared__ Float slab[SLAB_FLOATS];
@@ -605,13 +605,13 @@ __global__ void __launch_bounds__(BS, 2) tau_absorption_v7_kernel(TauV5 a) {
       const int sP = nT * nE * RS;
       const Float* M0 = slab + (rowsMaj + (regime == 2 ? rowsLo : 0)) * RS;
 #pragma unroll 1
-      for (int h = 0; h < GC; h += 8) {  // two halves of 8 g-points: bounded register footprint
-        Float acc[8];
+      for (int h = 0; h < GC; h += HW) {  // HW g-points at a time: bounded register footprint
+        Float acc[HW];
         Float* tp = a.tau + cl + (size_t)ncl * (g0 + h);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = tp[(size_t)ncl * j];
+        for (int j = 0; j < HW; ++j) acc[j] = tp[(size_t)ncl * j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < HW; ++j) {
           // :791-801 with col_mix folded into the weights
           Float m = w0 * A0[h + j];
           m = fma(w1, A0[RS + h + j], m);
@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(BS, 2) tau_absorption_v7_kernel(TauV5 a) {
 #pragma unroll
           for (int q = 1; q < MAXM; ++q) scaling = (k == q) ? sc[q] : scaling;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 0; j < HW; ++j) {
             // :757-760, :493
             Float s_ = f0 * r1[j];
             s_ = fma(f1, r1[RS + j], s_);
@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(BS, 2) tau_absorption_v7_kernel(TauV5 a) {
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) tp[(size_t)ncl * j] = acc[j];
+        for (int j = 0; j < HW; ++j) tp[(size_t)ncl * j] = acc[j];
       }
     }
   }
@@ -1174,7 +1174,8 @@ void rrtmgp_compute_tau_absorption(
   HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
   {
     rte::ProfScope p("tau_absorption_kernel");
-    hipLaunchKernelGGL((tau_absorption_v7_kernel<BS>), dim3(cdiv(ncol, BS), nlay), dim3(BS), sizeof(BandMeta) * nbnd, st,
+    // <min waves per SIMD, g-points per register chunk>: measured best of {2,3} x {4,8,16} on MI355X
+    hipLaunchKernelGGL((tau_absorption_v7_kernel<BS, 2, 16>), dim3(cdiv(ncol, BS), nlay), dim3(BS), sizeof(BandMeta) * nbnd, st,
                        v);
   }
   {
