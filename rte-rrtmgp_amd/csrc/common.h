@@ -64,6 +64,12 @@ class Call {
 
 bool is_device_pointer(const void* p);
 
+// deferred zero fill (runtime.hip)
+bool defer_zero_enabled();
+void defer_zero(void* p, size_t bytes);
+bool take_pending_zero(const void* p, size_t bytes);
+void flush_pending_zeros();
+
 // kernel-level timing hooks (rte_hip_profile_*): record(name) brackets a launch with events
 void prof_begin(const char* kernel);
 void prof_end();

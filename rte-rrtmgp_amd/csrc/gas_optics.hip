@@ -259,6 +259,7 @@ struct TauArgs {
   const Float* kmajor;
   MinorTables lower, upper;
   const int* run_if;  // when non-null the kernel does nothing unless *run_if != 0
+  bool overwrite;     // tau is known to be zero (deferred zero_array): do not read it
   const int* lim;
   const Bool* tropo;
   const Float *col_mix, *fmajor, *fminor, *play, *tlay, *col_gas;
@@ -297,7 +298,7 @@ __device__ __forceinline__ void tau_direct_column(const TauArgs& a, int icol, in
   for (int g0 = gptS; g0 <= gptE; g0 += GC) {
     Float acc[GC];
 #pragma unroll
-    for (int j = 0; j < GC; ++j) acc[j] = (g0 + j <= gptE) ? a.tau[cl + ncl * (size_t)(g0 + j)] : (Float)0;
+    for (int j = 0; j < GC; ++j) acc[j] = (g0 + j <= gptE && !a.overwrite) ? a.tau[cl + ncl * (size_t)(g0 + j)] : (Float)0;
 #pragma unroll
     for (int j = 0; j < GC; ++j) {
       if (g0 + j <= gptE) {
@@ -403,6 +404,7 @@ struct TauV5 {
   Float* tau;
   const int* skip_if;  // device flag: some column has overlapping regimes -> the fallback kernel does the call
   int* worklist;       // [0] = count, then (tile, layer, band) triples for tau_absorption_worklist_kernel
+  bool overwrite;      // tau is known to be zero (deferred zero_array): do not read it
 };
 
 // wave-wide min / max by butterfly shuffles (LDS atomics on one address serialise lane by lane)
@@ -609,7 +611,7 @@ __global__ void __launch_bounds__(BS, MINW) tau_absorption_v7_kernel(TauV5 a) {
         Float acc[HW];
         Float* tp = a.tau + cl + (size_t)ncl * (g0 + h);
 #pragma unroll
-        for (int j = 0; j < HW; ++j) acc[j] = tp[(size_t)ncl * j];
+        for (int j = 0; j < HW; ++j) acc[j] = a.overwrite ? (Float)0 : tp[(size_t)ncl * j];
 #pragma unroll
         for (int j = 0; j < HW; ++j) {
           // :791-801 with col_mix folded into the weights
@@ -1030,6 +1032,8 @@ void rrtmgp_compute_tau_absorption(
             nflav = *nflav_, neta = *neta_, npres = *npres_, ntemp = *ntemp_;
   const int nlo = *nminorlower_, nup = *nminorupper_;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  // a deferred zero_array on exactly this buffer turns the accumulate into an overwrite
+  const bool overwrite = rte::take_pending_zero(tau, sizeof(Float) * (size_t)ncol * nlay * ngpt);
   rte::Call c("rrtmgp_compute_tau_absorption");
   const size_t ncl = (size_t)ncol * nlay;
   const size_t tn = (size_t)ntemp * neta;
@@ -1125,7 +1129,7 @@ void rrtmgp_compute_tau_absorption(
   a.kmajor = d_kmajor; a.lower = lo; a.upper = up;
   a.lim = lim; a.tropo = d_tropo; a.col_mix = d_col_mix; a.fmajor = d_fmajor; a.fminor = d_fminor;
   a.play = d_play; a.tlay = d_tlay; a.col_gas = d_col_gas; a.jeta = d_jeta; a.jtemp = d_jtemp; a.jpress = d_jpress;
-  a.tau = d_tau;
+  a.tau = d_tau; a.overwrite = overwrite;
   a.run_if = fast ? overlap : nullptr;
   {
     rte::ProfScope p(fast ? "tau_absorption_fallback" : "tau_absorption_kernel");
@@ -1167,7 +1171,7 @@ void rrtmgp_compute_tau_absorption(
   v.kmaj = kmaj_g; v.klo = klo_g; v.kup = kup_g;
   v.lim = lim; v.jeta = d_jeta; v.jtemp = d_jtemp; v.jpress = d_jpress; v.tropo = d_tropo;
   v.col_mix = d_col_mix; v.fmajor = d_fmajor; v.fminor = d_fminor; v.play = d_play; v.tlay = d_tlay;
-  v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap;
+  v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap; v.overwrite = overwrite;
   constexpr int BS = 256;
   const size_t wl_cap = (size_t)cdiv(ncol, BS) * nlay * nbnd;
   v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));

@@ -83,9 +83,41 @@ bool is_device_pointer(const void* p) {
          (a.type == hipMemoryTypeHost && a.devicePointer != nullptr);
 }
 
+// ---- deferred zero fill (opt-in, rte_hip_defer_zero) --------------------------------------------
+// The frontend zeroes tau and then calls compute_tau_absorption, which accumulates onto it
+// (mo_gas_optics_rrtmgp.F90:637,679).  On the device that is a 12 GB memset plus a 12 GB read that only
+// exist because the two steps are separate calls.  With the option on, zero_array_* on a device
+// buffer is recorded instead of executed; compute_tau_absorption on exactly that buffer consumes the
+// record and overwrites; ANY other library entry first materialises all recorded fills.  Only for
+// callers that touch the buffer exclusively through this library between the two calls.
+struct PendingZero { void* p; size_t bytes; };
+static std::vector<PendingZero> g_pending;
+static bool g_defer_zero = false;
+
+bool defer_zero_enabled() { return g_defer_zero; }
+void defer_zero(void* p, size_t bytes) {
+  std::lock_guard<std::recursive_mutex> l(g_mutex);
+  g_pending.push_back(PendingZero{p, bytes});
+}
+bool take_pending_zero(const void* p, size_t bytes) {
+  std::lock_guard<std::recursive_mutex> l(g_mutex);
+  for (size_t i = 0; i < g_pending.size(); ++i)
+    if (g_pending[i].p == p && g_pending[i].bytes == bytes) {
+      g_pending.erase(g_pending.begin() + i);
+      return true;
+    }
+  return false;
+}
+void flush_pending_zeros() {
+  std::lock_guard<std::recursive_mutex> l(g_mutex);
+  for (auto& z : g_pending) HIP_CHECK(hipMemsetAsync(z.p, 0, z.bytes, g_stream));
+  g_pending.clear();
+}
+
 // ---- Call ---------------------------------------------------------------------------------------
 Call::Call(const char* n) : name(n) {
   g_mutex.lock();
+  if (!g_pending.empty()) flush_pending_zeros();
   scratch_reset();
 }
 
@@ -174,11 +206,19 @@ extern "C" {
 
 int rte_hip_set_stream(void* s) {
   std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::flush_pending_zeros();
   rte::g_stream = (hipStream_t)s;
   return 0;
 }
 int rte_hip_sync(void) {
+  rte::flush_pending_zeros();
   HIP_CHECK(hipStreamSynchronize(rte::g_stream));
+  return 0;
+}
+// defer zero_array_* on device buffers until compute_tau_absorption consumes them (see runtime.hip)
+int rte_hip_defer_zero(int on) {
+  rte::flush_pending_zeros();
+  rte::g_defer_zero = on != 0;
   return 0;
 }
 int rte_hip_device_count(void) {
@@ -214,6 +254,7 @@ int rte_hip_profile_get(int i, char* buf, int buflen, long long* launches, doubl
 // release every device buffer held by the library (arena + persistent slots)
 int rte_hip_release(void) {
   std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::flush_pending_zeros();
   HIP_CHECK(hipStreamSynchronize(rte::g_stream));
   for (auto& b : rte::g_blocks) HIP_CHECK(hipFree(b.base));
   rte::g_blocks.clear();

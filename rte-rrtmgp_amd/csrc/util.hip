@@ -19,6 +19,10 @@ __global__ void __launch_bounds__(256) fill_kernel(Float* __restrict__ a, size_t
 
 void fill(const char* name, Float* a, size_t n, Float v) {
   if (n == 0) return;
+  if (v == (Float)0 && rte::defer_zero_enabled() && rte::is_device_pointer(a)) {
+    rte::defer_zero(a, n * sizeof(Float));  // materialised by the next library call unless consumed
+    return;
+  }
   rte::Call c(name);
   Float* d = c.out(a, n);
   rte::ProfScope p("fill_kernel");

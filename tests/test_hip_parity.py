@@ -140,6 +140,51 @@ def test_tau_absorption_paths_agree(hip, oracle_c):
     torch.cuda.synchronize()
 
 
+def test_deferred_zero_fill(hip, oracle_c):
+    """rte_hip_defer_zero(1): zero_array on a device buffer is recorded, consumed by
+    compute_tau_absorption on that buffer (overwrite instead of memset + accumulate), and materialised
+    by any other library entry.  Results must not change."""
+    import torch
+    from rte_rrtmgp_amd import synth
+
+    xp = frontend.TorchArrays("cuda:0")
+    hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 1)
+    try:
+        # (1) the LW chain on the production tau kernel (ncol >= 512, g256 table) and on the small-problem kernel
+        for name in ("lw_mid_ragged", "lw_g256"):
+            case = cases.CASES[name]
+            inp = cases.make_inputs(case)
+            ref = cases.run_suite(oracle_c, frontend.NumpyArrays(), case, inp, which="core")
+            out = cases.run_suite(hip, xp, case, inp, which="core")
+            for k in ref:
+                assert cases.rel_err(out[k], ref[k]) <= _tol(k), k
+        kd = synth.make_kdist("lw")
+        ncol, nlay = 700, 20
+        atm = synth.make_atmosphere(ncol, nlay, seed=5, kdist=kd)
+        go = frontend.GasOptics(hip, kd, xp)
+        A = xp.asarray
+        play, tlay, col_gas = A(atm.play), A(atm.tlay), A(atm.col_gas)
+        st = go.interpolation(ncol, nlay, play, tlay, col_gas)
+        tau = xp.full((ncol, nlay, kd.ngpt), 3.0)
+        hip.zero_array_3D(ncol, nlay, kd.ngpt, tau)      # deferred
+        go.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau)  # consumes it
+        hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 0)
+        tau2 = xp.full((ncol, nlay, kd.ngpt), 3.0)
+        hip.zero_array_3D(ncol, nlay, kd.ngpt, tau2)     # executed
+        go.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau2)
+        assert torch.equal(tau, tau2)
+        hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 1)
+        # (2) a deferred fill that nobody consumes is materialised by the next library call
+        z = xp.full((ncol, 7, 3), 5.0)
+        hip.zero_array_3D(ncol, 7, 3, z)
+        s = xp.empty((ncol, 7))
+        hip.rte_sum_broadband(ncol, 7, 3, z, s)
+        torch.cuda.synchronize()
+        assert float(s.abs().max()) == 0.0 and float(z.abs().max()) == 0.0
+    finally:
+        hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 0)
+
+
 @pytest.mark.parametrize("name", ["lw_tiny_top1", "sw_tiny_sfc1", "lw_mid_ragged"])
 def test_single_precision_build(name):
     """-DRTE_USE_SP build (the reference's RTE_ENABLE_SP): same kernels with Float = float, checked
