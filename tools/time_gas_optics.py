@@ -3,7 +3,7 @@ import ctypes, sys
 import torch
 sys.path.insert(0, ".")
 from rte_rrtmgp_amd import frontend, hiplib, synth
-lib = hiplib.load(); xp = frontend.TorchArrays("cuda:0")
+lib = hiplib.load(); hiplib.ext_call(lib, "rte_hip_defer_zero", ["i"], 1); xp = frontend.TorchArrays("cuda:0")
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 kd = synth.make_kdist("lw"); atm = synth.make_atmosphere(ncol, 60, seed=42, kdist=kd)
 go = frontend.GasOptics(lib, kd, xp); A = xp.asarray
