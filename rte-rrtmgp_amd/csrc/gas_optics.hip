@@ -389,6 +389,8 @@ struct MinorMeta {  // one minor interval
 };
 struct BandMeta {  // built on the host from the small index tables, uploaded per call
   int cnt[2];
+  int gS, gE;   // g-point range of the band (0-based)
+  int flav[2];  // flavor (0-based) of the band per tropo regime: gpoint_flavor(:, gS)
   MinorMeta m[2][MAXM];  // [0]: lower-regime intervals of the band, [1]: upper
 };
 
@@ -405,6 +407,9 @@ struct TauV5 {
   const int* skip_if;  // device flag: some column has overlapping regimes -> the fallback kernel does the call
   int* worklist;       // [0] = count, then (tile, layer, band) triples for tau_absorption_worklist_kernel
   bool overwrite;      // tau is known to be zero (deferred zero_array): do not read it
+#ifdef EXP_CLOCKS
+  unsigned long long* clocks;
+#endif
 };
 
 // wave-wide min / max by butterfly shuffles (LDS atomics on one address serialise lane by lane)
@@ -693,6 +698,343 @@ __global__ void __launch_bounds__(BS, MINW) tau_absorption_v7_kernel(TauV5 a) {
         for (int j = 0; j < HW; ++j) tp[(size_t)ncl * j] = acc[j];
 #endif
       }
+    }
+  }
+}
+
+
+#ifndef V9_NCW  // shape of the specialised-wave kernel (overridable for experiments: tools/variants.py)
+#define V9_NCW 8
+#define V9_NLW 2
+#endif
+#ifndef V9_SB
+#define V9_SB 8
+#endif
+// -------------------------------------------------------------------------------------------
+// compute_tau_absorption, specialised-wave kernel ("v9").
+//
+// Measured on the slab kernel above (tools/variants.py, per-phase cycle counters): staging, compute and
+// the tau stores of a stage run back to back -- vector-memory operations of a wave retire in order, so a
+// staging load issued after the previous stage's stores waits for them, and the range reductions, the
+// dependent index loads and two barriers per stage sit on the same critical path.  Here the work is split:
+//   * tau_geom_kernel (tiny pre-pass) computes, per (column tile, layer), the bounding box of LUT rows
+//     every band needs, and sends oversized (tile, layer, band) triples to the direct-gather worklist;
+//   * the main kernel runs one block per CU with NCW compute waves (lanes = columns) and NLW loader
+//     waves.  The loaders know the whole schedule from the geometry table: they stage the slab of stage
+//     s+1 into the other half of a double-buffered LDS slab while the compute waves work on stage s, with
+//     ONE barrier per stage.  The loaders' memory queue holds only table reads; the compute waves' queue
+//     holds weights (requested one stage ahead) and tau stores, so neither waits for the other's traffic.
+// -------------------------------------------------------------------------------------------
+struct TileGeom {   // one per (column tile, layer)
+  int Tmin, nT, Pmin, nP, has_lo, has_up, pad0, pad1;
+  int2 eg[MAXB];    // per band: (emin, nE); nE = 0 -> band handled by the direct kernel (or no work)
+};
+
+template <int TILE>
+__global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __restrict__ geom, int slab_floats) {
+  __shared__ int rng[6];
+  __shared__ int erng[MAXB][2];
+  __shared__ BandMeta bm[MAXB];
+  if (*a.skip_if) return;
+  const int tid = threadIdx.x;
+  const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
+  const unsigned ncl = ncol * nlay;
+  const int nbnd = a.nbnd;
+  if (tid == 0) { rng[0] = 1 << 30; rng[1] = -1; rng[2] = 1 << 30; rng[3] = -1; rng[4] = 0; rng[5] = 0; }
+  if (tid < MAXB) { erng[tid][0] = 1 << 30; erng[tid][1] = -1; }
+  {
+    const int* src = reinterpret_cast<const int*>(a.bmeta);
+    int* dst = reinterpret_cast<int*>(bm);
+    const int nw = nbnd * (int)(sizeof(BandMeta) / sizeof(int));
+    for (int i = tid; i < nw; i += TILE) dst[i] = src[i];
+  }
+  __syncthreads();
+  const unsigned icol = blockIdx.x * TILE + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  const unsigned cl = ic + ncol * ilay;
+  const int itropo = a.tropo[cl] ? 0 : 1;
+  const int jT = a.jtemp[cl];
+  const int jp = a.jpress[cl] + itropo + 1;
+  int regime;
+  {
+    const int lay1 = ilay + 1;
+    const int lo1 = a.lim[ic], lo2 = a.lim[ic + ncol];
+    const int up1 = a.lim[ic + 2 * (size_t)ncol], up2 = a.lim[ic + 3 * (size_t)ncol];
+    regime = ((lo1 > 0 && lay1 >= lo1 && lay1 <= lo2) ? 1 : 0) | ((up1 > 0 && lay1 >= up1 && lay1 <= up2) ? 2 : 0);
+  }
+  const int rsel = regime == 2 ? 1 : 0;
+  const int big = 1 << 30;
+  {
+    const int a0 = wave_min(valid ? jT : big), a1 = wave_max(valid ? jT + 1 : -1);
+    const int a2 = wave_min(valid ? jp - 1 : big), a3 = wave_max(valid ? jp : -1);
+    const int a4 = wave_max(valid ? (regime & 1) : 0), a5 = wave_max(valid ? (regime & 2) : 0);
+    if ((tid & 63) == 0) {
+      atomicMin(&rng[0], a0); atomicMax(&rng[1], a1); atomicMin(&rng[2], a2); atomicMax(&rng[3], a3);
+      if (a4) rng[4] = 1;
+      if (a5) rng[5] = 1;
+    }
+  }
+  for (int b = 0; b < nbnd; ++b) {
+    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * bm[b].flav[itropo]));
+    const int2 em = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * bm[b].flav[rsel]));
+    const int e0 = wave_min(valid ? min(min(je.x, je.y), min(em.x, em.y)) : big);
+    const int e1 = wave_max(valid ? max(max(je.x, je.y), max(em.x, em.y)) + 1 : -1);
+    if ((tid & 63) == 0) { atomicMin(&erng[b][0], e0); atomicMax(&erng[b][1], e1); }
+  }
+  __syncthreads();
+  TileGeom* out = geom + (blockIdx.x + (size_t)gridDim.x * ilay);
+  const int nT = rng[1] - rng[0] + 1, nP = rng[3] - rng[2] + 1;
+  if (tid == 0) {
+    out->Tmin = rng[0]; out->nT = nT; out->Pmin = rng[2]; out->nP = nP; out->has_lo = rng[4]; out->has_up = rng[5];
+    out->pad0 = 0; out->pad1 = 0;
+  }
+  if (tid < nbnd) {
+    const int emin = erng[tid][0], nE = erng[tid][1] - erng[tid][0] + 1;
+    const int n_lo = rng[4] ? bm[tid].cnt[0] : 0, n_up = rng[5] ? bm[tid].cnt[1] : 0;
+    const int rows = (nP + n_lo + n_up) * nT * nE;
+    const bool fits = rows * RS <= slab_floats;
+    if (!fits) {  // hand (tile, layer, band) to the direct kernel
+      const int w = atomicAdd(&a.worklist[0], 1);
+      a.worklist[1 + 3 * w] = blockIdx.x; a.worklist[2 + 3 * w] = ilay; a.worklist[3 + 3 * w] = tid;
+    }
+    out->eg[tid] = make_int2(emin, fits ? nE : 0);
+  }
+}
+
+template <int NCW, int NLW, int SLAB, bool OVERWRITE>
+__global__ void __launch_bounds__((NCW + NLW) * 64, (NCW + NLW + 3) / 4)
+tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
+  constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
+  __shared__ __align__(16) Float slab[2][SLAB];
+  __shared__ TileGeom tg;
+  extern __shared__ BandMeta bm[];  // [nbnd]
+  if (*a.skip_if) return;
+  const int tid = threadIdx.x;
+  const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
+  const unsigned ncl = ncol * nlay;  // host guarantees < 2^31
+  const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nbnd = a.nbnd;
+  {
+    const int* src = reinterpret_cast<const int*>(a.bmeta);
+    int* dst = reinterpret_cast<int*>(bm);
+    const int nw = nbnd * (int)(sizeof(BandMeta) / sizeof(int));
+    for (int i = tid; i < nw; i += NT) dst[i] = src[i];
+    const int* gs = reinterpret_cast<const int*>(geom + (blockIdx.x + (size_t)gridDim.x * ilay));
+    int* gd = reinterpret_cast<int*>(&tg);
+    for (int i = tid; i < (int)(sizeof(TileGeom) / sizeof(int)); i += NT) gd[i] = gs[i];
+  }
+  __syncthreads();
+  const int Tmin = tg.Tmin, nT = tg.nT, Pmin = tg.Pmin, nP = tg.nP;
+  const bool has_lo = tg.has_lo != 0, has_up = tg.has_up != 0;
+  const int nstage = ngpt / GC;  // host guarantees whole, 16-aligned chunks per band
+
+  if (tid >= TILE) {
+    // ================================ loader waves ================================
+    const int lt = tid - TILE;
+    const float inv_nT = 1.0f / (float)nT;
+    constexpr int SB = V9_SB;  // 16-byte pieces per lane requested back to back
+    int ibnd = 0;
+#pragma unroll 1
+    for (int s = 0; s < nstage; ++s) {
+      const int g0 = s * GC;
+      while (ibnd + 1 < nbnd && bm[ibnd].gE < g0) ++ibnd;
+      const int emin = tg.eg[ibnd].x, nE = tg.eg[ibnd].y;
+      if (nE > 0) {
+        const float inv_nE = 1.0f / (float)nE;
+        const int n_lo = has_lo ? bm[ibnd].cnt[0] : 0, n_up = has_up ? bm[ibnd].cnt[1] : 0;
+        const int rowsMaj = nP * nT * nE, rowsLo = n_lo * nT * nE, rowsUp = n_up * nT * nE;
+        const int nAll = (rowsMaj + rowsLo + rowsUp) * (GC / 2);
+        Float* sl = slab[s & 1];
+        // rows ordered [p][t][eta] (+ minor: [interval][t][eta]); piece = 16 bytes of a 128-byte row chunk
+        auto piece = [&](int idx) -> Float2 {
+          const int j = idx & 7, r = idx >> 3;
+          if (r < rowsMaj) {
+            const int rest = (int)(((float)r + 0.5f) * inv_nE), e = r - rest * nE;  // rows < 2^12: exact
+            const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
+            return *reinterpret_cast<const Float2*>(
+                a.kmaj + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
+          }
+          const int rm = r - rowsMaj;
+          const bool up = rm >= rowsLo;
+          const int rr = up ? rm - rowsLo : rm;
+          const int rest = (int)(((float)rr + 0.5f) * inv_nE), e = rr - rest * nE;
+          const int k = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - k * nT;
+          const MinorMeta& m = bm[ibnd].m[up ? 1 : 0][k];
+          const bool on = m.mS <= g0 && m.mE >= g0;  // off: any valid address, the row is never read
+          const Float* kg = up ? a.kup : a.klo;
+          const unsigned nk = up ? a.nk_up : a.nk_lo;
+          return *reinterpret_cast<const Float2*>(
+              kg + ((size_t)((emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * nk + (unsigned)m.kstart + (on ? g0 - m.mS : 0) + 2 * j));
+        };
+#pragma unroll 1
+        for (int base = lt; base < nAll; base += SB * NLT) {
+          Float2 v[SB];
+#pragma unroll
+          for (int u = 0; u < SB; ++u) v[u] = piece(min(base + u * NLT, nAll - 1));
+#pragma unroll
+          for (int u = 0; u < SB; ++u) {
+            const int idx = base + u * NLT;
+            if (idx < nAll) *reinterpret_cast<Float2*>(sl + (idx >> 3) * RS + 2 * (idx & 7)) = v[u];
+          }
+        }
+      }
+      __syncthreads();  // B(s): slab(s) complete; the compute waves are done with the other buffer
+    }
+    return;
+  }
+
+  // ================================ compute waves (lanes = columns) ================================
+  const unsigned icol = blockIdx.x * TILE + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  const unsigned cl = ic + ncol * ilay;
+  const unsigned cl8 = cl * (unsigned)sizeof(Float);
+  const int itropo = a.tropo[cl] ? 0 : 1;
+  const int jT = a.jtemp[cl];
+  const int jp = a.jpress[cl] + itropo + 1;  // levels jp-1, jp (1-based)
+  int regime;
+  {
+    const int lay1 = ilay + 1;
+    const int lo1 = a.lim[ic], lo2 = a.lim[ic + ncol];
+    const int up1 = a.lim[ic + 2 * (size_t)ncol], up2 = a.lim[ic + 3 * (size_t)ncol];
+    regime = ((lo1 > 0 && lay1 >= lo1 && lay1 <= lo2) ? 1 : 0) | ((up1 > 0 && lay1 >= up1 && lay1 <= up2) ? 2 : 0);
+  }
+  const int rsel = regime == 2 ? 1 : 0;
+  const Float P = a.play[cl], T = a.tlay[cl];
+  const Float dens = (Float)0.01 * P / T;                                                             // :469
+  const Float vmr_fact = (Float)1 / a.col_gas[cl];                                                    // :471
+  const Float dry_fact = (Float)1 / ((Float)1 + a.col_gas[cl + (size_t)ncl * a.idx_h2o] * vmr_fact);  // :472
+
+  // major weights + eta indices of band b (requested one stage ahead)
+  struct Major { Float2 fm[4], cm; int2 je; };
+  auto load_major = [&](int b, Major& x) {
+    const size_t clf = cl + (size_t)ncl * bm[b].flav[itropo];
+    const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x.fm[i] = fmp[i];
+    x.cm = *reinterpret_cast<const Float2*>(a.col_mix + 2 * clf);
+    x.je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
+  };
+  Major mj;
+  load_major(0, mj);
+  int ibnd = 0;
+#pragma unroll 1
+  for (int s = 0; s < nstage; ++s) {
+    const int g0 = s * GC;
+    while (ibnd + 1 < nbnd && bm[ibnd].gE < g0) ++ibnd;
+    const int emin = tg.eg[ibnd].x, nE = tg.eg[ibnd].y;
+    int ibnd_n = ibnd;
+    if (s + 1 < nstage) while (ibnd_n + 1 < nbnd && bm[ibnd_n].gE < g0 + GC) ++ibnd_n;
+    const bool run = nE > 0;  // block-uniform
+    // ---- requests, oldest first: minor column amounts and minor weights of THIS stage (used after the
+    // major pass), then the major weights of the NEXT stage
+    const int n_my = (run && regime > 0) ? bm[ibnd].cnt[rsel] : 0;
+    Float sc[MAXM], cgs[MAXM];
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) {
+      sc[k] = 0; cgs[k] = 0;
+      if (k < n_my) {
+        const MinorMeta& m = bm[ibnd].m[rsel][k];
+        sc[k] = a.col_gas[cl + (size_t)ncl * m.idx_minor];
+        if ((m.flags & 1) && m.idx_scaling > 0) cgs[k] = a.col_gas[cl + (size_t)ncl * m.idx_scaling];
+      }
+    }
+    const size_t clm = cl + (size_t)ncl * bm[ibnd].flav[rsel];  // minor absorbers use THEIR regime's flavor (:487)
+    const Float2* fnp = reinterpret_cast<const Float2*>(a.fminor + 4 * clm);
+    const Float2 fn0 = fnp[0], fn1 = fnp[1];
+    const int2 em = *reinterpret_cast<const int2*>(a.jeta + 2 * clm);
+    // this stage's major weights into locals (col_mix folded in), then request the next stage's
+    const Float w0 = mj.cm.x * mj.fm[0].x, w1 = mj.cm.x * mj.fm[0].y, w2 = mj.cm.x * mj.fm[1].x, w3 = mj.cm.x * mj.fm[1].y,
+                w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
+    const int je1 = mj.je.x, je2 = mj.je.y;
+    if (s + 1 < nstage && ibnd_n != ibnd) load_major(ibnd_n, mj);
+    __syncthreads();  // B(s): slab(s) is complete
+    if (!run) continue;
+    const Float* sl = slab[s & 1];
+    const int rowsMaj = nP * nT * nE;
+    const int rowsLo = (has_lo ? bm[ibnd].cnt[0] : 0) * nT * nE;
+    const Float* A0 = sl + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS;
+    const Float* B0 = sl + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
+    const int sP = nT * nE * RS;
+    const Float* M0 = sl + (rowsMaj + (regime == 2 ? rowsLo : 0)) * RS;
+    Float acc[GC];
+    // tau(:, :, g) = scalar plane base + this column's 32-bit byte offset (host guarantees 8*ncol*nlay < 2^32)
+    char* const tplane = reinterpret_cast<char*>(a.tau + (size_t)ncl * g0);
+    const size_t gstride = (size_t)ncl * sizeof(Float);
+    unsigned toff = cl8;
+    asm volatile("" : "+v"(toff));  // keep the 64-bit address out of the loop-invariant registers
+    auto tau_at = [&](int j) { return reinterpret_cast<Float*>(tplane + gstride * j + toff); };
+#pragma unroll
+    for (int j = 0; j < GC; ++j) acc[j] = 0;
+#pragma unroll
+    for (int j = 0; j < GC; j += 2) {
+      // :791-801 with col_mix folded into the weights; one 16-byte LDS read feeds two g-points
+      const Float2 k0 = ld2(A0 + j), k1 = ld2(A0 + RS + j), k2 = ld2(A0 + sP + j), k3 = ld2(A0 + sP + RS + j),
+                   k4 = ld2(B0 + j), k5 = ld2(B0 + RS + j), k6 = ld2(B0 + sP + j), k7 = ld2(B0 + sP + RS + j);
+      Float m = w0 * k0.x, n = w0 * k0.y;
+      m = fma(w1, k1.x, m); n = fma(w1, k1.y, n);
+      m = fma(w2, k2.x, m); n = fma(w2, k2.y, n);
+      m = fma(w3, k3.x, m); n = fma(w3, k3.y, n);
+      m = fma(w4, k4.x, m); n = fma(w4, k4.y, n);
+      m = fma(w5, k5.x, m); n = fma(w5, k5.y, n);
+      m = fma(w6, k6.x, m); n = fma(w6, k6.y, n);
+      m = fma(w7, k7.x, m); n = fma(w7, k7.y, n);
+      acc[j] = acc[j] + m;
+      acc[j + 1] = acc[j + 1] + n;
+      // pin the accumulation here: otherwise the FMA chains are sunk below the whole loop and all 64 reads stay live
+      asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
+      if ((j & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads (64 VGPRs) in flight
+    }
+    // ---- minor absorbers of this regime; scalings (:461-480)
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) {
+      if (k < n_my) {
+        const MinorMeta& m = bm[ibnd].m[rsel][k];
+        if (m.flags & 1) {
+          sc[k] = sc[k] * dens;     // :469
+          if (m.idx_scaling > 0) {  // :470-478
+            if (m.flags & 2)
+              sc[k] = sc[k] * ((Float)1 - cgs[k] * vmr_fact * dry_fact);
+            else
+              sc[k] = sc[k] * (cgs[k] * vmr_fact * dry_fact);
+          }
+        }
+      }
+    }
+    const Float f0 = fn0.x, f1 = fn0.y, f2 = fn1.x, f3 = fn1.y;
+#pragma unroll 1
+    for (int k = 0; k < n_my; ++k) {
+      const MinorMeta& mm = bm[ibnd].m[rsel][k];
+      if (mm.mE < g0 || mm.mS > g0) continue;  // intervals are whole 16-aligned chunks inside the band
+      Float scaling = sc[0];
+#pragma unroll
+      for (int q = 1; q < MAXM; ++q) scaling = (k == q) ? sc[q] : scaling;
+      const Float* r1 = M0 + ((k * nT + (jT - Tmin)) * nE + (em.x - emin)) * RS;
+      const Float* r2 = M0 + ((k * nT + (jT + 1 - Tmin)) * nE + (em.y - emin)) * RS;
+#pragma unroll
+      for (int j = 0; j < GC; j += 2) {
+        // :757-760, :493
+        const Float2 q0 = ld2(r1 + j), q1 = ld2(r1 + RS + j), q2 = ld2(r2 + j), q3 = ld2(r2 + RS + j);
+        Float s_ = f0 * q0.x, t_ = f0 * q0.y;
+        s_ = fma(f1, q1.x, s_); t_ = fma(f1, q1.y, t_);
+        s_ = fma(f2, q2.x, s_); t_ = fma(f2, q2.y, t_);
+        s_ = fma(f3, q3.x, s_); t_ = fma(f3, q3.y, t_);
+        acc[j] = fma(scaling, s_, acc[j]);
+        acc[j + 1] = fma(scaling, t_, acc[j + 1]);
+        asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
+        if ((j & 6) == 6) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads in flight
+      }
+    }
+    if (!OVERWRITE) {
+      // tau is inout (the reference accumulates onto it, :637,:679).  The stage's sum is added to the incoming
+      // value at the end: identical to the reference when tau comes in as zero (always, in the frontend),
+      // otherwise the same terms in a different order (1 ulp)
+#pragma unroll
+      for (int j = 0; j < GC; ++j) acc[j] = *tau_at(j) + acc[j];
+    }
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < GC; ++j) *tau_at(j) = acc[j];
     }
   }
 }
@@ -998,25 +1340,26 @@ __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
 // C ABI
 // ===============================================================================================
 static int g_tau_force_direct = 0;
+static int g_tau_variant = 9;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
 static int g_plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget cached host-side plans
 
 namespace {
 struct TauPlanCache {
-  const void* key[12] = {};
+  const void* key[13] = {};
   int dims[6] = {};
   int epoch = -1;
   bool fast_ok = false;
   std::vector<BandMeta> bands;
   bool matches(const void* const* k, const int* d, int e) const {
     if (e != epoch) return false;
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < 13; ++i)
       if (k[i] != key[i]) return false;
     for (int i = 0; i < 6; ++i)
       if (d[i] != dims[i]) return false;
     return true;
   }
   void set(const void* const* k, const int* d, int e) {
-    for (int i = 0; i < 12; ++i) key[i] = k[i];
+    for (int i = 0; i < 13; ++i) key[i] = k[i];
     for (int i = 0; i < 6; ++i) dims[i] = d[i];
     epoch = e;
   }
@@ -1026,6 +1369,7 @@ struct TauPlanCache {
 extern "C" {
 
 int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
+int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
 int rte_hip_invalidate_plans(void) { ++g_plan_epoch; return 0; }
 
 
@@ -1126,7 +1470,7 @@ void rrtmgp_compute_tau_absorption(
   // ---- host-side plan from the small index tables (cached while the caller's table pointers and
   // dimensions do not change; rte_hip_release() drops the cache)
   static TauPlanCache cache;
-  const void* key[12] = {band_lims_gpt, minor_limits_gpt_lower, minor_limits_gpt_upper, kminor_start_lower,
+  const void* key[13] = {gpoint_flavor, band_lims_gpt, minor_limits_gpt_lower, minor_limits_gpt_upper, kminor_start_lower,
                          kminor_start_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
                          idx_minor_scaling_upper, minor_scales_with_density_lower, scale_by_complement_lower,
                          scale_by_complement_upper};
@@ -1148,6 +1492,14 @@ void rrtmgp_compute_tau_absorption(
     bool ok = (ngpt % GC == 0) && sizeof(Float) == 8 && nbnd <= MAXB;
     for (int b = 0; b < nbnd; ++b) ok = ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;
     cache.bands.assign(nbnd > 0 ? nbnd : 1, BandMeta{});
+    {
+      const int* gf = c.host(gpoint_flavor, (size_t)2 * ngpt);
+      for (int b = 0; b < nbnd; ++b) {
+        BandMeta& bmh = cache.bands[b];
+        bmh.gS = bl[2 * b] - 1; bmh.gE = bl[2 * b + 1] - 1;
+        bmh.flav[0] = gf[2 * bmh.gS] - 1; bmh.flav[1] = gf[2 * bmh.gS + 1] - 1;
+      }
+    }
     for (int r = 0; r < 2 && ok; ++r) {
       ok = ok && (nn[r] == 0 || nk2[r] % 2 == 0);
       for (int i = 0; i < nn[r] && ok; ++i) {
@@ -1168,7 +1520,7 @@ void rrtmgp_compute_tau_absorption(
     cache.fast_ok = ok;
   }
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
-  const bool fast = cache.fast_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 31) &&
+  const bool fast = cache.fast_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) &&
                     al(d_fmajor, 16) && al(d_fminor, 16) && al(d_col_mix, 16) && al(d_jeta, 8);
 
   // native-layout direct kernel: always correct; the whole call when the fast path does not apply,
@@ -1233,15 +1585,48 @@ void rrtmgp_compute_tau_absorption(
 #define V7_SLAB SLAB_FLOATS
 #endif
   constexpr int BS = V7_BS;
-  const size_t wl_cap = (size_t)cdiv(ncol, BS) * nlay * nbnd;
+  const size_t wl_cap = (size_t)cdiv(ncol, 256) * nlay * nbnd;  // tiles are at least 256 columns wide
   v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
   HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
-  {
+  if (g_tau_variant == 9) {
+#ifdef EXP_CLOCKS
+    v.clocks = (unsigned long long*)rte::scratch(64);
+    HIP_CHECK(hipMemsetAsync(v.clocks, 0, 64, st));
+#endif
+#ifndef V9_NCW
+#define V9_NCW 4
+#define V9_NLW 2
+#endif
+    constexpr int NCW = V9_NCW, NLW = V9_NLW, SLAB9 = 8704;  // compute + loader waves, 2 x 68 KB slab: one block per CU
+    const unsigned tiles = cdiv(ncol, NCW * 64);
+    TileGeom* d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
+    {
+      rte::ProfScope p("tau_absorption_setup");
+      hipLaunchKernelGGL((tau_geom_kernel<NCW * 64>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, d_geom, SLAB9);
+    }
+    rte::ProfScope p("tau_absorption_kernel");
+    if (overwrite)
+      hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true>), dim3(tiles, nlay), dim3((NCW + NLW) * 64),
+                         sizeof(BandMeta) * nbnd, st, v, (const TileGeom*)d_geom);
+    else
+      hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false>), dim3(tiles, nlay), dim3((NCW + NLW) * 64),
+                         sizeof(BandMeta) * nbnd, st, v, (const TileGeom*)d_geom);
+  } else {
     rte::ProfScope p("tau_absorption_kernel");
     // <min waves per SIMD, g-points per register chunk>: measured best of {2,3} x {4,8,16} on MI355X
     hipLaunchKernelGGL((tau_absorption_v7_kernel<BS, V7_MINW, V7_HW, V7_SLAB>), dim3(cdiv(ncol, BS), nlay), dim3(BS), sizeof(BandMeta) * nbnd, st,
                        v);
   }
+#ifdef EXP_CLOCKS
+  if (g_tau_variant == 9) {
+    unsigned long long h[8];
+    HIP_CHECK(hipMemcpyAsync(h, v.clocks, 64, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const double n = (double)cdiv(ncol, V9_NCW * 64) * nlay * (ngpt / 16);
+    fprintf(stderr, "clocks/stage: looptop %.0f requests %.0f barrier %.0f major %.0f minor %.0f stores %.0f\n", h[0] / n, h[1] / n, h[2] / n,
+            h[3] / n, h[4] / n, h[5] / n);
+  }
+#endif
   {
     // runs only when *overlap != 0 (some column's lower and upper layer ranges intersect)
     rte::ProfScope p("tau_absorption_fallback");
@@ -1249,7 +1634,8 @@ void rrtmgp_compute_tau_absorption(
     // tiles whose LUT bounding box exceeded the LDS slab
     TauArgs aw = a;
     aw.run_if = nullptr;
-    hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(4096), dim3(256), 0, st, aw, (const int*)v.worklist, BS);
+    hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(4096), dim3(256), 0, st, aw, (const int*)v.worklist,
+                       g_tau_variant == 9 ? V9_NCW * 64 : BS);
   }
 }
 

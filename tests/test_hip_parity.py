@@ -172,7 +172,8 @@ def test_deferred_zero_fill(hip, oracle_c):
         tau2 = xp.full((ncol, nlay, kd.ngpt), 3.0)
         hip.zero_array_3D(ncol, nlay, kd.ngpt, tau2)     # executed
         go.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau2)
-        assert torch.equal(tau, tau2)
+        # two instantiations of the kernel (with / without the tau read): same sums, possibly different rounding
+        assert float(((tau - tau2).abs() / tau2.abs().clamp_min(1e-300)).max()) <= 1e-14
         hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 1)
         # (2) a deferred fill that nobody consumes is materialised by the next library call
         z = xp.full((ncol, 7, 3), 5.0)
