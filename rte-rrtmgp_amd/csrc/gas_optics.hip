@@ -1095,20 +1095,29 @@ __device__ __forceinline__ Float planck_1d(Float val, Float offset, Float delta_
   return t0 + frac * (t1 - t0);
 }
 
-__global__ void __launch_bounds__(256)
-planck_source_kernel(int ncol, int nlay, int ngpt, int neta, int npres, int ntemp, int nPlanckTemp,
-                     const Float* __restrict__ tlay, const Float* __restrict__ tlev,
-                     const Float* __restrict__ tsfc, int sfc_lay, const Float* __restrict__ fmajor,
-                     const int* __restrict__ jeta, const Bool* __restrict__ tropo,
-                     const int* __restrict__ jtemp, const int* __restrict__ jpress,
-                     const int* __restrict__ band_lims_gpt, const Float* __restrict__ pfracin,
-                     Float temp_ref_min, Float totplnk_delta_r, const Float* __restrict__ totplnk,
-                     const int* __restrict__ gpoint_flavor, Float* __restrict__ sfc_src,
-                     Float* __restrict__ lay_src, Float* __restrict__ lev_src,
-                     Float* __restrict__ sfc_source_Jac) {
-  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ibnd = blockIdx.y;
-  if (icol >= ncol) return;
+struct PlanckArgs {
+  int ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, sfc_lay;
+  const Float *tlay, *tlev, *tsfc, *fmajor;
+  const int* jeta;
+  const Bool* tropo;
+  const int *jtemp, *jpress, *band_lims_gpt;
+  const Float* pfracin;
+  Float temp_ref_min, totplnk_delta_r;
+  const Float* totplnk;
+  const int* gpoint_flavor;
+  Float *sfc_src, *lay_src, *lev_src, *sfc_source_Jac;
+};
+
+// one column, one band, native table layout: always applicable
+__device__ __forceinline__ void planck_direct_column(const PlanckArgs& q, const int icol, const int ibnd) {
+  const int ncol = q.ncol, nlay = q.nlay, ngpt = q.ngpt, neta = q.neta, npres = q.npres, ntemp = q.ntemp,
+            nPlanckTemp = q.nPlanckTemp, sfc_lay = q.sfc_lay;
+  const Float *tlay = q.tlay, *tlev = q.tlev, *tsfc = q.tsfc, *fmajor = q.fmajor, *pfracin = q.pfracin, *totplnk = q.totplnk;
+  const int *jeta = q.jeta, *jtemp = q.jtemp, *jpress = q.jpress, *band_lims_gpt = q.band_lims_gpt,
+            *gpoint_flavor = q.gpoint_flavor;
+  const Bool* tropo = q.tropo;
+  const Float temp_ref_min = q.temp_ref_min, totplnk_delta_r = q.totplnk_delta_r;
+  Float *sfc_src = q.sfc_src, *lay_src = q.lay_src, *lev_src = q.lev_src, *sfc_source_Jac = q.sfc_source_Jac;
   const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
   const int gptS = band_lims_gpt[2 * ibnd] - 1, gptE = band_lims_gpt[2 * ibnd + 1] - 1;
   const Float* tp = totplnk + (size_t)nPlanckTemp * ibnd;
@@ -1165,6 +1174,20 @@ planck_source_kernel(int ncol, int nlay, int ngpt, int neta, int npres, int ntem
   }
 }
 
+__global__ void __launch_bounds__(256) planck_source_kernel(PlanckArgs q) {
+  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+  if (icol < q.ncol) planck_direct_column(q, icol, blockIdx.y);
+}
+
+// (tile, band) pairs the slab kernel handed over (worklist[0] = count)
+__global__ void __launch_bounds__(256) planck_source_worklist_kernel(PlanckArgs q, const int* __restrict__ worklist) {
+  const int n = worklist[0];
+  for (int w = blockIdx.x; w < n; w += gridDim.x) {
+    const int icol = worklist[1 + 2 * w] * 256 + threadIdx.x;
+    if (icol < q.ncol) planck_direct_column(q, icol, worklist[2 + 2 * w]);
+  }
+}
+
 // -------------------------------------------------------------------------------------------
 // compute_Planck_source, production kernel: same scheme as tau_absorption_v7_kernel.
 // block = (256 columns, one band) and walks the LAYERS, so the previous layer's Planck fractions
@@ -1180,6 +1203,7 @@ struct PlanckV7 {
   const Bool* tropo;
   const Float *pf_g, *totplnk, *fmajor, *tlay, *tlev, *tsfc;
   Float *sfc_src, *lay_src, *lev_src, *sfc_jac;
+  int* worklist;  // [0] = count, then (tile, band) pairs for planck_source_worklist_kernel
 };
 
 template <int BS>
@@ -1258,15 +1282,38 @@ __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
       __syncthreads();  // ranges complete; previous layer's compute finished (slab is free)
       const int Tmin = r[0], nT = r[1] - r[0] + 1, Pmin = r[2], nP = r[3] - r[2] + 1, emin = r[4], nE = r[5] - r[4] + 1;
       const int rows = nP * nT * nE;
-      const bool use_lds = rows * RS <= PSLAB;
+      if (rows * RS > PSLAB) {  // block-uniform: this (tile, band) goes to the direct kernel as a whole
+        if (tid == 0) {
+          const int w = atomicAdd(&a.worklist[0], 1);
+          a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = ibnd;
+        }
+        return;
+      }
+      constexpr bool use_lds = true;
       if (tid < 6) rng[(l + 1) & 1][tid] = (tid % 2 == 0) ? (1 << 30) : -1;
       if (use_lds) {
-        for (int idx = tid; idx < rows * (GC / 2); idx += BS) {
+        // 16-byte pieces of the bounding box, SB per thread requested back to back (index clamped, so the
+        // count is fixed): the tile pays the L2 latency once per batch
+        constexpr int SB = 4;
+        const int nAll = rows * (GC / 2);
+        const float inv_nE = 1.0f / (float)nE, inv_nT = 1.0f / (float)nT;
+        auto piece = [&](int idx) -> Float2 {
           const int j = idx & 7, rr = idx >> 3;
-          const int e = rr % nE, rest = rr / nE, t_l = rest % nT, p_l = rest / nT;
-          const Float2 v = *reinterpret_cast<const Float2*>(
+          const int rest = (int)(((float)rr + 0.5f) * inv_nE), e = rr - rest * nE;  // rows < 2^12: exact
+          const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
+          return *reinterpret_cast<const Float2*>(
               a.pf_g + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
-          *reinterpret_cast<Float2*>(slab + rr * RS + 2 * j) = v;
+        };
+#pragma unroll 1
+        for (int base = tid; base < nAll; base += SB * BS) {
+          Float2 v[SB];
+#pragma unroll
+          for (int u = 0; u < SB; ++u) v[u] = piece(min(base + u * BS, nAll - 1));
+#pragma unroll
+          for (int u = 0; u < SB; ++u) {
+            const int idx = base + u * BS;
+            if (idx < nAll) *reinterpret_cast<Float2*>(slab + (idx >> 3) * RS + 2 * (idx & 7)) = v[u];
+          }
         }
       }
       // this layer's values into locals, then request the following layers' inputs
@@ -1286,7 +1333,7 @@ __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
       const bool sfc = (int)l == a.sfc_lay - 1;
       // one body, instantiated separately for LDS and for global rows (a merged pointer would be a
       // generic one and every gather a slow flat load)
-      auto body = [&](const Float* __restrict__ A0, const Float* __restrict__ B0, const size_t sE, const size_t sP) {
+      auto body = [&](const Float* __restrict__ A0, const Float* __restrict__ B0, const int sE, const int sP) {
 #pragma unroll
         for (int jj = 0; jj < GC; jj += 2) {
           // interpolate3D_byflav with scaling (1,1), :791-801; one 16-byte read feeds two g-points
@@ -1313,17 +1360,12 @@ __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
             }
             prev[j] = pf;
           }
-          __builtin_amdgcn_sched_barrier(0);  // at most 8 row reads (32 VGPRs) in flight
+          asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));  // keep the pair's arithmetic here (see tau kernel)
+          if ((jj & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads (64 VGPRs) in flight
         }
       };
-      if (use_lds) {
-        body(slab + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS,
-             slab + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS, (size_t)RS, (size_t)nT * nE * RS);
-      } else {  // tile too heterogeneous for the slab: same arithmetic from the g-fastest table
-        body(a.pf_g + ((size_t)((jp - 2) * TE + (je1 - 1) * ntemp + (jT - 1)) * ngpt + g0),
-             a.pf_g + ((size_t)((jp - 2) * TE + (je2 - 1) * ntemp + jT) * ngpt + g0), (size_t)ntemp * ngpt,
-             (size_t)TE * ngpt);
-      }
+      body(slab + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS,
+           slab + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS, RS, nT * nE * RS);
     }
     if (valid) {
       const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
@@ -1717,13 +1759,16 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
   const bool fast = bl_ok && ncol >= 512 && !g_tau_force_direct && (size_t)ncol * (nlay + 1) < ((size_t)1 << 31) &&
                     al(d_fmajor, 16) && al(d_jeta, 8);
+  PlanckArgs q;
+  q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.neta = neta; q.npres = npres; q.ntemp = ntemp; q.nPlanckTemp = nPlanckTemp;
+  q.sfc_lay = *sfc_lay_; q.tlay = d_tlay; q.tlev = d_tlev; q.tsfc = d_tsfc; q.fmajor = d_fmajor; q.jeta = d_jeta;
+  q.tropo = d_tropo; q.jtemp = d_jtemp; q.jpress = d_jpress; q.band_lims_gpt = d_band_lims; q.pfracin = d_pfracin;
+  q.temp_ref_min = *temp_ref_min; q.totplnk_delta_r = totplnk_delta_r; q.totplnk = d_totplnk;
+  q.gpoint_flavor = d_gpoint_flavor; q.sfc_src = d_sfc_src; q.lay_src = d_lay_src; q.lev_src = d_lev_src;
+  q.sfc_source_Jac = d_sfc_jac;
   if (!fast) {
     rte::ProfScope p("planck_source_kernel");
-    dim3 grid(cdiv(ncol, 256), nbnd), block(256);
-    hipLaunchKernelGGL(planck_source_kernel, grid, block, 0, st, ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp,
-                       d_tlay, d_tlev, d_tsfc, *sfc_lay_, d_fmajor, d_jeta, d_tropo, d_jtemp, d_jpress, d_band_lims,
-                       d_pfracin, *temp_ref_min, totplnk_delta_r, d_totplnk, d_gpoint_flavor, d_sfc_src, d_lay_src,
-                       d_lev_src, d_sfc_jac);
+    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q);
     return;
   }
   const int TE = ntemp * neta;
@@ -1740,10 +1785,19 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   v.jpress = d_jpress; v.tropo = d_tropo; v.pf_g = pf_g; v.totplnk = d_totplnk; v.fmajor = d_fmajor;
   v.tlay = d_tlay; v.tlev = d_tlev; v.tsfc = d_tsfc;
   v.sfc_src = d_sfc_src; v.lay_src = d_lay_src; v.lev_src = d_lev_src; v.sfc_jac = d_sfc_jac;
-  rte::ProfScope p("planck_source_kernel");
   constexpr int BS = 256;
-  hipLaunchKernelGGL((planck_source_v7_kernel<BS>), dim3(cdiv(ncol, BS), nbnd), dim3(BS), sizeof(Float) * nPlanckTemp, st,
-                     v);
+  v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 2 * (size_t)cdiv(ncol, BS) * nbnd));
+  HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
+  {
+    rte::ProfScope p("planck_source_kernel");
+    hipLaunchKernelGGL((planck_source_v7_kernel<BS>), dim3(cdiv(ncol, BS), nbnd), dim3(BS), sizeof(Float) * nPlanckTemp, st,
+                       v);
+  }
+  {
+    // (tile, band) pairs whose pfrac bounding box exceeded the LDS slab at some layer
+    rte::ProfScope p("planck_source_fallback");
+    hipLaunchKernelGGL(planck_source_worklist_kernel, dim3(1024), dim3(256), 0, st, q, (const int*)v.worklist);
+  }
 }
 
 }  // extern "C"
