@@ -218,14 +218,18 @@ def main():
         if dom and os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("ncol") == ncol and dom in pmc.get("kernels", {}):
-                    traffic = pmc["kernels"][dom]["hbm_GB_per_launch"]
+                if pmc.get("ncol") == ncol:
+                    if dom in pmc.get("kernels", {}):
+                        traffic = pmc["kernels"][dom]["hbm_GB_per_launch"]
+                    for k, v in pmc.get("kernels", {}).items():  # measured HBM GB per launch next to the model
+                        if k in per_kernel:
+                            per_kernel[k]["pmc_GB"] = v["hbm_GB_per_launch"]
             except Exception:
                 traffic = None
         roof = None
         if dom:
             roof = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic,
+                    "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic, "traffic_unit": "GB per launch (PMC)",
                     "chain": {"alg_GB_per_step": round(chain_gb, 3), "kernel_ms_per_step": round(chain_ms, 4),
                               "GBps": round(chain_gb / (chain_ms * 1e-3), 1),
                               "frac": round(chain_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4)},

@@ -11,7 +11,7 @@ G[fetch]="FETCH_SIZE TCC_HIT_sum"
 G[write]="WRITE_SIZE TCC_MISS_sum TCC_REQ_sum"
 G[tcp]="TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"
 for g in ${PMC_GROUPS:-sq1 sq2 fetch write tcp}; do
-  rocprofv3 --pmc ${G[$g]} --kernel-trace --output-format csv -d gpurun_out/pmc/${TAG}_$g -o p -- \
+  timeout 300 rocprofv3 --pmc ${G[$g]} --kernel-trace --output-format csv -d gpurun_out/pmc/${TAG}_$g -o p -- \
     python bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/pmc/${TAG}_$g.log 2>&1
   echo "$g: $(ls gpurun_out/pmc/${TAG}_$g 2>/dev/null | tr '\n' ' ')"
 done
