@@ -947,7 +947,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const Float w0 = mj.cm.x * mj.fm[0].x, w1 = mj.cm.x * mj.fm[0].y, w2 = mj.cm.x * mj.fm[1].x, w3 = mj.cm.x * mj.fm[1].y,
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
     const int je1 = mj.je.x, je2 = mj.je.y;
-    if (s + 1 < nstage && ibnd_n != ibnd) load_major(ibnd_n, mj);
+    load_major(ibnd_n, mj);  // always issued (a static request count keeps the waits counted ones)
     __syncthreads();  // B(s): slab(s) is complete
     if (!run) continue;
     const Float* sl = slab[s & 1];
@@ -1025,14 +1025,17 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         if ((j & 6) == 6) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads in flight
       }
     }
-    if (!OVERWRITE) {
+    if (OVERWRITE) {
+      // lanes past the last column repeat it (ic is clamped): same values to the same addresses.  Unconditional
+      // stores keep the count of outstanding memory operations static (counted waits instead of drains).
+#pragma unroll
+      for (int j = 0; j < GC; ++j) *tau_at(j) = acc[j];
+    } else if (valid) {
       // tau is inout (the reference accumulates onto it, :637,:679).  The stage's sum is added to the incoming
       // value at the end: identical to the reference when tau comes in as zero (always, in the frontend),
       // otherwise the same terms in a different order (1 ulp)
 #pragma unroll
       for (int j = 0; j < GC; ++j) acc[j] = *tau_at(j) + acc[j];
-    }
-    if (valid) {
 #pragma unroll
       for (int j = 0; j < GC; ++j) *tau_at(j) = acc[j];
     }
@@ -1180,12 +1183,14 @@ __global__ void __launch_bounds__(256) planck_source_kernel(PlanckArgs q) {
 }
 
 // (tile, band) pairs the slab kernel handed over (worklist[0] = count)
-__global__ void __launch_bounds__(256) planck_source_worklist_kernel(PlanckArgs q, const int* __restrict__ worklist) {
+__global__ void __launch_bounds__(256)
+planck_source_worklist_kernel(PlanckArgs q, const int* __restrict__ worklist, int tile) {
   const int n = worklist[0];
-  for (int w = blockIdx.x; w < n; w += gridDim.x) {
-    const int icol = worklist[1 + 2 * w] * 256 + threadIdx.x;
-    if (icol < q.ncol) planck_direct_column(q, icol, worklist[2 + 2 * w]);
-  }
+  for (int w = blockIdx.x; w < n; w += gridDim.x)
+    for (int c = threadIdx.x; c < tile; c += 256) {
+      const int icol = worklist[1 + 2 * w] * tile + c;
+      if (icol < q.ncol) planck_direct_column(q, icol, worklist[2 + 2 * w]);
+    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1204,6 +1209,9 @@ struct PlanckV7 {
   const Float *pf_g, *totplnk, *fmajor, *tlay, *tlev, *tsfc;
   Float *sfc_src, *lay_src, *lev_src, *sfc_jac;
   int* worklist;  // [0] = count, then (tile, band) pairs for planck_source_worklist_kernel
+#ifdef EXP_CLOCKS
+  unsigned long long* clocks;
+#endif
 };
 
 template <int BS>
@@ -1376,13 +1384,289 @@ __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// compute_Planck_source, specialised-wave kernel: the loader / compute split of tau_absorption_v9_kernel.
+// Block = (NCW*64 columns, one band): NCW compute waves (lanes = columns) walk the LAYERS, so the previous
+// layer's Planck fractions stay in registers for the geometric mean at the interface (:699); NLW loader
+// waves stage the bounding box of pfrac rows of layer l+1 into the other half of a double-buffered LDS slab
+// while layer l is computed; one barrier per layer.  planck_geom_kernel provides the boxes and sends
+// (tile, band) pairs that do not fit the slab at some layer to the direct kernel.
+// -------------------------------------------------------------------------------------------
+template <int TILE>
+__global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd, TileGeom* __restrict__ geom,
+                                                           int* __restrict__ flags, int slab_floats) {
+  __shared__ int rng[4];
+  __shared__ int erng[MAXB][2];
+  const int tid = threadIdx.x;
+  const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
+  const unsigned ncl = ncol * nlay;
+  if (tid == 0) { rng[0] = 1 << 30; rng[1] = -1; rng[2] = 1 << 30; rng[3] = -1; }
+  if (tid < MAXB) { erng[tid][0] = 1 << 30; erng[tid][1] = -1; }
+  __syncthreads();
+  const unsigned icol = blockIdx.x * TILE + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  const unsigned cl = ic + ncol * ilay;
+  const int itropo = a.tropo[cl] ? 0 : 1;
+  const int jT = a.jtemp[cl];
+  const int jp = a.jpress[cl] + itropo + 1;
+  const int big = 1 << 30;
+  {
+    const int a0 = wave_min(valid ? jT : big), a1 = wave_max(valid ? jT + 1 : -1);
+    const int a2 = wave_min(valid ? jp - 1 : big), a3 = wave_max(valid ? jp : -1);
+    if ((tid & 63) == 0) { atomicMin(&rng[0], a0); atomicMax(&rng[1], a1); atomicMin(&rng[2], a2); atomicMax(&rng[3], a3); }
+  }
+  for (int b = 0; b < nbnd; ++b) {
+    const int iflav = a.gpoint_flavor[itropo + 2 * (a.band_lims[2 * b] - 1)] - 1;
+    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * iflav));
+    const int e0 = wave_min(valid ? min(je.x, je.y) : big), e1 = wave_max(valid ? max(je.x, je.y) + 1 : -1);
+    if ((tid & 63) == 0) { atomicMin(&erng[b][0], e0); atomicMax(&erng[b][1], e1); }
+  }
+  __syncthreads();
+  TileGeom* out = geom + (blockIdx.x + (size_t)gridDim.x * ilay);
+  const int nT = rng[1] - rng[0] + 1, nP = rng[3] - rng[2] + 1;
+  if (tid == 0) {
+    out->Tmin = rng[0]; out->nT = nT; out->Pmin = rng[2]; out->nP = nP; out->has_lo = 0; out->has_up = 0;
+    out->pad0 = 0; out->pad1 = 0;
+  }
+  if (tid < nbnd) {
+    const int emin = erng[tid][0], nE = erng[tid][1] - erng[tid][0] + 1;
+    const bool fits = nP * nT * nE * RS <= slab_floats;
+    if (!fits && atomicCAS(&flags[blockIdx.x * nbnd + tid], 0, 1) == 0) {  // once per (tile, band)
+      const int w = atomicAdd(&a.worklist[0], 1);
+      a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = tid;
+    }
+    out->eg[tid] = make_int2(emin, nE);
+  }
+}
+
+template <int NCW, int NLW, int SLAB>
+__global__ void __launch_bounds__((NCW + NLW) * 64, (NCW + NLW + 3) / 4)
+planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom, const int* __restrict__ flags) {
+  constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
+  constexpr int MAXL = 256;  // layers per block held in the LDS geometry table (host checks nlay <= MAXL)
+  __shared__ __align__(16) Float slab[2][SLAB];
+  __shared__ int gl[MAXL][6];       // per layer: Tmin, nT, Pmin, nP, emin, nE
+  extern __shared__ Float tpl[];    // totplnk(:, ibnd)
+  const int tid = threadIdx.x;
+  const int ibnd = blockIdx.y;
+  if (flags[blockIdx.x * nbnd + ibnd]) return;  // block-uniform: the direct kernel does this (tile, band)
+  const unsigned ncol = a.ncol, nlay = a.nlay;
+  const unsigned ncl = ncol * nlay, nclv = ncol * (nlay + 1);  // host guarantees 8 * nclv < 2^32
+  const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nPT = a.nPlanckTemp;
+  const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
+  for (int i = tid; i < nPT; i += NT) tpl[i] = a.totplnk[(size_t)nPT * ibnd + i];
+  for (int l = tid; l < (int)nlay; l += NT) {
+    const TileGeom* g = geom + (blockIdx.x + (size_t)gridDim.x * l);
+    gl[l][0] = g->Tmin; gl[l][1] = g->nT; gl[l][2] = g->Pmin; gl[l][3] = g->nP;
+    gl[l][4] = g->eg[ibnd].x; gl[l][5] = g->eg[ibnd].y;
+  }
+  __syncthreads();
+  const int nchunk = (gptE - gptS + 1) / GC;  // host guarantees whole, 16-aligned chunks
+  // stages of a chunk: the layers in order, then -- unless the surface layer is the last one, whose Planck
+  // fractions are still in registers -- the surface layer once more for sfc_source (keeps those stores and
+  // their addresses out of the layer loop)
+  const int lsfc = a.sfc_lay - 1;
+  const int spc = (int)nlay + (lsfc == (int)nlay - 1 ? 0 : 1);
+  const int nstage = nchunk * spc;
+
+  if (tid >= TILE) {
+    // ================================ loader waves ================================
+    const int lt = tid - TILE;
+    constexpr int SB = 8;  // 16-byte pieces per lane requested back to back
+#pragma unroll 1
+    for (int s = 0; s < nstage; ++s) {
+      const int ls = s % spc, l = ls < (int)nlay ? ls : lsfc, g0 = gptS + (s / spc) * GC;
+      const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], nP = gl[l][3], emin = gl[l][4], nE = gl[l][5];
+      const float inv_nE = 1.0f / (float)nE, inv_nT = 1.0f / (float)nT;
+      const int nAll = nP * nT * nE * (GC / 2);
+      Float* sl = slab[s & 1];
+      auto piece = [&](int idx) -> Float2 {  // rows ordered [p][t][eta]
+        const int j = idx & 7, r = idx >> 3;
+        const int rest = (int)(((float)r + 0.5f) * inv_nE), e = r - rest * nE;  // rows < 2^12: exact
+        const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
+        return *reinterpret_cast<const Float2*>(
+            a.pf_g + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
+      };
+#pragma unroll 1
+      for (int base = lt; base < nAll; base += SB * NLT) {
+        Float2 v[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) v[u] = piece(min(base + u * NLT, nAll - 1));
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int idx = base + u * NLT;
+          if (idx < nAll) *reinterpret_cast<Float2*>(sl + (idx >> 3) * RS + 2 * (idx & 7)) = v[u];
+        }
+      }
+      __syncthreads();  // B(s): slab(s) complete; the compute waves are done with the other buffer
+    }
+    return;
+  }
+
+  // ================================ compute waves (lanes = columns) ================================
+  const unsigned icol = blockIdx.x * TILE + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  const int flav0 = a.gpoint_flavor[2 * gptS] - 1, flav1 = a.gpoint_flavor[1 + 2 * gptS] - 1;
+  auto planck = [&](Float t) {  // interpolate1D :715-737 on the LDS copy of the band's column
+    const Float val0 = (t - a.temp_ref_min) * a.totplnk_delta_r;
+    const Float frac = val0 - trunc(val0);
+    const int index = min(nPT - 1, max(1, (int)val0 + 1));
+    const Float t0 = tpl[index - 1], t1 = tpl[index];
+    return t0 + frac * (t1 - t0);
+  };
+  const Float pl_sfc = planck(a.tsfc[ic]);
+  const Float pl_sfc1 = planck(a.tsfc[ic] + (Float)1);
+
+  struct Idx { Bool tropo; int jT, jpress; Float tlay, tlev; };  // raw loaded values: nothing is derived at load
+  struct Wts { Float2 fm[4]; int je1, je2; };                     // time, so no request waits for another
+  auto load_idx = [&](unsigned l, Idx& x) {
+    const unsigned cl = ic + ncol * l;
+    x.tropo = a.tropo[cl];
+    x.jT = a.jtemp[cl];
+    x.jpress = a.jpress[cl];
+    x.tlay = a.tlay[cl];
+    x.tlev = a.tlev[cl];
+  };
+  auto load_wts = [&](unsigned l, const Idx& x, Wts& w) {
+    const size_t clf = (ic + ncol * l) + (size_t)ncl * (x.tropo ? flav0 : flav1);
+    const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.fm[i] = fmp[i];
+    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
+    w.je1 = je.x; w.je2 = je.y;
+  };
+  Idx x0, x1;   // layers l and l+1
+  Wts w0;       // layer l
+  Float prev[GC];
+  int s = 0;
+#ifdef EXP_CLOCKS
+  unsigned long long tk = clock64(), tacc[4] = {0, 0, 0, 0};
+#undef TICK
+#define TICK(i) do { const unsigned long long t2_ = clock64(); tacc[i] += t2_ - tk; tk = t2_; } while (0)
+#else
+#undef TICK
+#define TICK(i)
+#endif
+#pragma unroll 1
+  for (int g0 = gptS; g0 <= gptE; g0 += GC) {
+    load_idx(0, x0);
+    load_idx(min(1u, nlay - 1), x1);
+    load_wts(0, x0, w0);
+#pragma unroll
+    for (int j = 0; j < GC; ++j) prev[j] = 0;
+#pragma unroll 1
+    for (unsigned l = 0; l < nlay; ++l, ++s) {
+      TICK(0);
+      // this layer's values into locals, then request the following layers' inputs
+      const Float f0 = w0.fm[0].x, f1 = w0.fm[0].y, f2 = w0.fm[1].x, f3 = w0.fm[1].y, f4 = w0.fm[2].x, f5 = w0.fm[2].y,
+                  f6 = w0.fm[3].x, f7 = w0.fm[3].y;
+      const int je1 = w0.je1, je2 = w0.je2, jT = x0.jT, jp = x0.jpress + (x0.tropo ? 0 : 1) + 1;  // levels jp-1, jp
+      const Float tl = x0.tlay, tv = x0.tlev;
+      x0 = x1;
+      if (l + 1 < nlay) load_wts(l + 1, x0, w0);
+      if (l + 2 < nlay) load_idx(l + 2, x1);
+      const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], emin = gl[l][4], nE = gl[l][5];
+      const Float pl_lay = planck(tl), pl_lev = planck(tv);
+      TICK(1);
+      __syncthreads();  // B(s): slab(s) is complete
+      TICK(2);
+      const Float* sl = slab[s & 1];
+      const Float* A0 = sl + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS;
+      const Float* B0 = sl + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
+      const int sP = nT * nE * RS;
+      // byte offsets of this column in the (col, lay, g) / (col, lev, g) planes; scalar plane bases
+      unsigned olay = (ic + ncol * l) * (unsigned)sizeof(Float);
+      asm volatile("" : "+v"(olay));  // keep 64-bit addresses out of the loop-invariant registers
+      char* const play_ = reinterpret_cast<char*>(a.lay_src + (size_t)ncl * g0);
+      char* const plev_ = reinterpret_cast<char*>(a.lev_src + (size_t)nclv * g0);
+      const size_t slay = (size_t)ncl * sizeof(Float), slev = (size_t)nclv * sizeof(Float);
+#pragma unroll
+      for (int jj = 0; jj < GC; jj += 2) {
+        // interpolate3D_byflav with scaling (1,1), :791-801; one 16-byte read feeds two g-points
+        const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + RS + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + RS + jj),
+                     k4 = ld2(B0 + jj), k5 = ld2(B0 + RS + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + RS + jj);
+        Float pfv[2], pgv[2];
+        pfv[0] = f0 * k0.x; pfv[1] = f0 * k0.y;
+        pfv[0] = fma(f1, k1.x, pfv[0]); pfv[1] = fma(f1, k1.y, pfv[1]);
+        pfv[0] = fma(f2, k2.x, pfv[0]); pfv[1] = fma(f2, k2.y, pfv[1]);
+        pfv[0] = fma(f3, k3.x, pfv[0]); pfv[1] = fma(f3, k3.y, pfv[1]);
+        pgv[0] = f4 * k4.x; pgv[1] = f4 * k4.y;
+        pgv[0] = fma(f5, k5.x, pgv[0]); pgv[1] = fma(f5, k5.y, pgv[1]);
+        pgv[0] = fma(f6, k6.x, pgv[0]); pgv[1] = fma(f6, k6.y, pgv[1]);
+        pgv[0] = fma(f7, k7.x, pgv[0]); pgv[1] = fma(f7, k7.y, pgv[1]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = jj + u;
+          const Float pf = pfv[u] + pgv[u];
+          const Float vlay = pf * pl_lay;                                      // :674
+          const Float vlev = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;      // :695,:699
+          // lanes past the last column repeat it (ic is clamped) and store the same values to the same
+          // addresses: unconditional stores keep the number of outstanding memory operations static, so the
+          // wait for the next layer's weights is a counted one instead of a drain of these stores
+          *reinterpret_cast<Float*>(play_ + slay * j + olay) = vlay;
+          *reinterpret_cast<Float*>(plev_ + slev * j + olay) = vlev;  // level l of (ncol, nlay+1): same column offset
+          prev[j] = pf;
+        }
+        asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));  // keep the pair's arithmetic here
+        __builtin_amdgcn_sched_barrier(0);   // at most 8 row reads (32 VGPRs) in flight
+      }
+      TICK(3);
+    }
+    if (valid) {
+      const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
+#pragma unroll
+      for (int j = 0; j < GC; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
+    }
+    // ---- surface source (:651-653) from the Planck fractions of the surface layer
+    if (lsfc != (int)nlay - 1) {
+      load_idx(lsfc, x0);
+      load_wts(lsfc, x0, w0);
+      const int Tmin = gl[lsfc][0], nT = gl[lsfc][1], Pmin = gl[lsfc][2], emin = gl[lsfc][4], nE = gl[lsfc][5];
+      __syncthreads();  // B(s): the surface layer's slab is complete
+      const Float* sl = slab[s & 1];
+      ++s;
+      const int jps = x0.jpress + (x0.tropo ? 0 : 1) + 1;
+      const Float* A0 = sl + (((jps - 1 - Pmin) * nT + (x0.jT - Tmin)) * nE + (w0.je1 - emin)) * RS;
+      const Float* B0 = sl + (((jps - 1 - Pmin) * nT + (x0.jT + 1 - Tmin)) * nE + (w0.je2 - emin)) * RS;
+      const int sP = nT * nE * RS;
+#pragma unroll
+      for (int jj = 0; jj < GC; jj += 2) {
+        const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + RS + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + RS + jj),
+                     k4 = ld2(B0 + jj), k5 = ld2(B0 + RS + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + RS + jj);
+        Float pa = w0.fm[0].x * k0.x, pb = w0.fm[0].x * k0.y, qa = w0.fm[2].x * k4.x, qb = w0.fm[2].x * k4.y;
+        pa = fma(w0.fm[0].y, k1.x, pa); pb = fma(w0.fm[0].y, k1.y, pb); qa = fma(w0.fm[2].y, k5.x, qa); qb = fma(w0.fm[2].y, k5.y, qb);
+        pa = fma(w0.fm[1].x, k2.x, pa); pb = fma(w0.fm[1].x, k2.y, pb); qa = fma(w0.fm[3].x, k6.x, qa); qb = fma(w0.fm[3].x, k6.y, qb);
+        pa = fma(w0.fm[1].y, k3.x, pa); pb = fma(w0.fm[1].y, k3.y, pb); qa = fma(w0.fm[3].y, k7.x, qa); qb = fma(w0.fm[3].y, k7.y, qb);
+        prev[jj] = pa + qa; prev[jj + 1] = pb + qb;
+        asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < GC; ++j) {
+        a.sfc_src[ic + (size_t)ncol * (g0 + j)] = prev[j] * pl_sfc;
+        a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = prev[j] * (pl_sfc1 - pl_sfc);
+      }
+    }
+  }
+#ifdef EXP_CLOCKS
+  if (tid == 0)
+    for (int i = 0; i < 4; ++i) atomicAdd(&a.clocks[i], tacc[i]);
+#endif
+}
+
 }  // namespace
 
 // ===============================================================================================
 // C ABI
 // ===============================================================================================
 static int g_tau_force_direct = 0;
-static int g_tau_variant = 9;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
+static int g_tau_variant = 9;
+static int g_planck_variant = 9;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
 static int g_plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget cached host-side plans
 
 namespace {
@@ -1412,6 +1696,7 @@ extern "C" {
 
 int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
 int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
+int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
 int rte_hip_invalidate_plans(void) { ++g_plan_epoch; return 0; }
 
 
@@ -1788,15 +2073,44 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   constexpr int BS = 256;
   v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 2 * (size_t)cdiv(ncol, BS) * nbnd));
   HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
-  {
+  int wl_tile = BS;
+  if (g_planck_variant == 9 && nlay <= 256 && nbnd <= MAXB && (size_t)ncol * (nlay + 1) < ((size_t)1 << 29)) {
+    constexpr int NCW = 8, NLW = 2, SLAB9 = 8704;  // 8 compute + 2 loader waves, 2 x 68 KB slab: one block per CU
+    wl_tile = NCW * 64;
+    const unsigned tiles = cdiv(ncol, NCW * 64);
+    TileGeom* d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
+    int* d_flags = (int*)rte::scratch(sizeof(int) * (size_t)tiles * nbnd);
+    HIP_CHECK(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)tiles * nbnd, st));
+    {
+      rte::ProfScope p("planck_source_setup");
+      hipLaunchKernelGGL((planck_geom_kernel<NCW * 64>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, d_flags,
+                         SLAB9);
+    }
+#ifdef EXP_CLOCKS
+    v.clocks = (unsigned long long*)rte::scratch(64);
+    HIP_CHECK(hipMemsetAsync(v.clocks, 0, 64, st));
+#endif
+    rte::ProfScope p("planck_source_kernel");
+    hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9>), dim3(tiles, nbnd), dim3((NCW + NLW) * 64),
+                       sizeof(Float) * nPlanckTemp, st, v, nbnd, (const TileGeom*)d_geom, (const int*)d_flags);
+  } else {
     rte::ProfScope p("planck_source_kernel");
     hipLaunchKernelGGL((planck_source_v7_kernel<BS>), dim3(cdiv(ncol, BS), nbnd), dim3(BS), sizeof(Float) * nPlanckTemp, st,
                        v);
   }
+#ifdef EXP_CLOCKS
+  if (wl_tile != BS) {
+    unsigned long long h[8];
+    HIP_CHECK(hipMemcpyAsync(h, v.clocks, 64, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    const double n = (double)cdiv(ncol, wl_tile) * nbnd * nlay;
+    fprintf(stderr, "planck clocks/stage: top %.0f requests %.0f barrier %.0f compute+stores %.0f\n", h[0] / n, h[1] / n, h[2] / n, h[3] / n);
+  }
+#endif
   {
     // (tile, band) pairs whose pfrac bounding box exceeded the LDS slab at some layer
     rte::ProfScope p("planck_source_fallback");
-    hipLaunchKernelGGL(planck_source_worklist_kernel, dim3(1024), dim3(256), 0, st, q, (const int*)v.worklist);
+    hipLaunchKernelGGL(planck_source_worklist_kernel, dim3(1024), dim3(256), 0, st, q, (const int*)v.worklist, wl_tile);
   }
 }
 
