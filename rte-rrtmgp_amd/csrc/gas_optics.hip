@@ -1398,11 +1398,13 @@ __global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd,
                                                            int* __restrict__ flags, int slab_floats) {
   __shared__ int rng[4];
   __shared__ int erng[MAXB][2];
+  __shared__ int flav[MAXB][2];  // flavor (0-based) of band b per tropo regime
   const int tid = threadIdx.x;
   const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
   const unsigned ncl = ncol * nlay;
   if (tid == 0) { rng[0] = 1 << 30; rng[1] = -1; rng[2] = 1 << 30; rng[3] = -1; }
   if (tid < MAXB) { erng[tid][0] = 1 << 30; erng[tid][1] = -1; }
+  if (tid < 2 * nbnd) flav[tid >> 1][tid & 1] = a.gpoint_flavor[(tid & 1) + 2 * (a.band_lims[2 * (tid >> 1)] - 1)] - 1;
   __syncthreads();
   const unsigned icol = blockIdx.x * TILE + tid;
   const bool valid = icol < ncol;
@@ -1418,8 +1420,7 @@ __global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd,
     if ((tid & 63) == 0) { atomicMin(&rng[0], a0); atomicMax(&rng[1], a1); atomicMin(&rng[2], a2); atomicMax(&rng[3], a3); }
   }
   for (int b = 0; b < nbnd; ++b) {
-    const int iflav = a.gpoint_flavor[itropo + 2 * (a.band_lims[2 * b] - 1)] - 1;
-    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * iflav));
+    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * flav[b][itropo]));
     const int e0 = wave_min(valid ? min(je.x, je.y) : big), e1 = wave_max(valid ? max(je.x, je.y) + 1 : -1);
     if ((tid & 63) == 0) { atomicMin(&erng[b][0], e0); atomicMax(&erng[b][1], e1); }
   }

@@ -35,6 +35,30 @@ __global__ void __launch_bounds__(256) w_linear16(double2* __restrict__ out, siz
   for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) out[i] = make_double2((double)i, 1.0);
 }
 
+// R1: linear streaming read (grid-stride, 8 B per lane), sum kept in a register
+__global__ void __launch_bounds__(256) r_linear(const double* __restrict__ in, size_t n, double* __restrict__ sink) {
+  double acc = 0;
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += in[i];
+  if (acc == -1.2345) sink[0] = acc;
+}
+// R2: the LW solver's pattern: block = (64 columns, group of g planes) x 8 waves, wave s reads layers [8s, 8s+8)
+__global__ void __launch_bounds__(512) r_solver(const double* __restrict__ in, int ncol, int nlay, int ng, int gpb,
+                                                double* __restrict__ sink) {
+  const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const unsigned col = min(blockIdx.x * 64 + lane, (unsigned)ncol - 1);
+  const size_t ncl = (size_t)ncol * nlay;
+  double acc = 0;
+  for (int g = blockIdx.y * gpb; g < min(ng, (int)(blockIdx.y + 1) * gpb); ++g) {
+    const double* p = in + col + ncl * g;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int lay = min(8 * s + i, nlay - 1);
+      acc += p[(size_t)ncol * lay];
+    }
+  }
+  if (acc == -1.2345) sink[0] = acc;
+}
+
 int main() {
   const int ncol = 100000, nlay = 60, ng = 256;
   const size_t n = (size_t)ncol * nlay * ng;
@@ -59,5 +83,8 @@ int main() {
   timeit("C: linear 8 B/lane", [&] { hipLaunchKernelGGL(w_linear, dim3(4096), dim3(256), 0, 0, out, n); });
   timeit("D: linear 16 B/lane", [&] { hipLaunchKernelGGL(w_linear16, dim3(4096), dim3(256), 0, 0, (double2*)out, n / 2); });
   timeit("hipMemsetAsync", [&] { CK(hipMemsetAsync(out, 0, n * 8, 0)); });
+  double* sink; CK(hipMalloc(&sink, 8));
+  timeit("R1: linear read 8 B/lane", [&] { hipLaunchKernelGGL(r_linear, dim3(8192), dim3(256), 0, 0, out, n, sink); });
+  timeit("R2: solver pattern read (64 col x 8 waves x 8 lay, 16 g/block)", [&] { hipLaunchKernelGGL(r_solver, dim3((ncol + 63) / 64, ng / 16), dim3(512), 0, 0, out, ncol, nlay, ng, 16, sink); });
   return 0;
 }
