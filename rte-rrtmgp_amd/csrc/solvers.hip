@@ -619,6 +619,232 @@ __global__ void __launch_bounds__(256) sw_2stream_generic_kernel(Sw2Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SW two-stream, segmented (broadband output, nlay <= 64): the layout of lw_noscat_seg_kernel applied to
+// sw_dif_and_source + adding (reference :503-609, :985-1127, :1135-1245).
+// Block = S waves x 64 columns; wave s owns layers [8s, 8s+8) counted from the top; per g-point
+//   (1) each wave evaluates the two-stream coefficients of its layers, the direct-beam attenuation
+//       RELATIVE to the beam entering the segment, and the segment composite of the adding recurrence.
+//       One adding step (albedo a, source c below -> above: a' = R + T^2 a/(1-Ra), c' = su + T(c + a sd)/(1-Ra))
+//       is the projective map (a, c, 1) -> M (a, c, 1), M = [[T^2-R^2, 0, R], [T sd - su R, T, su], [-R, 0, 1]];
+//       products keep the zero pattern (7 entries), and the source entries m10, m12 are linear in the beam
+//       entering the segment, so they are formed with the relative beam and scaled after the exchange;
+//   (2) barrier; every wave chains the composites from the surface up to its own lower edge, then re-sweeps
+//       its layers from registers with the reference's own expressions (albedo, source, denom per level) and
+//       forms the affine maps of the downward diffuse flux, fd' = alpha fd + beta, and their composite;
+//   (3) barrier; chain from the top, final sweep, broadband accumulation in registers (partial slabs per
+//       g-group, reduced deterministically by reduce_parts_kernel).
+// Across segments the boundary values come from composites -- same mathematics, different rounding.
+// ---------------------------------------------------------------------------------------------
+struct Sw2SegArgs {
+  int ncol, nlay, ngpt, S, g_per_block;
+  bool top_at_1, has_dif_bc;
+  const Float *tau, *ssa, *g, *mu0, *sfc_alb_dir, *sfc_alb_dif, *inc_flux_dir, *inc_flux_dif;
+  Float *part_up, *part_dn, *part_dir;  // (ncol, nlev, ngroups)
+};
+
+template <int L>
+__global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
+  constexpr int SMAX = 8, NC1 = 8, NC2 = 2;
+  extern __shared__ Float lds[];  // X1[NC1][SMAX][64] (P, m00, m02, m10, m11, m12, m20, m22), X2[NC2][SMAX][64] (A, B)
+  Float* const X1 = lds;
+  Float* const X2 = lds + NC1 * SMAX * 64;
+  Float* const MU = X2 + NC2 * SMAX * 64;  // mu0 of this wave's layers: [SMAX][L][64]
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int S = a.S, ncol = a.ncol, nlay = a.nlay;
+  const int icol = blockIdx.x * 64 + lane;
+  const bool active = icol < ncol;
+  const int c = active ? icol : ncol - 1;  // clamp: inactive lanes compute on a valid column, never store
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const int p0 = s * L;
+  const int np = min(L, nlay - p0);  // layers in this segment (>= 1 by construction)
+  const bool last = (s == S - 1);
+  const int g_begin = blockIdx.y * a.g_per_block;
+  const int g_end = min(a.ngpt, g_begin + a.g_per_block);
+  const Float min_k = (Float)1.e4 * (Float)RTE_EPS;
+  const Float min_mu0 = sqrt((Float)RTE_EPS);
+  auto layer_of = [&](int i) {  // array index of the segment's i-th layer from the top (clamped to a valid one)
+    const int p = p0 + min(i, np - 1);
+    return a.top_at_1 ? p : nlay - 1 - p;
+  };
+
+  // per-layer cosine of the solar zenith angle: independent of the g-point, parked in LDS (lane-private slots)
+  Float* const mu0r = MU + (size_t)s * L * 64 + lane;  // element i at mu0r[i * 64]
+#pragma unroll
+  for (int i = 0; i < L; ++i) mu0r[i * 64] = a.mu0[c + (size_t)ncol * layer_of(i)];
+  const Float mu0_top = a.mu0[c + (size_t)ncol * (a.top_at_1 ? 0 : nlay - 1)];
+  const Float mu0_sfc = a.mu0[c + (size_t)ncol * (a.top_at_1 ? nlay - 1 : 0)];
+
+  Float acc_up[L + 1], acc_dn[L + 1], acc_dir[L + 1];
+#pragma unroll
+  for (int i = 0; i <= L; ++i) { acc_up[i] = 0; acc_dn[i] = 0; acc_dir[i] = 0; }
+
+  struct In { Float tau[L], ssa[L], g[L], inc_dir, alb_dir, alb_dif, inc_dif; };
+  auto load = [&](In& x, int igpt_) {
+    const int igpt = min(igpt_, g_end - 1);
+    const size_t cg = c + (size_t)ncol * igpt;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const size_t o = c + (size_t)ncol * layer_of(i) + ncl * igpt;
+      x.tau[i] = a.tau[o]; x.ssa[i] = a.ssa[o]; x.g[i] = a.g[o];
+    }
+    x.inc_dir = a.inc_flux_dir[cg]; x.alb_dir = a.sfc_alb_dir[cg]; x.alb_dif = a.sfc_alb_dif[cg];
+    x.inc_dif = a.has_dif_bc ? a.inc_flux_dif[cg] : (Float)0;  // :579-583
+  };
+
+  auto process = [&](In& x, int igpt_next) {
+    Float R[L], T[L], su[L], sd[L];  // Rdif, Tdif, source up / down (relative to the beam entering the segment)
+    Float Tn[L];                      // direct-beam transmission of the layer
+    Float P = 1;                      // direct-beam transmission of the layers above layer i in this segment
+    // ---- (1) two-stream coefficients and relative sources, top -> bottom (:1015-1114)
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (i < np) {  // wave-uniform
+        const Float tau_s = x.tau[i], w0_s = x.ssa[i], g_s = x.g[i];
+        const Float gamma1 = ((Float)8 - w0_s * ((Float)5 + (Float)3 * g_s)) * (Float).25;
+        const Float gamma2 = (Float)3 * (w0_s * ((Float)1 - g_s)) * (Float).25;
+        const Float kk = sqrt(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
+        const Float e1 = exp(-tau_s * kk);
+        const Float e2 = e1 * e1;
+        Float RT = (Float)1 / (kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
+        R[i] = RT * gamma2 * ((Float)1 - e2);
+        T[i] = RT * (Float)2 * kk * e1;
+        const Float mu0_s = fmax(min_mu0, mu0r[i * 64]);
+        const Float k_mu = kk * mu0_s;
+        const Float om = (Float)1 - k_mu * k_mu;
+        RT = w0_s * RT / (fabs(om) >= (Float)RTE_EPS ? om : (Float)RTE_EPS);
+        const Float gamma3 = ((Float)2 - (Float)3 * mu0_s * g_s) * (Float).25;
+        const Float gamma4 = (Float)1 - gamma3;
+        const Float alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
+        const Float alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
+        const Float k_gamma3 = kk * gamma3, k_gamma4 = kk * gamma4;
+        const Float Tnoscat = exp(-tau_s / mu0_s);
+        Float Rdir = RT * (((Float)1 - k_mu) * (alpha2 + k_gamma3) - ((Float)1 + k_mu) * (alpha2 - k_gamma3) * e2 -
+                           (Float)2.0 * (k_gamma3 - alpha2 * k_mu) * e1 * Tnoscat);
+        Float Tdir = -RT * (((Float)1 + k_mu) * (alpha1 + k_gamma4) * Tnoscat -
+                            ((Float)1 - k_mu) * (alpha1 - k_gamma4) * e2 * Tnoscat -
+                            (Float)2.0 * (k_gamma4 + alpha1 * k_mu) * e1);
+        Rdir = fmax((Float)0, fmin(Rdir, ((Float)1 - Tnoscat)));
+        Tdir = fmax((Float)0, fmin(Tdir, ((Float)1 - Tnoscat - Rdir)));
+        const bool sun = mu0r[i * 64] > (Float)0;  // :1122-1125
+        su[i] = sun ? Rdir * P : (Float)0;
+        sd[i] = sun ? Tdir * P : (Float)0;
+        Tn[i] = Tnoscat;
+        P = Tnoscat * P;
+      } else {  // neutral layer: identity in every recurrence
+        R[i] = 0; T[i] = 1; su[i] = 0; sd[i] = 0; Tn[i] = 1;
+      }
+    }
+    // ---- segment composite of the adding recurrence (bottom -> top product of the per-layer maps)
+    Float m00 = 1, m02 = 0, m10 = 0, m11 = 1, m12 = 0, m20 = 0, m22 = 1;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      const Float q00 = T[i] * T[i] - R[i] * R[i], q02 = R[i], q10 = T[i] * sd[i] - su[i] * R[i], q11 = T[i], q12 = su[i],
+                  q20 = -R[i];  // q22 = 1, q01 = q21 = 0
+      const Float n00 = q00 * m00 + q02 * m20, n02 = q00 * m02 + q02 * m22;
+      const Float n10 = q10 * m00 + q11 * m10 + q12 * m20, n11 = q11 * m11, n12 = q10 * m02 + q11 * m12 + q12 * m22;
+      const Float n20 = q20 * m00 + m20, n22 = q20 * m02 + m22;
+      m00 = n00; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m22 = n22;
+    }
+    // the layer inputs are dead: request the next g-point's into the same registers (in flight during (2), (3))
+    const Float inc_dir = x.inc_dir, alb_dir = x.alb_dir, alb_dif = x.alb_dif, inc_dif = x.inc_dif;
+    load(x, igpt_next);
+    X1[(0 * SMAX + s) * 64 + lane] = P;
+    X1[(1 * SMAX + s) * 64 + lane] = m00;
+    X1[(2 * SMAX + s) * 64 + lane] = m02;
+    X1[(3 * SMAX + s) * 64 + lane] = m10;
+    X1[(4 * SMAX + s) * 64 + lane] = m11;
+    X1[(5 * SMAX + s) * 64 + lane] = m12;
+    X1[(6 * SMAX + s) * 64 + lane] = m20;
+    X1[(7 * SMAX + s) * 64 + lane] = m22;
+    __syncthreads();
+    // ---- (2) beam entering every segment; adding chain from the surface up to this segment's lower edge
+    const Float dir_toa = inc_dir * mu0_top;  // :575
+    Float dir_in = dir_toa, dir_q = dir_toa;    // dir_q: beam entering segment q
+    Float dq[SMAX];
+#pragma unroll
+    for (int q = 0; q < SMAX; ++q) {
+      dq[q] = dir_q;
+      if (q == s) dir_in = dir_q;
+      if (q < S) dir_q = dir_q * X1[(0 * SMAX + q) * 64 + lane];
+    }
+    const Float dir_sfc = dir_q;
+    Float alb = alb_dif;                                                  // :1121
+    Float src = (mu0_sfc > (Float)0) ? dir_sfc * alb_dir : (Float)0;     // :1120
+#pragma unroll
+    for (int q = SMAX - 1; q > 0; --q) {
+      if (q < S && q > s) {  // wave-uniform
+        const Float c00 = X1[(1 * SMAX + q) * 64 + lane], c02 = X1[(2 * SMAX + q) * 64 + lane];
+        const Float c10 = X1[(3 * SMAX + q) * 64 + lane] * dq[q], c11 = X1[(4 * SMAX + q) * 64 + lane];
+        const Float c12 = X1[(5 * SMAX + q) * 64 + lane] * dq[q];
+        const Float c20 = X1[(6 * SMAX + q) * 64 + lane], c22 = X1[(7 * SMAX + q) * 64 + lane];
+        const Float w = (Float)1 / (c20 * alb + c22);
+        const Float a_new = (c00 * alb + c02) * w;
+        const Float s_new = (c10 * alb + c11 * src + c12) * w;
+        alb = a_new; src = s_new;
+      }
+    }
+    // ---- own layers, bottom -> top, the reference's expressions (:1174-1186 / :1214-1226); the beam at the
+    // levels is accumulated on the way (direct flux, and the direct part of flux_dn, :603,:606)
+    Float al[L + 1], sr[L + 1];  // albedo and source at the levels of the segment (slot i = top of layer i)
+    al[L] = alb; sr[L] = src;
+    Float fa[L], fb[L];           // downward diffuse flux below layer i = fa * (flux above) + fb
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      const Float sui = su[i] * dir_in, sdi = sd[i] * dir_in;
+      const Float denom = (Float)1 / ((Float)1 - R[i] * alb);
+      const Float src_new = sui + T[i] * denom * (src + alb * sdi);
+      const Float alb_new = R[i] + T[i] * T[i] * alb * denom;
+      fa[i] = T[i] * denom;
+      fb[i] = (R[i] * src + sdi) * denom;
+      alb = alb_new; src = src_new;
+      al[i] = alb; sr[i] = src;
+    }
+    Float A = 1, B = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) { B = fa[i] * B + fb[i]; A = fa[i] * A; }
+    X2[(0 * SMAX + s) * 64 + lane] = A;
+    X2[(1 * SMAX + s) * 64 + lane] = B;
+    __syncthreads();
+    // ---- (3) diffuse flux entering the segment from above, final sweep (:1188-1202 / :1228-1243)
+    Float fd = inc_dif;
+#pragma unroll
+    for (int q = 0; q < SMAX - 1; ++q)
+      if (q < s) fd = X2[(0 * SMAX + q) * 64 + lane] * fd + X2[(1 * SMAX + q) * 64 + lane];
+    Float dirl = dir_in;  // beam at the segment's levels
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      acc_up[i] += fd * al[i] + sr[i];
+      acc_dn[i] += fd + dirl;
+      acc_dir[i] += dirl;
+      fd = fa[i] * fd + fb[i];
+      dirl = Tn[i] * dirl;
+    }
+    acc_up[L] += fd * al[L] + sr[L];
+    acc_dn[L] += fd + dirl;
+    acc_dir[L] += dirl;
+  };
+
+  In cur;
+  load(cur, g_begin);
+  for (int igpt = g_begin; igpt < g_end; ++igpt) process(cur, igpt + 1);
+  if (active) {
+    const size_t base = icol + nclv * blockIdx.y;
+#pragma unroll
+    for (int i = 0; i <= L; ++i) {
+      if (i < np || (last && i == np)) {
+        const int p = p0 + i;  // level position from the top
+        const int ilev = a.top_at_1 ? p : nlay - p;
+        a.part_up[base + (size_t)ncol * ilev] = acc_up[i];
+        a.part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
+        a.part_dir[base + (size_t)ncol * ilev] = acc_dir[i];
+      }
+    }
+  }
+}
+
+
 // out(c,l) = sum over the ngroups partial slabs (in order), times scale; optionally accumulate
 __global__ void __launch_bounds__(256)
 reduce_parts_kernel(size_t n2, int ngroups, const Float* __restrict__ parts, Float* __restrict__ out, Float scale,
@@ -647,11 +873,13 @@ size_t pick_gchunk(size_t bytes_per_g, int ngpt) {
 // lev_source to a 2-D dummy and therefore uses g-point 1's level source everywhere.
 static int g_lw2str_gpt1_levsource = 0;
 static int g_lw_force_generic = 0;
+static int g_sw_force_generic = 0;
 
 extern "C" {
 
 int rte_hip_set_lw2str_bugcompat(int on) { g_lw2str_gpt1_levsource = on; return 0; }
 int rte_hip_force_generic_lw(int on) { g_lw_force_generic = on; return 0; }
+int rte_hip_force_generic_sw(int on) { g_sw_force_generic = on; return 0; }
 
 void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
                           const int* nmus_, const Float* Ds, const Float* weights, const Float* tau,
@@ -853,6 +1081,36 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
   } else {
     d_up = c.out(flux_up, nclv * ngpt); d_dn = c.out(flux_dn, nclv * ngpt); d_dir = c.out(flux_dir, nclv * ngpt);
   }
+  hipStream_t st0 = rte::stream();
+  // ------------------------------------------------------------------ production path (broadband, nlay <= 64)
+  if (do_broadband && nlay <= 64 && !g_sw_force_generic) {
+    constexpr int L = 8;
+    const int S = (nlay + L - 1) / L;
+    const int col_tiles = cdiv(ncol, 64);
+    int ngroups = 1;
+    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    const int g_per_block = (ngpt + ngroups - 1) / ngroups;
+    ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    Sw2SegArgs q;
+    q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = S; q.g_per_block = g_per_block;
+    q.top_at_1 = *top_at_1; q.has_dif_bc = *has_dif_bc;
+    q.tau = a.tau; q.ssa = a.ssa; q.g = a.g; q.mu0 = a.mu0; q.sfc_alb_dir = a.sfc_alb_dir; q.sfc_alb_dif = a.sfc_alb_dif;
+    q.inc_flux_dir = a.inc_flux_dir; q.inc_flux_dif = a.inc_flux_dif;
+    q.part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * 3);
+    q.part_dn = q.part_up + nclv * ngroups;
+    q.part_dir = q.part_dn + nclv * ngroups;
+    const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 8 * L);
+    {
+      rte::ProfScope p("sw_2stream_seg_kernel");
+      hipLaunchKernelGGL((sw_2stream_seg_kernel<L>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+    }
+    rte::ProfScope p("sw_reduce_parts");
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_up, d_bu, (Float)1, false);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_dn, d_bd, (Float)1, false);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_dir, d_bdir, (Float)1, false);
+    return;
+  }
+  // ------------------------------------------------------------------ generic path
   const size_t per_g = sizeof(Float) * (ncl * 5 + (do_broadband ? nclv * 3 : 0));
   const size_t gchunk = pick_gchunk(per_g, ngpt);
   a.ws = (Float*)rte::scratch(sizeof(Float) * ncl * 5 * gchunk);

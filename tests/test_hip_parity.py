@@ -87,6 +87,40 @@ def test_matches_golden_fixtures(hip, name):
     assert worst[0] <= NORTH_STAR_RTOL
 
 
+@pytest.mark.parametrize("name", ["sw_tiny_sfc1", "sw_mid_ragged", "sw_g224"])
+def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
+    """The production (segmented, composite-chained) and the generic SW two-stream kernels are two
+    implementations of one recurrence: they must agree to rounding -- also with night-time columns
+    (mu0 <= 0), a diffuse top boundary condition and strongly scattering layers."""
+    import numpy as np
+    case = cases.CASES[name]
+    inp = cases.make_inputs(case)
+    xp = frontend.TorchArrays("cuda:0")
+    a = cases.run_suite(hip, xp, case, inp)
+    hiplib.ext_call(hip, "rte_hip_force_generic_sw", ["i"], 1)
+    try:
+        b = cases.run_suite(hip, xp, case, inp)
+    finally:
+        hiplib.ext_call(hip, "rte_hip_force_generic_sw", ["i"], 0)
+    for k in ("sw.flux_up", "sw.flux_dn", "sw.flux_dir", "swc.flux_up", "swc.flux_dn", "swc.flux_dir"):
+        assert cases.rel_err(a[k], b[k]) <= 1e-12, k
+    # direct call: night columns + diffuse boundary condition, broadband, against the oracle
+    rng = np.random.default_rng(11)
+    ncol, nlay, ngpt = 70, 27, 16
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    tau, ssa, g = F(ncol, nlay, ngpt) * 3.0, F(ncol, nlay, ngpt) * 0.999, F(ncol, nlay, ngpt) * 0.9 - 0.1
+    mu0 = np.asfortranarray(np.repeat((rng.random(ncol) * 1.2 - 0.2)[:, None], nlay, axis=1))  # some <= 0
+    adir, adif, idir, idif = F(ncol, ngpt), F(ncol, ngpt), F(ncol, ngpt) * 100, F(ncol, ngpt) * 10
+    for top_at_1 in (False, True):
+        ref = frontend.rte_sw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, idir, adir, adif,
+                              inc_flux_dif=idif)
+        A = xp.asarray
+        out = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(ssa), A(g), A(mu0), A(idir), A(adir), A(adif),
+                              inc_flux_dif=A(idif))
+        for k in ("flux_up", "flux_dn", "flux_dir"):
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, top_at_1)
+
+
 @pytest.mark.parametrize("name", ["lw_mid_ragged", "lw_mid_top1", "lw_g256"])
 def test_segmented_and_generic_lw_solvers_agree(hip, name):
     """The production (segmented) and the generic LW kernels are two implementations of one
