@@ -1660,6 +1660,83 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
 #endif
 }
 
+
+// -------------------------------------------------------------------------------------------
+// compute_tau_rayleigh, production kernel.  The Rayleigh table has no pressure dimension: the whole
+// (T, eta) plane of a band's 16 g-points for both tropo regimes is 2 x ntemp*neta rows of 128 bytes
+// (32 KB), so a block = (256 columns, 16 g-points) stages it ONCE, walks the layers and gathers its
+// four corner rows from LDS with 16-byte reads (reference :506-565).  Inputs of layer l+1 are requested
+// while layer l is computed; no barrier in the layer loop.
+// -------------------------------------------------------------------------------------------
+struct RaylArgs {
+  int ncol, nlay, ngpt, neta, ntemp, idx_h2o;
+  const int *gpoint_flavor, *jeta, *jtemp;
+  const Float *krayl, *col_dry, *col_gas, *fminor;
+  const Bool* tropo;
+  Float* tau_rayleigh;
+};
+
+template <int BS>
+__global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
+  extern __shared__ __align__(16) Float rslab[];  // [2 tropo][neta][ntemp] rows of RS Floats
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.y * GC;  // host guarantees whole, 16-aligned chunks per band
+  const unsigned ncol = a.ncol, nlay = a.nlay;
+  const unsigned ncl = ncol * nlay;  // host guarantees 8 * ncl < 2^32
+  const int ntemp = a.ntemp, tn = a.ntemp * a.neta;
+  // stage: native layout (ntemp, neta, ngpt, 2) is contiguous along (T, eta) for a fixed g-point -> coalesced reads
+  for (int idx = tid; idx < 2 * GC * tn; idx += BS) {
+    const int te = idx % tn, gj = (idx / tn) % GC, r = idx / (tn * GC);
+    rslab[(r * tn + te) * RS + gj] = a.krayl[(size_t)te + (size_t)tn * ((g0 + gj) + (size_t)a.ngpt * r)];
+  }
+  __syncthreads();
+  const unsigned icol = blockIdx.x * BS + tid;
+  const unsigned ic = min(icol, ncol - 1);  // lanes past the last column repeat it (same values, same addresses)
+  const int flav0 = a.gpoint_flavor[2 * g0] - 1, flav1 = a.gpoint_flavor[1 + 2 * g0] - 1;
+  struct In { Bool tropo; int jT; Float h2o, dry; };
+  struct Wt { Float2 f01, f23; int2 je; };
+  auto load_in = [&](unsigned l, In& x) {
+    const unsigned cl = ic + ncol * l;
+    x.tropo = a.tropo[cl]; x.jT = a.jtemp[cl];
+    x.h2o = a.col_gas[cl + (size_t)ncl * a.idx_h2o]; x.dry = a.col_dry[cl];
+  };
+  auto load_wt = [&](unsigned l, const In& x, Wt& w) {
+    const size_t clf = (ic + ncol * l) + (size_t)ncl * (x.tropo ? flav0 : flav1);
+    const Float2* fp = reinterpret_cast<const Float2*>(a.fminor + 4 * clf);
+    w.f01 = fp[0]; w.f23 = fp[1];
+    w.je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
+  };
+  In x0, x1;
+  Wt w0;
+  load_in(0, x0);
+  load_in(min(1u, nlay - 1), x1);
+  load_wt(0, x0, w0);
+  char* const plane0 = reinterpret_cast<char*>(a.tau_rayleigh + (size_t)ncl * g0);
+  const size_t gstride = (size_t)ncl * sizeof(Float);
+#pragma unroll 1
+  for (unsigned l = 0; l < nlay; ++l) {
+    const Float f0 = w0.f01.x, f1 = w0.f01.y, f2 = w0.f23.x, f3 = w0.f23.y;
+    const int je1 = w0.je.x, je2 = w0.je.y, jT = x0.jT, r = x0.tropo ? 0 : 1;
+    const Float w = x0.h2o + x0.dry;  // :553
+    x0 = x1;
+    load_wt(min(l + 1, nlay - 1), x0, w0);
+    load_in(min(l + 2, nlay - 1), x1);
+    const Float* k1 = rslab + (r * tn + (jT - 1) + ntemp * (je1 - 1)) * RS;
+    const Float* k2 = rslab + (r * tn + jT + ntemp * (je2 - 1)) * RS;
+    unsigned off = (ic + ncol * l) * (unsigned)sizeof(Float);
+    asm volatile("" : "+v"(off));  // keep 64-bit store addresses out of the loop-invariant registers
+#pragma unroll
+    for (int j = 0; j < GC; j += 2) {
+      // interpolate2D :757-760 with the reference's association, then :555
+      const Float2 a0 = ld2(k1 + j), a1 = ld2(k1 + ntemp * RS + j), b0 = ld2(k2 + j), b1 = ld2(k2 + ntemp * RS + j);
+      const Float ka = f0 * a0.x + f1 * a1.x + f2 * b0.x + f3 * b1.x;
+      const Float kb = f0 * a0.y + f1 * a1.y + f2 * b0.y + f3 * b1.y;
+      *reinterpret_cast<Float*>(plane0 + gstride * j + off) = ka * w;
+      *reinterpret_cast<Float*>(plane0 + gstride * (j + 1) + off) = kb * w;
+    }
+  }
+}
+
 }  // namespace
 
 // ===============================================================================================
@@ -1990,6 +2067,28 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
   const Bool* d_tropo = c.in(tropo, ncl);
   const int* d_jtemp = c.in(jtemp, ncl);
   Float* d_tau = c.out(tau_rayleigh, ncl * ngpt);
+  // production kernel: 16-aligned whole-chunk bands (checked once per table pointer), aligned inputs
+  static const void* bl_key = nullptr;
+  static int bl_n = -1, bl_epoch = -1;
+  static bool bl_ok = false;
+  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch) {
+    const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
+    bl_ok = (ngpt % GC == 0) && sizeof(Float) == 8;
+    for (int b = 0; b < nbnd; ++b) bl_ok = bl_ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;
+    bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = g_plan_epoch;
+  }
+  const size_t slab_bytes = sizeof(Float) * 2 * (size_t)ntemp * neta * RS;
+  if (bl_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) && slab_bytes <= 64 * 1024 &&
+      ((uintptr_t)d_fminor % 16) == 0 && ((uintptr_t)d_jeta % 8) == 0) {
+    RaylArgs q;
+    q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.neta = neta; q.ntemp = ntemp; q.idx_h2o = *idx_h2o_;
+    q.gpoint_flavor = d_gpoint_flavor; q.jeta = d_jeta; q.jtemp = d_jtemp; q.krayl = d_krayl; q.col_dry = d_col_dry;
+    q.col_gas = d_col_gas; q.fminor = d_fminor; q.tropo = d_tropo; q.tau_rayleigh = d_tau;
+    rte::ProfScope p("tau_rayleigh_kernel");
+    hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256>), dim3(cdiv(ncol, 256), ngpt / GC), dim3(256), slab_bytes,
+                       rte::stream(), q);
+    return;
+  }
   rte::ProfScope p("tau_rayleigh_kernel");
   dim3 grid(cdiv(ncol, 256), nlay, nbnd), block(256);
   hipLaunchKernelGGL(tau_rayleigh_kernel, grid, block, 0, rte::stream(), ncol, nlay, ngpt, neta, ntemp,

@@ -174,6 +174,40 @@ def test_tau_absorption_paths_agree(hip, oracle_c):
     torch.cuda.synchronize()
 
 
+def test_tau_rayleigh_paths_agree(hip, oracle_c):
+    """The production Rayleigh kernel (whole (T, eta) plane of a band staged in LDS, layers walked by the
+    block) keeps the reference's association: bit-identical to the direct-gather kernel and to the oracle.
+    1100 columns exercises its ragged last tile; both vertical orientations."""
+    from rte_rrtmgp_amd import synth
+
+    kd = synth.make_kdist("sw")
+    ncol, nlay = 1100, 17
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    for top_at_1 in (False, True):
+        atm = synth.make_atmosphere(ncol, nlay, seed=31, kdist=kd, top_at_1=top_at_1)
+        go = frontend.GasOptics(hip, kd, xp)
+        play, tlay, col_gas, col_dry = A(atm.play), A(atm.tlay), A(atm.col_gas), A(atm.col_dry)
+        st = go.interpolation(ncol, nlay, play, tlay, col_gas)
+
+        def run():
+            t = xp.full((ncol, nlay, kd.ngpt), -1.0)
+            go.compute_tau_rayleigh(ncol, nlay, st, col_dry, col_gas, t)
+            return xp.to_numpy(t).copy()
+
+        t_fast = run()
+        hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 1)
+        t_dir = run()
+        hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 0)
+        assert np.array_equal(t_fast, t_dir)
+        xn = frontend.NumpyArrays()
+        gon = frontend.GasOptics(oracle_c, kd, xn)
+        stn = gon.interpolation(ncol, nlay, atm.play, atm.tlay, atm.col_gas)
+        tn = xn.full((ncol, nlay, kd.ngpt), -1.0)
+        gon.compute_tau_rayleigh(ncol, nlay, stn, atm.col_dry, atm.col_gas, tn)
+        assert cases.rel_err(t_fast, tn) <= RTOL_GAS
+
+
 def test_deferred_zero_fill(hip, oracle_c):
     """rte_hip_defer_zero(1): zero_array on a device buffer is recorded, consumed by
     compute_tau_absorption on that buffer (overwrite instead of memset + accumulate), and materialised

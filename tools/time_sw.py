@@ -14,7 +14,7 @@ bufs, rb = {}, {}
 def step():
     go.gas_optics_sw(ncol, nlay, play, plev, tlay, col_gas, col_dry, buffers=bufs)
     frontend.rte_sw(lib, xp, ncol, nlay, kd.ngpt, False, bufs["tau"], bufs["ssa"], bufs["g"], mu0, bufs["toa_src"], alb, alb, buffers=rb)
-step(); torch.cuda.synchronize()
+step(); step(); step(); torch.cuda.synchronize()
 hiplib.ext_call(lib, "rte_hip_profile_reset", []); hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
 t0 = time.perf_counter()
 for _ in range(3): step()
