@@ -845,6 +845,168 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// LW two-stream, segmented (spectral output as the interface defines it, nlay <= 64): the scheme of
+// sw_2stream_seg_kernel without the direct beam (reference :377-440, lw_two_stream :854-909,
+// lw_source_2str :917-967, adding :1135-1245).  The layer sources are absolute here, so one exchange
+// carries the projective composites of the adding recurrence and a second one the affine composites of
+// the downward flux; every wave writes the fluxes at the levels it owns.
+// ---------------------------------------------------------------------------------------------
+struct Lw2SegArgs {
+  int ncol, nlay, ngpt, S, g_per_block;
+  bool top_at_1, lev_gpt1;
+  const Float *tau, *ssa, *g, *lev_source, *sfc_emis, *sfc_src, *inc_flux;
+  Float *flux_up, *flux_dn;  // (ncol, nlev, ngpt)
+};
+
+template <int L>
+__global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
+  constexpr int SMAX = 8, NC1 = 7, NC2 = 2;
+  extern __shared__ Float lds[];  // X1[NC1][SMAX][64] (m00, m02, m10, m11, m12, m20, m22), X2[NC2][SMAX][64] (A, B)
+  Float* const X1 = lds;
+  Float* const X2 = lds + NC1 * SMAX * 64;
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int S = a.S, ncol = a.ncol, nlay = a.nlay;
+  const int icol = blockIdx.x * 64 + lane;
+  const bool active = icol < ncol;
+  const int c = active ? icol : ncol - 1;  // clamp: inactive lanes compute on a valid column, never store
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const int p0 = s * L;
+  const int np = min(L, nlay - p0);  // layers in this segment (>= 1 by construction)
+  const bool last = (s == S - 1);
+  const int g_begin = blockIdx.y * a.g_per_block;
+  const int g_end = min(a.ngpt, g_begin + a.g_per_block);
+  const Float LW_diff_sec = (Float)1.66f;  // :870: default-real literal widened to wp
+
+  struct In { Float tau[L], ssa[L], g[L], lev[L + 1], emis, ssrc, inc; };
+  auto load = [&](In& x, int igpt_) {
+    const int igpt = min(igpt_, g_end - 1);
+    const size_t cg = c + (size_t)ncol * igpt;
+    const Float* lev = a.lev_source + c + nclv * (a.lev_gpt1 ? 0 : igpt);
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const int p = p0 + min(i, np - 1);
+      const size_t o = c + (size_t)ncol * (a.top_at_1 ? p : nlay - 1 - p) + ncl * igpt;
+      x.tau[i] = a.tau[o]; x.ssa[i] = a.ssa[o]; x.g[i] = a.g[o];
+    }
+#pragma unroll
+    for (int i = 0; i <= L; ++i) {
+      const int p = p0 + min(i, np);
+      x.lev[i] = lev[(size_t)ncol * (a.top_at_1 ? p : nlay - p)];
+    }
+    x.emis = a.sfc_emis[cg]; x.ssrc = a.sfc_src[cg]; x.inc = a.inc_flux[cg];
+  };
+
+  auto process = [&](In& x, int igpt, int igpt_next) {
+    Float R[L], T[L], su[L], sd[L];
+    // ---- (1) two-stream coefficients and sources of this segment's layers (slot i: top level i, bottom i+1)
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (i < np) {  // wave-uniform
+        const Float t = x.tau[i], w0 = x.ssa[i], g = x.g[i];
+        const Float gamma1 = LW_diff_sec * ((Float)1 - (Float)0.5 * w0 * ((Float)1 + g));
+        const Float gamma2 = LW_diff_sec * (Float)0.5 * w0 * ((Float)1 - g);
+        const Float kk = sqrt(fmax((gamma1 - gamma2) * (gamma1 + gamma2), (Float)1.e-12));
+        const Float e1 = exp(-t * kk);
+        const Float e2 = e1 * e1;
+        const Float RT = (Float)1 / (kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
+        const Float Rdif = RT * gamma2 * ((Float)1 - e2);
+        const Float Tdif = RT * (Float)2 * kk * e1;
+        const Float lev_top = x.lev[i], lev_bot = x.lev[i + 1];
+        Float s_up = 0, s_dn = 0;
+        if (t > (Float)1.0e-8) {
+          const Float Z = (lev_bot - lev_top) / (t * (gamma1 + gamma2));
+          const Float Zup_top = Z + lev_top, Zup_bottom = Z + lev_bot;
+          const Float Zdn_top = -Z + lev_top, Zdn_bottom = -Z + lev_bot;
+          s_up = kPi * (Zup_top - Rdif * Zdn_top - Tdif * Zup_bottom);
+          s_dn = kPi * (Zdn_bottom - Rdif * Zup_bottom - Tdif * Zdn_top);
+        }
+        R[i] = Rdif; T[i] = Tdif; su[i] = s_up; sd[i] = s_dn;
+      } else {  // neutral layer: identity in every recurrence
+        R[i] = 0; T[i] = 1; su[i] = 0; sd[i] = 0;
+      }
+    }
+    // ---- segment composite of the adding recurrence (see sw_2stream_seg_kernel)
+    Float m00 = 1, m02 = 0, m10 = 0, m11 = 1, m12 = 0, m20 = 0, m22 = 1;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      const Float q00 = T[i] * T[i] - R[i] * R[i], q02 = R[i], q10 = T[i] * sd[i] - su[i] * R[i], q11 = T[i], q12 = su[i],
+                  q20 = -R[i];
+      const Float n00 = q00 * m00 + q02 * m20, n02 = q00 * m02 + q02 * m22;
+      const Float n10 = q10 * m00 + q11 * m10 + q12 * m20, n11 = q11 * m11, n12 = q10 * m02 + q11 * m12 + q12 * m22;
+      const Float n20 = q20 * m00 + m20, n22 = q20 * m02 + m22;
+      m00 = n00; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m22 = n22;
+    }
+    const Float emis = x.emis, ssrc = x.ssrc, inc = x.inc;
+    load(x, igpt_next);  // the layer inputs are dead: the next g-point's go into the same registers
+    X1[(0 * SMAX + s) * 64 + lane] = m00;
+    X1[(1 * SMAX + s) * 64 + lane] = m02;
+    X1[(2 * SMAX + s) * 64 + lane] = m10;
+    X1[(3 * SMAX + s) * 64 + lane] = m11;
+    X1[(4 * SMAX + s) * 64 + lane] = m12;
+    X1[(5 * SMAX + s) * 64 + lane] = m20;
+    X1[(6 * SMAX + s) * 64 + lane] = m22;
+    __syncthreads();
+    // ---- (2) adding chain from the surface up to this segment's lower edge, then the own layers
+    Float alb = (Float)1 - emis;        // :428
+    Float src = kPi * emis * ssrc;      // :965
+#pragma unroll
+    for (int q = SMAX - 1; q > 0; --q) {
+      if (q < S && q > s) {  // wave-uniform
+        const Float c00 = X1[(0 * SMAX + q) * 64 + lane], c02 = X1[(1 * SMAX + q) * 64 + lane];
+        const Float c10 = X1[(2 * SMAX + q) * 64 + lane], c11 = X1[(3 * SMAX + q) * 64 + lane];
+        const Float c12 = X1[(4 * SMAX + q) * 64 + lane];
+        const Float c20 = X1[(5 * SMAX + q) * 64 + lane], c22 = X1[(6 * SMAX + q) * 64 + lane];
+        const Float w = (Float)1 / (c20 * alb + c22);
+        const Float a_new = (c00 * alb + c02) * w;
+        const Float s_new = (c10 * alb + c11 * src + c12) * w;
+        alb = a_new; src = s_new;
+      }
+    }
+    Float al[L + 1], sr[L + 1], fa[L], fb[L];
+    al[L] = alb; sr[L] = src;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {  // :1174-1186 / :1214-1226
+      const Float denom = (Float)1 / ((Float)1 - R[i] * alb);
+      const Float src_new = su[i] + T[i] * denom * (src + alb * sd[i]);
+      const Float alb_new = R[i] + T[i] * T[i] * alb * denom;
+      fa[i] = T[i] * denom;
+      fb[i] = (R[i] * src + sd[i]) * denom;
+      alb = alb_new; src = src_new;
+      al[i] = alb; sr[i] = src;
+    }
+    Float A = 1, B = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) { B = fa[i] * B + fb[i]; A = fa[i] * A; }
+    X2[(0 * SMAX + s) * 64 + lane] = A;
+    X2[(1 * SMAX + s) * 64 + lane] = B;
+    __syncthreads();
+    // ---- (3) flux entering the segment from above, final sweep (:1188-1202 / :1228-1243)
+    Float fd = inc;  // :432
+#pragma unroll
+    for (int q = 0; q < SMAX - 1; ++q)
+      if (q < s) fd = X2[(0 * SMAX + q) * 64 + lane] * fd + X2[(1 * SMAX + q) * 64 + lane];
+    Float* fup = a.flux_up + icol + nclv * igpt;
+    Float* fdn = a.flux_dn + icol + nclv * igpt;
+#pragma unroll
+    for (int i = 0; i <= L; ++i) {
+      if (active && (i < np || (last && i == np))) {
+        const int p = p0 + i;  // level position from the top
+        const size_t ol = (size_t)ncol * (a.top_at_1 ? p : nlay - p);
+        fup[ol] = fd * al[i] + sr[i];
+        fdn[ol] = fd;
+      }
+      if (i < L) fd = fa[i] * fd + fb[i];
+    }
+  };
+
+  In cur;
+  load(cur, g_begin);
+  for (int igpt = g_begin; igpt < g_end; ++igpt) process(cur, igpt, igpt + 1);
+}
+
+
 // out(c,l) = sum over the ngroups partial slabs (in order), times scale; optionally accumulate
 __global__ void __launch_bounds__(256)
 reduce_parts_kernel(size_t n2, int ngroups, const Float* __restrict__ parts, Float* __restrict__ out, Float scale,
@@ -1029,6 +1191,25 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
   a.lay_source = c.in(lay_source, ncl * ngpt); a.lev_source = c.in(lev_source, nclv * ngpt);
   a.sfc_emis = c.in(sfc_emis, ncg); a.sfc_src = c.in(sfc_src, ncg); a.inc_flux = c.in(inc_flux, ncg);
   a.flux_up = c.out(flux_up, nclv * ngpt); a.flux_dn = c.out(flux_dn, nclv * ngpt);
+  // ------------------------------------------------------------------ production path (nlay <= 64)
+  if (nlay <= 64 && !g_lw_force_generic) {
+    constexpr int L = 8;
+    const int S = (nlay + L - 1) / L;
+    const int col_tiles = cdiv(ncol, 64);
+    int ngroups = 1;
+    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    const int g_per_block = (ngpt + ngroups - 1) / ngroups;
+    ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    Lw2SegArgs q;
+    q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = S; q.g_per_block = g_per_block;
+    q.top_at_1 = *top_at_1; q.lev_gpt1 = a.lev_gpt1;
+    q.tau = a.tau; q.ssa = a.ssa; q.g = a.g; q.lev_source = a.lev_source; q.sfc_emis = a.sfc_emis; q.sfc_src = a.sfc_src;
+    q.inc_flux = a.inc_flux; q.flux_up = a.flux_up; q.flux_dn = a.flux_dn;
+    rte::ProfScope p("lw_2stream_seg_kernel");
+    hipLaunchKernelGGL((lw_2stream_seg_kernel<L>), dim3(col_tiles, ngroups), dim3(64 * S), sizeof(Float) * 64 * 8 * (7 + 2),
+                       rte::stream(), q);
+    return;
+  }
   const size_t gchunk = pick_gchunk(sizeof(Float) * ncl * 4, ngpt);
   a.ws = (Float*)rte::scratch(sizeof(Float) * ncl * 4 * gchunk);
   rte::ProfScope p("lw_2stream_generic_kernel");

@@ -136,6 +136,9 @@ def test_segmented_and_generic_lw_solvers_agree(hip, name):
         hiplib.ext_call(hip, "rte_hip_force_generic_lw", ["i"], 0)
     for k in ("lw1.flux_up", "lw1.flux_dn", "lw3j.flux_up", "lw3j.flux_dn", "lw3j.flux_up_jac"):
         assert cases.rel_err(a[k], b[k]) <= 1e-13, k
+    # the two-stream solver (segmented with projective composites vs thread-per-column generic kernel)
+    for k in ("lw2str.gpt_flux_up", "lw2str.gpt_flux_dn"):
+        assert cases.rel_err(a[k], b[k]) <= 1e-12, k
 
 
 def test_tau_absorption_paths_agree(hip, oracle_c):
