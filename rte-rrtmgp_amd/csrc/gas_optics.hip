@@ -1753,6 +1753,7 @@ struct TauPlanCache {
   int dims[6] = {};
   int epoch = -1;
   bool fast_ok = false;
+  bool uploads_pending = false;  // bands changed since the last upload to the device
   std::vector<BandMeta> bands;
   bool matches(const void* const* k, const int* d, int e) const {
     if (e != epoch) return false;
@@ -1874,13 +1875,22 @@ void rrtmgp_compute_tau_absorption(
   }
   // ---- host-side plan from the small index tables (cached while the caller's table pointers and
   // dimensions do not change; rte_hip_release() drops the cache)
-  static TauPlanCache cache;
+  // a few plans are kept (e.g. an LW and an SW k-distribution used alternately), least recently built evicted
+  constexpr int NPLAN = 4;
+  static TauPlanCache plans[NPLAN];
+  static int plan_next = 0;
   const void* key[13] = {gpoint_flavor, band_lims_gpt, minor_limits_gpt_lower, minor_limits_gpt_upper, kminor_start_lower,
                          kminor_start_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
                          idx_minor_scaling_upper, minor_scales_with_density_lower, scale_by_complement_lower,
                          scale_by_complement_upper};
   const int dims[6] = {nbnd, ngpt, nlo, nup, *nminorklower_, *nminorkupper_};
-  if (!cache.matches(key, dims, g_plan_epoch)) {
+  int plan_slot = -1;
+  for (int i = 0; i < NPLAN; ++i)
+    if (plans[i].matches(key, dims, g_plan_epoch)) plan_slot = i;
+  const bool plan_hit = plan_slot >= 0;
+  if (!plan_hit) { plan_slot = plan_next; plan_next = (plan_next + 1) % NPLAN; }
+  TauPlanCache& cache = plans[plan_slot];
+  if (!plan_hit) {
     cache.set(key, dims, g_plan_epoch);
     const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
     const int* ml[2] = {c.host(minor_limits_gpt_lower, (size_t)2 * nlo), c.host(minor_limits_gpt_upper, (size_t)2 * nup)};
@@ -1923,6 +1933,7 @@ void rrtmgp_compute_tau_absorption(
       }
     }
     cache.fast_ok = ok;
+    cache.uploads_pending = true;
   }
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
   const bool fast = cache.fast_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) &&
@@ -1961,10 +1972,17 @@ void rrtmgp_compute_tau_absorption(
   Float* kmaj_g = (Float*)rte::scratch(sizeof(Float) * tn * (npres + 1) * ngpt);
   Float* klo_g = (Float*)rte::scratch(sizeof(Float) * tn * (nkl > 0 ? nkl : 1));
   Float* kup_g = (Float*)rte::scratch(sizeof(Float) * tn * (nku > 0 ? nku : 1));
-  BandMeta* d_bm = (BandMeta*)rte::scratch(sizeof(BandMeta) * nbnd);
+  // band metadata lives in a persistent device buffer and is uploaded only when the host plan was rebuilt
+  // (a per-call copy from pageable host memory stalls the submitting thread)
+  bool bm_fresh = false;
+  BandMeta* d_bm = (BandMeta*)rte::persistent(plan_slot, sizeof(BandMeta) * MAXB, &bm_fresh);
   {
     rte::ProfScope p("relayout_gfast_kernel");
-    HIP_CHECK(hipMemcpyAsync(d_bm, cache.bands.data(), sizeof(BandMeta) * nbnd, hipMemcpyHostToDevice, st));
+    if (bm_fresh || cache.uploads_pending) {
+      HIP_CHECK(hipMemcpyAsync(d_bm, cache.bands.data(), sizeof(BandMeta) * nbnd, hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));  // cache.bands is host memory that the next rebuild overwrites
+      cache.uploads_pending = false;
+    }
     const size_t tile_bytes = sizeof(Float) * TE * 33;
     hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(ngpt, 32), npres + 1), dim3(256), tile_bytes, st, TE,
                        npres + 1, ngpt, d_kmajor, kmaj_g);
