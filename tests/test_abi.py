@@ -28,7 +28,10 @@ def test_library_builds_and_exports_every_header_symbol():
     for name in cabi.header_symbols(HEADER):
         assert hasattr(dll, name), f"{name} declared in the header but not exported"
     for ext in ("rte_hip_set_stream", "rte_hip_sync", "rte_hip_profile_enable", "rte_hip_profile_get",
-                "rte_hip_combine_abs_and_rayleigh_2str", "rte_hip_broadcast_gpt", "rte_hip_release"):
+                "rte_hip_combine_abs_and_rayleigh_2str", "rte_hip_broadcast_gpt", "rte_hip_release",
+                "rte_hip_defer_zero", "rte_hip_tau_variant", "rte_hip_planck_variant", "rte_hip_force_direct_gather",
+                "rte_hip_force_generic_lw", "rte_hip_force_generic_sw", "rte_hip_invalidate_plans",
+                "rte_hip_set_lw2str_bugcompat", "rte_hip_device_count"):
         assert hasattr(dll, ext)
 
 
