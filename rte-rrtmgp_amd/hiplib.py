@@ -49,13 +49,26 @@ def build(precision: str = "dp", force: bool = False, verbose: bool = False, ext
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build librte_rrtmgp_hip.so")
-    cmd = [hipcc] + HIPCC_FLAGS + list(extra) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    if precision == "sp":
-        cmd.append("-DRTE_USE_SP")
-    cmd += sources() + ["-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # one builder at a time (several ranks of a multi-GPU launch may get here together): the others wait
+    # and then find the library up to date; the link goes to a temporary name and is renamed into place
+    import fcntl
+
+    with open(out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale(out):
+                return out
+            tmp = f"{out}.{os.getpid()}.tmp"
+            cmd = [hipcc] + HIPCC_FLAGS + list(extra) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+            if precision == "sp":
+                cmd.append("-DRTE_USE_SP")
+            cmd += sources() + ["-o", tmp]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, out)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return out
 
 
