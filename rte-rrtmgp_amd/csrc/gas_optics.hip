@@ -1750,7 +1750,7 @@ static int g_plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget ca
 namespace {
 struct TauPlanCache {
   const void* key[13] = {};
-  int dims[6] = {};
+  int dims[7] = {};
   int epoch = -1;
   bool fast_ok = false;
   bool uploads_pending = false;  // bands changed since the last upload to the device
@@ -1759,13 +1759,13 @@ struct TauPlanCache {
     if (e != epoch) return false;
     for (int i = 0; i < 13; ++i)
       if (k[i] != key[i]) return false;
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
       if (d[i] != dims[i]) return false;
     return true;
   }
   void set(const void* const* k, const int* d, int e) {
     for (int i = 0; i < 13; ++i) key[i] = k[i];
-    for (int i = 0; i < 6; ++i) dims[i] = d[i];
+    for (int i = 0; i < 7; ++i) dims[i] = d[i];
     epoch = e;
   }
 };
@@ -1883,7 +1883,32 @@ void rrtmgp_compute_tau_absorption(
                          kminor_start_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
                          idx_minor_scaling_upper, minor_scales_with_density_lower, scale_by_complement_lower,
                          scale_by_complement_upper};
-  const int dims[6] = {nbnd, ngpt, nlo, nup, *nminorklower_, *nminorkupper_};
+  // Tables in HOST memory (what the Fortran frontend passes) are fingerprinted, so a plan is never reused for
+  // different contents at the same address.  Device-resident tables cannot be inspected without draining the
+  // stream: their owner calls rte_hip_invalidate_plans() after (re)uploading tables (frontend.GasOptics does).
+  auto fnv = [](unsigned h, const void* p, size_t bytes) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 16777619u;
+    return h;
+  };
+  unsigned fp = 2166136261u;
+  if (!rte::is_device_pointer(band_lims_gpt)) {
+    fp = fnv(fp, band_lims_gpt, sizeof(int) * 2 * nbnd);
+    fp = fnv(fp, gpoint_flavor, sizeof(int) * 2 * ngpt);
+    fp = fnv(fp, minor_limits_gpt_lower, sizeof(int) * 2 * nlo);
+    fp = fnv(fp, minor_limits_gpt_upper, sizeof(int) * 2 * nup);
+    fp = fnv(fp, kminor_start_lower, sizeof(int) * nlo);
+    fp = fnv(fp, kminor_start_upper, sizeof(int) * nup);
+    fp = fnv(fp, idx_minor_lower, sizeof(int) * nlo);
+    fp = fnv(fp, idx_minor_upper, sizeof(int) * nup);
+    fp = fnv(fp, idx_minor_scaling_lower, sizeof(int) * nlo);
+    fp = fnv(fp, idx_minor_scaling_upper, sizeof(int) * nup);
+    fp = fnv(fp, minor_scales_with_density_lower, sizeof(Bool) * nlo);
+    fp = fnv(fp, minor_scales_with_density_upper, sizeof(Bool) * nup);
+    fp = fnv(fp, scale_by_complement_lower, sizeof(Bool) * nlo);
+    fp = fnv(fp, scale_by_complement_upper, sizeof(Bool) * nup);
+  }
+  const int dims[7] = {nbnd, ngpt, nlo, nup, *nminorklower_, *nminorkupper_, (int)fp};
   int plan_slot = -1;
   for (int i = 0; i < NPLAN; ++i)
     if (plans[i].matches(key, dims, g_plan_epoch)) plan_slot = i;
@@ -2089,7 +2114,12 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
   static const void* bl_key = nullptr;
   static int bl_n = -1, bl_epoch = -1;
   static bool bl_ok = false;
-  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch) {
+  unsigned bl_fp = 0;
+  if (!rte::is_device_pointer(band_lims_gpt))  // host tables: fingerprint the contents (see compute_tau_absorption)
+    for (int i = 0; i < 2 * nbnd; ++i) bl_fp = (bl_fp ^ (unsigned)band_lims_gpt[i]) * 16777619u;
+  static unsigned bl_fp_seen = 0;
+  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch || bl_fp != bl_fp_seen) {
+    bl_fp_seen = bl_fp;
     const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
     bl_ok = (ngpt % GC == 0) && sizeof(Float) == 8;
     for (int b = 0; b < nbnd; ++b) bl_ok = bl_ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;
@@ -2153,7 +2183,12 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   static const void* bl_key = nullptr;
   static int bl_n = -1, bl_epoch = -1;
   static bool bl_ok = false;
-  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch) {
+  unsigned bl_fp = 0;
+  if (!rte::is_device_pointer(band_lims_gpt))  // host tables: fingerprint the contents (see compute_tau_absorption)
+    for (int i = 0; i < 2 * nbnd; ++i) bl_fp = (bl_fp ^ (unsigned)band_lims_gpt[i]) * 16777619u;
+  static unsigned bl_fp_seen = 0;
+  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch || bl_fp != bl_fp_seen) {
+    bl_fp_seen = bl_fp;
     const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
     bl_ok = (ngpt % GC == 0) && sizeof(Float) == 8;
     for (int b = 0; b < nbnd; ++b) bl_ok = bl_ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;

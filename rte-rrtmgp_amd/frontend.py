@@ -147,6 +147,17 @@ class GasOptics:
         self.kd = kdist
         self.xp = arrays
         self.t = {n: arrays.asarray(kdist.arrays[n]) for n in self.LUT_NAMES if n in kdist.arrays}
+        # The HIP library caches small host-side plans keyed by the DEVICE addresses of the index tables (it
+        # cannot cheaply look inside device memory).  Freshly uploaded tables may reuse the addresses of
+        # released ones, so uploading tables invalidates those plans (no-op for other libraries).
+        inval = getattr(lib, "raw", None)
+        if inval is not None:
+            try:
+                fn = lib.raw("rte_hip_invalidate_plans")
+            except Exception:  # oracle / reference libraries have no such entry
+                fn = None
+            if fn is not None:
+                fn()
         self.ngas, self.nflav, self.neta = kdist.ngas, kdist.nflav, kdist.neta
         self.npres, self.ntemp = kdist.npres, kdist.ntemp
         self.nbnd, self.ngpt = kdist.nbnd, kdist.ngpt

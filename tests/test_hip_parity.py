@@ -177,6 +177,45 @@ def test_tau_absorption_paths_agree(hip, oracle_c):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("nbnd,ngpt,top_at_1", [(2, 64, False), (3, 96, True), (4, 64, True)])
+def test_wide_bands_on_production_kernels(hip, oracle_c, nbnd, ngpt, top_at_1):
+    """Bands wider than the 16 g-point stage (32 g-points here): the production tau / Planck / Rayleigh
+    kernels walk them in several stages with the same band metadata.  Against the oracle and the direct
+    kernels, LW and SW tables, 700 columns (ragged last tile), both vertical orientations (the surface
+    layer is the first or the last one the Planck kernel visits)."""
+    from rte_rrtmgp_amd import synth
+
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    ncol, nlay = 700, 19
+    for kind in ("lw", "sw"):
+        kd = synth.make_kdist(kind, ngpt=ngpt, nbnd=nbnd)
+        atm = synth.make_atmosphere(ncol, nlay, seed=3, kdist=kd, top_at_1=top_at_1)
+        outs = {}
+        for mode in ("fast", "direct", "oracle"):
+            if mode == "oracle":
+                lib, arr, conv = oracle_c, frontend.NumpyArrays(), (lambda v: v)
+            else:
+                lib, arr, conv = hip, xp, A
+            hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 1 if mode == "direct" else 0)
+            try:
+                go = frontend.GasOptics(lib, kd, arr)
+                if kind == "lw":
+                    b = go.gas_optics_lw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.tsfc),
+                                         conv(atm.col_gas), conv(atm.tlev), atm.top_at_1)
+                    keys = ("tau", "lay_src", "lev_src", "sfc_src", "sfc_src_jac")
+                else:
+                    b = go.gas_optics_sw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.col_gas),
+                                         conv(atm.col_dry))
+                    keys = ("tau_abs", "tau_rayleigh", "tau", "ssa")
+                outs[mode] = {k: np.array(arr.to_numpy(b[k])) for k in keys}
+            finally:
+                hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 0)
+        for k in outs["oracle"]:
+            assert cases.rel_err(outs["fast"][k], outs["direct"][k]) <= 1e-13, (kind, k)
+            assert cases.rel_err(outs["fast"][k], outs["oracle"][k]) <= RTOL_GAS, (kind, k)
+
+
 def test_tau_rayleigh_paths_agree(hip, oracle_c):
     """The production Rayleigh kernel (whole (T, eta) plane of a band staged in LDS, layers walked by the
     block) keeps the reference's association: bit-identical to the direct-gather kernel and to the oracle.
