@@ -710,6 +710,12 @@ __global__ void __launch_bounds__(BS, MINW) tau_absorption_v7_kernel(TauV5 a) {
 #ifndef V9_SB
 #define V9_SB 8
 #endif
+#ifndef V9_SLAB
+#define V9_SLAB 8704   // floats per slab buffer (two buffers per block)
+#endif
+#ifndef V9_MINW
+#define V9_MINW ((V9_NCW + V9_NLW + 3) / 4)  // waves per SIMD the register budget must allow
+#endif
 // -------------------------------------------------------------------------------------------
 // compute_tau_absorption, specialised-wave kernel ("v9").
 //
@@ -803,7 +809,7 @@ __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __res
 }
 
 template <int NCW, int NLW, int SLAB, bool OVERWRITE>
-__global__ void __launch_bounds__((NCW + NLW) * 64, (NCW + NLW + 3) / 4)
+__global__ void __launch_bounds__((NCW + NLW) * 64, V9_MINW)
 tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
   __shared__ __align__(16) Float slab[2][SLAB];
@@ -2045,7 +2051,7 @@ void rrtmgp_compute_tau_absorption(
 #define V9_NCW 4
 #define V9_NLW 2
 #endif
-    constexpr int NCW = V9_NCW, NLW = V9_NLW, SLAB9 = 8704;  // compute + loader waves, 2 x 68 KB slab: one block per CU
+    constexpr int NCW = V9_NCW, NLW = V9_NLW, SLAB9 = V9_SLAB;  // compute + loader waves, 2 x 68 KB slab: one block per CU
     const unsigned tiles = cdiv(ncol, NCW * 64);
     TileGeom* d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
     {
