@@ -136,7 +136,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run: one process per GPU over RCCL
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
