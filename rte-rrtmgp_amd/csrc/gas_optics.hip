@@ -65,7 +65,6 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
   const int itropo = trop ? 0 : 1;
   const int igas_1 = flavor[2 * iflav], igas_2 = flavor[2 * iflav + 1];
   const Float cg1 = col_gas[cl + ncl * igas_1], cg2 = col_gas[cl + ncl * igas_2];
-  const size_t clf = cl + ncl * iflav;
   Float fmn[4], fmj[8], cm[2];
   int je[2];
 #pragma unroll
@@ -360,23 +359,23 @@ relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, 
 }
 
 // -------------------------------------------------------------------------------------------
-// compute_tau_absorption, production kernel.
+// compute_tau_absorption, production kernels (LDS slab).
 //
-// What the measurements on MI355X said (profiles/r01_tau_absorption_notes.md): every variant that
-// gathers LUT values with lanes = columns (native layout, g-fastest layout, LDS-staged slab) runs
-// at ~20 ms per 1e5 columns: each lane pulls its own cache line and the vector L1 retires about one
-// distinct line per clock (TCP_TOTAL_CACHE_ACCESSES ~ 1/clk/CU), and the kernels were instruction-
-// bound on 64-bit address arithmetic and SGPR spills from an over-wide argument list.  Hence:
-//
-//   block   = (tile of NC columns, one layer); the block walks the bands.
-//   phase 1 : lanes = columns.  The column's interpolation state for the band is read ONCE,
-//             coalesced and one band ahead of its use; the minor-species scalings (:461-480) are
-//             formed and a compact record {col_mix*fmajor[8], fminor[4], scaling[<=8], row offsets}
-//             is parked in LDS.
-//   phase 2 : lanes = (8 columns) x (8 pairs of g-points).  The 8 lanes of a column read one
-//             128-byte row of the g-fastest table with a single 16-byte load each, i.e. one cache
-//             line per column per corner -- the minimum -- and the per-column weights come from
-//             LDS as broadcasts.  tau is read-modified-written in 64-byte segments.
+// What the measurements on MI355X said (tools/membench.hip): kernels that gather
+// LUT values straight from global memory with lanes = columns run at ~20 ms per 1e5 columns whatever the
+// table layout, because each lane pulls its own cache line and the vector L1 retires about one distinct
+// line per clock.  Both kernels below therefore
+//   * copy the tables to a g-point-fastest layout per call (relayout_gfast_kernel), so that the 16 g-points
+//     of a stage are one 128-byte row piece;
+//   * stage, per (column tile, layer, band), the BOUNDING BOX of the rows the tile's columns need --
+//     pressure x temperature x eta ranges for kmajor, temperature x eta per minor interval -- into an LDS
+//     slab with a row stride of 18 doubles;
+//   * keep lanes = columns: every thread gathers its 8 major + 4-per-interval minor corner rows with
+//     16-byte LDS reads (two g-points per read) and writes tau with coalesced 512-byte wave stores.
+// tau_absorption_v7_kernel does all of it with one kind of wave and two barriers per band;
+// tau_absorption_v9_kernel (default) splits the roles: loader waves stage the next stage's slab into the
+// other half of a double-buffered slab while compute waves gather, one barrier per stage.
+// Tiles whose box does not fit the slab go to a worklist for the direct-gather kernel.
 // Arithmetic: the same products and sums as the reference (:791-801, :757-760) evaluated with
 // fused multiply-adds and col_mix folded into the major weights; differences from the reference
 // association are a few ulp (tests: 1e-12 relative).
@@ -425,11 +424,6 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
-struct BandIn {  // flavor-dependent inputs of one band for one column, prefetched one band ahead
-  Float2 fm[4], fn[2], cm;
-  int je1, je2, em1, em2;
-};
-
 // LDS slab row stride in Floats: 18 = nine 16-byte quads.  Rows are read with ds_read_b128 (two g-points per
 // read), which the LDS serves in groups of 16 lanes x 4 banks: an odd quad stride puts the rows of a group on
 // distinct banks (MI355X_MICROARCH.md, LDS), and b128 reaches the LDS peak with one wave per SIMD where
@@ -440,10 +434,10 @@ constexpr int SLAB_FLOATS = 8704;  // 68 KB of LUT slab per block (2 blocks per 
 // lanes = columns; block = (256 columns, one layer), walks the bands.  Per band the block stages the
 // bounding box of LUT rows its columns need (pressure x temperature x eta ranges of the tile) from the
 // g-fastest tables into LDS -- each 128-byte row piece is one coalesced line -- and every thread then
-// gathers its 8 major + 4-per-interval minor corner rows with 8-byte LDS reads (measured on MI355X:
-// lane-private ds_read_b64 sustains ~100 B/clk/CU, lane-private global loads 1 line/clk, see
-// tools/membench.hip).  Inputs of band b+1 are requested before band b is computed.  A tile whose
-// bounding box does not fit the slab is appended to a worklist for tau_absorption_kernel.
+// gathers its 8 major + 4-per-interval minor corner rows with 16-byte LDS reads.  The staging pieces of a
+// band are requested back to back (one L2 latency per batch); the eta indices of band b+1 are requested
+// before band b is computed.  A tile whose bounding box does not fit the slab is appended to a worklist
+// for tau_absorption_worklist_kernel.
 template <int BS, int MINW, int HW, int SLAB>
 __global__ void __launch_bounds__(BS, MINW) tau_absorption_v7_kernel(TauV5 a) {
   __shared__ int rng[6];      // Tmin, Tmax, Pmin, Pmax, has_lower, has_upper
@@ -1119,7 +1113,7 @@ struct PlanckArgs {
 
 // one column, one band, native table layout: always applicable
 __device__ __forceinline__ void planck_direct_column(const PlanckArgs& q, const int icol, const int ibnd) {
-  const int ncol = q.ncol, nlay = q.nlay, ngpt = q.ngpt, neta = q.neta, npres = q.npres, ntemp = q.ntemp,
+  const int ncol = q.ncol, nlay = q.nlay, neta = q.neta, npres = q.npres, ntemp = q.ntemp,
             nPlanckTemp = q.nPlanckTemp, sfc_lay = q.sfc_lay;
   const Float *tlay = q.tlay, *tlev = q.tlev, *tsfc = q.tsfc, *fmajor = q.fmajor, *pfracin = q.pfracin, *totplnk = q.totplnk;
   const int *jeta = q.jeta, *jtemp = q.jtemp, *jpress = q.jpress, *band_lims_gpt = q.band_lims_gpt,

@@ -861,8 +861,8 @@ struct Lw2SegArgs {
 
 template <int L>
 __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
-  constexpr int SMAX = 8, NC1 = 7, NC2 = 2;
-  extern __shared__ Float lds[];  // X1[NC1][SMAX][64] (m00, m02, m10, m11, m12, m20, m22), X2[NC2][SMAX][64] (A, B)
+  constexpr int SMAX = 8, NC1 = 7;
+  extern __shared__ Float lds[];  // X1[NC1][SMAX][64] (m00, m02, m10, m11, m12, m20, m22), X2[2][SMAX][64] (A, B)
   Float* const X1 = lds;
   Float* const X2 = lds + NC1 * SMAX * 64;
   const int lane = threadIdx.x & 63;

@@ -59,6 +59,44 @@ __global__ void __launch_bounds__(512) r_solver(const double* __restrict__ in, i
   if (acc == -1.2345) sink[0] = acc;
 }
 
+// R3: three arrays in the solver's pattern: tau and lay (ncol, nlay, ng), lev (ncol, nlay+1, ng); wave s reads layers
+// [8s, 8s+8) of tau and lay and levels [8s, 8s+9) of lev, PF g-points requested before the previous ones are consumed
+template <int PF>
+__global__ void __launch_bounds__(512) r_solver3(const double* __restrict__ tau, const double* __restrict__ lay,
+                                                 const double* __restrict__ lev, int ncol, int nlay, int ng, int gpb,
+                                                 double* __restrict__ sink) {
+  const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const unsigned col = min(blockIdx.x * 64 + lane, (unsigned)ncol - 1);
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  double acc = 0;
+  const int gb = blockIdx.y * gpb, ge = min(ng, (int)(blockIdx.y + 1) * gpb);
+  double buf[PF][25];
+  auto load = [&](double (&b)[25], int g) {
+    g = min(g, ge - 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int l = min(8 * s + i, nlay - 1);
+      b[i] = tau[col + (size_t)ncol * l + ncl * g];
+      b[8 + i] = lay[col + (size_t)ncol * l + ncl * g];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) b[16 + i] = lev[col + (size_t)ncol * min(8 * s + i, nlay) + nclv * g];
+  };
+#pragma unroll
+  for (int p = 0; p < PF; ++p) load(buf[p], gb + p);
+  for (int g = gb; g < ge; g += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      double t = 0;
+#pragma unroll
+      for (int i = 0; i < 25; ++i) t += buf[p][i];
+      acc += t;
+      load(buf[p], g + PF + p);
+    }
+  }
+  if (acc == -1.2345) sink[0] = acc;
+}
+
 int main() {
   const int ncol = 100000, nlay = 60, ng = 256;
   const size_t n = (size_t)ncol * nlay * ng;
@@ -86,5 +124,21 @@ int main() {
   double* sink; CK(hipMalloc(&sink, 8));
   timeit("R1: linear read 8 B/lane", [&] { hipLaunchKernelGGL(r_linear, dim3(8192), dim3(256), 0, 0, out, n, sink); });
   timeit("R2: solver pattern read (64 col x 8 waves x 8 lay, 16 g/block)", [&] { hipLaunchKernelGGL(r_solver, dim3((ncol + 63) / 64, ng / 16), dim3(512), 0, 0, out, ncol, nlay, ng, 16, sink); });
+  {
+    double *lay, *lev;
+    CK(hipMalloc(&lay, n * 8)); CK(hipMalloc(&lev, (size_t)ncol * (nlay + 1) * ng * 8));
+    CK(hipMemset(lay, 0, n * 8)); CK(hipMemset(lev, 0, (size_t)ncol * (nlay + 1) * ng * 8));
+    const double nn = 3.0 * n + (double)ncol * ng;  // elements read
+    auto t3 = [&](const char* name, auto launch) {
+      launch(); CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < 3; ++r) launch();
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
+      printf("%-60s %7.3f ms  %7.1f GB/s\n", name, ms, nn * 8 / (ms * 1e-3) / 1e9);
+    };
+    t3("R3/1: tau+lay+lev solver pattern, 1 g-point ahead", [&] { hipLaunchKernelGGL(r_solver3<1>, dim3((ncol + 63) / 64, ng / 16), dim3(512), 0, 0, out, lay, lev, ncol, nlay, ng, 16, sink); });
+    t3("R3/2: tau+lay+lev solver pattern, 2 g-points ahead", [&] { hipLaunchKernelGGL(r_solver3<2>, dim3((ncol + 63) / 64, ng / 16), dim3(512), 0, 0, out, lay, lev, ncol, nlay, ng, 16, sink); });
+  }
   return 0;
 }
