@@ -53,11 +53,15 @@ def algorithmic_bytes_per_collay(nflav=10, ngas=8, ngpt=NGPT, nlay=NLAY, defer_z
         "tau_absorption_kernel": (25 + 120 * F + 8 * (G + 1)) + 8 * N + (0 if defer_zero else 8 * N),
         "planck_source_kernel": (25 + 72 * F + 8 * r) + (8 * N + 8 * N * r),
         "lw_noscat_seg_kernel": (16 * N + 8 * N * r + 32 * N / nlay) + 16 * r,
+        # --workload sw (config 3: SW gas optics + two-stream solver, broadband fluxes)
+        "tau_rayleigh_kernel": (40 * F + 21) + 8 * N,
+        "combine_2str_kernel": 16 * N + 24 * N,
+        "sw_2stream_seg_kernel": (24 * N + 8 + 32 * N / nlay) + 24 * r,
     }
     return k
 
 
-def cpu_baseline(ncol_block=32, target_seconds=12.0):
+def cpu_baseline(ncol_block=32, target_seconds=12.0, workload="lw"):
     """Reference (or port) CPU kernels on the host cores, bounded sample of the same workload."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -74,14 +78,23 @@ def cpu_baseline(ncol_block=32, target_seconds=12.0):
     if lib is None:
         lib, kind = O.load_c(), "port"
     cores = os.cpu_count() or 1
-    kd = synth.make_kdist("lw")
+    kd = synth.make_kdist(workload)
     xp = frontend.NumpyArrays()
 
     def one_block(seed):
         atm = synth.make_atmosphere(ncol_block, NLAY, seed=seed, kdist=kd)
         go = frontend.GasOptics(lib, kd, xp)
         emis = xp.full((ncol_block, kd.ngpt), 0.98)
+        mu0, alb = xp.full((ncol_block, NLAY), 0.86), xp.full((ncol_block, kd.ngpt), 0.06)
         bufs, rb = {}, {}
+
+        def run_sw():
+            go.gas_optics_sw(ncol_block, NLAY, atm.play, atm.plev, atm.tlay, atm.col_gas, atm.col_dry, buffers=bufs)
+            frontend.rte_sw(lib, xp, ncol_block, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["ssa"], bufs["g"], mu0,
+                            bufs["toa_src"], alb, alb, buffers=rb)
+
+        if workload == "sw":
+            return run_sw
 
         def run():
             go.gas_optics_lw(ncol_block, NLAY, atm.play, atm.plev, atm.tlay, atm.tsfc, atm.col_gas, atm.tlev,
@@ -123,6 +136,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ncol", type=int, default=100000, help="columns per GPU")
+    ap.add_argument("--workload", choices=("lw", "sw"), default="lw",
+                    help="lw: the headline chain (default); sw: SW gas optics + sw_solver_2stream (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
     args = ap.parse_args()
@@ -152,7 +167,7 @@ def main():
     dev = f"cuda:{local_rank}"
     xp = frontend.TorchArrays(dev)
     ncol = args.ncol
-    kd = synth.make_kdist("lw")
+    kd = synth.make_kdist(args.workload)
     atm = synth.make_atmosphere(ncol, NLAY, seed=42 + rank, kdist=kd)  # each rank owns different columns
     go = frontend.GasOptics(lib, kd, xp)
     A = xp.asarray
@@ -160,14 +175,26 @@ def main():
     emis = xp.full((ncol, kd.ngpt), 0.98)
     bufs, rb = {}, {}
     mean_profile = torch.zeros(2, NLAY + 1, dtype=torch.float64, device=dev)
+    if args.workload == "sw":
+        col_dry = A(atm.col_dry)
+        mu0, alb = xp.full((ncol, NLAY), 0.86), xp.full((ncol, kd.ngpt), 0.06)
 
-    def step():
+    def step_sw():
+        go.gas_optics_sw(ncol, NLAY, play, plev, tlay, col_gas, col_dry, buffers=bufs)
+        frontend.rte_sw(lib, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["ssa"], bufs["g"], mu0,
+                        bufs["toa_src"], alb, alb, buffers=rb)
+        if dist is not None:
+            mean_profile.copy_(sharding.allreduce_mean_profile(rb["flux_up"], rb["flux_dn"], ncol * world))
+
+    def step_lw():
         go.gas_optics_lw(ncol, NLAY, play, plev, tlay, tsfc, col_gas, tlev, atm.top_at_1, buffers=bufs)
         frontend.rte_lw(lib, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["lay_src"], bufs["lev_src"],
                         emis, bufs["sfc_src"], buffers=rb)
         if dist is not None:
             # the path's only exchange: domain-mean broadband flux profile (RCCL all-reduce)
             mean_profile.copy_(sharding.allreduce_mean_profile(rb["flux_up"], rb["flux_dn"], ncol * world))
+
+    step = step_sw if args.workload == "sw" else step_lw
 
     def fence():
         if dist is not None:
@@ -215,7 +242,7 @@ def main():
         chain_ms = sum(v["avg_ms"] for v in per_kernel.values()) + sum(others.values())
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if dom and os.path.exists(pmc_path):
+        if dom and args.workload == "lw" and os.path.exists(pmc_path):  # the counters were collected on the LW chain
             try:
                 pmc = json.load(open(pmc_path))
                 if pmc.get("ncol") == ncol:
@@ -235,18 +262,22 @@ def main():
                               "frac": round(chain_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4)},
                     "per_kernel": per_kernel, "other_kernels_avg_ms": others}
         res = {
-            "metric": "columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)",
+            "metric": ("columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)" if args.workload == "lw" else
+                       "columns/sec (SW gas-optics + sw_solver_2stream, 224 gpt x 60 lay)"),
             "value": ncol * world * args.steps / dt, "unit": "columns/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"RFMIP-like clear-sky LW, {ncol} synthetic columns per GPU x {NLAY} layers x "
-                                   f"{kd.ngpt} g-points (BASELINE configs[1]), synthetic g256-shaped k-distribution",
+            "config": {"workload": (f"RFMIP-like clear-sky LW, {ncol} synthetic columns per GPU x {NLAY} layers x "
+                                    f"{kd.ngpt} g-points (BASELINE configs[1]), synthetic g256-shaped k-distribution"
+                                    if args.workload == "lw" else
+                                    f"clear-sky SW gas optics + two-stream solver, {ncol} synthetic columns per GPU x {NLAY} "
+                                    f"layers x {kd.ngpt} g-points (BASELINE configs[2] shape), synthetic g224-shaped k-distribution"),
                        "columns_per_gpu": ncol, "nlay": NLAY, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline()
+                res["cpu_baseline"] = cpu_baseline(workload=args.workload)
             except Exception as e:  # noqa: BLE001
                 res["cpu_baseline"] = {"value": None, "unit": "columns/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
