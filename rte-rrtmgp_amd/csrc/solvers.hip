@@ -1192,8 +1192,8 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
   a.sfc_emis = c.in(sfc_emis, ncg); a.sfc_src = c.in(sfc_src, ncg); a.inc_flux = c.in(inc_flux, ncg);
   a.flux_up = c.out(flux_up, nclv * ngpt); a.flux_dn = c.out(flux_dn, nclv * ngpt);
   // ------------------------------------------------------------------ production path (nlay <= 64)
-  if (nlay <= 64 && !g_lw_force_generic) {
-    constexpr int L = 8;
+  if (nlay <= 80 && !g_lw_force_generic) {
+    const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);  // layers per wave (always 8 waves), see rte_sw_solver_2stream
     const int S = (nlay + L - 1) / L;
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
@@ -1206,8 +1206,10 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     q.tau = a.tau; q.ssa = a.ssa; q.g = a.g; q.lev_source = a.lev_source; q.sfc_emis = a.sfc_emis; q.sfc_src = a.sfc_src;
     q.inc_flux = a.inc_flux; q.flux_up = a.flux_up; q.flux_dn = a.flux_dn;
     rte::ProfScope p("lw_2stream_seg_kernel");
-    hipLaunchKernelGGL((lw_2stream_seg_kernel<L>), dim3(col_tiles, ngroups), dim3(64 * S), sizeof(Float) * 64 * 8 * (7 + 2),
-                       rte::stream(), q);
+    const size_t lds_bytes = sizeof(Float) * 64 * 8 * (7 + 2);
+    if (L == 8) hipLaunchKernelGGL((lw_2stream_seg_kernel<8>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
+    else if (L == 9) hipLaunchKernelGGL((lw_2stream_seg_kernel<9>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
+    else hipLaunchKernelGGL((lw_2stream_seg_kernel<10>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
     return;
   }
   const size_t gchunk = pick_gchunk(sizeof(Float) * ncl * 4, ngpt);
@@ -1264,8 +1266,9 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
   }
   hipStream_t st0 = rte::stream();
   // ------------------------------------------------------------------ production path (broadband, nlay <= 64)
-  if (do_broadband && nlay <= 64 && !g_sw_force_generic) {
-    constexpr int L = 8;
+  if (do_broadband && nlay <= 80 && !g_sw_force_generic) {
+    // layers per wave: 8 up to 64 layers, then 9 (72 layers: the all-sky configuration) or 10 -- always 8 waves
+    const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);
     const int S = (nlay + L - 1) / L;
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
@@ -1283,7 +1286,9 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 8 * L);
     {
       rte::ProfScope p("sw_2stream_seg_kernel");
-      hipLaunchKernelGGL((sw_2stream_seg_kernel<L>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+      if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+      else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+      else hipLaunchKernelGGL((sw_2stream_seg_kernel<10>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
     }
     rte::ProfScope p("sw_reduce_parts");
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_up, d_bu, (Float)1, false);

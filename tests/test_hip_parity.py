@@ -106,19 +106,28 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
         assert cases.rel_err(a[k], b[k]) <= 1e-12, k
     # direct call: night columns + diffuse boundary condition, broadband, against the oracle
     rng = np.random.default_rng(11)
-    ncol, nlay, ngpt = 70, 27, 16
     F = lambda *sh: np.asfortranarray(rng.random(sh))
-    tau, ssa, g = F(ncol, nlay, ngpt) * 3.0, F(ncol, nlay, ngpt) * 0.999, F(ncol, nlay, ngpt) * 0.9 - 0.1
-    mu0 = np.asfortranarray(np.repeat((rng.random(ncol) * 1.2 - 0.2)[:, None], nlay, axis=1))  # some <= 0
-    adir, adif, idir, idif = F(ncol, ngpt), F(ncol, ngpt), F(ncol, ngpt) * 100, F(ncol, ngpt) * 10
-    for top_at_1 in (False, True):
+    A = xp.asarray
+    for nlay, top_at_1 in ((27, False), (27, True), (72, False), (75, True)):  # 72/75: nine / ten layers per wave
+        ncol, ngpt = 70, 16
+        tau, ssa, g = F(ncol, nlay, ngpt) * 3.0, F(ncol, nlay, ngpt) * 0.999, F(ncol, nlay, ngpt) * 0.9 - 0.1
+        mu0 = np.asfortranarray(np.repeat((rng.random(ncol) * 1.2 - 0.2)[:, None], nlay, axis=1))  # some <= 0
+        adir, adif, idir, idif = F(ncol, ngpt), F(ncol, ngpt), F(ncol, ngpt) * 100, F(ncol, ngpt) * 10
         ref = frontend.rte_sw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, idir, adir, adif,
                               inc_flux_dif=idif)
-        A = xp.asarray
         out = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(ssa), A(g), A(mu0), A(idir), A(adir), A(adif),
                               inc_flux_dif=A(idif))
         for k in ("flux_up", "flux_dn", "flux_dir"):
-            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, top_at_1)
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
+        # the LW two-stream solver on the same optical properties (segmented kernel) against the oracle
+        lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
+        emis, sfc, inc = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10, F(ncol, ngpt)
+        ref = frontend.rte_lw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, lay, lev, emis, sfc, ssa=ssa, g=g,
+                              use_2stream=True, inc_flux=inc)
+        out = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(lay), A(lev), A(emis), A(sfc), ssa=A(ssa), g=A(g),
+                              use_2stream=True, inc_flux=A(inc))
+        for k in ("gpt_flux_up", "gpt_flux_dn"):
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
 
 
 @pytest.mark.parametrize("name", ["lw_mid_ragged", "lw_mid_top1", "lw_g256"])

@@ -9,7 +9,7 @@ g = torch.Generator(device="cuda").manual_seed(7)
 def R(*sh, lo=0.0, hi=1.0):
     t = xp.empty(sh); t.uniform_(lo, hi, generator=g); return t
 worst = {}
-for ncol, nlay, ngpt, top in itertools.product((1, 63, 64, 65, 200), (1, 2, 7, 8, 9, 16, 33, 63, 64), (1, 5, 16, 37), (False, True)):
+for ncol, nlay, ngpt, top in itertools.product((1, 63, 64, 65, 200), (1, 2, 7, 8, 9, 16, 33, 63, 64, 65, 72, 73, 80, 81), (1, 5, 16, 37), (False, True)):
     tau, ssa, gg = R(ncol, nlay, ngpt, hi=3.0), R(ncol, nlay, ngpt, hi=0.999), R(ncol, nlay, ngpt, lo=-0.3, hi=0.9)
     lay, lev = R(ncol, nlay, ngpt, lo=1, hi=10), R(ncol, nlay + 1, ngpt, lo=1, hi=10)
     emis, sfc, inc = R(ncol, ngpt, lo=0.8, hi=1.0), R(ncol, ngpt, hi=10), R(ncol, ngpt)
