@@ -41,7 +41,7 @@ CASES = {
     "sw_tiny_sfc1": Case("sw_tiny_sfc1", "sw", 5, 10, False, TINY),
     "sw_tiny_top1": Case("sw_tiny_top1", "sw", 5, 10, True, TINY),
     "lw_mid_ragged": Case("lw_mid_ragged", "lw", 70, 33, False, MID, seed=5),   # ncol not a multiple of 64
-    "lw_mid_top1": Case("lw_mid_top1", "lw", 67, 72, True, MID, seed=6),        # nlay > 64: 16-layer segments
+    "lw_mid_top1": Case("lw_mid_top1", "lw", 67, 72, True, MID, seed=6),        # nlay > 64: 9-layer segments
     "sw_mid_ragged": Case("sw_mid_ragged", "sw", 70, 33, True, MID, seed=7),
     "lw_g256": Case("lw_g256", "lw", 3, 60, False, {}, seed=8),                  # the benchmark table shapes
     "sw_g224": Case("sw_g224", "sw", 3, 60, False, {}, seed=9),

@@ -22,3 +22,6 @@ for gen in (0, 1):
     timed(f"72 layers, {tag}: rte_lw_solver_2stream", lambda: lib.rte_lw_solver_2stream(ncol, nlay, ngpt, False, tau, ssa, gg, lay, lev, emis, sfc, inc, fu, fd))
     rb = {}
     timed(f"72 layers, {tag}: rte_sw (2-stream, broadband)", lambda: frontend.rte_sw(lib, xp, ncol, nlay, ngpt, False, tau, ssa, gg, mu0, idir, alb, alb, buffers=rb))
+hiplib.ext_call(lib, "rte_hip_force_generic_lw", ["i"], 0); hiplib.ext_call(lib, "rte_hip_force_generic_sw", ["i"], 0)
+rb2 = {}
+timed("72 layers: rte_lw (no scattering, broadband, 1 angle)", lambda: frontend.rte_lw(lib, xp, ncol, nlay, ngpt, False, tau, lay, lev, emis, sfc, buffers=rb2))
