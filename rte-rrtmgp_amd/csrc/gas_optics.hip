@@ -730,8 +730,10 @@ struct TileGeom {   // one per (column tile, layer)
   int2 eg[MAXB];    // per band: (emin, nE); nE = 0 -> band handled by the direct kernel (or no work)
 };
 
-template <int TILE>
+template <int TILE, int G>
 __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __restrict__ geom, int slab_floats) {
+  constexpr int RS = G + 2;
+
   __shared__ int rng[6];
   __shared__ int erng[MAXB][2];
   __shared__ BandMeta bm[MAXB];
@@ -802,10 +804,11 @@ __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __res
   }
 }
 
-template <int NCW, int NLW, int SLAB, bool OVERWRITE>
+template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G>
 __global__ void __launch_bounds__((NCW + NLW) * 64, V9_MINW)
 tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
+  constexpr int RS = G + 2, PPR = G / 2, PSH = G == 16 ? 3 : 2;  // row stride, 16-byte pieces per row, log2(PPR)
   __shared__ __align__(16) Float slab[2][SLAB];
   __shared__ TileGeom tg;
   extern __shared__ BandMeta bm[];  // [nbnd]
@@ -826,7 +829,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   __syncthreads();
   const int Tmin = tg.Tmin, nT = tg.nT, Pmin = tg.Pmin, nP = tg.nP;
   const bool has_lo = tg.has_lo != 0, has_up = tg.has_up != 0;
-  const int nstage = ngpt / GC;  // host guarantees whole, 16-aligned chunks per band
+  const int nstage = ngpt / G;  // host guarantees whole, G-aligned chunks per band
 
   if (tid >= TILE) {
     // ================================ loader waves ================================
@@ -836,18 +839,18 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     int ibnd = 0;
 #pragma unroll 1
     for (int s = 0; s < nstage; ++s) {
-      const int g0 = s * GC;
+      const int g0 = s * G;
       while (ibnd + 1 < nbnd && bm[ibnd].gE < g0) ++ibnd;
       const int emin = tg.eg[ibnd].x, nE = tg.eg[ibnd].y;
       if (nE > 0) {
         const float inv_nE = 1.0f / (float)nE;
         const int n_lo = has_lo ? bm[ibnd].cnt[0] : 0, n_up = has_up ? bm[ibnd].cnt[1] : 0;
         const int rowsMaj = nP * nT * nE, rowsLo = n_lo * nT * nE, rowsUp = n_up * nT * nE;
-        const int nAll = (rowsMaj + rowsLo + rowsUp) * (GC / 2);
+        const int nAll = (rowsMaj + rowsLo + rowsUp) * (G / 2);
         Float* sl = slab[s & 1];
         // rows ordered [p][t][eta] (+ minor: [interval][t][eta]); piece = 16 bytes of a 128-byte row chunk
         auto piece = [&](int idx) -> Float2 {
-          const int j = idx & 7, r = idx >> 3;
+          const int j = idx & (PPR - 1), r = idx >> PSH;
           if (r < rowsMaj) {
             const int rest = (int)(((float)r + 0.5f) * inv_nE), e = r - rest * nE;  // rows < 2^12: exact
             const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
@@ -874,7 +877,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
           for (int u = 0; u < SB; ++u) {
             const int idx = base + u * NLT;
-            if (idx < nAll) *reinterpret_cast<Float2*>(sl + (idx >> 3) * RS + 2 * (idx & 7)) = v[u];
+            if (idx < nAll) *reinterpret_cast<Float2*>(sl + (idx >> PSH) * RS + 2 * (idx & (PPR - 1))) = v[u];
           }
         }
       }
@@ -920,11 +923,11 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   int ibnd = 0;
 #pragma unroll 1
   for (int s = 0; s < nstage; ++s) {
-    const int g0 = s * GC;
+    const int g0 = s * G;
     while (ibnd + 1 < nbnd && bm[ibnd].gE < g0) ++ibnd;
     const int emin = tg.eg[ibnd].x, nE = tg.eg[ibnd].y;
     int ibnd_n = ibnd;
-    if (s + 1 < nstage) while (ibnd_n + 1 < nbnd && bm[ibnd_n].gE < g0 + GC) ++ibnd_n;
+    if (s + 1 < nstage) while (ibnd_n + 1 < nbnd && bm[ibnd_n].gE < g0 + G) ++ibnd_n;
     const bool run = nE > 0;  // block-uniform
     // ---- requests, oldest first: minor column amounts and minor weights of THIS stage (used after the
     // major pass), then the major weights of the NEXT stage
@@ -957,7 +960,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const Float* B0 = sl + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
     const int sP = nT * nE * RS;
     const Float* M0 = sl + (rowsMaj + (regime == 2 ? rowsLo : 0)) * RS;
-    Float acc[GC];
+    Float acc[G];
     // tau(:, :, g) = scalar plane base + this column's 32-bit byte offset (host guarantees 8*ncol*nlay < 2^32)
     char* const tplane = reinterpret_cast<char*>(a.tau + (size_t)ncl * g0);
     const size_t gstride = (size_t)ncl * sizeof(Float);
@@ -965,9 +968,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     asm volatile("" : "+v"(toff));  // keep the 64-bit address out of the loop-invariant registers
     auto tau_at = [&](int j) { return reinterpret_cast<Float*>(tplane + gstride * j + toff); };
 #pragma unroll
-    for (int j = 0; j < GC; ++j) acc[j] = 0;
+    for (int j = 0; j < G; ++j) acc[j] = 0;
 #pragma unroll
-    for (int j = 0; j < GC; j += 2) {
+    for (int j = 0; j < G; j += 2) {
       // :791-801 with col_mix folded into the weights; one 16-byte LDS read feeds two g-points
       const Float2 k0 = ld2(A0 + j), k1 = ld2(A0 + RS + j), k2 = ld2(A0 + sP + j), k3 = ld2(A0 + sP + RS + j),
                    k4 = ld2(B0 + j), k5 = ld2(B0 + RS + j), k6 = ld2(B0 + sP + j), k7 = ld2(B0 + sP + RS + j);
@@ -1012,7 +1015,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       const Float* r1 = M0 + ((k * nT + (jT - Tmin)) * nE + (em.x - emin)) * RS;
       const Float* r2 = M0 + ((k * nT + (jT + 1 - Tmin)) * nE + (em.y - emin)) * RS;
 #pragma unroll
-      for (int j = 0; j < GC; j += 2) {
+      for (int j = 0; j < G; j += 2) {
         // :757-760, :493
         const Float2 q0 = ld2(r1 + j), q1 = ld2(r1 + RS + j), q2 = ld2(r2 + j), q3 = ld2(r2 + RS + j);
         Float s_ = f0 * q0.x, t_ = f0 * q0.y;
@@ -1029,15 +1032,15 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       // lanes past the last column repeat it (ic is clamped): same values to the same addresses.  Unconditional
       // stores keep the count of outstanding memory operations static (counted waits instead of drains).
 #pragma unroll
-      for (int j = 0; j < GC; ++j) *tau_at(j) = acc[j];
+      for (int j = 0; j < G; ++j) *tau_at(j) = acc[j];
     } else if (valid) {
       // tau is inout (the reference accumulates onto it, :637,:679).  The stage's sum is added to the incoming
       // value at the end: identical to the reference when tau comes in as zero (always, in the frontend),
       // otherwise the same terms in a different order (1 ulp)
 #pragma unroll
-      for (int j = 0; j < GC; ++j) acc[j] = *tau_at(j) + acc[j];
+      for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
 #pragma unroll
-      for (int j = 0; j < GC; ++j) *tau_at(j) = acc[j];
+      for (int j = 0; j < G; ++j) *tau_at(j) = acc[j];
     }
   }
 }
@@ -1393,9 +1396,10 @@ __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
 // while layer l is computed; one barrier per layer.  planck_geom_kernel provides the boxes and sends
 // (tile, band) pairs that do not fit the slab at some layer to the direct kernel.
 // -------------------------------------------------------------------------------------------
-template <int TILE>
+template <int TILE, int G>
 __global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd, TileGeom* __restrict__ geom,
                                                            int* __restrict__ flags, int slab_floats) {
+  constexpr int RS = G + 2;
   __shared__ int rng[4];
   __shared__ int erng[MAXB][2];
   __shared__ int flav[MAXB][2];  // flavor (0-based) of band b per tropo regime
@@ -1442,10 +1446,11 @@ __global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd,
   }
 }
 
-template <int NCW, int NLW, int SLAB>
+template <int NCW, int NLW, int SLAB, int G>
 __global__ void __launch_bounds__((NCW + NLW) * 64, (NCW + NLW + 3) / 4)
 planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom, const int* __restrict__ flags) {
   constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
+  constexpr int RS = G + 2, PPR = G / 2, PSH = G == 16 ? 3 : 2;  // row stride, 16-byte pieces per row, log2(PPR)
   constexpr int MAXL = 256;  // layers per block held in the LDS geometry table (host checks nlay <= MAXL)
   __shared__ __align__(16) Float slab[2][SLAB];
   __shared__ int gl[MAXL][6];       // per layer: Tmin, nT, Pmin, nP, emin, nE
@@ -1464,7 +1469,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
     gl[l][4] = g->eg[ibnd].x; gl[l][5] = g->eg[ibnd].y;
   }
   __syncthreads();
-  const int nchunk = (gptE - gptS + 1) / GC;  // host guarantees whole, 16-aligned chunks
+  const int nchunk = (gptE - gptS + 1) / G;  // host guarantees whole, 16-aligned chunks
   // stages of a chunk: the layers in order, then -- unless the surface layer is the last one, whose Planck
   // fractions are still in registers -- the surface layer once more for sfc_source (keeps those stores and
   // their addresses out of the layer loop)
@@ -1478,13 +1483,13 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
     constexpr int SB = 8;  // 16-byte pieces per lane requested back to back
 #pragma unroll 1
     for (int s = 0; s < nstage; ++s) {
-      const int ls = s % spc, l = ls < (int)nlay ? ls : lsfc, g0 = gptS + (s / spc) * GC;
+      const int ls = s % spc, l = ls < (int)nlay ? ls : lsfc, g0 = gptS + (s / spc) * G;
       const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], nP = gl[l][3], emin = gl[l][4], nE = gl[l][5];
       const float inv_nE = 1.0f / (float)nE, inv_nT = 1.0f / (float)nT;
-      const int nAll = nP * nT * nE * (GC / 2);
+      const int nAll = nP * nT * nE * (G / 2);
       Float* sl = slab[s & 1];
       auto piece = [&](int idx) -> Float2 {  // rows ordered [p][t][eta]
-        const int j = idx & 7, r = idx >> 3;
+        const int j = idx & (PPR - 1), r = idx >> PSH;
         const int rest = (int)(((float)r + 0.5f) * inv_nE), e = r - rest * nE;  // rows < 2^12: exact
         const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
         return *reinterpret_cast<const Float2*>(
@@ -1498,7 +1503,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
           const int idx = base + u * NLT;
-          if (idx < nAll) *reinterpret_cast<Float2*>(sl + (idx >> 3) * RS + 2 * (idx & 7)) = v[u];
+          if (idx < nAll) *reinterpret_cast<Float2*>(sl + (idx >> PSH) * RS + 2 * (idx & (PPR - 1))) = v[u];
         }
       }
       __syncthreads();  // B(s): slab(s) complete; the compute waves are done with the other buffer
@@ -1541,7 +1546,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
   };
   Idx x0, x1;   // layers l and l+1
   Wts w0;       // layer l
-  Float prev[GC];
+  Float prev[G];
   int s = 0;
 #ifdef EXP_CLOCKS
   unsigned long long tk = clock64(), tacc[4] = {0, 0, 0, 0};
@@ -1552,12 +1557,12 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
 #define TICK(i)
 #endif
 #pragma unroll 1
-  for (int g0 = gptS; g0 <= gptE; g0 += GC) {
+  for (int g0 = gptS; g0 <= gptE; g0 += G) {
     load_idx(0, x0);
     load_idx(min(1u, nlay - 1), x1);
     load_wts(0, x0, w0);
 #pragma unroll
-    for (int j = 0; j < GC; ++j) prev[j] = 0;
+    for (int j = 0; j < G; ++j) prev[j] = 0;
 #pragma unroll 1
     for (unsigned l = 0; l < nlay; ++l, ++s) {
       TICK(0);
@@ -1585,7 +1590,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
       char* const plev_ = reinterpret_cast<char*>(a.lev_src + (size_t)nclv * g0);
       const size_t slay = (size_t)ncl * sizeof(Float), slev = (size_t)nclv * sizeof(Float);
 #pragma unroll
-      for (int jj = 0; jj < GC; jj += 2) {
+      for (int jj = 0; jj < G; jj += 2) {
         // interpolate3D_byflav with scaling (1,1), :791-801; one 16-byte read feeds two g-points
         const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + RS + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + RS + jj),
                      k4 = ld2(B0 + jj), k5 = ld2(B0 + RS + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + RS + jj);
@@ -1619,7 +1624,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
     if (valid) {
       const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
 #pragma unroll
-      for (int j = 0; j < GC; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
+      for (int j = 0; j < G; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
     }
     // ---- surface source (:651-653) from the Planck fractions of the surface layer
     if (lsfc != (int)nlay - 1) {
@@ -1634,7 +1639,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
       const Float* B0 = sl + (((jps - 1 - Pmin) * nT + (x0.jT + 1 - Tmin)) * nE + (w0.je2 - emin)) * RS;
       const int sP = nT * nE * RS;
 #pragma unroll
-      for (int jj = 0; jj < GC; jj += 2) {
+      for (int jj = 0; jj < G; jj += 2) {
         const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + RS + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + RS + jj),
                      k4 = ld2(B0 + jj), k5 = ld2(B0 + RS + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + RS + jj);
         Float pa = w0.fm[0].x * k0.x, pb = w0.fm[0].x * k0.y, qa = w0.fm[2].x * k4.x, qb = w0.fm[2].x * k4.y;
@@ -1648,7 +1653,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
     }
     if (valid) {
 #pragma unroll
-      for (int j = 0; j < GC; ++j) {
+      for (int j = 0; j < G; ++j) {
         a.sfc_src[ic + (size_t)ncol * (g0 + j)] = prev[j] * pl_sfc;
         a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = prev[j] * (pl_sfc1 - pl_sfc);
       }
@@ -1676,17 +1681,18 @@ struct RaylArgs {
   Float* tau_rayleigh;
 };
 
-template <int BS>
+template <int BS, int G>
 __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
+  constexpr int RS = G + 2;
   extern __shared__ __align__(16) Float rslab[];  // [2 tropo][neta][ntemp] rows of RS Floats
   const int tid = threadIdx.x;
-  const int g0 = blockIdx.y * GC;  // host guarantees whole, 16-aligned chunks per band
+  const int g0 = blockIdx.y * G;  // host guarantees whole, 16-aligned chunks per band
   const unsigned ncol = a.ncol, nlay = a.nlay;
   const unsigned ncl = ncol * nlay;  // host guarantees 8 * ncl < 2^32
   const int ntemp = a.ntemp, tn = a.ntemp * a.neta;
   // stage: native layout (ntemp, neta, ngpt, 2) is contiguous along (T, eta) for a fixed g-point -> coalesced reads
-  for (int idx = tid; idx < 2 * GC * tn; idx += BS) {
-    const int te = idx % tn, gj = (idx / tn) % GC, r = idx / (tn * GC);
+  for (int idx = tid; idx < 2 * G * tn; idx += BS) {
+    const int te = idx % tn, gj = (idx / tn) % G, r = idx / (tn * G);
     rslab[(r * tn + te) * RS + gj] = a.krayl[(size_t)te + (size_t)tn * ((g0 + gj) + (size_t)a.ngpt * r)];
   }
   __syncthreads();
@@ -1726,7 +1732,7 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
     unsigned off = (ic + ncol * l) * (unsigned)sizeof(Float);
     asm volatile("" : "+v"(off));  // keep 64-bit store addresses out of the loop-invariant registers
 #pragma unroll
-    for (int j = 0; j < GC; j += 2) {
+    for (int j = 0; j < G; j += 2) {
       // interpolate2D :757-760 with the reference's association, then :555
       const Float2 a0 = ld2(k1 + j), a1 = ld2(k1 + ntemp * RS + j), b0 = ld2(k2 + j), b1 = ld2(k2 + ntemp * RS + j);
       const Float ka = f0 * a0.x + f1 * a1.x + f2 * b0.x + f3 * b1.x;
@@ -1753,6 +1759,7 @@ struct TauPlanCache {
   int dims[7] = {};
   int epoch = -1;
   bool fast_ok = false;
+  int gw = 0;  // g-points per stage of the production kernels (16 or 8)
   bool uploads_pending = false;  // bands changed since the last upload to the device
   std::vector<BandMeta> bands;
   bool matches(const void* const* k, const int* d, int e) const {
@@ -1926,11 +1933,19 @@ void rrtmgp_compute_tau_absorption(
     const Bool* sc[2] = {c.host(scale_by_complement_lower, (size_t)nlo), c.host(scale_by_complement_upper, (size_t)nup)};
     const int nn[2] = {nlo, nup};
     const int nk2[2] = {*nminorklower_, *nminorkupper_};
-    // Eligibility of the production kernel: every band and every minor interval is made of whole,
-    // 16-aligned chunks of 16 g-points and lies inside one band (true for the g256 / g224
-    // k-distributions), k-offsets are even, at most MAXM intervals per (band, regime).
-    bool ok = (ngpt % GC == 0) && sizeof(Float) == 8 && nbnd <= MAXB;
-    for (int b = 0; b < nbnd; ++b) ok = ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;
+    // Eligibility of the production kernels: every band and every minor interval is made of whole,
+    // aligned chunks of gw g-points and lies inside one band, k-offsets are even, at most MAXM intervals
+    // per (band, regime).
+    // The stage width gw is 16 g-points when everything is 16-aligned (g256 / g224 tables), else 8 (g128 / g112).
+    auto aligned = [&](int w) {
+      bool al_ = ngpt % w == 0;
+      for (int b = 0; b < nbnd; ++b) al_ = al_ && (bl[2 * b] - 1) % w == 0 && bl[2 * b + 1] % w == 0;
+      for (int r = 0; r < 2; ++r)
+        for (int i = 0; i < nn[r]; ++i) al_ = al_ && (ml[r][2 * i] - 1) % w == 0 && ml[r][2 * i + 1] % w == 0;
+      return al_;
+    };
+    const int gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);
+    bool ok = gw > 0 && sizeof(Float) == 8 && nbnd <= MAXB;
     cache.bands.assign(nbnd > 0 ? nbnd : 1, BandMeta{});
     {
       const int* gf = c.host(gpoint_flavor, (size_t)2 * ngpt);
@@ -1943,7 +1958,7 @@ void rrtmgp_compute_tau_absorption(
     for (int r = 0; r < 2 && ok; ++r) {
       ok = ok && (nn[r] == 0 || nk2[r] % 2 == 0);
       for (int i = 0; i < nn[r] && ok; ++i) {
-        ok = ok && (ml[r][2 * i] - 1) % GC == 0 && ml[r][2 * i + 1] % GC == 0 && (ks[r][i] - 1) % 2 == 0;
+        ok = ok && (ks[r][i] - 1) % 2 == 0;
         int band = -1;
         for (int b = 0; b < nbnd; ++b)
           if (ml[r][2 * i] >= bl[2 * b] && ml[r][2 * i + 1] <= bl[2 * b + 1]) band = b;
@@ -1958,6 +1973,7 @@ void rrtmgp_compute_tau_absorption(
       }
     }
     cache.fast_ok = ok;
+    cache.gw = ok ? gw : 0;
     cache.uploads_pending = true;
   }
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
@@ -2036,29 +2052,30 @@ void rrtmgp_compute_tau_absorption(
   const size_t wl_cap = (size_t)cdiv(ncol, 256) * nlay * nbnd;  // tiles are at least 256 columns wide
   v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
   HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
-  if (g_tau_variant == 9) {
+  const bool use_v9 = g_tau_variant == 9 || cache.gw != 16;  // the single-role kernel exists for 16-wide stages only
+  if (use_v9) {
 #ifdef EXP_CLOCKS
     v.clocks = (unsigned long long*)rte::scratch(64);
     HIP_CHECK(hipMemsetAsync(v.clocks, 0, 64, st));
 #endif
-#ifndef V9_NCW
-#define V9_NCW 4
-#define V9_NLW 2
-#endif
     constexpr int NCW = V9_NCW, NLW = V9_NLW, SLAB9 = V9_SLAB;  // compute + loader waves, 2 x 68 KB slab: one block per CU
     const unsigned tiles = cdiv(ncol, NCW * 64);
     TileGeom* d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
-    {
-      rte::ProfScope p("tau_absorption_setup");
-      hipLaunchKernelGGL((tau_geom_kernel<NCW * 64>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, d_geom, SLAB9);
-    }
-    rte::ProfScope p("tau_absorption_kernel");
-    if (overwrite)
-      hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true>), dim3(tiles, nlay), dim3((NCW + NLW) * 64),
-                         sizeof(BandMeta) * nbnd, st, v, (const TileGeom*)d_geom);
-    else
-      hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false>), dim3(tiles, nlay), dim3((NCW + NLW) * 64),
-                         sizeof(BandMeta) * nbnd, st, v, (const TileGeom*)d_geom);
+    const dim3 grid(tiles, nlay), blk((NCW + NLW) * 64);
+    const size_t dyn = sizeof(BandMeta) * nbnd;
+    const TileGeom* cg = d_geom;
+#define RTE_LAUNCH_TAU9(GW)                                                                                       \
+  do {                                                                                                            \
+    {                                                                                                             \
+      rte::ProfScope p("tau_absorption_setup");                                                                   \
+      hipLaunchKernelGGL((tau_geom_kernel<NCW * 64, GW>), grid, dim3(NCW * 64), 0, st, v, d_geom, SLAB9);         \
+    }                                                                                                             \
+    rte::ProfScope p("tau_absorption_kernel");                                                                    \
+    if (overwrite) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW>), grid, blk, dyn, st, v, cg); \
+    else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW>), grid, blk, dyn, st, v, cg);   \
+  } while (0)
+    if (cache.gw == 16) RTE_LAUNCH_TAU9(16); else RTE_LAUNCH_TAU9(8);
+#undef RTE_LAUNCH_TAU9
   } else {
     rte::ProfScope p("tau_absorption_kernel");
     // <min waves per SIMD, g-points per register chunk>: measured best of {2,3} x {4,8,16} on MI355X
@@ -2066,7 +2083,7 @@ void rrtmgp_compute_tau_absorption(
                        v);
   }
 #ifdef EXP_CLOCKS
-  if (g_tau_variant == 9) {
+  if (use_v9) {
     unsigned long long h[8];
     HIP_CHECK(hipMemcpyAsync(h, v.clocks, 64, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
@@ -2083,7 +2100,7 @@ void rrtmgp_compute_tau_absorption(
     TauArgs aw = a;
     aw.run_if = nullptr;
     hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(4096), dim3(256), 0, st, aw, (const int*)v.worklist,
-                       g_tau_variant == 9 ? V9_NCW * 64 : BS);
+                       use_v9 ? V9_NCW * 64 : BS);
   }
 }
 
@@ -2114,6 +2131,7 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
   static const void* bl_key = nullptr;
   static int bl_n = -1, bl_epoch = -1;
   static bool bl_ok = false;
+  static int bl_gw = 0;
   unsigned bl_fp = 0;
   if (!rte::is_device_pointer(band_lims_gpt))  // host tables: fingerprint the contents (see compute_tau_absorption)
     for (int i = 0; i < 2 * nbnd; ++i) bl_fp = (bl_fp ^ (unsigned)band_lims_gpt[i]) * 16777619u;
@@ -2121,11 +2139,16 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
   if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch || bl_fp != bl_fp_seen) {
     bl_fp_seen = bl_fp;
     const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
-    bl_ok = (ngpt % GC == 0) && sizeof(Float) == 8;
-    for (int b = 0; b < nbnd; ++b) bl_ok = bl_ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;
+    auto aligned = [&](int w) {
+      bool al_ = ngpt % w == 0;
+      for (int b = 0; b < nbnd; ++b) al_ = al_ && (bl[2 * b] - 1) % w == 0 && bl[2 * b + 1] % w == 0;
+      return al_;
+    };
+    bl_gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);  // g-points per stage of the production kernel
+    bl_ok = bl_gw > 0 && sizeof(Float) == 8;
     bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = g_plan_epoch;
   }
-  const size_t slab_bytes = sizeof(Float) * 2 * (size_t)ntemp * neta * RS;
+  const size_t slab_bytes = sizeof(Float) * 2 * (size_t)ntemp * neta * (bl_gw + 2);
   if (bl_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) && slab_bytes <= 64 * 1024 &&
       ((uintptr_t)d_fminor % 16) == 0 && ((uintptr_t)d_jeta % 8) == 0) {
     RaylArgs q;
@@ -2133,8 +2156,12 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
     q.gpoint_flavor = d_gpoint_flavor; q.jeta = d_jeta; q.jtemp = d_jtemp; q.krayl = d_krayl; q.col_dry = d_col_dry;
     q.col_gas = d_col_gas; q.fminor = d_fminor; q.tropo = d_tropo; q.tau_rayleigh = d_tau;
     rte::ProfScope p("tau_rayleigh_kernel");
-    hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256>), dim3(cdiv(ncol, 256), ngpt / GC), dim3(256), slab_bytes,
-                       rte::stream(), q);
+    if (bl_gw == 16)
+      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 16>), dim3(cdiv(ncol, 256), ngpt / 16), dim3(256), slab_bytes,
+                         rte::stream(), q);
+    else
+      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 8>), dim3(cdiv(ncol, 256), ngpt / 8), dim3(256), slab_bytes,
+                         rte::stream(), q);
     return;
   }
   rte::ProfScope p("tau_rayleigh_kernel");
@@ -2183,6 +2210,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   static const void* bl_key = nullptr;
   static int bl_n = -1, bl_epoch = -1;
   static bool bl_ok = false;
+  static int bl_gw = 0;
   unsigned bl_fp = 0;
   if (!rte::is_device_pointer(band_lims_gpt))  // host tables: fingerprint the contents (see compute_tau_absorption)
     for (int i = 0; i < 2 * nbnd; ++i) bl_fp = (bl_fp ^ (unsigned)band_lims_gpt[i]) * 16777619u;
@@ -2190,8 +2218,13 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch || bl_fp != bl_fp_seen) {
     bl_fp_seen = bl_fp;
     const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
-    bl_ok = (ngpt % GC == 0) && sizeof(Float) == 8;
-    for (int b = 0; b < nbnd; ++b) bl_ok = bl_ok && (bl[2 * b] - 1) % GC == 0 && bl[2 * b + 1] % GC == 0;
+    auto aligned = [&](int w) {
+      bool al_ = ngpt % w == 0;
+      for (int b = 0; b < nbnd; ++b) al_ = al_ && (bl[2 * b] - 1) % w == 0 && bl[2 * b + 1] % w == 0;
+      return al_;
+    };
+    bl_gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);  // g-points per stage of the production kernel
+    bl_ok = bl_gw > 0 && sizeof(Float) == 8;
     bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = g_plan_epoch;
   }
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
@@ -2227,25 +2260,37 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 2 * (size_t)cdiv(ncol, BS) * nbnd));
   HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
   int wl_tile = BS;
-  if (g_planck_variant == 9 && nlay <= 256 && nbnd <= MAXB && (size_t)ncol * (nlay + 1) < ((size_t)1 << 29)) {
+  const bool planck9 = (g_planck_variant == 9 || bl_gw != 16) && nlay <= 256 && nbnd <= MAXB &&
+                       (size_t)ncol * (nlay + 1) < ((size_t)1 << 29);
+  if (!planck9 && bl_gw != 16) {  // 8-wide stages exist only in the specialised-wave kernel
+    rte::ProfScope p("planck_source_kernel");
+    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q);
+    return;
+  }
+  if (planck9) {
     constexpr int NCW = 8, NLW = 2, SLAB9 = 8704;  // 8 compute + 2 loader waves, 2 x 68 KB slab: one block per CU
     wl_tile = NCW * 64;
     const unsigned tiles = cdiv(ncol, NCW * 64);
     TileGeom* d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
     int* d_flags = (int*)rte::scratch(sizeof(int) * (size_t)tiles * nbnd);
     HIP_CHECK(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)tiles * nbnd, st));
-    {
-      rte::ProfScope p("planck_source_setup");
-      hipLaunchKernelGGL((planck_geom_kernel<NCW * 64>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, d_flags,
-                         SLAB9);
-    }
 #ifdef EXP_CLOCKS
     v.clocks = (unsigned long long*)rte::scratch(64);
     HIP_CHECK(hipMemsetAsync(v.clocks, 0, 64, st));
 #endif
-    rte::ProfScope p("planck_source_kernel");
-    hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9>), dim3(tiles, nbnd), dim3((NCW + NLW) * 64),
-                       sizeof(Float) * nPlanckTemp, st, v, nbnd, (const TileGeom*)d_geom, (const int*)d_flags);
+#define RTE_LAUNCH_PLANCK9(GW)                                                                                    \
+  do {                                                                                                            \
+    {                                                                                                             \
+      rte::ProfScope p("planck_source_setup");                                                                    \
+      hipLaunchKernelGGL((planck_geom_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, \
+                         d_flags, SLAB9);                                                                         \
+    }                                                                                                             \
+    rte::ProfScope p("planck_source_kernel");                                                                     \
+    hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW>), dim3(tiles, nbnd), dim3((NCW + NLW) * 64),  \
+                       sizeof(Float) * nPlanckTemp, st, v, nbnd, (const TileGeom*)d_geom, (const int*)d_flags);   \
+  } while (0)
+    if (bl_gw == 16) RTE_LAUNCH_PLANCK9(16); else RTE_LAUNCH_PLANCK9(8);
+#undef RTE_LAUNCH_PLANCK9
   } else {
     rte::ProfScope p("planck_source_kernel");
     hipLaunchKernelGGL((planck_source_v7_kernel<BS>), dim3(cdiv(ncol, BS), nbnd), dim3(BS), sizeof(Float) * nPlanckTemp, st,

@@ -186,9 +186,10 @@ def test_tau_absorption_paths_agree(hip, oracle_c):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("nbnd,ngpt,top_at_1", [(2, 64, False), (3, 96, True), (4, 64, True)])
+@pytest.mark.parametrize("nbnd,ngpt,top_at_1", [(2, 64, False), (3, 96, True), (4, 64, True), (8, 64, False), (16, 128, True)])
 def test_wide_bands_on_production_kernels(hip, oracle_c, nbnd, ngpt, top_at_1):
-    """Bands wider than the 16 g-point stage (32 g-points here): the production tau / Planck / Rayleigh
+    """Bands wider than the 16 g-point stage (32 g-points) and NARROWER ones (8 g-points, the shape of the
+    reduced g128 / g112 k-distributions, handled with 8-wide stages): the production tau / Planck / Rayleigh
     kernels walk them in several stages with the same band metadata.  Against the oracle and the direct
     kernels, LW and SW tables, 700 columns (ragged last tile), both vertical orientations (the surface
     layer is the first or the last one the Planck kernel visits)."""
