@@ -1945,7 +1945,7 @@ void rrtmgp_compute_tau_absorption(
       return al_;
     };
     const int gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);
-    bool ok = gw > 0 && sizeof(Float) == 8 && nbnd <= MAXB;
+    bool ok = gw > 0 && nbnd <= MAXB;
     cache.bands.assign(nbnd > 0 ? nbnd : 1, BandMeta{});
     {
       const int* gf = c.host(gpoint_flavor, (size_t)2 * ngpt);
@@ -2145,7 +2145,7 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
       return al_;
     };
     bl_gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);  // g-points per stage of the production kernel
-    bl_ok = bl_gw > 0 && sizeof(Float) == 8;
+    bl_ok = bl_gw > 0;
     bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = g_plan_epoch;
   }
   const size_t slab_bytes = sizeof(Float) * 2 * (size_t)ntemp * neta * (bl_gw + 2);
@@ -2224,7 +2224,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
       return al_;
     };
     bl_gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);  // g-points per stage of the production kernel
-    bl_ok = bl_gw > 0 && sizeof(Float) == 8;
+    bl_ok = bl_gw > 0;
     bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = g_plan_epoch;
   }
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };

@@ -326,6 +326,46 @@ def test_single_precision_build(name):
             assert cases.rel_err(out[k], ref[k]) <= 1e-3, (k, cases.rel_err(out[k], ref[k]))
 
 
+def test_single_precision_production_kernels():
+    """The production gas-optics kernels (LDS slabs, loader / compute waves) in the -DRTE_USE_SP build at a
+    size that takes them (700 columns): against the same build's direct kernels (1e-5: float rounding of a
+    different association) and the single-precision oracle."""
+    from oracle import oracle as O
+    from rte_rrtmgp_amd import synth
+
+    hip_sp = hiplib.load("sp")
+    xp = frontend.TorchArrays("cuda:0", "sp")
+    A = xp.asarray
+    ncol, nlay = 700, 21
+    for kind in ("lw", "sw"):
+        kd = synth.make_kdist(kind, ngpt=64, nbnd=4)
+        atm = synth.make_atmosphere(ncol, nlay, seed=17, kdist=kd)
+        outs = {}
+        for mode in ("fast", "direct", "oracle"):
+            if mode == "oracle":
+                lib, arr = O.load_c("sp"), frontend.NumpyArrays("sp")
+                conv = arr.asarray  # float64 inputs must become float32 before they cross the C ABI
+            else:
+                lib, arr, conv = hip_sp, xp, A
+            hiplib.ext_call(hip_sp, "rte_hip_force_direct_gather", ["i"], 1 if mode == "direct" else 0)
+            try:
+                go = frontend.GasOptics(lib, kd, arr)
+                if kind == "lw":
+                    b = go.gas_optics_lw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.tsfc),
+                                         conv(atm.col_gas), conv(atm.tlev), atm.top_at_1)
+                    keys = ("tau", "lay_src", "lev_src", "sfc_src")
+                else:
+                    b = go.gas_optics_sw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.col_gas),
+                                         conv(atm.col_dry))
+                    keys = ("tau_abs", "tau_rayleigh", "tau")
+                outs[mode] = {k: np.array(arr.to_numpy(b[k])) for k in keys}
+            finally:
+                hiplib.ext_call(hip_sp, "rte_hip_force_direct_gather", ["i"], 0)
+        for k in outs["oracle"]:
+            assert cases.rel_err(outs["fast"][k], outs["direct"][k]) <= 1e-5, (kind, k, cases.rel_err(outs["fast"][k], outs["direct"][k]))
+            assert cases.rel_err(outs["fast"][k], outs["oracle"][k]) <= 1e-3, (kind, k)
+
+
 def test_gray_radiative_equilibrium_on_device(hip):
     from test_host_logic import _gray_equilibrium
 
