@@ -1007,6 +1007,176 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// LW no-scattering solver WITH rescaling (Tang et al. 2018; reference :154-178, lw_transport_1rescl :753-844),
+// segmented, broadband output.  Three affine sweeps per g-point, each chained across the segments through
+// LDS: (1) down with the rescaled optical depth; (2) up from the surface with the source adjusted by the
+// downward radiance of sweep 1 at the layer top; (3) down again with the source adjusted by the upward
+// radiance (at the layer's top level when top_at_1, at its bottom level otherwise -- the reference's own
+// indexing).  All three share the segment transmission; three barriers per g-point.
+// ---------------------------------------------------------------------------------------------
+struct LwRescArgs {
+  int ncol, nlay, ngpt, S, g_per_block;
+  bool top_at_1, do_jac;
+  Float weight;
+  const Float *D, *tau, *ssa, *g, *lay_source, *lev_source, *sfc_emis, *sfc_src, *inc_flux, *sfc_srcJac;
+  Float *part_up, *part_dn, *part_jac;  // (ncol, nlev, ngroups)
+};
+
+template <int L, bool do_jac>
+__global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArgs a) {
+#pragma clang fp contract(fast)
+  constexpr int SMAX = 8;
+  extern __shared__ Float lds[];  // X[2 buffers (g-point parity)][4 (T, Sd1, Su2, Sd3)][SMAX][64]
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int S = a.S, ncol = a.ncol, nlay = a.nlay;
+  const int icol = blockIdx.x * 64 + lane;
+  const bool active = icol < ncol;
+  const int c = active ? icol : ncol - 1;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const int p0 = s * L;
+  const int np = min(L, nlay - p0);
+  const bool last = (s == S - 1);
+  const Float piw = kPi * a.weight;
+  const int g_begin = blockIdx.y * a.g_per_block;
+  const int g_end = min(a.ngpt, g_begin + a.g_per_block);
+
+  Float acc_dn[L + 1], acc_up[L + 1], acc_j[do_jac ? L + 1 : 1];
+#pragma unroll
+  for (int i = 0; i <= L; ++i) { acc_dn[i] = 0; acc_up[i] = 0; if (do_jac) acc_j[i] = 0; }
+
+  struct In { Float tau[L], ssa[L], g[L], lay[L], lev[L + 1], D, emis, ssrc, inc, sjac; };
+  auto load = [&](In& x, int igpt_) {
+    const int igpt = min(igpt_, g_end - 1);
+    const size_t cg = c + (size_t)ncol * igpt;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const int p = p0 + min(i, np - 1);
+      const size_t o = c + (size_t)ncol * (a.top_at_1 ? p : nlay - 1 - p) + ncl * igpt;
+      x.tau[i] = a.tau[o]; x.ssa[i] = a.ssa[o]; x.g[i] = a.g[o]; x.lay[i] = a.lay_source[o];
+    }
+#pragma unroll
+    for (int i = 0; i <= L; ++i) {
+      const int p = p0 + min(i, np);
+      x.lev[i] = a.lev_source[c + (size_t)ncol * (a.top_at_1 ? p : nlay - p) + nclv * igpt];
+    }
+    x.D = a.D[cg]; x.emis = a.sfc_emis[cg]; x.ssrc = a.sfc_src[cg]; x.inc = a.inc_flux[cg];
+    x.sjac = do_jac ? a.sfc_srcJac[cg] : (Float)0;
+  };
+
+  auto process = [&](In& x, int igpt_next, int buf) {
+#pragma clang fp contract(fast)
+    // composites of g-point g live in buffer g & 1: a wave may start g+1 while another still chains g
+    auto X = [&](int kind, int q) -> Float& { return lds[((buf * 4 + kind) * SMAX + q) * 64 + lane]; };
+    Float t[L], sd[L], su[L], Cn[L];
+    // ---- pass 1: rescaled optical depth, transmissivity, Clough sources (:154-190); composite of sweep 1
+    Float Td = 1, Sd = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (i < np) {  // wave-uniform
+        const Float ssal = x.ssa[i];
+        const Float wb = ssal * ((Float)1 - x.g[i]) * (Float)0.5;
+        const Float scaleTau = ((Float)1 - ssal + wb);
+        Cn[i] = (Float)0.4 * wb / scaleTau;
+        const Float tau_loc = x.tau[i] * x.D * scaleTau;
+        const Float tr = exp(-tau_loc);
+        lw_source_layer(tau_loc, tr, x.lay[i], x.lev[i], x.lev[i + 1], sd[i], su[i]);
+        t[i] = tr;
+      } else {  // neutral layer
+        t[i] = 1; sd[i] = 0; su[i] = 0; Cn[i] = 0;
+      }
+      Sd = t[i] * Sd + sd[i];
+      Td = Td * t[i];
+    }
+    const Float emis = x.emis, ssrc = x.ssrc, inc = x.inc, sjac = x.sjac;
+    load(x, igpt_next);  // the layer inputs are dead: the next g-point's go into the same registers
+    X(0, s) = Td; X(1, s) = Sd;
+    __syncthreads();
+    // ---- sweep 1 (down) across the segments, then inside this one
+    Float r = inc / piw;  // :144
+    const Float r_top = r;
+    Float r_in = r;
+    for (int q = 0; q < S; ++q) {
+      if (q == s) r_in = r;
+      r = X(0, q) * r + X(1, q);
+    }
+    const Float u_sfc = r * ((Float)1 - emis) + emis * ssrc;  // :198-200
+    // own levels of sweep 1 and the adjusted upward sources (:771-775 / :806-810): An = 1 - trans^2
+    Float su2[L];
+    {
+      Float d = r_in;
+#pragma unroll
+      for (int i = 0; i < L; ++i) {
+        su2[i] = su[i] + Cn[i] * (((Float)1 - t[i] * t[i]) * d - t[i] * sd[i] - su[i]);
+        d = t[i] * d + sd[i];
+      }
+    }
+    Float Su = 0;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) Su = t[i] * Su + su2[i];
+    X(2, s) = Su;
+    __syncthreads();
+    // ---- sweep 2 (up) from the surface
+    Float u = u_sfc;
+    Float jv = do_jac ? emis * sjac : (Float)0;
+    for (int q = S - 1; q > s; --q) {
+      const Float Tq = X(0, q);
+      u = Tq * u + X(2, q);
+      jv = Tq * jv;
+    }
+    Float ul[L + 1];
+    ul[L] = u;
+    acc_up[L] += u;
+    if (do_jac) acc_j[L] += jv;
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      u = t[i] * u + su2[i];
+      ul[i] = u;
+      acc_up[i] += u;
+      if (do_jac) { jv = t[i] * jv; acc_j[i] += jv; }
+    }
+    // adjusted downward sources of sweep 3 (:787-791 / :822-826): the upward radiance at the layer's top level
+    // when top_at_1, at its bottom level otherwise (the reference indexes radn_up(ilev) in both branches)
+    Float Sd3 = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const Float usel = a.top_at_1 ? ul[i] : ul[i + 1];
+      su2[i] = sd[i] + Cn[i] * (((Float)1 - t[i] * t[i]) * usel - t[i] * su[i] - sd[i]);  // reused as sd3
+      Sd3 = t[i] * Sd3 + su2[i];
+    }
+    X(3, s) = Sd3;
+    __syncthreads();
+    // ---- sweep 3 (down again)
+    r = r_top;
+    for (int q = 0; q < s; ++q) r = X(0, q) * r + X(3, q);
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      acc_dn[i] += r;
+      r = t[i] * r + su2[i];
+    }
+    acc_dn[L] += r;
+  };
+
+  In cur;
+  load(cur, g_begin);
+  for (int igpt = g_begin; igpt < g_end; ++igpt) process(cur, igpt + 1, igpt & 1);
+  if (active) {
+    const size_t base = icol + nclv * blockIdx.y;
+#pragma unroll
+    for (int i = 0; i <= L; ++i) {
+      if (i < np || (last && i == np)) {
+        const int p = p0 + i;
+        const int ilev = a.top_at_1 ? p : nlay - p;
+        a.part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
+        a.part_up[base + (size_t)ncol * ilev] = acc_up[i];
+        if (do_jac) a.part_jac[base + (size_t)ncol * ilev] = acc_j[i];
+      }
+    }
+  }
+}
+
+
 // out(c,l) = sum over the ngroups partial slabs (in order), times scale; optionally accumulate
 __global__ void __launch_bounds__(256)
 reduce_parts_kernel(size_t n2, int ngroups, const Float* __restrict__ parts, Float* __restrict__ out, Float scale,
@@ -1079,6 +1249,42 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
   // lose to the generic kernel (measured: 12 layers per wave 20.6 vs 18.4 ms, 16 per wave 44 vs 19 ms at 1e5 x 128)
   const int L = nlay <= 64 ? 8 : nlay <= 72 ? 9 : 10;
   const int S = (nlay + L - 1) / L;
+  if (do_broadband && do_rescaling && nlay <= 72 && !g_lw_force_generic) {
+    // ------------------------------------------------------------------ production path with rescaling
+    const int Lr = nlay <= 64 ? 8 : 9;
+    const int Sr = (nlay + Lr - 1) / Lr;
+    const int col_tiles = cdiv(ncol, 64);
+    int ngroups = 1;
+    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    const int g_per_block = (ngpt + ngroups - 1) / ngroups;
+    ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    LwRescArgs q;
+    q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = Sr; q.g_per_block = g_per_block; q.top_at_1 = *top_at_1; q.do_jac = do_jac;
+    q.tau = d_tau; q.ssa = d_ssa; q.g = d_g; q.lay_source = d_lay; q.lev_source = d_lev; q.sfc_emis = d_emis; q.sfc_src = d_sfc;
+    q.inc_flux = d_inc; q.sfc_srcJac = d_srcJac;
+    q.part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
+    q.part_dn = q.part_up + nclv * ngroups;
+    q.part_jac = do_jac ? q.part_dn + nclv * ngroups : nullptr;
+    const size_t lds_bytes = sizeof(Float) * 2 * 4 * 8 * 64;
+    for (int imu = 0; imu < nmus; ++imu) {
+      q.weight = w_h[imu]; q.D = d_Ds + ncg * imu;
+      {
+        rte::ProfScope p("lw_noscat_rescale_seg_kernel");
+#define RTE_LAUNCH_RESC(LL, JJ) \
+  hipLaunchKernelGGL((lw_noscat_rescale_seg_kernel<LL, JJ>), dim3(col_tiles, ngroups), dim3(64 * Sr), lds_bytes, st, q)
+        if (Lr == 8) { if (do_jac) RTE_LAUNCH_RESC(8, true); else RTE_LAUNCH_RESC(8, false); }
+        else         { if (do_jac) RTE_LAUNCH_RESC(9, true); else RTE_LAUNCH_RESC(9, false); }
+#undef RTE_LAUNCH_RESC
+      }
+      rte::ProfScope p("lw_reduce_parts");
+      const Float piw = (Float)3.14159265358979323846264338327950288 * w_h[imu];
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, q.part_up, d_bb_up, piw, imu > 0);
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, q.part_dn, d_bb_dn, piw, imu > 0);
+      if (do_jac)
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, q.part_jac, d_jac, piw, imu > 0);
+    }
+    return;
+  }
   if (do_broadband && !do_rescaling && nlay <= 80 && !g_lw_force_generic) {
     // g-points per block: enough blocks to fill the chip several times over, few enough partial slabs
     const int col_tiles = cdiv(ncol, 64);

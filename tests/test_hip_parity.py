@@ -128,6 +128,15 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
                               use_2stream=True, inc_flux=A(inc))
         for k in ("gpt_flux_up", "gpt_flux_dn"):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
+        # the no-scattering solver with Tang rescaling (what rte_lw does with 2-stream cloudy optical properties
+        # by default), broadband, two quadrature angles, with Jacobian: segmented three-sweep kernel vs oracle
+        sj = F(ncol, ngpt)
+        ref = frontend.rte_lw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, lay, lev, emis, sfc, ssa=ssa, g=g,
+                              inc_flux=inc, n_gauss_angles=2, sfc_src_jac=sj, do_jacobians=True)
+        out = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(lay), A(lev), A(emis), A(sfc), ssa=A(ssa), g=A(g),
+                              inc_flux=A(inc), n_gauss_angles=2, sfc_src_jac=A(sj), do_jacobians=True)
+        for k in ("flux_up", "flux_dn", "flux_up_jac"):
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
 
 
 @pytest.mark.parametrize("name", ["lw_mid_ragged", "lw_mid_top1", "lw_g256"])

@@ -22,6 +22,8 @@ for ncol, nlay, ngpt, top in itertools.product((1, 63, 64, 65, 200), (1, 2, 7, 8
         o["lw.up"], o["lw.dn"] = r["flux_up"].clone(), r["flux_dn"].clone()
         r = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top, tau, lay, lev, emis, sfc, ssa=ssa, g=gg, use_2stream=True, inc_flux=inc, buffers={})
         o["lw2.up"], o["lw2.dn"] = r["flux_up"].clone(), r["flux_dn"].clone()
+        r = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top, tau, lay, lev, emis, sfc, ssa=ssa, g=gg, inc_flux=inc, buffers={})
+        o["lwr.up"], o["lwr.dn"] = r["flux_up"].clone(), r["flux_dn"].clone()
         r = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top, tau, ssa, gg, mu0, idir, adir, adif, inc_flux_dif=inc, buffers={})
         o["sw.up"], o["sw.dn"], o["sw.dir"] = r["flux_up"].clone(), r["flux_dn"].clone(), r["flux_dir"].clone()
         res.append(o)

@@ -25,3 +25,5 @@ for gen in (0, 1):
 hiplib.ext_call(lib, "rte_hip_force_generic_lw", ["i"], 0); hiplib.ext_call(lib, "rte_hip_force_generic_sw", ["i"], 0)
 rb2 = {}
 timed("72 layers: rte_lw (no scattering, broadband, 1 angle)", lambda: frontend.rte_lw(lib, xp, ncol, nlay, ngpt, False, tau, lay, lev, emis, sfc, buffers=rb2))
+rb3 = {}
+timed("72 layers: rte_lw with Tang rescaling (2str clouds, no-scattering solver)", lambda: frontend.rte_lw(lib, xp, ncol, nlay, ngpt, False, tau, lay, lev, emis, sfc, ssa=ssa, g=gg, buffers=rb3))
