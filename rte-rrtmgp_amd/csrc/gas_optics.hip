@@ -1456,15 +1456,18 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
   __shared__ int gl[MAXL][6];       // per layer: Tmin, nT, Pmin, nP, emin, nE
   extern __shared__ Float tpl[];    // totplnk(:, ibnd)
   const int tid = threadIdx.x;
-  const int ibnd = blockIdx.y;
-  if (flags[blockIdx.x * nbnd + ibnd]) return;  // block-uniform: the direct kernel does this (tile, band)
+  // the bands of one column tile are neighbours in launch order (band = fast grid index): they run at about the
+  // same time and share the tile's index arrays and, per flavor, its interpolation weights in the caches
+  const int ibnd = blockIdx.x;
+  const unsigned tile = blockIdx.y, ntiles = gridDim.y;
+  if (flags[tile * nbnd + ibnd]) return;  // block-uniform: the direct kernel does this (tile, band)
   const unsigned ncol = a.ncol, nlay = a.nlay;
   const unsigned ncl = ncol * nlay, nclv = ncol * (nlay + 1);  // host guarantees 8 * nclv < 2^32
   const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nPT = a.nPlanckTemp;
   const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
   for (int i = tid; i < nPT; i += NT) tpl[i] = a.totplnk[(size_t)nPT * ibnd + i];
   for (int l = tid; l < (int)nlay; l += NT) {
-    const TileGeom* g = geom + (blockIdx.x + (size_t)gridDim.x * l);
+    const TileGeom* g = geom + (tile + (size_t)ntiles * l);
     gl[l][0] = g->Tmin; gl[l][1] = g->nT; gl[l][2] = g->Pmin; gl[l][3] = g->nP;
     gl[l][4] = g->eg[ibnd].x; gl[l][5] = g->eg[ibnd].y;
   }
@@ -1512,7 +1515,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, const TileGeom* __restrict__ geom,
   }
 
   // ================================ compute waves (lanes = columns) ================================
-  const unsigned icol = blockIdx.x * TILE + tid;
+  const unsigned icol = tile * TILE + tid;
   const bool valid = icol < ncol;
   const unsigned ic = min(icol, ncol - 1);
   const int flav0 = a.gpoint_flavor[2 * gptS] - 1, flav1 = a.gpoint_flavor[1 + 2 * gptS] - 1;
@@ -2286,7 +2289,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
                          d_flags, SLAB9);                                                                         \
     }                                                                                                             \
     rte::ProfScope p("planck_source_kernel");                                                                     \
-    hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW>), dim3(tiles, nbnd), dim3((NCW + NLW) * 64),  \
+    hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW>), dim3(nbnd, tiles), dim3((NCW + NLW) * 64),  \
                        sizeof(Float) * nPlanckTemp, st, v, nbnd, (const TileGeom*)d_geom, (const int*)d_flags);   \
   } while (0)
     if (bl_gw == 16) RTE_LAUNCH_PLANCK9(16); else RTE_LAUNCH_PLANCK9(8);
