@@ -1689,7 +1689,8 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
   constexpr int RS = G + 2;
   extern __shared__ __align__(16) Float rslab[];  // [2 tropo][neta][ntemp] rows of RS Floats
   const int tid = threadIdx.x;
-  const int g0 = blockIdx.y * G;  // host guarantees whole, 16-aligned chunks per band
+  // the g-point chunk is the fast grid index: the chunks of one column tile run together and share its inputs in cache
+  const int g0 = blockIdx.x * G;  // host guarantees whole, G-aligned chunks per band
   const unsigned ncol = a.ncol, nlay = a.nlay;
   const unsigned ncl = ncol * nlay;  // host guarantees 8 * ncl < 2^32
   const int ntemp = a.ntemp, tn = a.ntemp * a.neta;
@@ -1699,7 +1700,7 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
     rslab[(r * tn + te) * RS + gj] = a.krayl[(size_t)te + (size_t)tn * ((g0 + gj) + (size_t)a.ngpt * r)];
   }
   __syncthreads();
-  const unsigned icol = blockIdx.x * BS + tid;
+  const unsigned icol = blockIdx.y * BS + tid;
   const unsigned ic = min(icol, ncol - 1);  // lanes past the last column repeat it (same values, same addresses)
   const int flav0 = a.gpoint_flavor[2 * g0] - 1, flav1 = a.gpoint_flavor[1 + 2 * g0] - 1;
   struct In { Bool tropo; int jT; Float h2o, dry; };
@@ -2160,10 +2161,10 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
     q.col_gas = d_col_gas; q.fminor = d_fminor; q.tropo = d_tropo; q.tau_rayleigh = d_tau;
     rte::ProfScope p("tau_rayleigh_kernel");
     if (bl_gw == 16)
-      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 16>), dim3(cdiv(ncol, 256), ngpt / 16), dim3(256), slab_bytes,
+      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 16>), dim3(ngpt / 16, cdiv(ncol, 256)), dim3(256), slab_bytes,
                          rte::stream(), q);
     else
-      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 8>), dim3(cdiv(ncol, 256), ngpt / 8), dim3(256), slab_bytes,
+      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 8>), dim3(ngpt / 8, cdiv(ncol, 256)), dim3(256), slab_bytes,
                          rte::stream(), q);
     return;
   }
