@@ -76,6 +76,41 @@ combine_2str_kernel(size_t n, const Float* __restrict__ tau_abs, const Float* __
   g[i] = 0;
 }
 // out(icol, igpt) = per_gpt(igpt): toa_src broadcast, reference mo_gas_optics_rrtmgp.F90:405-411
+// Frontend glue of cloud_optics (rrtmgp/frontend/mo_cloud_optics_rrtmgp.F90:334-341): masks = water path > 0
+__global__ void __launch_bounds__(256)
+cloud_masks_kernel(size_t n, const Float* __restrict__ clwp, const Float* __restrict__ ciwp, Bool* __restrict__ liqmsk,
+                   Bool* __restrict__ icemsk) {
+  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (i >= n) return;
+  liqmsk[i] = clwp[i] > (Float)0;
+  icemsk[i] = ciwp[i] > (Float)0;
+}
+
+// ... and its liquid + ice combination (:392-425): absorption optical depth for 1scl, (tau, ssa, g) for 2str
+template <bool TWOSTR>
+__global__ void __launch_bounds__(256)
+cloud_combine_kernel(size_t n, const Float* __restrict__ ltau, const Float* __restrict__ ltaussa,
+                     const Float* __restrict__ ltaussag, const Float* __restrict__ itau, const Float* __restrict__ itaussa,
+                     const Float* __restrict__ itaussag, Float* __restrict__ tau, Float* __restrict__ ssa,
+                     Float* __restrict__ g) {
+  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (i >= n) return;
+  if (!TWOSTR) {
+    tau[i] = (ltau[i] - ltaussa[i]) + (itau[i] - itaussa[i]);  // (1 - ssa) tau = tau - taussa
+  } else {
+    const Float t = ltau[i] + itau[i];
+    const Float ts = ltaussa[i] + itaussa[i];
+#ifdef RTE_USE_SP
+    const Float eps = 1.1920929e-07f;  // epsilon(tau)
+#else
+    const Float eps = 2.220446049250313e-16;  // epsilon(tau)
+#endif
+    g[i] = (ltaussag[i] + itaussag[i]) / fmax(eps, ts);
+    ssa[i] = ts / fmax(eps, t);
+    tau[i] = t;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 broadcast_gpt_kernel(int ncol, int ngpt, const Float* __restrict__ per_gpt, Float* __restrict__ out) {
   const int icol = blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,6 +192,37 @@ int rte_hip_broadcast_gpt(int ncol, int ngpt, const Float* per_gpt, Float* out) 
   Float* o = c.out(out, (size_t)ncol * ngpt);
   rte::ProfScope p("broadcast_gpt_kernel");
   hipLaunchKernelGGL(broadcast_gpt_kernel, dim3(cdiv(ncol, 256), ngpt), dim3(256), 0, rte::stream(), ncol, ngpt, pg, o);
+  return 0;
+}
+
+// liqmsk = clwp > 0, icemsk = ciwp > 0 (mo_cloud_optics_rrtmgp.F90:334-341)
+int rte_hip_cloud_masks(int ncol, int nlay, const Float* clwp, const Float* ciwp, Bool* liqmsk, Bool* icemsk) {
+  const size_t n = (size_t)ncol * nlay;
+  if (n == 0) return 0;
+  rte::Call c("rte_hip_cloud_masks");
+  const Float *l = c.in(clwp, n), *i = c.in(ciwp, n);
+  Bool *lm = c.out(liqmsk, n), *im = c.out(icemsk, n);
+  rte::ProfScope p("cloud_masks_kernel");
+  hipLaunchKernelGGL(cloud_masks_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, l, i, lm, im);
+  return 0;
+}
+// liquid + ice -> cloud optical properties (mo_cloud_optics_rrtmgp.F90:392-425); twostr = 0: tau only
+int rte_hip_cloud_combine(int ncol, int nlay, int nspec, int twostr, const Float* ltau, const Float* ltaussa,
+                          const Float* ltaussag, const Float* itau, const Float* itaussa, const Float* itaussag,
+                          Float* tau, Float* ssa, Float* g) {
+  const size_t n = (size_t)ncol * nlay * nspec;
+  if (n == 0) return 0;
+  rte::Call c("rte_hip_cloud_combine");
+  const Float *a0 = c.in(ltau, n), *a1 = c.in(ltaussa, n), *a2 = c.in(ltaussag, n);
+  const Float *b0 = c.in(itau, n), *b1 = c.in(itaussa, n), *b2 = c.in(itaussag, n);
+  Float* t = c.out(tau, n);
+  Float* s_ = twostr ? c.out(ssa, n) : nullptr;
+  Float* g_ = twostr ? c.out(g, n) : nullptr;
+  rte::ProfScope p("cloud_combine_kernel");
+  if (twostr)
+    hipLaunchKernelGGL((cloud_combine_kernel<true>), dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, a0, a1, a2, b0, b1, b2, t, s_, g_);
+  else
+    hipLaunchKernelGGL((cloud_combine_kernel<false>), dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, a0, a1, a2, b0, b1, b2, t, s_, g_);
   return 0;
 }
 }

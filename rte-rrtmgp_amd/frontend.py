@@ -284,6 +284,22 @@ class NumpyGlue:
     def broadcast_gpt(self, ncol, ngpt, per_gpt, out):
         out[...] = np.asarray(per_gpt)[None, :]
 
+    # cloud_optics: masks (mo_cloud_optics_rrtmgp.F90:334-341) and liquid + ice combination (:392-425)
+    def cloud_masks(self, ncol, nlay, clwp, ciwp, liqmsk, icemsk):
+        liqmsk[...] = clwp > 0
+        icemsk[...] = ciwp > 0
+
+    def cloud_combine(self, ncol, nlay, nspec, twostr, liq, ice, tau, ssa, g):
+        (lt, lts, ltsg), (it, its, itsg) = liq, ice
+        if not twostr:
+            tau[...] = (lt - lts) + (it - its)
+            return
+        t, ts = lt + it, lts + its
+        eps = np.finfo(t.dtype).eps
+        g[...] = (ltsg + itsg) / np.maximum(eps, ts)
+        ssa[...] = ts / np.maximum(eps, t)
+        tau[...] = t
+
 
 class HipGlue:
     """Device glue: extension entry points of the HIP library (names ``rte_hip_*``)."""
@@ -302,9 +318,82 @@ class HipGlue:
 
         ext_call(self.lib, "rte_hip_broadcast_gpt", ["i", "i", "a", "a"], ncol, ngpt, per_gpt, out)
 
+    def cloud_masks(self, ncol, nlay, clwp, ciwp, liqmsk, icemsk):
+        from .hiplib import ext_call
+
+        ext_call(self.lib, "rte_hip_cloud_masks", ["i", "i", "a", "a", "a", "a"], ncol, nlay, clwp, ciwp, liqmsk, icemsk)
+
+    def cloud_combine(self, ncol, nlay, nspec, twostr, liq, ice, tau, ssa, g):
+        from .hiplib import ext_call
+
+        ext_call(self.lib, "rte_hip_cloud_combine", ["i", "i", "i", "i"] + ["a"] * 9, ncol, nlay, nspec, 1 if twostr else 0,
+                 *liq, *ice, tau, ssa if twostr else tau, g if twostr else tau)
+
 
 def default_glue(lib, arrays):
     return NumpyGlue() if isinstance(arrays, NumpyArrays) else HipGlue(lib)
+
+
+# --------------------------------------------------------------------------------------
+# Cloud optics (rrtmgp/frontend/mo_cloud_optics_rrtmgp.F90) and the all-sky assembly
+# --------------------------------------------------------------------------------------
+class CloudOptics:
+    """The kernel-facing part of ``ty_cloud_optics_rrtmgp%cloud_optics`` (look-up-table branch, :276-430):
+    cloud optical properties per band from liquid / ice water paths and particle sizes."""
+
+    def __init__(self, lib, tables, arrays):
+        self.lib, self.xp, self.tb = lib, arrays, tables
+        self.nbnd = tables["extliq"].shape[1]
+        self.t = {k: arrays.asarray(v) for k, v in tables.items() if hasattr(v, "shape")}
+
+    def cloud_optics(self, ncol, nlay, clwp, ciwp, reliq, deice, twostr, buffers=None, glue=None):
+        xp, tb, nb = self.xp, self.tb, self.nbnd
+        b = buffers if buffers is not None else {}
+
+        def buf(name, shape, kind="f"):
+            if name not in b:
+                b[name] = xp.empty(shape, kind)
+            return b[name]
+
+        gl = glue or default_glue(self.lib, xp)
+        liqmsk, icemsk = buf("liqmsk", (ncol, nlay), "b"), buf("icemsk", (ncol, nlay), "b")
+        gl.cloud_masks(ncol, nlay, clwp, ciwp, liqmsk, icemsk)
+        liq = [buf(n, (ncol, nlay, nb)) for n in ("ltau", "ltaussa", "ltaussag")]
+        ice = [buf(n, (ncol, nlay, nb)) for n in ("itau", "itaussa", "itaussag")]
+        t = self.t
+        self.lib.rrtmgp_compute_cld_from_table(ncol, nlay, nb, liqmsk, clwp, reliq, tb["liq_nsteps"], tb["liq_step_size"],
+                                               tb["radliq_lwr"], t["extliq"], t["ssaliq"], t["asyliq"], *liq)   # :372-375
+        self.lib.rrtmgp_compute_cld_from_table(ncol, nlay, nb, icemsk, ciwp, deice, tb["ice_nsteps"], tb["ice_step_size"],
+                                               tb["diamice_lwr"], t["extice"], t["ssaice"], t["asyice"], *ice)   # :379-384
+        tau = buf("cld_tau", (ncol, nlay, nb))
+        ssa = buf("cld_ssa", (ncol, nlay, nb)) if twostr else None
+        g = buf("cld_g", (ncol, nlay, nb)) if twostr else None
+        gl.cloud_combine(ncol, nlay, nb, twostr, liq, ice, tau, ssa, g)                                           # :392-425
+        return b
+
+
+def allsky_lw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds, sfc_emis_gpt, gb=None, cb=None, rb=None):
+    """LW half of examples/all-sky/rrtmgp_allsky.F90:362-380: clouds as absorbers (1scl) added to the gas optical
+    depth band by band, then rte_lw without scattering."""
+    gb = go.gas_optics_lw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["tsfc"], atm["col_gas"], atm["tlev"],
+                          atm["top_at_1"], buffers=gb)
+    cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], False, buffers=cb)
+    lib.rte_inc_1scalar_by_1scalar_bybnd(ncol, nlay, go.ngpt, gb["tau"], cb["cld_tau"], go.nbnd, go.t["band_lims_gpt"])  # :374
+    rb = rte_lw(lib, xp, ncol, nlay, go.ngpt, atm["top_at_1"], gb["tau"], gb["lay_src"], gb["lev_src"], sfc_emis_gpt,
+                gb["sfc_src"], buffers=rb)
+    return gb, cb, rb
+
+
+def allsky_sw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds, mu0, sfc_alb_gpt, gb=None, cb=None, rb=None):
+    """SW half (:382-404): two-stream clouds, delta-scaled, added to the gas optical properties band by band."""
+    gb = go.gas_optics_sw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["col_gas"], atm["col_dry"], buffers=gb)
+    cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], True, buffers=cb)
+    lib.rte_delta_scale_2str_k(ncol, nlay, co.nbnd, cb["cld_tau"], cb["cld_ssa"], cb["cld_g"])                       # :394
+    lib.rte_inc_2stream_by_2stream_bybnd(ncol, nlay, go.ngpt, gb["tau"], gb["ssa"], gb["g"], cb["cld_tau"], cb["cld_ssa"],
+                                         cb["cld_g"], go.nbnd, go.t["band_lims_gpt"])                               # :395
+    rb = rte_sw(lib, xp, ncol, nlay, go.ngpt, atm["top_at_1"], gb["tau"], gb["ssa"], gb["g"], mu0, gb["toa_src"],
+                sfc_alb_gpt, sfc_alb_gpt, buffers=rb)
+    return gb, cb, rb
 
 
 # --------------------------------------------------------------------------------------

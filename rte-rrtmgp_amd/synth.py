@@ -257,3 +257,34 @@ def make_atmosphere(ncol: int, nlay: int = 60, seed: int = 42, top_at_1: bool = 
         vmr, col_dry, col_gas = vmr[:, ::-1], col_dry[:, ::-1], col_gas[:, ::-1]
     return Atmosphere(ncol, nlay, top_at_1, F(play), F(plev), F(tlay), F(tlev), F(tsfc), F(vmr),
                       F(col_dry), F(col_gas))
+
+
+def make_cloud_optics(nbnd: int, seed: int = 77) -> dict:
+    """Synthetic cloud-optics look-up tables with the shapes and ranges of the RRTMGP cloud files
+    (rrtmgp/frontend/mo_cloud_optics_rrtmgp.F90:36-75; one ice roughness already selected): extinction
+    [m2/g] falling with particle size, single-scattering albedo < 1, asymmetry 0.7 - 0.95."""
+    rng = np.random.default_rng(seed)
+    tb = {"liq_nsteps": 58, "liq_step_size": 0.3, "radliq_lwr": 2.5, "ice_nsteps": 94, "ice_step_size": 2.0,
+          "diamice_lwr": 10.0}
+    for ph, n, r0, dr in (("liq", 58, 2.5, 0.3), ("ice", 94, 10.0, 2.0)):
+        r = r0 + dr * np.arange(n)
+        ext = (1.5 / r)[:, None] * rng.uniform(0.8, 1.2, size=(1, nbnd)) * (1.0 + 0.05 * rng.standard_normal((n, nbnd)))
+        tb[f"ext{ph}"] = F(np.abs(ext))
+        tb[f"ssa{ph}"] = F(np.clip(rng.uniform(0.4, 0.999, size=(1, nbnd)) - 0.002 * r[:, None], 0.05, 0.9999))
+        tb[f"asy{ph}"] = F(np.clip(rng.uniform(0.75, 0.9, size=(1, nbnd)) + 0.001 * r[:, None], 0.0, 0.97))
+    tb["radliq_upr"] = tb["radliq_lwr"] + tb["liq_step_size"] * (tb["liq_nsteps"] - 1)
+    tb["diamice_upr"] = tb["diamice_lwr"] + tb["ice_step_size"] * (tb["ice_nsteps"] - 1)
+    return tb
+
+
+def make_cloud_field(atm: "Atmosphere", tb: dict) -> dict:
+    """The cloud field of examples/all-sky/rrtmgp_allsky.F90:645-662: clouds between 100 and 900 hPa in two
+    columns out of three, liquid above 263 K, ice below 273 K, 10 g/m2 each, mid-range particle sizes."""
+    ncol = atm.play.shape[0]
+    icol1 = np.arange(1, ncol + 1)[:, None]
+    mask = (atm.play > 100.0 * 100.0) & (atm.play < 900.0 * 100.0) & (icol1 % 3 != 0)
+    lwp = np.where(mask & (atm.tlay > 263.0), 10.0, 0.0)
+    iwp = np.where(mask & (atm.tlay < 273.0), 10.0, 0.0)
+    rel_val = 0.5 * (tb["radliq_lwr"] + tb["radliq_upr"])
+    dei_val = 0.5 * (tb["diamice_lwr"] + tb["diamice_upr"])
+    return {"lwp": F(lwp), "iwp": F(iwp), "rel": F(np.where(lwp > 0, rel_val, 0.0)), "dei": F(np.where(iwp > 0, dei_val, 0.0))}
