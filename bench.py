@@ -61,6 +61,28 @@ def algorithmic_bytes_per_collay(nflav=10, ngas=8, ngpt=NGPT, nlay=NLAY, defer_z
     return k
 
 
+def allsky_bytes_per_collay(kd_lw, kd_sw, nlay):
+    """Algorithmic bytes per (column, layer) and STEP of the all-sky chain, by kernel name (several launches of
+    one kernel per step are summed): LW and SW gas optics and solvers as above, plus the cloud look-up, the
+    liquid + ice combination, delta scaling and the band-wise increments (all arrays once in, once out)."""
+    lw = algorithmic_bytes_per_collay(kd_lw.nflav, kd_lw.ngas, kd_lw.ngpt, nlay, defer_zero=True)
+    sw = algorithmic_bytes_per_collay(kd_sw.nflav, kd_sw.ngas, kd_sw.ngpt, nlay, defer_zero=True)
+    N1, N2, b1, b2 = kd_lw.ngpt, kd_sw.ngpt, kd_lw.nbnd, kd_sw.nbnd
+    return {
+        "interpolation_kernel": lw["interpolation_kernel"] + sw["interpolation_kernel"],
+        "tau_absorption_kernel": lw["tau_absorption_kernel"] + sw["tau_absorption_kernel"],
+        "planck_source_kernel": lw["planck_source_kernel"],
+        "lw_noscat_seg_kernel": lw["lw_noscat_seg_kernel"],
+        "tau_rayleigh_kernel": sw["tau_rayleigh_kernel"],
+        "combine_2str_kernel": sw["combine_2str_kernel"],
+        "sw_2stream_seg_kernel": sw["sw_2stream_seg_kernel"],
+        "cld_from_table_kernel": 2 * (17 + 24 * b1) + 2 * (17 + 24 * b2),
+        "cloud_combine_kernel": (32 * b1 + 8 * b1) + (48 * b2 + 24 * b2),
+        "delta_scale_kernel": 48 * b2,
+        "increment_kernel": (16 * N1 + 8 * b1) + (48 * N2 + 24 * b2),
+    }
+
+
 def cpu_baseline(ncol_block=32, target_seconds=12.0, workload="lw"):
     """Reference (or port) CPU kernels on the host cores, bounded sample of the same workload."""
     import threading
@@ -78,10 +100,33 @@ def cpu_baseline(ncol_block=32, target_seconds=12.0, workload="lw"):
     if lib is None:
         lib, kind = O.load_c(), "port"
     cores = os.cpu_count() or 1
-    kd = synth.make_kdist(workload)
     xp = frontend.NumpyArrays()
+    nlay_b = 72 if workload == "allsky" else NLAY
+
+    def one_block_allsky(seed):
+        kdl, kds = synth.make_kdist("lw"), synth.make_kdist("sw")
+        atm = synth.make_atmosphere(ncol_block, nlay_b, seed=seed, kdist=kdl)
+        a = {k: getattr(atm, k) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry")}
+        a["top_at_1"] = atm.top_at_1
+        gol, gos = frontend.GasOptics(lib, kdl, xp), frontend.GasOptics(lib, kds, xp)
+        tbl, tbs = synth.make_cloud_optics(kdl.nbnd), synth.make_cloud_optics(kds.nbnd)
+        col, cos_ = frontend.CloudOptics(lib, tbl, xp), frontend.CloudOptics(lib, tbs, xp)
+        cl = synth.make_cloud_field(atm, tbl)
+        emis = xp.full((ncol_block, kdl.ngpt), 0.98)
+        mu0, alb = xp.full((ncol_block, nlay_b), 0.86), xp.full((ncol_block, kds.ngpt), 0.06)
+        st = {}
+
+        def run():
+            st["l"] = frontend.allsky_lw(lib, xp, gol, col, ncol_block, nlay_b, a, cl, emis, *st.get("l", (None, None, None)))
+            st["s"] = frontend.allsky_sw(lib, xp, gos, cos_, ncol_block, nlay_b, a, cl, mu0, alb, *st.get("s", (None, None, None)))
+
+        return run
+
+    kd = synth.make_kdist("lw" if workload == "allsky" else workload)
 
     def one_block(seed):
+        if workload == "allsky":
+            return one_block_allsky(seed)
         atm = synth.make_atmosphere(ncol_block, NLAY, seed=seed, kdist=kd)
         go = frontend.GasOptics(lib, kd, xp)
         emis = xp.full((ncol_block, kd.ngpt), 0.98)
@@ -126,8 +171,8 @@ def cpu_baseline(ncol_block=32, target_seconds=12.0, workload="lw"):
         threading.stack_size(old)
     ncols = cores * reps * ncol_block
     return {"value": ncols / dt, "unit": "columns/s", "cores": cores, "kind": kind,
-            "sample": f"{ncols} columns ({cores} threads x {reps} blocks of {ncol_block} columns x {NLAY} lay x "
-                      f"{kd.ngpt} gpt), same kernel chain, {dt:.1f} s"}
+            "sample": f"{ncols} columns ({cores} threads x {reps} blocks of {ncol_block} columns x {nlay_b} lay x "
+                      f"{'256 + 224' if workload == 'allsky' else kd.ngpt} gpt), same kernel chain, {dt:.1f} s"}
 
 
 def main():
@@ -136,8 +181,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ncol", type=int, default=100000, help="columns per GPU")
-    ap.add_argument("--workload", choices=("lw", "sw"), default="lw",
-                    help="lw: the headline chain (default); sw: SW gas optics + sw_solver_2stream (BASELINE configs[2])")
+    ap.add_argument("--workload", choices=("lw", "sw", "allsky"), default="lw",
+                    help="lw: the headline chain (default); sw: SW gas optics + sw_solver_2stream (BASELINE configs[2]); "
+                         "allsky: LW + SW with cloud optics at 72 layers (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
     args = ap.parse_args()
@@ -167,14 +213,33 @@ def main():
     dev = f"cuda:{local_rank}"
     xp = frontend.TorchArrays(dev)
     ncol = args.ncol
-    kd = synth.make_kdist(args.workload)
-    atm = synth.make_atmosphere(ncol, NLAY, seed=42 + rank, kdist=kd)  # each rank owns different columns
+    nlay_w = 72 if args.workload == "allsky" else NLAY
+    kd = synth.make_kdist("lw" if args.workload == "allsky" else args.workload)
+    atm = synth.make_atmosphere(ncol, nlay_w, seed=42 + rank, kdist=kd)  # each rank owns different columns
     go = frontend.GasOptics(lib, kd, xp)
     A = xp.asarray
     play, plev, tlay, tlev, tsfc, col_gas = (A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas"))
     emis = xp.full((ncol, kd.ngpt), 0.98)
     bufs, rb = {}, {}
-    mean_profile = torch.zeros(2, NLAY + 1, dtype=torch.float64, device=dev)
+    mean_profile = torch.zeros(2, nlay_w + 1, dtype=torch.float64, device=dev)
+    if args.workload == "allsky":
+        kds = synth.make_kdist("sw")
+        gos = frontend.GasOptics(lib, kds, xp)
+        tbl, tbs = synth.make_cloud_optics(kd.nbnd), synth.make_cloud_optics(kds.nbnd)
+        col, cos_ = frontend.CloudOptics(lib, tbl, xp), frontend.CloudOptics(lib, tbs, xp)
+        clouds = {k: A(v) for k, v in synth.make_cloud_field(atm, tbl).items()}
+        a_dev = {"play": play, "plev": plev, "tlay": tlay, "tlev": tlev, "tsfc": tsfc, "col_gas": col_gas,
+                 "col_dry": A(atm.col_dry), "top_at_1": atm.top_at_1}
+        mu0, alb = xp.full((ncol, nlay_w), 0.86), xp.full((ncol, kds.ngpt), 0.06)
+        st_as = {}
+
+    def step_allsky():
+        st_as["l"] = frontend.allsky_lw(lib, xp, go, col, ncol, nlay_w, a_dev, clouds, emis, *st_as.get("l", (None, None, None)))
+        st_as["s"] = frontend.allsky_sw(lib, xp, gos, cos_, ncol, nlay_w, a_dev, clouds, mu0, alb, *st_as.get("s", (None, None, None)))
+        rb.update(st_as["l"][2])
+        if dist is not None:
+            mean_profile.copy_(sharding.allreduce_mean_profile(rb["flux_up"], rb["flux_dn"], ncol * world))
+
     if args.workload == "sw":
         col_dry = A(atm.col_dry)
         mu0, alb = xp.full((ncol, NLAY), 0.86), xp.full((ncol, kd.ngpt), 0.06)
@@ -194,7 +259,7 @@ def main():
             # the path's only exchange: domain-mean broadband flux profile (RCCL all-reduce)
             mean_profile.copy_(sharding.allreduce_mean_profile(rb["flux_up"], rb["flux_dn"], ncol * world))
 
-    step = step_sw if args.workload == "sw" else step_lw
+    step = {"sw": step_sw, "allsky": step_allsky}.get(args.workload, step_lw)
 
     def fence():
         if dist is not None:
@@ -225,14 +290,18 @@ def main():
         buf = ctypes.create_string_buffer(128)
         cnt, ms = ctypes.c_longlong(0), ctypes.c_double(0)
         lib.raw("rte_hip_profile_get")(ctypes.c_int(i), buf, ctypes.c_int(128), ctypes.byref(cnt), ctypes.byref(ms))
-        kern[buf.value.decode()] = {"launches": int(cnt.value), "avg_ms": ms.value / max(1, cnt.value)}
+        # several launches of one kernel per step (all-sky) count together: time per STEP
+        kern[buf.value.decode()] = {"launches": int(cnt.value), "avg_ms": ms.value / max(1, args.steps)}
 
     if rank == 0:
-        ab = algorithmic_bytes_per_collay(kd.nflav, kd.ngas, kd.ngpt, NLAY, defer_zero=not args.no_defer_zero)
+        if args.workload == "allsky":
+            ab = allsky_bytes_per_collay(kd, kds, nlay_w)
+        else:
+            ab = algorithmic_bytes_per_collay(kd.nflav, kd.ngas, kd.ngpt, NLAY, defer_zero=not args.no_defer_zero)
         per_kernel = {}
         for name, bytes_cl in ab.items():
             if name in kern:
-                gb = bytes_cl * ncol * NLAY / 1e9
+                gb = bytes_cl * ncol * nlay_w / 1e9
                 ms = kern[name]["avg_ms"]
                 per_kernel[name] = {"avg_ms": round(ms, 4), "alg_GB": round(gb, 3),
                                     "GBps": round(gb / (ms * 1e-3), 1), "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
@@ -262,8 +331,9 @@ def main():
                               "frac": round(chain_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4)},
                     "per_kernel": per_kernel, "other_kernels_avg_ms": others}
         res = {
-            "metric": ("columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)" if args.workload == "lw" else
-                       "columns/sec (SW gas-optics + sw_solver_2stream, 224 gpt x 60 lay)"),
+            "metric": {"lw": "columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)",
+                       "sw": "columns/sec (SW gas-optics + sw_solver_2stream, 224 gpt x 60 lay)",
+                       "allsky": "columns/sec (all-sky LW + SW with cloud optics, 256 + 224 gpt x 72 lay)"}[args.workload],
             "value": ncol * world * args.steps / dt, "unit": "columns/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -271,8 +341,12 @@ def main():
                                     f"{kd.ngpt} g-points (BASELINE configs[1]), synthetic g256-shaped k-distribution"
                                     if args.workload == "lw" else
                                     f"clear-sky SW gas optics + two-stream solver, {ncol} synthetic columns per GPU x {NLAY} "
-                                    f"layers x {kd.ngpt} g-points (BASELINE configs[2] shape), synthetic g224-shaped k-distribution"),
-                       "columns_per_gpu": ncol, "nlay": NLAY, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero},
+                                    f"layers x {kd.ngpt} g-points (BASELINE configs[2] shape), synthetic g224-shaped k-distribution"
+                                    if args.workload == "sw" else
+                                    f"all-sky LW (clouds as absorbers) + SW (two-stream clouds, delta-scaled), {ncol} synthetic "
+                                    f"columns per GPU x {nlay_w} layers, 256 + 224 g-points (BASELINE configs[3] shape), "
+                                    f"synthetic k-distributions and cloud tables, cloud field of examples/all-sky"),
+                       "columns_per_gpu": ncol, "nlay": nlay_w, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -30,25 +30,8 @@ struct IncArgs {
   const Float *tau2, *ssa2, *g2 /* g2, or p2 with leading dimension nmom2 */;
 };
 
-// band of g-point g (0-based), or -1 when no band covers it (the reference then leaves it untouched)
-__device__ __forceinline__ int band_of(const int* __restrict__ lims, int nbnd, int g) {
-  int b = -1;
-  for (int i = 0; i < nbnd; ++i)
-    if (g + 1 >= lims[2 * i] && g + 1 <= lims[2 * i + 1]) b = i;
-  return b;
-}
-
 template <int OP>
-__global__ void __launch_bounds__(256) increment_kernel(IncArgs a) {
-  const int cl = blockIdx.x * blockDim.x + threadIdx.x;
-  const int g = blockIdx.y;
-  if (cl >= a.ncl) return;
-  int g2idx = g;
-  if (a.lims) {
-    g2idx = band_of(a.lims, a.nbnd, g);
-    if (g2idx < 0) return;
-  }
-  const size_t i = (size_t)cl + (size_t)a.ncl * g, i2 = (size_t)cl + (size_t)a.ncl * g2idx;
+__device__ __forceinline__ void increment_one(const IncArgs& a, const size_t i, const size_t i2) {
   if (OP == OP_1S_1S) {
     a.tau1[i] = a.tau1[i] + a.tau2[i2];
   } else if (OP == OP_1S_2S) {
@@ -87,6 +70,27 @@ __global__ void __launch_bounds__(256) increment_kernel(IncArgs a) {
   }
 }
 
+// One thread = one (column, layer) and, when operand 2 is given by band, all g-points of that band (its values
+// are then the same for the whole run and stay in L1; g-points that no band covers are never visited, as in the
+// reference); one g-point otherwise (measured: a run of 16 planes per thread is slower there, 7.1 vs 6.2 ms).
+template <int OP>
+__global__ void __launch_bounds__(256) increment_kernel(IncArgs a) {
+  const int cl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cl >= a.ncl) return;
+  int gS, gE;
+  if (a.lims) {
+    gS = a.lims[2 * blockIdx.y] - 1; gE = a.lims[2 * blockIdx.y + 1] - 1;
+  } else {
+    gS = gE = blockIdx.y;
+  }
+  const size_t i2b = (size_t)cl + (size_t)a.ncl * blockIdx.y;
+#pragma unroll 4
+  for (int g = gS; g <= gE; ++g) {
+    const size_t i = (size_t)cl + (size_t)a.ncl * g;
+    increment_one<OP>(a, i, a.lims ? i2b : i);
+  }
+}
+
 template <int OP>
 void increment(const char* name, int ncol, int nlay, int ngpt, Float* tau1, Float* ssa1, Float* g1, int nmom1,
                const Float* tau2, const Float* ssa2, const Float* g2, int nmom2, int nbnd, const int* lims) {
@@ -103,7 +107,8 @@ void increment(const char* name, int ncol, int nlay, int ngpt, Float* tau1, Floa
   a.ssa2 = ssa2 ? c.in(ssa2, n2) : nullptr;
   a.g2 = g2 ? c.in(g2, n2 * a.nmom2) : nullptr;
   rte::ProfScope p("increment_kernel");
-  hipLaunchKernelGGL(increment_kernel<OP>, dim3(cdiv(a.ncl, 256), ngpt), dim3(256), 0, rte::stream(), a);
+  hipLaunchKernelGGL(increment_kernel<OP>, dim3(cdiv(a.ncl, 256), lims ? nbnd : ngpt), dim3(256), 0,
+                     rte::stream(), a);
 }
 
 // :44-98
