@@ -83,11 +83,9 @@ def allsky_bytes_per_collay(kd_lw, kd_sw, nlay):
     }
 
 
-def cpu_baseline(ncol_block=32, target_seconds=12.0, workload="lw"):
-    """Reference (or port) CPU kernels on the host cores, bounded sample of the same workload."""
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
-
+def _cpu_chain(workload, seed, ncol_block):
+    """One closure that runs the workload's kernel chain once on a block of columns with the CPU kernels
+    (reference build if present, else the C restatement).  Returns (run, kind, gpt-description, nlay)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import oracle as O
     from rte_rrtmgp_amd import frontend, synth
@@ -99,11 +97,9 @@ def cpu_baseline(ncol_block=32, target_seconds=12.0, workload="lw"):
         lib = None
     if lib is None:
         lib, kind = O.load_c(), "port"
-    cores = os.cpu_count() or 1
     xp = frontend.NumpyArrays()
     nlay_b = 72 if workload == "allsky" else NLAY
-
-    def one_block_allsky(seed):
+    if workload == "allsky":
         kdl, kds = synth.make_kdist("lw"), synth.make_kdist("sw")
         atm = synth.make_atmosphere(ncol_block, nlay_b, seed=seed, kdist=kdl)
         a = {k: getattr(atm, k) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry")}
@@ -120,62 +116,122 @@ def cpu_baseline(ncol_block=32, target_seconds=12.0, workload="lw"):
             st["l"] = frontend.allsky_lw(lib, xp, gol, col, ncol_block, nlay_b, a, cl, emis, *st.get("l", (None, None, None)))
             st["s"] = frontend.allsky_sw(lib, xp, gos, cos_, ncol_block, nlay_b, a, cl, mu0, alb, *st.get("s", (None, None, None)))
 
-        return run
+        return run, kind, "256 + 224", nlay_b
+    kd = synth.make_kdist(workload)
+    atm = synth.make_atmosphere(ncol_block, NLAY, seed=seed, kdist=kd)
+    go = frontend.GasOptics(lib, kd, xp)
+    emis = xp.full((ncol_block, kd.ngpt), 0.98)
+    mu0, alb = xp.full((ncol_block, NLAY), 0.86), xp.full((ncol_block, kd.ngpt), 0.06)
+    bufs, rb = {}, {}
 
-    kd = synth.make_kdist("lw" if workload == "allsky" else workload)
+    def run_sw():
+        go.gas_optics_sw(ncol_block, NLAY, atm.play, atm.plev, atm.tlay, atm.col_gas, atm.col_dry, buffers=bufs)
+        frontend.rte_sw(lib, xp, ncol_block, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["ssa"], bufs["g"], mu0,
+                        bufs["toa_src"], alb, alb, buffers=rb)
 
-    def one_block(seed):
-        if workload == "allsky":
-            return one_block_allsky(seed)
-        atm = synth.make_atmosphere(ncol_block, NLAY, seed=seed, kdist=kd)
-        go = frontend.GasOptics(lib, kd, xp)
-        emis = xp.full((ncol_block, kd.ngpt), 0.98)
-        mu0, alb = xp.full((ncol_block, NLAY), 0.86), xp.full((ncol_block, kd.ngpt), 0.06)
-        bufs, rb = {}, {}
+    def run_lw():
+        go.gas_optics_lw(ncol_block, NLAY, atm.play, atm.plev, atm.tlay, atm.tsfc, atm.col_gas, atm.tlev,
+                         atm.top_at_1, buffers=bufs)
+        frontend.rte_lw(lib, xp, ncol_block, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["lay_src"],
+                        bufs["lev_src"], emis, bufs["sfc_src"], buffers=rb)
 
-        def run_sw():
-            go.gas_optics_sw(ncol_block, NLAY, atm.play, atm.plev, atm.tlay, atm.col_gas, atm.col_dry, buffers=bufs)
-            frontend.rte_sw(lib, xp, ncol_block, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["ssa"], bufs["g"], mu0,
-                            bufs["toa_src"], alb, alb, buffers=rb)
+    return (run_sw if workload == "sw" else run_lw), kind, str(kd.ngpt), NLAY
 
-        if workload == "sw":
-            return run_sw
 
-        def run():
-            go.gas_optics_lw(ncol_block, NLAY, atm.play, atm.plev, atm.tlay, atm.tsfc, atm.col_gas, atm.tlev,
-                             atm.top_at_1, buffers=bufs)
-            frontend.rte_lw(lib, xp, ncol_block, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["lay_src"],
-                            bufs["lev_src"], emis, bufs["sfc_src"], buffers=rb)
+def cpu_worker(workload, seed, ncol_block):
+    """Body of one `bench.py --cpu-worker` process: ONE single-threaded process per core (no GIL shared
+    between cores).  Protocol on stdin/stdout: prints "ready <kind> <gpt> <nlay>" after set-up and one
+    untimed block, then for every line "go <seconds>" runs whole blocks until the time is up and prints
+    "done <blocks> <elapsed seconds>"; exits on EOF."""
+    import threading
 
-        return run
+    threading.stack_size(1 << 30)  # flang keeps automatic arrays such as pfrac(ncol,nlay,ngpt) on the stack
 
-    old = threading.stack_size(512 << 20)  # flang keeps automatic arrays on the stack
+    def body():
+        run, kind, gpt, nlay_b = _cpu_chain(workload, seed, ncol_block)
+        run()
+        print(f"ready {kind} {gpt.replace(' ', '')} {nlay_b}", flush=True)
+        for line in sys.stdin:
+            parts = line.split()
+            if not parts or parts[0] != "go":
+                break
+            seconds, blocks = float(parts[1]), 0
+            t0 = time.perf_counter()
+            while True:
+                run()
+                blocks += 1
+                dt = time.perf_counter() - t0
+                if dt >= seconds:
+                    break
+            print(f"done {blocks} {dt:.6f}", flush=True)
+
+    t = threading.Thread(target=body)
+    t.start()
+    t.join()
+
+
+def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw"):
+    """Reference (or port) CPU kernels on the host cores, bounded sample of the same workload: one
+    single-threaded PROCESS per core, each looping over blocks of `ncol_block` columns (the reference's own
+    usage pattern) for a fixed time.  Reports the all-core rate (`value`) and the 1-core rate
+    (`value_1core`, one process running alone)."""
+    import subprocess
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", workload, str(1000 + i),
+                               str(ncol_block)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
+             for i in range(cores)]
     try:
-        runs = [one_block(1000 + i) for i in range(cores)]
-        reps = 1
+        ready = [p.stdout.readline().split() for p in procs]
+        bad = [r for r in ready if len(r) != 4 or r[0] != "ready"]
+        if bad:
+            raise RuntimeError(f"{len(bad)} of {cores} CPU workers failed to start: {bad[0]}")
+        _, kind, gpt, nlay_b = ready[0]
 
-        def worker(i):
-            for _ in range(reps):
-                runs[i]()
+        def timed(ps, seconds):
+            for p in ps:
+                p.stdin.write(f"go {seconds}\n")
+                p.stdin.flush()
+            res = [p.stdout.readline().split() for p in ps]
+            blocks = [int(r[1]) for r in res]
+            dts = [float(r[2]) for r in res]
+            # every worker ran whole blocks for at least `seconds`: aggregate rate = sum of the workers' own rates
+            return sum(b * ncol_block / dt for b, dt in zip(blocks, dts)), sum(blocks), max(dts)
 
-        with ThreadPoolExecutor(cores) as ex:
-            # calibrate with every core busy (memory contention makes one block much slower than alone)
-            t0 = time.perf_counter()
-            list(ex.map(worker, range(cores)))
-            t_cal = time.perf_counter() - t0
-            reps = max(1, min(200, int(target_seconds / max(t_cal, 1e-3))))
-            t0 = time.perf_counter()
-            list(ex.map(worker, range(cores)))
-            dt = time.perf_counter() - t0
+        rate1, blocks1, dt1 = timed(procs[:1], seconds_one)
+        rate, blocks, dt = timed(procs, seconds_all)
     finally:
-        threading.stack_size(old)
-    ncols = cores * reps * ncol_block
-    return {"value": ncols / dt, "unit": "columns/s", "cores": cores, "kind": kind,
-            "sample": f"{ncols} columns ({cores} threads x {reps} blocks of {ncol_block} columns x {nlay_b} lay x "
-                      f"{'256 + 224' if workload == 'allsky' else kd.ngpt} gpt), same kernel chain, {dt:.1f} s"}
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                p.kill()
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    gpt = gpt.replace("+", " + ")
+    return {"value": rate, "unit": "columns/s", "cores": cores, "kind": kind,
+            "value_1core": rate1, "per_core_at_full_load": rate / cores, "cpu_model": model,
+            "sample": f"{blocks * ncol_block} columns in {dt:.1f} s ({cores} single-threaded processes, one per core, "
+                      f"{blocks} blocks of {ncol_block} columns x {nlay_b} lay x {gpt} gpt), same kernel chain; "
+                      f"1-core figure: {blocks1 * ncol_block} columns in {dt1:.1f} s by one process alone"}
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":  # internal: one process of cpu_baseline()
+        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -309,7 +365,7 @@ def main():
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
         chain_gb = sum(v["alg_GB"] for v in per_kernel.values())
         chain_ms = sum(v["avg_ms"] for v in per_kernel.values()) + sum(others.values())
-        traffic = None
+        traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if dom and args.workload == "lw" and os.path.exists(pmc_path):  # the counters were collected on the LW chain
             try:
@@ -317,6 +373,9 @@ def main():
                 if pmc.get("ncol") == ncol:
                     if dom in pmc.get("kernels", {}):
                         traffic = pmc["kernels"][dom]["hbm_GB_per_launch"]
+                        # NOT measured in this run: rocprofv3 --pmc passes cannot run inside the timed bench
+                        traffic_source = (f"replayed from profiles/pmc_traffic.json ({pmc.get('round', 'r01')}, "
+                                          f"{pmc.get('source', 'separate rocprofv3 --pmc passes of this command')})")
                     for k, v in pmc.get("kernels", {}).items():  # measured HBM GB per launch next to the model
                         if k in per_kernel:
                             per_kernel[k]["pmc_GB"] = v["hbm_GB_per_launch"]
@@ -326,6 +385,7 @@ def main():
         if dom:
             roof = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic, "traffic_unit": "GB per launch (PMC)",
+                    "traffic_source": traffic_source,
                     "chain": {"alg_GB_per_step": round(chain_gb, 3), "kernel_ms_per_step": round(chain_ms, 4),
                               "GBps": round(chain_gb / (chain_ms * 1e-3), 1),
                               "frac": round(chain_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4)},
