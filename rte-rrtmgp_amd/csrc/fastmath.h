@@ -1,0 +1,85 @@
+// fastmath.h -- fp64 exp / reciprocal / division / square root for the solver kernels (gfx950).
+//
+// The solvers are fp64-issue bound where they are not HBM bound, and the device libm / IEEE-division
+// sequences the compiler emits are long: exp() ~35 instructions (Horner steps as v_mov + v_fmac pairs, range
+// selects), a/b 12, sqrt ~12.  The replacements below are written for the argument ranges these kernels
+// actually have and stay within ~1-2 ulp of the correctly rounded result (the tests assert 1e-10 on fluxes
+// against the reference kernels, whose libm is itself only faithful to ~1 ulp):
+//   exp_nonpos(x)  x <= 0 (optical depths): no overflow path, underflow through v_ldexp          19 instr
+//   rcp_nr(d), div_nr(n, d)  d normal and away from the exponent range limits                       6 / 8
+//   sqrt_nr(x), rsqrt_nr(x)  x >= 0 normal or zero                                                   8
+// Single-precision builds (RTE_USE_SP) map to the plain functions.
+#pragma once
+#include <math.h>
+
+#include "common.h"
+
+namespace rte {
+
+#ifdef RTE_USE_SP
+__device__ __forceinline__ float exp_nonpos(float x) { return expf(x); }
+__device__ __forceinline__ float rcp_nr(float d) { return 1.0f / d; }
+__device__ __forceinline__ float div_nr(float n, float d) { return n / d; }
+__device__ __forceinline__ float sqrt_nr(float x) { return sqrtf(x); }
+#else
+// Horner step with the coefficient as the addend; the constant sits in a register pair of its own (VGPRs: these kernels have no scalar registers to spare),
+// so a step is ONE v_fma_f64 instead of the v_mov_b64 + v_fmac_f64 pair the generic code gets
+__device__ __forceinline__ double fma_c(double p, double r, double c) {
+  double o;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
+  return o;
+}
+
+__device__ __forceinline__ double exp_nonpos(double x) {
+  // x = k ln2 + r, |r| <= ln2/2; exp(r) by its Taylor polynomial of degree 13 (truncation 4e-18 relative)
+  x = fmax(x, -1100.0);  // exp underflows to 0 long before; keeps k and r finite for any input
+  const double k = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(k, -6.93147180369123816490e-01, x);  // ln2 high part: k * hi is exact
+  r = __builtin_fma(k, -1.90821492927058770002e-10, r);         // ln2 low part
+  double p = 1.0 / 6227020800.0;
+  p = fma_c(p, r, 1.0 / 479001600.0);
+  p = fma_c(p, r, 1.0 / 39916800.0);
+  p = fma_c(p, r, 1.0 / 3628800.0);
+  p = fma_c(p, r, 1.0 / 362880.0);
+  p = fma_c(p, r, 1.0 / 40320.0);
+  p = fma_c(p, r, 1.0 / 5040.0);
+  p = fma_c(p, r, 1.0 / 720.0);
+  p = fma_c(p, r, 1.0 / 120.0);
+  p = fma_c(p, r, 1.0 / 24.0);
+  p = fma_c(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)k);  // gradual underflow / 0 for large |x|
+}
+
+// 1/d: hardware estimate + two Newton steps (quadratic: 2^-26 -> 2^-52 -> rounding level)
+__device__ __forceinline__ double rcp_nr(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  e = __builtin_fma(-d, x, 1.0);
+  x = __builtin_fma(x, e, x);
+  return x;
+}
+// n/d: reciprocal, then one residual correction of the quotient (result within 1 ulp)
+__device__ __forceinline__ double div_nr(double n, double d) {
+  const double x = rcp_nr(d);
+  const double q = n * x;
+  const double res = __builtin_fma(-d, q, n);
+  return __builtin_fma(res, x, q);
+}
+// sqrt(x), x >= 0: hardware rsq estimate, one Newton step on y = 1/sqrt(x), then Heron correction of s = x*y
+__device__ __forceinline__ double sqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x > 0.0 ? x : 1.0);
+  double s = x * y;               // ~ sqrt(x)
+  double h = 0.5 * y;
+  double e = __builtin_fma(-h, s, 0.5);
+  s = __builtin_fma(s, e, s);
+  h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-s, s, x);    // residual
+  return __builtin_fma(e, h, s);
+}
+#endif
+
+}  // namespace rte

@@ -18,6 +18,8 @@
 
 #include <vector>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -869,6 +871,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
           return *reinterpret_cast<const Float2*>(
               kg + ((size_t)((emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * nk + (unsigned)m.kstart + (on ? g0 - m.mS : 0) + 2 * j));
         };
+#ifdef X9_NOSTAGE
+        if (a.ncol < 0)
+#endif
 #pragma unroll 1
         for (int base = lt; base < nAll; base += SB * NLT) {
           Float2 v[SB];
@@ -918,8 +923,39 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     x.cm = *reinterpret_cast<const Float2*>(a.col_mix + 2 * clf);
     x.je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
   };
+  // minor column amounts, weights and eta indices of one stage
+  struct Minor { Float sc[MAXM], cgs[MAXM]; Float2 fn0, fn1; int2 em; };
+  auto load_minor = [&](int b, int n, Minor& x) {
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) {
+      x.sc[k] = 0; x.cgs[k] = 0;
+      if (k < n) {
+        const MinorMeta& m = bm[b].m[rsel][k];
+        x.sc[k] = a.col_gas[cl + (size_t)ncl * m.idx_minor];
+        if ((m.flags & 1) && m.idx_scaling > 0) x.cgs[k] = a.col_gas[cl + (size_t)ncl * m.idx_scaling];
+      }
+    }
+    const size_t clm = cl + (size_t)ncl * bm[b].flav[rsel];  // minor absorbers use THEIR regime's flavor (:487)
+    const Float2* fnp = reinterpret_cast<const Float2*>(a.fminor + 4 * clm);
+    x.fn0 = fnp[0]; x.fn1 = fnp[1];
+    x.em = *reinterpret_cast<const int2*>(a.jeta + 2 * clm);
+  };
+  auto n_minor = [&](int b) { return (tg.eg[b].y > 0 && regime > 0) ? bm[b].cnt[rsel] : 0; };
+  // Vector-memory operations of a wave retire IN ORDER, stores included: a request issued after a stage's 16 tau
+  // stores is served only when those have drained.  The minor weights and column amounts of stage s+1 are
+  // therefore requested at the END of stage s, just BEFORE its stores (the stores then drain behind them while
+  // stage s+1 gathers its major species), and the major weights of stage s+1 after the major pass of stage s.
+  // The order below is only kept by the compiler's wait-count pass when every path through the loop issues the
+  // same memory operations: blocks in which some band goes to the direct kernel (no stores for its stages) run a
+  // second instance of the loop (ALLRUN = false) that pays the drains.
+  bool all_run = true;
+  for (int b = 0; b < nbnd; ++b) all_run = all_run && tg.eg[b].y > 0;
+  auto run_stages = [&](auto allrun_tag) {
+  constexpr bool ALLRUN = decltype(allrun_tag)::value;
   Major mj;
+  Minor mn;
   load_major(0, mj);
+  load_minor(0, n_minor(0), mn);
   int ibnd = 0;
 #pragma unroll 1
   for (int s = 0; s < nstage; ++s) {
@@ -929,30 +965,22 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     int ibnd_n = ibnd;
     if (s + 1 < nstage) while (ibnd_n + 1 < nbnd && bm[ibnd_n].gE < g0 + G) ++ibnd_n;
     const bool run = nE > 0;  // block-uniform
-    // ---- requests, oldest first: minor column amounts and minor weights of THIS stage (used after the
-    // major pass), then the major weights of the NEXT stage
-    const int n_my = (run && regime > 0) ? bm[ibnd].cnt[rsel] : 0;
+    const int n_my = n_minor(ibnd);
     Float sc[MAXM], cgs[MAXM];
 #pragma unroll
-    for (int k = 0; k < MAXM; ++k) {
-      sc[k] = 0; cgs[k] = 0;
-      if (k < n_my) {
-        const MinorMeta& m = bm[ibnd].m[rsel][k];
-        sc[k] = a.col_gas[cl + (size_t)ncl * m.idx_minor];
-        if ((m.flags & 1) && m.idx_scaling > 0) cgs[k] = a.col_gas[cl + (size_t)ncl * m.idx_scaling];
-      }
-    }
-    const size_t clm = cl + (size_t)ncl * bm[ibnd].flav[rsel];  // minor absorbers use THEIR regime's flavor (:487)
-    const Float2* fnp = reinterpret_cast<const Float2*>(a.fminor + 4 * clm);
-    const Float2 fn0 = fnp[0], fn1 = fnp[1];
-    const int2 em = *reinterpret_cast<const int2*>(a.jeta + 2 * clm);
-    // this stage's major weights into locals (col_mix folded in), then request the next stage's
+    for (int k = 0; k < MAXM; ++k) { sc[k] = mn.sc[k]; cgs[k] = mn.cgs[k]; }
+    const Float2 fn0 = mn.fn0, fn1 = mn.fn1;
+    const int2 em = mn.em;
+    // this stage's major weights into locals (col_mix folded in)
     const Float w0 = mj.cm.x * mj.fm[0].x, w1 = mj.cm.x * mj.fm[0].y, w2 = mj.cm.x * mj.fm[1].x, w3 = mj.cm.x * mj.fm[1].y,
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
     const int je1 = mj.je.x, je2 = mj.je.y;
-    load_major(ibnd_n, mj);  // always issued (a static request count keeps the waits counted ones)
     __syncthreads();  // B(s): slab(s) is complete
-    if (!run) continue;
+    if (!ALLRUN && !run) {
+      load_major(ibnd_n, mj);
+      load_minor(ibnd_n, n_minor(ibnd_n), mn);
+      continue;
+    }
     const Float* sl = slab[s & 1];
     const int rowsMaj = nP * nT * nE;
     const int rowsLo = (has_lo ? bm[ibnd].cnt[0] : 0) * nT * nE;
@@ -972,8 +1000,12 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
     for (int j = 0; j < G; j += 2) {
       // :791-801 with col_mix folded into the weights; one 16-byte LDS read feeds two g-points
+#ifdef X9_NOGATHER
+      const Float2 k0{w1, w2}, k1{w2, w3}, k2{w3, w4}, k3{w4, w5}, k4{w5, w6}, k5{w6, w7}, k6{w7, w0}, k7{w0, w1};
+#else
       const Float2 k0 = ld2(A0 + j), k1 = ld2(A0 + RS + j), k2 = ld2(A0 + sP + j), k3 = ld2(A0 + sP + RS + j),
                    k4 = ld2(B0 + j), k5 = ld2(B0 + RS + j), k6 = ld2(B0 + sP + j), k7 = ld2(B0 + sP + RS + j);
+#endif
       Float m = w0 * k0.x, n = w0 * k0.y;
       m = fma(w1, k1.x, m); n = fma(w1, k1.y, n);
       m = fma(w2, k2.x, m); n = fma(w2, k2.y, n);
@@ -988,6 +1020,12 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
       if ((j & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads (64 VGPRs) in flight
     }
+    // next stage's major weights: their registers are free now, and the request is a minor pass ahead of its use
+#ifdef X9_NOLOAD
+    if (a.ncol < 0)
+#endif
+    load_major(ibnd_n, mj);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- minor absorbers of this regime; scalings (:461-480)
 #pragma unroll
     for (int k = 0; k < MAXM; ++k) {
@@ -1017,7 +1055,12 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
       for (int j = 0; j < G; j += 2) {
         // :757-760, :493
+#ifdef X9_NOGATHER
+        const Float2 q0{f1, f2}, q1{f2, f3}, q2{f3, scaling}, q3{scaling, f0};
+        (void)r1; (void)r2;
+#else
         const Float2 q0 = ld2(r1 + j), q1 = ld2(r1 + RS + j), q2 = ld2(r2 + j), q3 = ld2(r2 + RS + j);
+#endif
         Float s_ = f0 * q0.x, t_ = f0 * q0.y;
         s_ = fma(f1, q1.x, s_); t_ = fma(f1, q1.y, t_);
         s_ = fma(f2, q2.x, s_); t_ = fma(f2, q2.y, t_);
@@ -1028,6 +1071,20 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         if ((j & 6) == 6) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads in flight
       }
     }
+#ifdef X9_NOLOAD
+    if (a.ncol < 0)
+#endif
+    load_minor(ibnd_n, n_minor(ibnd_n), mn);
+    __builtin_amdgcn_sched_barrier(0);  // keep these requests ahead of the stores that follow
+#ifdef X9_NOSTORE
+    {
+      Float t_ = 0;
+#pragma unroll
+      for (int j = 0; j < G; ++j) t_ += acc[j];
+      if (t_ == (Float)-1.2345) *tau_at(0) = t_;
+    }
+    if (a.ncol < 0)
+#endif
     if (OVERWRITE) {
       // lanes past the last column repeat it (ic is clamped): same values to the same addresses.  Unconditional
       // stores keep the count of outstanding memory operations static (counted waits instead of drains).
@@ -1043,6 +1100,8 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       for (int j = 0; j < G; ++j) *tau_at(j) = acc[j];
     }
   }
+  };
+  if (all_run) run_stages(std::true_type{}); else run_stages(std::false_type{});
 }
 
 // (tile, layer, band) triples the slab kernel could not hold, done by the direct-gather code

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "fastmath.h"
 
 namespace {
 
@@ -48,6 +49,20 @@ __device__ __forceinline__ void lw_source_layer(Float tau_loc, Float trans, Floa
     fact = tau_loc * ((Float)0.5 + tau_loc * (-(Float)1 / (Float)3 + tau_loc * (Float)1 / (Float)8));
   src_inc = ((Float)1 - trans) * lev_hi + (Float)2 * fact * (lay - lev_hi);
   src_dec = ((Float)1 - trans) * lev_lo + (Float)2 * fact * (lay - lev_lo);
+}
+
+// the same for the segmented kernels: both branches evaluated and selected (no divergent branch), the quotient by
+// reciprocal + Newton (fastmath.h); tau_loc > tau_thresh ~ 1.2e-4 where the quotient is taken
+__device__ __forceinline__ void lw_source_layer_fast(Float tau_loc, Float trans, Float lay, Float lev_lo, Float lev_hi,
+                                                     Float& src_inc, Float& src_dec) {
+#pragma clang fp contract(fast)
+  const Float tau_thresh = sqrt(sqrt((Float)RTE_EPS));
+  const Float omt = (Float)1 - trans;
+  const Float big = rte::div_nr(omt, tau_loc > tau_thresh ? tau_loc : (Float)1) - trans;
+  const Float small = tau_loc * ((Float)0.5 + tau_loc * (-(Float)1 / (Float)3 + tau_loc * (Float)1 / (Float)8));
+  const Float fact2 = (Float)2 * (tau_loc > tau_thresh ? big : small);
+  src_inc = omt * lev_hi + fact2 * (lay - lev_hi);
+  src_dec = omt * lev_lo + fact2 * (lay - lev_lo);
 }
 
 // broadband(c,l) = [prev +] scale * sum_g spectral(c,l,g)   (sequential over g like the reference)
@@ -225,40 +240,66 @@ struct SegTile {  // one g-point's inputs for one thread's segment
   Float tau[L], lay[L], lev[L + 1], D, emis, ssrc, inc, sjac;
 };
 
-template <int L, bool do_jac>
-__device__ __forceinline__ void seg_load(SegTile<L>& t, int igpt, int c, int ncol, int nlay, int p0, int np,
-                                         bool top_at_1, const Float* __restrict__ Dsec,
-                                         const Float* __restrict__ tau_, const Float* __restrict__ lay_source_,
-                                         const Float* __restrict__ lev_source_, const Float* __restrict__ sfc_emis,
-                                         const Float* __restrict__ sfc_src, const Float* __restrict__ inc_flux,
-                                         const Float* __restrict__ sfc_srcJac) {
-  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
-  const size_t cg = c + (size_t)ncol * igpt;
-  const Float* tau = tau_ + c + ncl * igpt;
-  const Float* lay = lay_source_ + c + ncl * igpt;
-  const Float* lev = lev_source_ + c + nclv * igpt;
+// Loop-invariant 32-bit BYTE offsets of a thread's rows inside one g-point plane: every load of the g-point loop is
+// then (scalar plane base, advanced per g-point) + (VGPR offset) -- the saddr form of global_load, no per-load
+// address arithmetic.  Needs 8 * ncol * (nlay + 1) < 2^32 (checked by the host, else the generic kernel runs).
+template <int L>
+struct SegOffsets {
+  unsigned lay[L], lev[L + 1], cg;
+};
+
+template <int L>
+__device__ __forceinline__ void seg_offsets(SegOffsets<L>& o, int c, int ncol, int nlay, int p0, int np, bool top_at_1) {
 #pragma unroll
   for (int i = 0; i < L; ++i) {
     // out-of-segment slots (only the last segment can have them) re-read a valid layer and are then
-    // made NEUTRAL: tau = 0, sources = 0  ->  trans = 1, layer sources = 0, so the sweeps need no
-    // predication and the slot after the last real layer naturally receives the surface values
+    // made NEUTRAL (see seg_load)
     const int p = p0 + min(i, np - 1);
     const int ilay = top_at_1 ? p : nlay - 1 - p;
-    const Float tv = tau[(size_t)ncol * ilay], lv = lay[(size_t)ncol * ilay];
-    t.tau[i] = i < np ? tv : (Float)0;
-    t.lay[i] = i < np ? lv : (Float)0;
+    o.lay[i] = ((unsigned)c + (unsigned)ncol * (unsigned)ilay) * (unsigned)sizeof(Float);
+    asm volatile("" : "+v"(o.lay[i]));  // keep it a 32-bit VGPR value (not re-derived per load in 64 bits)
   }
 #pragma unroll
   for (int i = 0; i <= L; ++i) {
     const int p = p0 + min(i, np);
-    const Float lv = lev[(size_t)ncol * (top_at_1 ? p : nlay - p)];
-    t.lev[i] = i <= np ? lv : (Float)0;
+    o.lev[i] = ((unsigned)c + (unsigned)ncol * (unsigned)(top_at_1 ? p : nlay - p)) * (unsigned)sizeof(Float);
+    asm volatile("" : "+v"(o.lev[i]));
   }
-  t.D = Dsec[cg];
-  t.emis = sfc_emis[cg];
-  t.ssrc = sfc_src[cg];
-  t.inc = inc_flux[cg];
-  t.sjac = do_jac ? sfc_srcJac[cg] : (Float)0;
+  o.cg = (unsigned)c * (unsigned)sizeof(Float);
+  asm volatile("" : "+v"(o.cg));
+}
+
+template <int L, bool do_jac>
+__device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, int igpt, int ncol, int nlay, int np,
+                                         const Float* __restrict__ Dsec,
+                                         const Float* __restrict__ tau_, const Float* __restrict__ lay_source_,
+                                         const Float* __restrict__ lev_source_, const Float* __restrict__ sfc_emis,
+                                         const Float* __restrict__ sfc_src, const Float* __restrict__ inc_flux,
+                                         const Float* __restrict__ sfc_srcJac) {
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1), ncg = (size_t)ncol * igpt;
+  auto at = [](const Float* plane, unsigned off) {  // plane is wave-uniform
+    asm volatile("" : "+v"(off));  // opaque here, inside the g-point loop: its 64-bit extension cannot be hoisted
+    return *reinterpret_cast<const Float*>(reinterpret_cast<const char*>(plane) + off);
+  };
+  const Float* tau = tau_ + ncl * igpt;
+  const Float* lay = lay_source_ + ncl * igpt;
+  const Float* lev = lev_source_ + nclv * igpt;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    // tau = 0 alone makes an out-of-segment slot NEUTRAL whatever finite sources it carries: trans = 1,
+    // 1 - trans = 0, fact = 0 -> layer sources = 0, so the sweeps need no predication and the slot after
+    // the last real layer naturally receives the surface values
+    const Float tv = at(tau, o.lay[i]);
+    t.tau[i] = i < np ? tv : (Float)0;
+    t.lay[i] = at(lay, o.lay[i]);
+  }
+#pragma unroll
+  for (int i = 0; i <= L; ++i) t.lev[i] = at(lev, o.lev[i]);
+  t.D = at(Dsec + ncg, o.cg);
+  t.emis = at(sfc_emis + ncg, o.cg);
+  t.ssrc = at(sfc_src + ncg, o.cg);
+  t.inc = at(inc_flux + ncg, o.cg);
+  t.sjac = do_jac ? at(sfc_srcJac + ncg, o.cg) : (Float)0;
 }
 
 template <int L, bool do_jac>
@@ -301,10 +342,10 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       const Float tau_loc = cur.tau[i] * cur.D;
-      const Float tr = exp(-tau_loc);
+      const Float tr = rte::exp_nonpos(-tau_loc);
       // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo): "toward bottom" uses the
       // bottom level source, "toward top" the top level source
-      lw_source_layer(tau_loc, tr, cur.lay[i], cur.lev[i], cur.lev[i + 1], sd[i], su[i]);
+      lw_source_layer_fast(tau_loc, tr, cur.lay[i], cur.lev[i], cur.lev[i + 1], sd[i], su[i]);
       t[i] = tr;
       Sd = tr * Sd + sd[i];
       Td = Td * tr;
@@ -354,8 +395,10 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       if (do_jac) { jv = t[i] * jv; acc_j[i] += jv; }
     }
   };
+  SegOffsets<L> offs;
+  seg_offsets<L>(offs, c, ncol, nlay, p0, np, top_at_1);
   auto load = [&](SegTile<L>& tile, int igpt) {
-    seg_load<L, do_jac>(tile, min(igpt, g_end - 1), c, ncol, nlay, p0, np, top_at_1, Dsec, tau_, lay_source_, lev_source_,
+    seg_load<L, do_jac>(tile, offs, min(igpt, g_end - 1), ncol, nlay, np, Dsec, tau_, lay_source_, lev_source_,
                         sfc_emis, sfc_src, inc_flux, sfc_srcJac);
   };
   // software prefetch: the next g-point's loads are in flight while this one is computed
@@ -1206,12 +1249,14 @@ size_t pick_gchunk(size_t bytes_per_g, int ngpt) {
 static int g_lw2str_gpt1_levsource = 0;
 static int g_lw_force_generic = 0;
 static int g_sw_force_generic = 0;
+static int g_seg_groups = 0;  // > 0: g-point groups per column tile of the segmented solvers (rte_hip_seg_groups; 0 = automatic)
 
 extern "C" {
 
 int rte_hip_set_lw2str_bugcompat(int on) { g_lw2str_gpt1_levsource = on; return 0; }
 int rte_hip_force_generic_lw(int on) { g_lw_force_generic = on; return 0; }
 int rte_hip_force_generic_sw(int on) { g_sw_force_generic = on; return 0; }
+int rte_hip_seg_groups(int n) { g_seg_groups = n; return 0; }
 
 void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
                           const int* nmus_, const Float* Ds, const Float* weights, const Float* tau,
@@ -1256,6 +1301,7 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
     while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
     const int g_per_block = (ngpt + ngroups - 1) / ngroups;
     ngroups = (ngpt + g_per_block - 1) / g_per_block;
     LwRescArgs q;
@@ -1285,11 +1331,12 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     }
     return;
   }
-  if (do_broadband && !do_rescaling && nlay <= 80 && !g_lw_force_generic) {
+  if (do_broadband && !do_rescaling && nlay <= 80 && !g_lw_force_generic && nclv < ((size_t)1 << 29)) {  // 32-bit in-plane byte offsets
     // g-points per block: enough blocks to fill the chip several times over, few enough partial slabs
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
     while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
     const int g_per_block = (ngpt + ngroups - 1) / ngroups;
     ngroups = (ngpt + g_per_block - 1) / g_per_block;
     Float* part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
@@ -1407,6 +1454,7 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
     while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
     const int g_per_block = (ngpt + ngroups - 1) / ngroups;
     ngroups = (ngpt + g_per_block - 1) / g_per_block;
     Lw2SegArgs q;
@@ -1482,6 +1530,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
     while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
     const int g_per_block = (ngpt + ngroups - 1) / ngroups;
     ngroups = (ngpt + g_per_block - 1) / g_per_block;
     Sw2SegArgs q;
