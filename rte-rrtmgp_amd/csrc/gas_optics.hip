@@ -806,6 +806,146 @@ __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __res
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// Tile geometry by bit masks ("geom2"): the pre-pass of both specialised-wave kernels.
+//
+// The first version walked the bands, loading the band's eta indices and reducing them with 12 cross-lane
+// shuffles per band -- 16 dependent load -> reduce steps per block (0.31 + 0.27 ms per step of the LW chain).
+// Here every thread requests the eta indices of ALL flavors up front (4 at a time), turns each index pair into a
+// bit mask of the LUT rows it touches (row r -> bit r; neta, ntemp < 31, npres + 1 < 63 checked by the host),
+// and masks are OR-reduced: six DPP steps inside the wave (no LDS traffic), one LDS atomic per wave and word.
+// A band's eta range is then the span of the masks of its two flavors, keyed by the regime of the columns
+// that use them -- the same box as before.
+// -------------------------------------------------------------------------------------------
+// OR over the 64 lanes of a wave, result returned as a wave-uniform value: inclusive scan inside each row of 16
+// lanes (row_shr 1, 2, 4, 8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15), then rows 0-1 -> rows 2-3
+// (row_bcast:31); lane 63 holds the total
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+
+constexpr int MAXFLAV = 32;
+
+struct Geom2Args {
+  int ncol, nlay, nbnd, nflav, slab_floats;
+  bool planck;               // Planck: box = pressure x temperature x eta of pfrac; no minor rows, no regime ranges
+  const int* lim;            // (ncol, 4) regime layer limits (tau only)
+  const int *jeta, *jtemp, *jpress;
+  const Bool* tropo;
+  const BandMeta* bmeta;     // tau: band flavors and minor counts
+  const int *band_lims, *gpoint_flavor;  // Planck: band flavors
+  const int* skip_if;        // tau: the direct kernel does the whole call
+  int* worklist;             // tau: (tile, layer, band) triples; Planck: (tile, band) pairs
+  int* flags;                // Planck: one worklist entry per (tile, band)
+};
+
+template <int TILE, int G>
+__global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom* __restrict__ geom) {
+  constexpr int RS = G + 2;
+  __shared__ unsigned mT, mP[2], mReg;
+  __shared__ unsigned mE[MAXFLAV][2];
+  __shared__ int flav[MAXB][2], cnt[MAXB][2];
+  if (a.skip_if && *a.skip_if) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
+  const unsigned ncl = ncol * nlay;
+  const int nbnd = a.nbnd, nflav = a.nflav;
+  if (tid == 0) { mT = 0; mP[0] = 0; mP[1] = 0; mReg = 0; }
+  if (tid < 2 * MAXFLAV) mE[tid >> 1][tid & 1] = 0;
+  if (tid < 2 * nbnd) {
+    const int b = tid >> 1, r = tid & 1;
+    if (a.planck) {
+      flav[b][r] = a.gpoint_flavor[r + 2 * (a.band_lims[2 * b] - 1)] - 1;
+      cnt[b][r] = 0;
+    } else {
+      flav[b][r] = a.bmeta[b].flav[r];
+      cnt[b][r] = a.bmeta[b].cnt[r];
+    }
+  }
+  __syncthreads();
+  const unsigned icol = blockIdx.x * TILE + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  const unsigned cl = ic + ncol * ilay;
+  const int itropo = a.tropo[cl] ? 0 : 1;
+  const int jT = a.jtemp[cl];
+  const int jp = a.jpress[cl] + itropo + 1;  // levels jp-1, jp (1-based)
+  int regime = 0;
+  if (!a.planck) {
+    const int lay1 = ilay + 1;
+    const int lo1 = a.lim[ic], lo2 = a.lim[ic + ncol];
+    const int up1 = a.lim[ic + 2 * (size_t)ncol], up2 = a.lim[ic + 3 * (size_t)ncol];
+    regime = ((lo1 > 0 && lay1 >= lo1 && lay1 <= lo2) ? 1 : 0) | ((up1 > 0 && lay1 >= up1 && lay1 <= up2) ? 2 : 0);
+  }
+  const int rsel = regime == 2 ? 1 : 0;  // regime whose flavor the minor absorbers use
+  // a column's eta rows count for the regimes whose flavor table it uses: itropo (major species, Planck
+  // fractions) and rsel (minor species; differs from itropo only for non-contiguous tropo masks)
+  const bool key0 = valid && (itropo == 0 || (!a.planck && rsel == 0));
+  const bool key1 = valid && (itropo == 1 || (!a.planck && rsel == 1));
+  {
+    const unsigned long long pm = valid ? (3ull << (jp - 1)) : 0ull;
+    const unsigned t = wave_or(valid ? (3u << jT) : 0u);
+    const unsigned p0 = wave_or((unsigned)pm), p1 = wave_or((unsigned)(pm >> 32));
+    const unsigned rg = wave_or(valid ? (unsigned)regime : 0u);
+    if (lane == 0) { atomicOr(&mT, t); atomicOr(&mP[0], p0); atomicOr(&mP[1], p1); atomicOr(&mReg, rg); }
+  }
+  for (int f0 = 0; f0 < nflav; f0 += 4) {
+    int2 je[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      je[k] = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * min(f0 + k, nflav - 1)));
+    unsigned w[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned m = (3u << je[k].x) | (3u << je[k].y);  // rows eta, eta + 1 of both temperature corners
+      w[k][0] = wave_or(key0 ? m : 0u);
+      w[k][1] = wave_or(key1 ? m : 0u);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (f0 + k < nflav) { atomicOr(&mE[f0 + k][0], w[k][0]); atomicOr(&mE[f0 + k][1], w[k][1]); }
+    }
+  }
+  __syncthreads();
+  TileGeom* out = geom + (blockIdx.x + (size_t)gridDim.x * ilay);
+  const int Tmin = __ffs(mT) - 1, nT = (32 - __clz(mT)) - Tmin;
+  const unsigned long long pmask = ((unsigned long long)mP[1] << 32) | mP[0];
+  const int Pmin = __ffsll((long long)pmask) - 1, nP = (64 - __clzll((long long)pmask)) - Pmin;
+  const int has_lo = mReg & 1, has_up = (mReg >> 1) & 1;
+  if (tid == 0) {
+    out->Tmin = Tmin; out->nT = nT; out->Pmin = Pmin; out->nP = nP; out->has_lo = has_lo; out->has_up = has_up;
+    out->pad0 = 0; out->pad1 = 0;
+  }
+  if (tid < nbnd) {
+    const unsigned me = mE[flav[tid][0]][0] | mE[flav[tid][1]][1];
+    const int emin = me ? __ffs(me) - 1 : 1, nE = me ? (32 - __clz(me)) - emin : 0;
+    const int n_lo = has_lo ? cnt[tid][0] : 0, n_up = has_up ? cnt[tid][1] : 0;
+    const int rows = (nP + n_lo + n_up) * nT * nE;
+    const bool fits = rows * RS <= a.slab_floats;
+    if (a.planck) {
+      if (!fits && atomicCAS(&a.flags[blockIdx.x * nbnd + tid], 0, 1) == 0) {  // once per (tile, band)
+        const int w = atomicAdd(&a.worklist[0], 1);
+        a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = tid;
+      }
+      out->eg[tid] = make_int2(emin, nE);
+    } else {
+      if (!fits) {  // hand (tile, layer, band) to the direct kernel
+        const int w = atomicAdd(&a.worklist[0], 1);
+        a.worklist[1 + 3 * w] = blockIdx.x; a.worklist[2 + 3 * w] = ilay; a.worklist[3 + 3 * w] = tid;
+      }
+      out->eg[tid] = make_int2(emin, fits ? nE : 0);
+    }
+  }
+}
+
 template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G>
 __global__ void __launch_bounds__((NCW + NLW) * 64, V9_MINW)
 tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
@@ -1820,6 +1960,7 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
 static int g_tau_force_direct = 0;
 static int g_tau_variant = 9;
 static int g_planck_variant = 9;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
+static int g_geom_variant = 2;  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
 static int g_plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget cached host-side plans
 
 namespace {
@@ -1853,6 +1994,7 @@ int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
 int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
 int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
 int rte_hip_invalidate_plans(void) { ++g_plan_epoch; return 0; }
+int rte_hip_geom_variant(int v) { g_geom_variant = v; return 0; }
 
 
 void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, const int* nflav_,
@@ -2133,11 +2275,17 @@ void rrtmgp_compute_tau_absorption(
     const dim3 grid(tiles, nlay), blk((NCW + NLW) * 64);
     const size_t dyn = sizeof(BandMeta) * nbnd;
     const TileGeom* cg = d_geom;
+    const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
+    Geom2Args ga{};
+    ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = false;
+    ga.lim = lim; ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.bmeta = d_bm;
+    ga.skip_if = overlap; ga.worklist = v.worklist;
 #define RTE_LAUNCH_TAU9(GW)                                                                                       \
   do {                                                                                                            \
     {                                                                                                             \
       rte::ProfScope p("tau_absorption_setup");                                                                   \
-      hipLaunchKernelGGL((tau_geom_kernel<NCW * 64, GW>), grid, dim3(NCW * 64), 0, st, v, d_geom, SLAB9);         \
+      if (geom2) hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), grid, dim3(NCW * 64), 0, st, ga, d_geom);  \
+      else hipLaunchKernelGGL((tau_geom_kernel<NCW * 64, GW>), grid, dim3(NCW * 64), 0, st, v, d_geom, SLAB9);    \
     }                                                                                                             \
     rte::ProfScope p("tau_absorption_kernel");                                                                    \
     if (overwrite) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW>), grid, blk, dyn, st, v, cg); \
@@ -2347,12 +2495,18 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     v.clocks = (unsigned long long*)rte::scratch(64);
     HIP_CHECK(hipMemsetAsync(v.clocks, 0, 64, st));
 #endif
+    const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
+    Geom2Args ga{};
+    ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = true;
+    ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.band_lims = d_band_lims;
+    ga.gpoint_flavor = d_gpoint_flavor; ga.worklist = v.worklist; ga.flags = d_flags;
 #define RTE_LAUNCH_PLANCK9(GW)                                                                                    \
   do {                                                                                                            \
     {                                                                                                             \
       rte::ProfScope p("planck_source_setup");                                                                    \
-      hipLaunchKernelGGL((planck_geom_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, \
-                         d_flags, SLAB9);                                                                         \
+      if (geom2) hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, ga, d_geom); \
+      else hipLaunchKernelGGL((planck_geom_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, \
+                              d_flags, SLAB9);                                                                    \
     }                                                                                                             \
     rte::ProfScope p("planck_source_kernel");                                                                     \
     hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW>), dim3(nbnd * 8 * cdiv(tiles, 8)),          \

@@ -295,10 +295,14 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, 
   }
 #pragma unroll
   for (int i = 0; i <= L; ++i) t.lev[i] = at(lev, o.lev[i]);
+#ifdef LWX_NOSFC
+  t.D = 1.5; t.emis = 0.9; t.ssrc = 1; t.inc = 0; (void)ncg;
+#else
   t.D = at(Dsec + ncg, o.cg);
   t.emis = at(sfc_emis + ncg, o.cg);
   t.ssrc = at(sfc_src + ncg, o.cg);
   t.inc = at(inc_flux + ncg, o.cg);
+#endif
   t.sjac = do_jac ? at(sfc_srcJac + ncg, o.cg) : (Float)0;
 }
 
@@ -311,7 +315,7 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
                      const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
                      Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac) {
 #pragma clang fp contract(fast)  // this kernel is fp64-issue bound: fuse the recurrences' a*b+c
-  extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][S][64]
+  extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][MAXS][64]
   const int lane = threadIdx.x & 63;
   // the wave index is wave-uniform: tell the compiler, so layer offsets live in SGPRs and every load is
   // (uniform 64-bit base) + (32-bit lane offset) instead of per-lane 64-bit address arithmetic
@@ -325,8 +329,15 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   const int np = min(L, nlay - p0);  // layers in this segment (>= 1 by construction)
   const bool last = (s == S - 1);
   const Float piw = kPi * weight;
+  const Float inv_piw = (Float)1 / piw;
   const int g_begin = blockIdx.y * g_per_block;
   const int g_end = min(ngpt, g_begin + g_per_block);
+  constexpr int MAXS = 8;  // waves per block at most
+  // neutral composites (Td, Sd, Su) = (1, 0, 0) for the segment slots no wave owns (read after the first barrier)
+  for (int i = threadIdx.x; i < 2 * 3 * MAXS * 64; i += blockDim.x) {
+    const int q = (i >> 6) % MAXS, k = (i >> 6) / MAXS % 3;
+    if (q >= S) lds[i] = k == 0 ? (Float)1 : (Float)0;
+  }
 
   Float acc_dn[L + 1], acc_up[L + 1], acc_j[do_jac ? L + 1 : 1];
 #pragma unroll
@@ -342,10 +353,18 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       const Float tau_loc = cur.tau[i] * cur.D;
+#ifdef LWX_NOEXP
+      const Float tr = (Float)1 - tau_loc * (Float)0.001;
+#else
       const Float tr = rte::exp_nonpos(-tau_loc);
+#endif
       // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo): "toward bottom" uses the
       // bottom level source, "toward top" the top level source
+#ifdef LWX_NOSRC
+      sd[i] = tr * cur.lev[i + 1] + cur.lay[i]; su[i] = tr * cur.lev[i] + cur.lay[i];
+#else
       lw_source_layer_fast(tau_loc, tr, cur.lay[i], cur.lev[i], cur.lev[i + 1], sd[i], su[i]);
+#endif
       t[i] = tr;
       Sd = tr * Sd + sd[i];
       Td = Td * tr;
@@ -354,25 +373,51 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     Float Su = 0;
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) Su = t[i] * Su + su[i];
-    // ---- exchange segment composites
-    Float* X = lds + (size_t)buf * 3 * S * 64;
-    X[(0 * S + s) * 64 + lane] = Td;
-    X[(1 * S + s) * 64 + lane] = Sd;
-    X[(2 * S + s) * 64 + lane] = Su;
+#ifdef LWX_NOPASS2
+    acc_dn[0] += Td + Sd + Su;
+    return;
+#endif
+    // ---- exchange segment composites: slots [buffer][Td, Sd, Su][MAXS segments][64 lanes]; slots of segments
+    // that do not exist hold the neutral composite (1, 0, 0), so the chains below have a fixed length and all
+    // their LDS reads are issued back to back (a read per chain step costs one LDS latency per step)
+    Float* X = lds + (size_t)buf * 3 * MAXS * 64;
+    X[(0 * MAXS + s) * 64 + lane] = Td;
+    X[(1 * MAXS + s) * 64 + lane] = Sd;
+    X[(2 * MAXS + s) * 64 + lane] = Su;
+#ifndef LWX_NOBARRIER
     __syncthreads();
-    Float r = cur.inc / piw;  // radiance entering segment 0 from above (:144)
+#endif
+    Float r = cur.inc * inv_piw;  // radiance entering segment 0 from above (:144)
     Float r_in = r;
-    for (int q = 0; q < S; ++q) {
-      if (q == s) r_in = r;
-      r = X[(0 * S + q) * 64 + lane] * r + X[(1 * S + q) * 64 + lane];
-    }
-    const Float u_sfc = r * ((Float)1 - cur.emis) + cur.emis * cur.ssrc;  // :198-200
-    Float u = u_sfc;
-    Float jv = do_jac ? cur.emis * cur.sjac : (Float)0;
-    for (int q = S - 1; q > s; --q) {
-      const Float Tq = X[(0 * S + q) * 64 + lane];
-      u = Tq * u + X[(2 * S + q) * 64 + lane];
-      jv = Tq * jv;
+    Float u, jv;
+    if constexpr (L <= 8 && !do_jac) {  // the register budget allows all composites at once
+      Float Tq[MAXS], Sq[MAXS];
+#pragma unroll
+      for (int q = 0; q < MAXS; ++q) { Tq[q] = X[(0 * MAXS + q) * 64 + lane]; Sq[q] = X[(1 * MAXS + q) * 64 + lane]; }
+#pragma unroll
+      for (int q = 0; q < MAXS; ++q) {
+        r_in = (q == s) ? r : r_in;
+        r = Tq[q] * r + Sq[q];
+      }
+#pragma unroll
+      for (int q = 1; q < MAXS; ++q) Sq[q] = X[(2 * MAXS + q) * 64 + lane];  // Su of the segments below
+      u = r * ((Float)1 - cur.emis) + cur.emis * cur.ssrc;  // :198-200
+      jv = 0;
+#pragma unroll
+      for (int q = MAXS - 1; q >= 1; --q)
+        if (q > s) u = Tq[q] * u + Sq[q];  // wave-uniform
+    } else {
+      for (int q = 0; q < S; ++q) {
+        if (q == s) r_in = r;
+        r = X[(0 * MAXS + q) * 64 + lane] * r + X[(1 * MAXS + q) * 64 + lane];
+      }
+      u = r * ((Float)1 - cur.emis) + cur.emis * cur.ssrc;  // :198-200
+      jv = do_jac ? cur.emis * cur.sjac : (Float)0;
+      for (int q = S - 1; q > s; --q) {
+        const Float Tq = X[(0 * MAXS + q) * 64 + lane];
+        u = Tq * u + X[(2 * MAXS + q) * 64 + lane];
+        jv = Tq * jv;
+      }
     }
     // the level below the segment's last slot (used only by a FULL last segment: the surface)
     acc_up[L] += u;
@@ -401,7 +446,8 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     seg_load<L, do_jac>(tile, offs, min(igpt, g_end - 1), ncol, nlay, np, Dsec, tau_, lay_source_, lev_source_,
                         sfc_emis, sfc_src, inc_flux, sfc_srcJac);
   };
-  // software prefetch: the next g-point's loads are in flight while this one is computed
+  // software prefetch: the next g-point's loads are in flight while this one is computed.  (A ring of tiles
+  // unrolled so that no tile is copied measures the same and needs 45 more registers; two g-points ahead spill.)
   SegTile<L> cur;
   load(cur, g_begin);
   int buf = 0;
@@ -1342,7 +1388,7 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     Float* part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
     Float* part_dn = part_up + nclv * ngroups;
     Float* part_jac = do_jac ? part_dn + nclv * ngroups : nullptr;
-    const size_t lds_bytes = sizeof(Float) * 2 * 3 * S * 64;
+    const size_t lds_bytes = sizeof(Float) * 2 * 3 * 8 * 64;
     for (int imu = 0; imu < nmus; ++imu) {
       {
         rte::ProfScope p("lw_noscat_seg_kernel");

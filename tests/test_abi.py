@@ -31,7 +31,8 @@ def test_library_builds_and_exports_every_header_symbol():
                 "rte_hip_combine_abs_and_rayleigh_2str", "rte_hip_broadcast_gpt", "rte_hip_release",
                 "rte_hip_defer_zero", "rte_hip_tau_variant", "rte_hip_planck_variant", "rte_hip_force_direct_gather",
                 "rte_hip_force_generic_lw", "rte_hip_force_generic_sw", "rte_hip_invalidate_plans",
-                "rte_hip_set_lw2str_bugcompat", "rte_hip_device_count", "rte_hip_cloud_masks", "rte_hip_cloud_combine"):
+                "rte_hip_set_lw2str_bugcompat", "rte_hip_device_count", "rte_hip_cloud_masks", "rte_hip_cloud_combine",
+                "rte_hip_geom_variant", "rte_hip_seg_groups"):
         assert hasattr(dll, ext)
 
 

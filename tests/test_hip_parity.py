@@ -234,6 +234,36 @@ def test_wide_bands_on_production_kernels(hip, oracle_c, nbnd, ngpt, top_at_1):
             assert cases.rel_err(outs["fast"][k], outs["direct"][k]) <= 1e-13, (kind, k)
             assert cases.rel_err(outs["fast"][k], outs["oracle"][k]) <= RTOL_GAS, (kind, k)
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("top_at_1", [False, True])
+def test_tile_geometry_prepasses_agree(hip, top_at_1):
+    """The bit-mask tile geometry pre-pass (DPP OR-reductions, rte_hip_geom_variant(2), default) and the
+    band-walking pre-passes (variant 1) give the production tau / Planck kernels the same LUT boxes: results
+    are bit-identical, including ragged last tiles, tropopause layers (both regimes in one tile) and tiles
+    that overflow to the direct-gather worklist."""
+    from rte_rrtmgp_amd import synth
+
+    kd = synth.make_kdist("lw")  # g256 shape: 16 bands of 16, 10 flavors
+    ncol, nlay = 1500, 30
+    atm = synth.make_atmosphere(ncol, nlay, seed=11, kdist=kd, top_at_1=top_at_1)
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    go = frontend.GasOptics(hip, kd, xp)
+    args = [A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tsfc", "col_gas", "tlev")]
+    outs = {}
+    try:
+        for variant in (1, 2):
+            hiplib.ext_call(hip, "rte_hip_geom_variant", ["i"], variant)
+            bufs = {}
+            go.gas_optics_lw(ncol, nlay, *args, atm.top_at_1, buffers=bufs)
+            outs[variant] = {k: xp.to_numpy(bufs[k]).copy() for k in ("tau", "lay_src", "lev_src", "sfc_src")}
+    finally:
+        hiplib.ext_call(hip, "rte_hip_geom_variant", ["i"], 2)
+    for k in outs[1]:
+        assert np.array_equal(outs[1][k], outs[2][k]), k
+        assert np.isfinite(outs[2][k]).all() and outs[2][k].max() > 0, k
+
+
 
 def test_tau_rayleigh_paths_agree(hip, oracle_c):
     """The production Rayleigh kernel (whole (T, eta) plane of a band staged in LDS, layers walked by the

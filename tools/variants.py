@@ -12,6 +12,6 @@ for spec in sys.argv[2:]:
         hiplib.build("dp", force=True, extra=[f for f in flags.split(",") if f])
     else:
         code = (f"import sys; sys.path.insert(0,'.'); from rte_rrtmgp_amd import hiplib; hiplib.LIB_NAMES['dp']='{name}'; "
-                "sys.argv=['x','100000']; exec(open('tools/time_gas_optics.py').read())")
+                "import os; sys.argv=['x']+os.environ.get('VARIANT_ARGS','100000').split(); exec(open(os.environ.get('VARIANT_SCRIPT','tools/time_gas_optics.py')).read())")
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
         print(tag, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:])
