@@ -946,7 +946,9 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
   }
 }
 
-template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G>
+// MM = minor intervals per (band, regime) kept in registers (column amounts of the current and of the next stage):
+// 4 when no band of the table has more (saves 16 VGPRs and their selects), else MAXM
+template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G, int MM>
 __global__ void __launch_bounds__((NCW + NLW) * 64, V9_MINW)
 tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
@@ -1064,10 +1066,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     x.je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
   };
   // minor column amounts, weights and eta indices of one stage
-  struct Minor { Float sc[MAXM], cgs[MAXM]; Float2 fn0, fn1; int2 em; };
+  struct Minor { Float sc[MM], cgs[MM]; Float2 fn0, fn1; int2 em; };
   auto load_minor = [&](int b, int n, Minor& x) {
 #pragma unroll
-    for (int k = 0; k < MAXM; ++k) {
+    for (int k = 0; k < MM; ++k) {
       x.sc[k] = 0; x.cgs[k] = 0;
       if (k < n) {
         const MinorMeta& m = bm[b].m[rsel][k];
@@ -1106,9 +1108,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     if (s + 1 < nstage) while (ibnd_n + 1 < nbnd && bm[ibnd_n].gE < g0 + G) ++ibnd_n;
     const bool run = nE > 0;  // block-uniform
     const int n_my = n_minor(ibnd);
-    Float sc[MAXM], cgs[MAXM];
+    Float sc[MM], cgs[MM];
 #pragma unroll
-    for (int k = 0; k < MAXM; ++k) { sc[k] = mn.sc[k]; cgs[k] = mn.cgs[k]; }
+    for (int k = 0; k < MM; ++k) { sc[k] = mn.sc[k]; cgs[k] = mn.cgs[k]; }
     const Float2 fn0 = mn.fn0, fn1 = mn.fn1;
     const int2 em = mn.em;
     // this stage's major weights into locals (col_mix folded in)
@@ -1161,6 +1163,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       if ((j & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads (64 VGPRs) in flight
     }
     // next stage's major weights: their registers are free now, and the request is a minor pass ahead of its use
+    // (requested with the minor weights at the end of the stage, their latency is exposed: 5.5 -> 5.9 ms)
 #ifdef X9_NOLOAD
     if (a.ncol < 0)
 #endif
@@ -1168,7 +1171,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- minor absorbers of this regime; scalings (:461-480)
 #pragma unroll
-    for (int k = 0; k < MAXM; ++k) {
+    for (int k = 0; k < MM; ++k) {
       if (k < n_my) {
         const MinorMeta& m = bm[ibnd].m[rsel][k];
         if (m.flags & 1) {
@@ -1189,7 +1192,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       if (mm.mE < g0 || mm.mS > g0) continue;  // intervals are whole 16-aligned chunks inside the band
       Float scaling = sc[0];
 #pragma unroll
-      for (int q = 1; q < MAXM; ++q) scaling = (k == q) ? sc[q] : scaling;
+      for (int q = 1; q < MM; ++q) scaling = (k == q) ? sc[q] : scaling;
       const Float* r1 = M0 + ((k * nT + (jT - Tmin)) * nE + (em.x - emin)) * RS;
       const Float* r2 = M0 + ((k * nT + (jT + 1 - Tmin)) * nE + (em.y - emin)) * RS;
 #pragma unroll
@@ -1245,13 +1248,17 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 }
 
 // (tile, layer, band) triples the slab kernel could not hold, done by the direct-gather code
+// (work item = one entry x one 64-column chunk, taken by waves in grid stride: the few hundred entries of a call
+// spread over all CUs instead of one block walking an entry's 512 columns)
 __global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a, const int* __restrict__ worklist, int tile) {
   const int n = worklist[0];
-  for (int w = blockIdx.x; w < n; w += gridDim.x)
-    for (int c = threadIdx.x; c < tile; c += 256) {
-      const int icol = worklist[1 + 3 * w] * tile + c;
-      if (icol < a.ncol) tau_direct_column(a, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
-    }
+  const int chunks = tile / 64;
+  const int items = n * chunks;
+  for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += gridDim.x * 4) {
+    const int w = it / chunks, ch = it - w * chunks;
+    const int icol = worklist[1 + 3 * w] * tile + ch * 64 + (threadIdx.x & 63);
+    if (icol < a.ncol) tau_direct_column(a, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
+  }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -2275,6 +2282,8 @@ void rrtmgp_compute_tau_absorption(
     const dim3 grid(tiles, nlay), blk((NCW + NLW) * 64);
     const size_t dyn = sizeof(BandMeta) * nbnd;
     const TileGeom* cg = d_geom;
+    bool mm4 = true;
+    for (const BandMeta& bmh : cache.bands) mm4 = mm4 && bmh.cnt[0] <= 4 && bmh.cnt[1] <= 4;
     const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
     Geom2Args ga{};
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = false;
@@ -2288,8 +2297,13 @@ void rrtmgp_compute_tau_absorption(
       else hipLaunchKernelGGL((tau_geom_kernel<NCW * 64, GW>), grid, dim3(NCW * 64), 0, st, v, d_geom, SLAB9);    \
     }                                                                                                             \
     rte::ProfScope p("tau_absorption_kernel");                                                                    \
-    if (overwrite) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW>), grid, blk, dyn, st, v, cg); \
-    else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW>), grid, blk, dyn, st, v, cg);   \
+    if (mm4) {                                                                                                    \
+      if (overwrite) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4>), grid, blk, dyn, st, v, cg); \
+      else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4>), grid, blk, dyn, st, v, cg); \
+    } else {                                                                                                      \
+      if (overwrite) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MAXM>), grid, blk, dyn, st, v, cg); \
+      else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, MAXM>), grid, blk, dyn, st, v, cg); \
+    }                                                                                                             \
   } while (0)
     if (cache.gw == 16) RTE_LAUNCH_TAU9(16); else RTE_LAUNCH_TAU9(8);
 #undef RTE_LAUNCH_TAU9
