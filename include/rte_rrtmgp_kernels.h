@@ -345,6 +345,35 @@ void rrtmgp_compute_cld_from_table(const int* ncol, const int* nlay, const int* 
                                    const Float* asy_table,        /* (nsteps,ngpt) */
                                    Float* tau, Float* taussa, Float* taussag); /* (ncol,nlay,ngpt) */
 
+/* ------------------------------------------------------------------------
+ * Planck function on a wavenumber grid (reference rte/kernels/api/mo_gas_optics_utils.F90:6-34;
+ * default impl rte/kernels/mo_gas_optics_utils.F90:36-95): source = B_nu(T, nus) * dnus
+ * ---------------------------------------------------------------------- */
+void rte_compute_Planck_source_2D(const int* ncol, const int* nlay, const int* nnu,
+                                  const Float* nus, const Float* dnus, /* (nnu) */
+                                  const Float* T,                      /* (ncol,nlay) */
+                                  Float* source);                      /* (ncol,nlay,nnu) */
+void rte_compute_Planck_source_1D(const int* ncol, const int* nnu,
+                                  const Float* nus, const Float* dnus, /* (nnu) */
+                                  const Float* T,                      /* (ncol) */
+                                  Float* source);                      /* (ncol,nnu) */
+
+/* ------------------------------------------------------------------------
+ * By-band flux reductions (reference rte/extensions/mo_fluxes_byband.F90:156-209, bind(C) there);
+ * band_lims = (2,nbnd) 1-based inclusive g-point limits
+ * ---------------------------------------------------------------------- */
+void rte_sum_byband(const int* ncol, const int* nlev, const int* ngpt, const int* nbnd,
+                    const int* band_lims,
+                    const Float* spectral_flux,  /* (ncol,nlev,ngpt) */
+                    Float* byband_flux);         /* (ncol,nlev,nbnd) */
+void rte_net_byband_full(const int* ncol, const int* nlev, const int* ngpt, const int* nbnd,
+                         const int* band_lims,
+                         const Float* spectral_flux_dn, const Float* spectral_flux_up, /* (ncol,nlev,ngpt) */
+                         Float* byband_flux_net);                                     /* (ncol,nlev,nbnd) */
+void net_byband_precalc(const int* ncol, const int* nlev, const int* nbnd,
+                        const Float* byband_flux_dn, const Float* byband_flux_up,     /* (ncol,nlev,nbnd) */
+                        Float* byband_flux_net);                                      /* (ncol,nlev,nbnd) */
+
 #ifdef __cplusplus
 }
 #endif

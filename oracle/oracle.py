@@ -33,10 +33,9 @@ def _pkg():
 
 def build_c(force: bool = False) -> None:
     need = force or not all(os.path.exists(os.path.join(HERE, n)) for n in ("liboracle.so", "liboracle_sp.so"))
-    src = os.path.join(HERE, "rte_rrtmgp_oracle.c")
     if not need:
-        need = any(os.path.getmtime(src) > os.path.getmtime(os.path.join(HERE, n))
-                   for n in ("liboracle.so", "liboracle_sp.so"))
+        need = any(os.path.getmtime(os.path.join(HERE, src)) > os.path.getmtime(os.path.join(HERE, n))
+                   for src in ("rte_rrtmgp_oracle.c", "glue_oracle.c") for n in ("liboracle.so", "liboracle_sp.so"))
     if need:
         subprocess.check_call(["make", "-C", HERE, "liboracle.so", "liboracle_sp.so"],
                               stdout=subprocess.DEVNULL)

@@ -76,6 +76,12 @@ SIGNATURES: Dict[str, List[Arg]] = {
     "rte_net_broadband_full": _sig(
         "i:ncol i:nlev i:ngpt a:spectral_flux_dn a:spectral_flux_up a:broadband_flux_net"),
     "rte_net_broadband_precalc": _sig("i:ncol i:nlev a:flux_dn a:flux_up a:broadband_flux_net"),
+    "rte_compute_Planck_source_2D": _sig("i:ncol i:nlay i:nnu a:nus a:dnus a:T a:source"),
+    "rte_compute_Planck_source_1D": _sig("i:ncol i:nnu a:nus a:dnus a:T a:source"),
+    "rte_sum_byband": _sig("i:ncol i:nlev i:ngpt i:nbnd a:band_lims a:spectral_flux a:byband_flux"),
+    "rte_net_byband_full": _sig(
+        "i:ncol i:nlev i:ngpt i:nbnd a:band_lims a:spectral_flux_dn a:spectral_flux_up a:byband_flux_net"),
+    "net_byband_precalc": _sig("i:ncol i:nlev i:nbnd a:byband_flux_dn a:byband_flux_up a:byband_flux_net"),
     "zero_array_1D": _sig("i:ni a:array"),
     "zero_array_2D": _sig("i:ni i:nj a:array"),
     "zero_array_3D": _sig("i:ni i:nj i:nk a:array"),
