@@ -58,11 +58,13 @@ class Call {
   Back back_[16];
   int n_back_ = 0;
   bool staged_in_ = false;
-  void* host_tmp_[16];
+  bool host_visible_ = false;  // some array is pinned / registered / managed host memory used in place
+  void* host_tmp_[24];
   int n_host_tmp_ = 0;
 };
 
-bool is_device_pointer(const void* p);
+bool is_device_pointer(const void* p);  // a kernel can address it (device, or pinned / registered / managed host memory)
+bool is_device_memory(const void* p);   // device memory proper: calls on it are asynchronous
 
 // deferred zero fill (runtime.hip)
 bool defer_zero_enabled();

@@ -135,6 +135,50 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
 }
 
 // -------------------------------------------------------------------------------------------
+// Plan guards.  The host-side plans of the production kernels (band / minor-interval metadata, stage width) are
+// cached per table address; device-resident tables cannot be inspected by the host without draining the stream.
+// Instead of trusting the addresses, every call re-checks the tables ON THE DEVICE against the cached plan: an
+// order-independent weighted checksum of the index tables (tau) or the band alignment (Planck, Rayleigh).  On a
+// mismatch the guard flag is raised, the production kernels return at once and the direct kernels -- which read the
+// caller's tables themselves -- do the call; the host learns about it at its next plan look-up.  So tables changed in
+// place, or re-uploaded at the same addresses, give correct results without rte_hip_invalidate_plans().
+// -------------------------------------------------------------------------------------------
+__host__ __device__ inline unsigned guard_term(unsigned value, unsigned index) {
+  return (value + 0x9e3779b9u) * (2u * index + 1u);
+}
+struct GuardTables {
+  const int* ip[10];    // int tables
+  int in[10];
+  const Bool* bp[4];    // logical tables
+  int bn[4];
+};
+__global__ void __launch_bounds__(256) tables_guard_kernel(GuardTables t, unsigned expected, int* __restrict__ flag,
+                                                           int* __restrict__ stale) {
+  __shared__ unsigned acc;
+  if (threadIdx.x == 0) acc = 0;
+  __syncthreads();
+  unsigned h = 0, base = 0;
+  for (int a = 0; a < 10; ++a) {
+    for (int i = threadIdx.x; i < t.in[a]; i += 256) h += guard_term((unsigned)t.ip[a][i], base + (unsigned)i);
+    base += (unsigned)t.in[a];
+  }
+  for (int a = 0; a < 4; ++a) {
+    for (int i = threadIdx.x; i < t.bn[a]; i += 256) h += guard_term(t.bp[a][i] ? 1u : 0u, base + (unsigned)i);
+    base += (unsigned)t.bn[a];
+  }
+  atomicAdd(&acc, h);
+  __syncthreads();
+  if (threadIdx.x == 0 && acc != expected) { *flag = 1; *stale = 1; }
+}
+// band limits: whole chunks of gw g-points, ngpt a multiple of gw (what the stage loops of the production kernels assume)
+__global__ void bands_guard_kernel(int nbnd, int ngpt, const int* __restrict__ band_lims, int gw, int* __restrict__ flag,
+                                   int* __restrict__ stale) {
+  bool ok = gw > 0 && ngpt % gw == 0;
+  for (int b = threadIdx.x; b < nbnd; b += 64) ok = ok && (band_lims[2 * b] - 1) % gw == 0 && band_lims[2 * b + 1] % gw == 0;
+  if (!ok) { *flag = 1; *stale = 1; }
+}
+
+// -------------------------------------------------------------------------------------------
 // layer limits of the lower / upper atmosphere: reference :274-285 (minloc/maxloc with mask,
 // first extremal location; 0 = no such layer)
 // -------------------------------------------------------------------------------------------
@@ -1270,7 +1314,8 @@ tau_rayleigh_kernel(int ncol, int nlay, int ngpt, int neta, int ntemp, int idx_h
                     const Float* __restrict__ krayl, const Float* __restrict__ col_dry,
                     const Float* __restrict__ col_gas, const Float* __restrict__ fminor,
                     const int* __restrict__ jeta, const Bool* __restrict__ tropo,
-                    const int* __restrict__ jtemp, Float* __restrict__ tau_rayleigh) {
+                    const int* __restrict__ jtemp, Float* __restrict__ tau_rayleigh, const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   const int icol = blockIdx.x * blockDim.x + threadIdx.x;
   const int ilay = blockIdx.y, ibnd = blockIdx.z;
   if (icol >= ncol) return;
@@ -1386,7 +1431,8 @@ __device__ __forceinline__ void planck_direct_column(const PlanckArgs& q, const 
   }
 }
 
-__global__ void __launch_bounds__(256) planck_source_kernel(PlanckArgs q) {
+__global__ void __launch_bounds__(256) planck_source_kernel(PlanckArgs q, const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
   const int icol = blockIdx.x * blockDim.x + threadIdx.x;
   if (icol < q.ncol) planck_direct_column(q, icol, blockIdx.y);
 }
@@ -1418,6 +1464,7 @@ struct PlanckV7 {
   const Float *pf_g, *totplnk, *fmajor, *tlay, *tlev, *tsfc;
   Float *sfc_src, *lay_src, *lev_src, *sfc_jac;
   int* worklist;  // [0] = count, then (tile, band) pairs for planck_source_worklist_kernel
+  const int* skip_if;  // plan guard raised: the direct kernel does the call
 #ifdef EXP_CLOCKS
   unsigned long long* clocks;
 #endif
@@ -1429,6 +1476,7 @@ __global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
   constexpr int PSLAB = 8704;  // 68 KB: no minor tables here and 2 blocks per CU, so the slab can be larger
   __shared__ __align__(16) Float slab[PSLAB];
   extern __shared__ Float tpl[];  // totplnk(:, ibnd)
+  if (*a.skip_if) return;
   const int tid = threadIdx.x;
   const int ibnd = blockIdx.y;
   const unsigned ncol = a.ncol, nlay = a.nlay;
@@ -1609,6 +1657,7 @@ __global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd,
   __shared__ int rng[4];
   __shared__ int erng[MAXB][2];
   __shared__ int flav[MAXB][2];  // flavor (0-based) of band b per tropo regime
+  if (*a.skip_if) return;
   const int tid = threadIdx.x;
   const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
   const unsigned ncl = ncol * nlay;
@@ -1662,6 +1711,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
   __shared__ __align__(16) Float slab[2][SLAB];
   __shared__ int gl[MAXL][6];       // per layer: Tmin, nT, Pmin, nP, emin, nE
   extern __shared__ Float tpl[];    // totplnk(:, ibnd)
+  if (*a.skip_if) return;
   const int tid = threadIdx.x;
   // the bands of one column tile are neighbours in launch order (band = fast grid index): they run at about the
   // same time and share the tile's index arrays and, per flavor, its interpolation weights in the caches
@@ -1888,6 +1938,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
 // while layer l is computed; no barrier in the layer loop.
 // -------------------------------------------------------------------------------------------
 struct RaylArgs {
+  const int* skip_if;  // plan guard raised: the direct kernel does the call
   int ncol, nlay, ngpt, neta, ntemp, idx_h2o;
   const int *gpoint_flavor, *jeta, *jtemp;
   const Float *krayl, *col_dry, *col_gas, *fminor;
@@ -1899,6 +1950,7 @@ template <int BS, int G>
 __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
   constexpr int RS = G + 2;
   extern __shared__ __align__(16) Float rslab[];  // [2 tropo][neta][ntemp] rows of RS Floats
+  if (*a.skip_if) return;
   const int tid = threadIdx.x;
   // the g-point chunk is the fast grid index: the chunks of one column tile run together and share its inputs in cache
   // (pinning a tile's chunks to one XCD, as planck_source_v9_kernel does, measured slower here: 2.8 vs 2.45 ms)
@@ -1969,6 +2021,26 @@ static int g_tau_variant = 9;
 static int g_planck_variant = 9;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
 static int g_geom_variant = 2;  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
 static int g_plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget cached host-side plans
+// Raised ON THE DEVICE by the plan guards when a cached plan no longer matches the caller's tables: one int in pinned,
+// device-mapped host memory that the guard kernels write directly.  The host looks at it at every plan look-up and then
+// drops the cached plans, so that they are rebuilt instead of the direct kernels doing every later call.
+static volatile int* g_stale_host = nullptr;
+static int* g_stale_dev = nullptr;
+static int* stale_flag() {
+  if (!g_stale_dev) {
+    HIP_CHECK(hipHostMalloc((void**)&g_stale_host, sizeof(int), hipHostMallocMapped));
+    *g_stale_host = 0;
+    HIP_CHECK(hipHostGetDevicePointer((void**)&g_stale_dev, (void*)g_stale_host, 0));
+  }
+  return g_stale_dev;
+}
+static void stale_poll() {
+  (void)stale_flag();
+  if (*g_stale_host) {  // a guard fired in an earlier call: forget every plan
+    ++g_plan_epoch;
+    *g_stale_host = 0;
+  }
+}
 
 namespace {
 struct TauPlanCache {
@@ -1978,6 +2050,7 @@ struct TauPlanCache {
   bool fast_ok = false;
   int gw = 0;  // g-points per stage of the production kernels (16 or 8)
   bool uploads_pending = false;  // bands changed since the last upload to the device
+  unsigned guard = 0;            // checksum of the index tables the plan was built from (tables_guard_kernel)
   std::vector<BandMeta> bands;
   bool matches(const void* const* k, const int* d, int e) const {
     if (e != epoch) return false;
@@ -2098,6 +2171,8 @@ void rrtmgp_compute_tau_absorption(
     hipLaunchKernelGGL(tropo_limits_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, st, ncol, nlay, d_play, d_tropo, lim,
                        overlap);
   }
+  int* d_stale = stale_flag();
+  stale_poll();
   // ---- host-side plan from the small index tables (cached while the caller's table pointers and
   // dimensions do not change; rte_hip_release() drops the cache)
   // a few plans are kept (e.g. an LW and an SW k-distribution used alternately), least recently built evicted
@@ -2190,9 +2265,37 @@ void rrtmgp_compute_tau_absorption(
         m.flags = (sd[r][i] ? 1 : 0) | (sc[r][i] ? 2 : 0);
       }
     }
+    {  // checksum of everything the plan depends on, in the order tables_guard_kernel walks it
+      const int* gf = c.host(gpoint_flavor, (size_t)2 * ngpt);
+      const int* ia[10] = {gf, bl, ml[0], ml[1], ks[0], ks[1], im[0], im[1], is[0], is[1]};
+      const int in[10] = {2 * ngpt, 2 * nbnd, 2 * nlo, 2 * nup, nlo, nup, nlo, nup, nlo, nup};
+      const Bool* ba[4] = {sd[0], sd[1], sc[0], sc[1]};
+      const int bn[4] = {nlo, nup, nlo, nup};
+      unsigned h = 0, base = 0;
+      for (int a_ = 0; a_ < 10; ++a_) {
+        for (int i = 0; i < in[a_]; ++i) h += guard_term((unsigned)ia[a_][i], base + (unsigned)i);
+        base += (unsigned)in[a_];
+      }
+      for (int a_ = 0; a_ < 4; ++a_) {
+        for (int i = 0; i < bn[a_]; ++i) h += guard_term(ba[a_][i] ? 1u : 0u, base + (unsigned)i);
+        base += (unsigned)bn[a_];
+      }
+      cache.guard = h;
+    }
     cache.fast_ok = ok;
     cache.gw = ok ? gw : 0;
     cache.uploads_pending = true;
+  }
+  // A deferred zero fill turns the accumulate into an overwrite of the g-points the bands cover; if the bands do not
+  // tile 1..ngpt the fill is executed after all (zero_array would have zeroed the uncovered g-points too)
+  bool overwrite_ok = overwrite;
+  if (overwrite) {
+    std::vector<char> covered((size_t)ngpt, 0);
+    for (const BandMeta& bmh : cache.bands)
+      for (int g = bmh.gS; g <= bmh.gE && g < ngpt; ++g)
+        if (g >= 0) covered[g] = 1;
+    for (int g = 0; g < ngpt; ++g) overwrite_ok = overwrite_ok && covered[g];
+    if (!overwrite_ok) HIP_CHECK(hipMemsetAsync(d_tau, 0, sizeof(Float) * ncl * ngpt, st));
   }
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
   const bool fast = cache.fast_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) &&
@@ -2210,7 +2313,7 @@ void rrtmgp_compute_tau_absorption(
   a.kmajor = d_kmajor; a.lower = lo; a.upper = up;
   a.lim = lim; a.tropo = d_tropo; a.col_mix = d_col_mix; a.fmajor = d_fmajor; a.fminor = d_fminor;
   a.play = d_play; a.tlay = d_tlay; a.col_gas = d_col_gas; a.jeta = d_jeta; a.jtemp = d_jtemp; a.jpress = d_jpress;
-  a.tau = d_tau; a.overwrite = overwrite;
+  a.tau = d_tau; a.overwrite = overwrite_ok;
   a.run_if = fast ? overlap : nullptr;
   {
     rte::ProfScope p(fast ? "tau_absorption_fallback" : "tau_absorption_kernel");
@@ -2252,6 +2355,18 @@ void rrtmgp_compute_tau_absorption(
       hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(nku, 32), 1), dim3(256), tile_bytes, st, TE, 1, nku, up.kminor,
                          kup_g);
   }
+  {  // plan guard: the tables on the device must be the ones the cached plan was built from
+    GuardTables gt{};
+    const int* ia[10] = {d_gpoint_flavor, d_band_lims, lo.limits, up.limits, lo.kminor_start, up.kminor_start,
+                         lo.idx_minor, up.idx_minor, lo.idx_minor_scaling, up.idx_minor_scaling};
+    const int in[10] = {2 * ngpt, 2 * nbnd, 2 * nlo, 2 * nup, nlo, nup, nlo, nup, nlo, nup};
+    const Bool* ba[4] = {lo.scales_with_density, up.scales_with_density, lo.scale_by_complement, up.scale_by_complement};
+    const int bn[4] = {nlo, nup, nlo, nup};
+    for (int i = 0; i < 10; ++i) { gt.ip[i] = ia[i]; gt.in[i] = in[i]; }
+    for (int i = 0; i < 4; ++i) { gt.bp[i] = ba[i]; gt.bn[i] = bn[i]; }
+    rte::ProfScope p("tau_absorption_setup");
+    hipLaunchKernelGGL(tables_guard_kernel, dim3(1), dim3(256), 0, st, gt, cache.guard, overlap, d_stale);
+  }
   TauV5 v;
   v.ncol = ncol; v.nlay = nlay; v.ngpt = ngpt; v.nbnd = nbnd; v.ntemp = ntemp; v.TE = TE; v.idx_h2o = *idx_h2o_;
   v.nk_lo = nkl; v.nk_up = nku;
@@ -2259,7 +2374,7 @@ void rrtmgp_compute_tau_absorption(
   v.kmaj = kmaj_g; v.klo = klo_g; v.kup = kup_g;
   v.lim = lim; v.jeta = d_jeta; v.jtemp = d_jtemp; v.jpress = d_jpress; v.tropo = d_tropo;
   v.col_mix = d_col_mix; v.fmajor = d_fmajor; v.fminor = d_fminor; v.play = d_play; v.tlay = d_tlay;
-  v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap; v.overwrite = overwrite;
+  v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap; v.overwrite = overwrite_ok;
 #ifndef V7_BS
 #define V7_BS 256
 #define V7_MINW 2
@@ -2298,10 +2413,10 @@ void rrtmgp_compute_tau_absorption(
     }                                                                                                             \
     rte::ProfScope p("tau_absorption_kernel");                                                                    \
     if (mm4) {                                                                                                    \
-      if (overwrite) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4>), grid, blk, dyn, st, v, cg); \
+      if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4>), grid, blk, dyn, st, v, cg); \
       else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4>), grid, blk, dyn, st, v, cg); \
     } else {                                                                                                      \
-      if (overwrite) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MAXM>), grid, blk, dyn, st, v, cg); \
+      if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MAXM>), grid, blk, dyn, st, v, cg); \
       else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, MAXM>), grid, blk, dyn, st, v, cg); \
     }                                                                                                             \
   } while (0)
@@ -2358,6 +2473,7 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
   const Bool* d_tropo = c.in(tropo, ncl);
   const int* d_jtemp = c.in(jtemp, ncl);
   Float* d_tau = c.out(tau_rayleigh, ncl * ngpt);
+  stale_poll();
   // production kernel: 16-aligned whole-chunk bands (checked once per table pointer), aligned inputs
   static const void* bl_key = nullptr;
   static int bl_n = -1, bl_epoch = -1;
@@ -2380,26 +2496,34 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
     bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = g_plan_epoch;
   }
   const size_t slab_bytes = sizeof(Float) * 2 * (size_t)ntemp * neta * (bl_gw + 2);
-  if (bl_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) && slab_bytes <= 64 * 1024 &&
-      ((uintptr_t)d_fminor % 16) == 0 && ((uintptr_t)d_jeta % 8) == 0) {
+  hipStream_t st = rte::stream();
+  const bool fast = bl_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) && slab_bytes <= 64 * 1024 &&
+                    ((uintptr_t)d_fminor % 16) == 0 && ((uintptr_t)d_jeta % 8) == 0;
+  int* guard = nullptr;
+  if (fast) {
+    // plan guard: the band limits on the device must have the alignment the cached stage width assumes
+    guard = (int*)rte::scratch(sizeof(int));
+    HIP_CHECK(hipMemsetAsync(guard, 0, sizeof(int), st));
+    hipLaunchKernelGGL(bands_guard_kernel, dim3(1), dim3(64), 0, st, nbnd, ngpt, d_band_lims, bl_gw, guard, stale_flag());
     RaylArgs q;
+    q.skip_if = guard;
     q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.neta = neta; q.ntemp = ntemp; q.idx_h2o = *idx_h2o_;
     q.gpoint_flavor = d_gpoint_flavor; q.jeta = d_jeta; q.jtemp = d_jtemp; q.krayl = d_krayl; q.col_dry = d_col_dry;
     q.col_gas = d_col_gas; q.fminor = d_fminor; q.tropo = d_tropo; q.tau_rayleigh = d_tau;
     rte::ProfScope p("tau_rayleigh_kernel");
     if (bl_gw == 16)
-      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 16>), dim3(ngpt / 16, cdiv(ncol, 256)), dim3(256), slab_bytes,
-                         rte::stream(), q);
+      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 16>), dim3(ngpt / 16, cdiv(ncol, 256)), dim3(256), slab_bytes, st, q);
     else
-      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 8>), dim3(ngpt / 8, cdiv(ncol, 256)), dim3(256), slab_bytes,
-                         rte::stream(), q);
-    return;
+      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 8>), dim3(ngpt / 8, cdiv(ncol, 256)), dim3(256), slab_bytes, st, q);
   }
-  rte::ProfScope p("tau_rayleigh_kernel");
-  dim3 grid(cdiv(ncol, 256), nlay, nbnd), block(256);
-  hipLaunchKernelGGL(tau_rayleigh_kernel, grid, block, 0, rte::stream(), ncol, nlay, ngpt, neta, ntemp,
-                     *idx_h2o_, d_gpoint_flavor, d_band_lims, d_krayl, d_col_dry, d_col_gas, d_fminor, d_jeta,
-                     d_tropo, d_jtemp, d_tau);
+  {
+    // the direct kernel: the whole call when the production kernel does not apply, otherwise only if the guard fired
+    rte::ProfScope p(fast ? "tau_rayleigh_fallback" : "tau_rayleigh_kernel");
+    dim3 grid(cdiv(ncol, 256), nlay, nbnd), block(256);
+    hipLaunchKernelGGL(tau_rayleigh_kernel, grid, block, 0, st, ncol, nlay, ngpt, neta, ntemp,
+                       *idx_h2o_, d_gpoint_flavor, d_band_lims, d_krayl, d_col_dry, d_col_gas, d_fminor, d_jeta,
+                       d_tropo, d_jtemp, d_tau, (const int*)guard);
+  }
 }
 
 void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int* nbnd_,
@@ -2437,6 +2561,8 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   Float* d_sfc_jac = c.out(sfc_source_Jac, (size_t)ncol * ngpt);
   const Float totplnk_delta_r = (Float)1 / *totplnk_delta;  // :636
   hipStream_t st = rte::stream();
+  int* d_stale = stale_flag();
+  stale_poll();
   // production kernel: 16-aligned whole-chunk bands (checked once per table pointer), aligned inputs
   static const void* bl_key = nullptr;
   static int bl_n = -1, bl_epoch = -1;
@@ -2470,9 +2596,13 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   q.sfc_source_Jac = d_sfc_jac;
   if (!fast) {
     rte::ProfScope p("planck_source_kernel");
-    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q);
+    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)nullptr);
     return;
   }
+  // plan guard: the band limits on the device must have the alignment the cached stage width assumes
+  int* guard = (int*)rte::scratch(sizeof(int));
+  HIP_CHECK(hipMemsetAsync(guard, 0, sizeof(int), st));
+  hipLaunchKernelGGL(bands_guard_kernel, dim3(1), dim3(64), 0, st, nbnd, ngpt, d_band_lims, bl_gw, guard, d_stale);
   const int TE = ntemp * neta;
   Float* pf_g = (Float*)rte::scratch(sizeof(Float) * (size_t)TE * (npres + 1) * ngpt);
   {
@@ -2487,6 +2617,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   v.jpress = d_jpress; v.tropo = d_tropo; v.pf_g = pf_g; v.totplnk = d_totplnk; v.fmajor = d_fmajor;
   v.tlay = d_tlay; v.tlev = d_tlev; v.tsfc = d_tsfc;
   v.sfc_src = d_sfc_src; v.lay_src = d_lay_src; v.lev_src = d_lev_src; v.sfc_jac = d_sfc_jac;
+  v.skip_if = guard;
   constexpr int BS = 256;
   v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 2 * (size_t)cdiv(ncol, BS) * nbnd));
   HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
@@ -2495,7 +2626,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
                        (size_t)ncol * (nlay + 1) < ((size_t)1 << 29);
   if (!planck9 && bl_gw != 16) {  // 8-wide stages exist only in the specialised-wave kernel
     rte::ProfScope p("planck_source_kernel");
-    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q);
+    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)nullptr);
     return;
   }
   if (planck9) {
@@ -2513,7 +2644,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     Geom2Args ga{};
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = true;
     ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.band_lims = d_band_lims;
-    ga.gpoint_flavor = d_gpoint_flavor; ga.worklist = v.worklist; ga.flags = d_flags;
+    ga.gpoint_flavor = d_gpoint_flavor; ga.worklist = v.worklist; ga.flags = d_flags; ga.skip_if = guard;
 #define RTE_LAUNCH_PLANCK9(GW)                                                                                    \
   do {                                                                                                            \
     {                                                                                                             \
@@ -2547,6 +2678,8 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     // (tile, band) pairs whose pfrac bounding box exceeded the LDS slab at some layer
     rte::ProfScope p("planck_source_fallback");
     hipLaunchKernelGGL(planck_source_worklist_kernel, dim3(1024), dim3(256), 0, st, q, (const int*)v.worklist, wl_tile);
+    // the whole call on the direct kernel if the guard fired
+    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)guard);
   }
 }
 

@@ -71,16 +71,30 @@ void* persistent(int slot, size_t bytes, bool* fresh) {
 }
 
 // ---- pointer classification ------------------------------------------------------------------
-bool is_device_pointer(const void* p) {
-  if (!p) return true;
+// 0: ordinary host memory (staged through the arena), 1: device memory (launch in place, asynchronously),
+// 2: host-VISIBLE memory a kernel can address (pinned / registered host memory, managed memory): launched in place
+//    through `dev`, but the host may read it as soon as the call returns, so the call must drain the stream.
+static int classify(const void* p, void** dev) {
+  *dev = const_cast<void*>(p);
+  if (!p) return 1;
   hipPointerAttribute_t a;
   hipError_t e = hipPointerGetAttributes(&a, p);
   if (e != hipSuccess) {
     (void)hipGetLastError();  // plain malloc'ed host memory: "invalid value"
-    return false;
+    return 0;
   }
-  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged ||
-         (a.type == hipMemoryTypeHost && a.devicePointer != nullptr);
+  if (a.type == hipMemoryTypeDevice) return 1;
+  if (a.type == hipMemoryTypeManaged) return 2;
+  if (a.type == hipMemoryTypeHost && a.devicePointer != nullptr) { *dev = a.devicePointer; return 2; }
+  return 0;
+}
+bool is_device_pointer(const void* p) {
+  void* d;
+  return classify(p, &d) != 0;
+}
+bool is_device_memory(const void* p) {
+  void* d;
+  return p && classify(p, &d) == 1;
 }
 
 // ---- deferred zero fill (opt-in, rte_hip_defer_zero) --------------------------------------------
@@ -122,7 +136,11 @@ Call::Call(const char* n) : name(n) {
 }
 
 void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out) {
-  if (!p || bytes == 0 || is_device_pointer(p)) return p;
+  if (!p || bytes == 0) return p;
+  void* dv;
+  const int kind = classify(p, &dv);
+  if (kind == 1) return p;
+  if (kind == 2) { host_visible_ = true; return dv; }  // in place, but synchronous for the caller (see ~Call)
   void* d = scratch(bytes);
   if (copy_in) {
     HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, g_stream));
@@ -137,6 +155,10 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out) {
 
 const void* Call::to_host(const void* p, size_t bytes) {
   if (!p || bytes == 0 || !is_device_pointer(p)) return p;
+  if (n_host_tmp_ >= (int)(sizeof(host_tmp_) / sizeof(host_tmp_[0]))) {
+    fprintf(stderr, "rte_rrtmgp_hip: %s: too many host copies of device tables\n", name);
+    abort();
+  }
   void* h = malloc(bytes);
   HIP_CHECK(hipMemcpyAsync(h, p, bytes, hipMemcpyDeviceToHost, g_stream));
   HIP_CHECK(hipStreamSynchronize(g_stream));
@@ -147,7 +169,8 @@ const void* Call::to_host(const void* p, size_t bytes) {
 Call::~Call() {
   for (int i = 0; i < n_back_; ++i)
     HIP_CHECK(hipMemcpyAsync(back_[i].host, back_[i].dev, back_[i].bytes, hipMemcpyDeviceToHost, g_stream));
-  if (n_back_ > 0 || staged_in_) HIP_CHECK(hipStreamSynchronize(g_stream));
+  // host arrays (staged, or host-visible memory used in place): the caller owns them again when the call returns
+  if (n_back_ > 0 || staged_in_ || host_visible_) HIP_CHECK(hipStreamSynchronize(g_stream));
   for (int i = 0; i < n_host_tmp_; ++i) free(host_tmp_[i]);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -206,7 +229,11 @@ extern "C" {
 
 int rte_hip_set_stream(void* s) {
   std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  if ((hipStream_t)s == rte::g_stream) return 0;
+  // work queued on the old stream still uses the scratch arena, the persistent slots and recorded zero fills:
+  // materialise the fills there and drain it before anything is launched on the new stream
   rte::flush_pending_zeros();
+  HIP_CHECK(hipStreamSynchronize(rte::g_stream));
   rte::g_stream = (hipStream_t)s;
   return 0;
 }

@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(256) fill_kernel(Float* __restrict__ a, size_t
 
 void fill(const char* name, Float* a, size_t n, Float v) {
   if (n == 0) return;
-  if (v == (Float)0 && rte::defer_zero_enabled() && rte::is_device_pointer(a)) {
+  if (v == (Float)0 && rte::defer_zero_enabled() && rte::is_device_memory(a)) {
     rte::defer_zero(a, n * sizeof(Float));  // materialised by the next library call unless consumed
     return;
   }

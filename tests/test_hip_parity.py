@@ -264,6 +264,102 @@ def test_tile_geometry_prepasses_agree(hip, top_at_1):
         assert np.isfinite(outs[2][k]).all() and outs[2][k].max() > 0, k
 
 
+def test_plans_follow_tables_changed_in_place(hip, oracle_c):
+    """The host-side plans of the production kernels are cached per table ADDRESS; the device-side plan guards must
+    notice tables whose CONTENTS changed behind those addresses (no rte_hip_invalidate_plans()): the call then runs
+    on the direct kernels, and the next one on a rebuilt plan.  Checked for the minor-interval metadata
+    (tau_absorption) and for band limits that no longer have the cached stage alignment (Planck, tau)."""
+    import torch
+    from rte_rrtmgp_amd import synth
+
+    xp, xn = frontend.TorchArrays("cuda:0"), frontend.NumpyArrays()
+    ncol, nlay = 1100, 18
+
+    def both(kd, atm, go):
+        A = xp.asarray
+        args = [A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tsfc", "col_gas", "tlev")]
+        b = go.gas_optics_lw(ncol, nlay, *args, atm.top_at_1)
+        gon = frontend.GasOptics(oracle_c, kd, xn)
+        bn = gon.gas_optics_lw(ncol, nlay, atm.play, atm.plev, atm.tlay, atm.tsfc, atm.col_gas, atm.tlev, atm.top_at_1)
+        for k in ("tau", "lay_src", "lev_src", "sfc_src"):
+            assert cases.rel_err(xp.to_numpy(b[k]), bn[k]) <= RTOL_GAS, k
+
+    kd = synth.make_kdist("lw", ngpt=64, nbnd=4, nminor_lower=11, nminor_upper=7)
+    atm = synth.make_atmosphere(ncol, nlay, seed=21, kdist=kd)
+    go = frontend.GasOptics(hip, kd, xp)
+    both(kd, atm, go)  # builds the plans
+    # 1. other absorbers / scalings behind the same device addresses
+    rng = np.random.default_rng(3)
+    for reg in ("lower", "upper"):
+        n = kd.arrays[f"idx_minor_{reg}"].shape[0]
+        kd.arrays[f"idx_minor_{reg}"][:] = rng.integers(1, kd.ngas + 1, n)
+        kd.arrays[f"minor_scales_with_density_{reg}"][:] = ~kd.arrays[f"minor_scales_with_density_{reg}"]
+        go.t[f"idx_minor_{reg}"].copy_(torch.from_numpy(kd.arrays[f"idx_minor_{reg}"]))
+        go.t[f"minor_scales_with_density_{reg}"].copy_(torch.from_numpy(kd.arrays[f"minor_scales_with_density_{reg}"]))
+    both(kd, atm, go)  # guard fires: direct kernels
+    both(kd, atm, go)  # rebuilt plan
+    # 2. band limits that break the 16-alignment the cached stage width assumed: bands of 24 + 8 + 16 + 16 g-points
+    bl = np.asfortranarray(np.array([[1, 25, 33, 49], [24, 32, 48, 64]], dtype=np.int32))
+    kd.arrays["band_lims_gpt"][:] = bl
+    go.t["band_lims_gpt"].copy_(torch.from_numpy(np.ascontiguousarray(bl.T)))
+    gb = np.repeat(np.arange(1, 5), [24, 8, 16, 16]).astype(np.int32)
+    kd.arrays["gpoint_bands"][:] = gb
+    go.t["gpoint_bands"].copy_(torch.from_numpy(gb))
+    for reg in ("lower", "upper"):  # minor intervals stay whole bands
+        lims = kd.arrays[f"minor_limits_gpt_{reg}"]
+        band_of = (lims[0] - 1) // 16
+        lims[0], lims[1] = bl[0][band_of], bl[1][band_of]
+        kd.arrays[f"kminor_start_{reg}"][:] = 1 + np.concatenate([[0], np.cumsum(lims[1] - lims[0] + 1)[:-1]])
+        go.t[f"minor_limits_gpt_{reg}"].copy_(torch.from_numpy(np.ascontiguousarray(lims.T)))
+        go.t[f"kminor_start_{reg}"].copy_(torch.from_numpy(kd.arrays[f"kminor_start_{reg}"]))
+    gf = kd.arrays["gpoint_flavor"]
+    gf[:, :] = gf[:, bl[0][gb - 1] - 1]  # flavors stay constant within the new bands
+    go.t["gpoint_flavor"].copy_(torch.from_numpy(np.ascontiguousarray(gf.T)))
+    both(kd, atm, go)
+    both(kd, atm, go)
+    torch.cuda.synchronize()
+
+
+def test_pinned_host_arrays_are_synchronous(hip, oracle_c):
+    """Host-VISIBLE memory (pinned: hipHostMalloc / torch pin_memory) is addressed by the kernels in place, but it is
+    the caller's host array: the call must have finished when it returns (no stale fluxes read by the host)."""
+    import torch
+
+    ncol, nlay, ngpt = 3000, 40, 64
+    rng = np.random.default_rng(8)
+
+    def pinned(shape, fill):
+        t = torch.empty(tuple(reversed(shape)), dtype=torch.float64).pin_memory()
+        a = t.numpy().T  # Fortran-ordered view of the pinned buffer
+        a[...] = fill
+        return t, a
+
+    keep = []
+    arrs = {}
+    for name, shape, fill in (("tau", (ncol, nlay, ngpt), rng.uniform(0.0, 2.0, (ncol, nlay, ngpt))),
+                              ("lay", (ncol, nlay, ngpt), rng.uniform(1.0, 9.0, (ncol, nlay, ngpt))),
+                              ("lev", (ncol, nlay + 1, ngpt), rng.uniform(1.0, 9.0, (ncol, nlay + 1, ngpt))),
+                              ("emis", (ncol, ngpt), 0.97), ("sfc", (ncol, ngpt), 5.0), ("inc", (ncol, ngpt), 0.0),
+                              ("Ds", (ncol, ngpt, 1), 1.66), ("up", (ncol, nlay + 1), -1.0), ("dn", (ncol, nlay + 1), -1.0)):
+        t, a = pinned(shape, fill)
+        keep.append(t)
+        arrs[name] = a
+    w = np.array([1.0])
+    for _ in range(3):
+        arrs["up"][...] = -1.0
+        hip.rte_lw_solver_noscat(ncol, nlay, ngpt, False, 1, arrs["Ds"], w, arrs["tau"], arrs["lay"], arrs["lev"], arrs["emis"],
+                                 arrs["sfc"], arrs["inc"], arrs["tau"], arrs["tau"], True, arrs["up"], arrs["dn"], False,
+                                 arrs["sfc"], arrs["up"], False, arrs["tau"], arrs["tau"])
+        got_up = arrs["up"].copy()  # read immediately: no torch / HIP synchronisation by the caller
+        assert (got_up > 0).all()
+    F = np.asfortranarray
+    ru, rd = F(np.empty((ncol, nlay + 1))), F(np.empty((ncol, nlay + 1)))
+    oracle_c.rte_lw_solver_noscat(ncol, nlay, ngpt, False, 1, F(arrs["Ds"]), w, F(arrs["tau"]), F(arrs["lay"]), F(arrs["lev"]),
+                                  F(arrs["emis"]), F(arrs["sfc"]), F(arrs["inc"]), F(arrs["tau"]), F(arrs["tau"]), True, ru, rd, False,
+                                  F(arrs["sfc"]), ru.copy(order="F"), False, F(arrs["tau"]), F(arrs["tau"]))
+    assert cases.rel_err(got_up, ru) <= RTOL_FLUX
+
+
 
 def test_tau_rayleigh_paths_agree(hip, oracle_c):
     """The production Rayleigh kernel (whole (T, eta) plane of a band staged in LDS, layers walked by the
