@@ -251,3 +251,23 @@ def rel_err(a, b):
     if den == 0:
         return float(np.max(np.abs(a)))
     return float(np.max(np.abs(a - b)) / den)
+
+
+def elem_err(a, b, floor_frac=1e-8):
+    """Elementwise relative error  max |a-b| / max(|b|, floor)  with the absolute floor taken PER PLANE of the last
+    (g-point / band) axis: floor = floor_frac * max|b[..., g]|.  Unlike rel_err (one max-norm over the whole array),
+    an O(1) relative error in a weak g-point -- optical depths and sources span many decades across g-points --
+    cannot hide behind the strong ones; the floor only forgives values that are negligible inside their own plane."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind in "ib" or b.dtype.kind in "ib":
+        return 0.0 if np.array_equal(a, b) else float("inf")
+    if b.size == 0:
+        return 0.0
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    if b.ndim >= 2:
+        plane_max = np.max(np.abs(b).reshape(-1, b.shape[-1]), axis=0)
+        floor = (floor_frac * plane_max).reshape((1,) * (b.ndim - 1) + (-1,))
+    else:
+        floor = floor_frac * np.max(np.abs(b))
+    den = np.maximum(np.abs(b), np.maximum(floor, 1e-300))
+    return float(np.max(np.abs(a - b) / den))

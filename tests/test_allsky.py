@@ -70,3 +70,62 @@ def test_hip_matches_oracle(kind, top_at_1):
     out = _run(hip, frontend.TorchArrays("cuda:0"), kind, kd, atm, tb, cl, ncol, nlay)
     for k in ref:
         assert _rel(out[k], ref[k]) <= 1e-12, k
+
+
+def _golden():
+    import importlib.util
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_allsky_golden", os.path.join(here, "make_allsky_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, np.load(os.path.join(here, "allsky_72.npz"))
+
+
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+def test_oracle_matches_allsky_golden(kind):
+    """The C oracle on the all-sky chain at the real shape of BASELINE configs[3] (72 layers, g256 / g224 tables)
+    against the committed fixture, which holds the REFERENCE kernels' results (tests/golden/make_allsky_golden.py)."""
+    from oracle import oracle as O
+
+    mk, z = _golden()
+    kd, atm, tb, cl = mk.setup(kind)
+    assert str(z[f"{kind}.__digest__"]) == mk.digest(kd, atm, tb, cl), "fixture was made from different inputs"
+    got = mk.run(O.load_c(), frontend.NumpyArrays(), kind, kd, atm, tb, cl, mk.NCOL)
+    for k, v in got.items():
+        ref = z[f"{kind}.{k}|full"] if v.ndim == 2 else z[f"{kind}.{k}|sample"]
+        mine = v if v.ndim == 2 else v.ravel(order="F")[::mk.SAMPLE]
+        assert _rel(mine, ref) <= 1e-12, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+def test_hip_matches_allsky_golden(kind):
+    """The HIP chain against the same fixture.  The fixture's 24 columns are tiled 30 times (720 columns: columns are
+    independent, so every copy must reproduce the golden column) -- that puts the call on the PRODUCTION kernels: slab
+    gas optics with g256 / g224 tables and the 9-layers-per-wave segmented solvers that `bench.py --workload allsky`
+    runs at 72 layers."""
+    from rte_rrtmgp_amd import hiplib
+
+    mk, z = _golden()
+    rep = 30
+    kd, atm, tb, cl = mk.setup(kind)
+    assert str(z[f"{kind}.__digest__"]) == mk.digest(kd, atm, tb, cl)
+    tile = lambda a: np.asfortranarray(np.concatenate([a] * rep, axis=0))  # noqa: E731
+    for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry", "vmr"):
+        setattr(atm, k, tile(getattr(atm, k)))
+    atm.ncol = mk.NCOL * rep
+    cl = {k: tile(v) for k, v in cl.items()}
+    out = mk.run(hiplib.load(), frontend.TorchArrays("cuda:0"), kind, kd, atm, tb, cl, mk.NCOL * rep)
+    for k, v in out.items():
+        if v.ndim == 2:  # broadband fluxes: every copy of the 24 columns against the golden values
+            ref = z[f"{kind}.{k}|full"]
+            for r in range(rep):
+                blk = v[r * mk.NCOL:(r + 1) * mk.NCOL]
+                assert _rel(blk, ref) <= 1e-10, (k, r)
+                assert np.max(np.abs(blk - ref) / np.maximum(np.abs(ref), 1e-4 * np.abs(ref).max())) <= 1e-8, (k, r)
+        else:  # optical properties: the first copy at the fixture's sample points
+            first = v[:mk.NCOL].ravel(order="F")[::mk.SAMPLE]
+            assert _rel(first, z[f"{kind}.{k}|sample"]) <= 1e-12, k
+            assert np.array_equal(v[:mk.NCOL], v[mk.NCOL:2 * mk.NCOL]), k  # copies are bit-identical

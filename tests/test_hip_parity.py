@@ -41,12 +41,20 @@ def oracle_c():
     return O.load_c()
 
 
+# elementwise metric (cases.elem_err): per-element relative error, absolute floor per g-point plane.  Fluxes are sums
+# and differences of terms of either sign, so the floor is higher there (1e-4 of the plane's maximum).
+ETOL_GAS, ETOL_FLUX = 1e-11, 1e-8
+
+
 def _check(out, ref, label):
     assert set(ref) <= set(out)
     worst = (0.0, None)
     for k in ref:
         e = cases.rel_err(out[k], ref[k])
         assert e <= _tol(k), f"{label}: {k} rel err {e:.3e} > {_tol(k):.1e}"
+        gas = _tol(k) == RTOL_GAS
+        ee = cases.elem_err(out[k], ref[k], 1e-8 if gas else 1e-4)
+        assert ee <= (ETOL_GAS if gas else ETOL_FLUX), f"{label}: {k} elementwise rel err {ee:.3e}"
         assert np.isfinite(np.asarray(out[k], dtype=np.float64)).all(), k
         if e > worst[0]:
             worst = (e, k)
