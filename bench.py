@@ -56,6 +56,8 @@ def algorithmic_bytes_per_collay(nflav=10, ngas=8, ngpt=NGPT, nlay=NLAY, defer_z
         # --workload sw (config 3: SW gas optics + two-stream solver, broadband fluxes)
         "tau_rayleigh_kernel": (40 * F + 21) + 8 * N,
         "combine_2str_kernel": 16 * N + 24 * N,
+        # compute_tau_rayleigh fused with combine_abs_and_rayleigh (library extension): tau_abs in, tau / ssa / g out
+        "tau_rayleigh_combine_kernel": (40 * F + 21) + 8 * N + 24 * N,
         "sw_2stream_seg_kernel": (24 * N + 8 + 32 * N / nlay) + 24 * r,
     }
     return k
@@ -75,6 +77,7 @@ def allsky_bytes_per_collay(kd_lw, kd_sw, nlay):
         "lw_noscat_seg_kernel": lw["lw_noscat_seg_kernel"],
         "tau_rayleigh_kernel": sw["tau_rayleigh_kernel"],
         "combine_2str_kernel": sw["combine_2str_kernel"],
+        "tau_rayleigh_combine_kernel": sw["tau_rayleigh_combine_kernel"],
         "sw_2stream_seg_kernel": sw["sw_2stream_seg_kernel"],
         "cld_from_table_kernel": 2 * (17 + 24 * b1) + 2 * (17 + 24 * b2),
         "cloud_combine_kernel": (32 * b1 + 8 * b1) + (48 * b2 + 24 * b2),
@@ -301,7 +304,7 @@ def main():
         mu0, alb = xp.full((ncol, NLAY), 0.86), xp.full((ncol, kd.ngpt), 0.06)
 
     def step_sw():
-        go.gas_optics_sw(ncol, NLAY, play, plev, tlay, col_gas, col_dry, buffers=bufs)
+        go.gas_optics_sw(ncol, NLAY, play, plev, tlay, col_gas, col_dry, buffers=bufs, fuse_rayleigh=True)
         frontend.rte_sw(lib, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["ssa"], bufs["g"], mu0,
                         bufs["toa_src"], alb, alb, buffers=rb)
         if dist is not None:

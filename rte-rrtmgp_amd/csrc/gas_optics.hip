@@ -1308,35 +1308,59 @@ __global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a,
 // -------------------------------------------------------------------------------------------
 // compute_tau_rayleigh: reference :506-565
 // -------------------------------------------------------------------------------------------
+// combine_abs_and_rayleigh, 2-stream branch (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:1983-2002), applied to one value
+struct RaylCombine {
+  const Float* tau_abs;  // nullptr: plain compute_tau_rayleigh
+  Float *tau, *ssa, *g;  // tau may alias tau_abs
+};
+__device__ __forceinline__ void rayl_store(const RaylCombine& cb, Float* tau_rayleigh, size_t idx, Float tr) {
+  if (cb.tau_abs == nullptr) { tau_rayleigh[idx] = tr; return; }
+#ifdef RTE_USE_SP
+  const Float tiny2 = (Float)2 * 1.17549435e-38f;
+#else
+  const Float tiny2 = (Float)2 * 2.2250738585072014e-308;
+#endif
+  const Float t = cb.tau_abs[idx] + tr;
+  cb.ssa[idx] = t > tiny2 ? tr / t : (Float)0;
+  cb.tau[idx] = t;
+  cb.g[idx] = (Float)0;
+}
+
+// direct kernel: work items (column tile, layer, band) in grid stride (a small grid when it only stands by for the plan guard)
 __global__ void __launch_bounds__(256)
-tau_rayleigh_kernel(int ncol, int nlay, int ngpt, int neta, int ntemp, int idx_h2o,
+tau_rayleigh_kernel(int ncol, int nlay, int nbnd, int ngpt, int neta, int ntemp, int idx_h2o,
                     const int* __restrict__ gpoint_flavor, const int* __restrict__ band_lims_gpt,
                     const Float* __restrict__ krayl, const Float* __restrict__ col_dry,
                     const Float* __restrict__ col_gas, const Float* __restrict__ fminor,
                     const int* __restrict__ jeta, const Bool* __restrict__ tropo,
-                    const int* __restrict__ jtemp, Float* __restrict__ tau_rayleigh, const int* __restrict__ run_if) {
+                    const int* __restrict__ jtemp, Float* __restrict__ tau_rayleigh, RaylCombine cb,
+                    const int* __restrict__ run_if) {
   if (run_if && *run_if == 0) return;
-  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ilay = blockIdx.y, ibnd = blockIdx.z;
-  if (icol >= ncol) return;
-  const size_t ncl = (size_t)ncol * nlay;
-  const size_t cl = icol + (size_t)ncol * ilay;
-  const int gptS = band_lims_gpt[2 * ibnd] - 1, gptE = band_lims_gpt[2 * ibnd + 1] - 1;
-  const int itropo = tropo[cl] ? 0 : 1;
-  const int iflav = gpoint_flavor[itropo + 2 * gptS] - 1;
-  const size_t clf = cl + ncl * iflav;
-  const Float f0 = fminor[4 * clf], f1 = fminor[4 * clf + 1], f2 = fminor[4 * clf + 2], f3 = fminor[4 * clf + 3];
-  const int je1 = jeta[2 * clf], je2 = jeta[2 * clf + 1];
-  const int jT = jtemp[cl];
-  const size_t tn = (size_t)ntemp * neta;
-  const Float* kr = krayl + tn * ngpt * (size_t)itropo;
-  const size_t o1 = (size_t)(jT - 1) + (size_t)ntemp * (je1 - 1);
-  const size_t o2 = (size_t)jT + (size_t)ntemp * (je2 - 1);
-  const Float w = col_gas[cl + ncl * idx_h2o] + col_dry[cl];
-  for (int g = gptS; g <= gptE; ++g) {
-    const Float* kk = kr + tn * (size_t)g;
-    const Float k = f0 * kk[o1] + f1 * kk[o1 + ntemp] + f2 * kk[o2] + f3 * kk[o2 + ntemp];
-    tau_rayleigh[cl + ncl * (size_t)g] = k * w;
+  const unsigned tiles_x = (ncol + 255) / 256;
+  const size_t total = (size_t)tiles_x * nlay * nbnd;
+  for (size_t wi = blockIdx.x; wi < total; wi += gridDim.x) {
+    const int icol = (int)(wi % tiles_x) * 256 + threadIdx.x;
+    const int ilay = (int)((wi / tiles_x) % nlay), ibnd = (int)(wi / ((size_t)tiles_x * nlay));
+    if (icol >= ncol) continue;
+    const size_t ncl = (size_t)ncol * nlay;
+    const size_t cl = icol + (size_t)ncol * ilay;
+    const int gptS = band_lims_gpt[2 * ibnd] - 1, gptE = band_lims_gpt[2 * ibnd + 1] - 1;
+    const int itropo = tropo[cl] ? 0 : 1;
+    const int iflav = gpoint_flavor[itropo + 2 * gptS] - 1;
+    const size_t clf = cl + ncl * iflav;
+    const Float f0 = fminor[4 * clf], f1 = fminor[4 * clf + 1], f2 = fminor[4 * clf + 2], f3 = fminor[4 * clf + 3];
+    const int je1 = jeta[2 * clf], je2 = jeta[2 * clf + 1];
+    const int jT = jtemp[cl];
+    const size_t tn = (size_t)ntemp * neta;
+    const Float* kr = krayl + tn * ngpt * (size_t)itropo;
+    const size_t o1 = (size_t)(jT - 1) + (size_t)ntemp * (je1 - 1);
+    const size_t o2 = (size_t)jT + (size_t)ntemp * (je2 - 1);
+    const Float w = col_gas[cl + ncl * idx_h2o] + col_dry[cl];
+    for (int g = gptS; g <= gptE; ++g) {
+      const Float* kk = kr + tn * (size_t)g;
+      const Float k = f0 * kk[o1] + f1 * kk[o1 + ntemp] + f2 * kk[o2] + f3 * kk[o2 + ntemp];
+      rayl_store(cb, tau_rayleigh, cl + ncl * (size_t)g, k * w);
+    }
   }
 }
 
@@ -1939,6 +1963,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
 // -------------------------------------------------------------------------------------------
 struct RaylArgs {
   const int* skip_if;  // plan guard raised: the direct kernel does the call
+  RaylCombine cb;      // cb.tau_abs != nullptr: fused with combine_abs_and_rayleigh (2-stream)
   int ncol, nlay, ngpt, neta, ntemp, idx_h2o;
   const int *gpoint_flavor, *jeta, *jtemp;
   const Float *krayl, *col_dry, *col_gas, *fminor;
@@ -1946,7 +1971,7 @@ struct RaylArgs {
   Float* tau_rayleigh;
 };
 
-template <int BS, int G>
+template <int BS, int G, bool COMBINE>
 __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
   constexpr int RS = G + 2;
   extern __shared__ __align__(16) Float rslab[];  // [2 tropo][neta][ntemp] rows of RS Floats
@@ -1999,14 +2024,41 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
     const Float* k2 = rslab + (r * tn + jT + ntemp * (je2 - 1)) * RS;
     unsigned off = (ic + ncol * l) * (unsigned)sizeof(Float);
     asm volatile("" : "+v"(off));  // keep 64-bit store addresses out of the loop-invariant registers
+    Float ta[COMBINE ? G : 1];
+    if (COMBINE) {  // this layer's absorption optical depths, requested before the table arithmetic
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+        ta[j] = *reinterpret_cast<const Float*>(reinterpret_cast<const char*>(a.cb.tau_abs) + (size_t)ncl * (g0 + j) * sizeof(Float) + off);
+    }
 #pragma unroll
     for (int j = 0; j < G; j += 2) {
       // interpolate2D :757-760 with the reference's association, then :555
       const Float2 a0 = ld2(k1 + j), a1 = ld2(k1 + ntemp * RS + j), b0 = ld2(k2 + j), b1 = ld2(k2 + ntemp * RS + j);
       const Float ka = f0 * a0.x + f1 * a1.x + f2 * b0.x + f3 * b1.x;
       const Float kb = f0 * a0.y + f1 * a1.y + f2 * b0.y + f3 * b1.y;
-      *reinterpret_cast<Float*>(plane0 + gstride * j + off) = ka * w;
-      *reinterpret_cast<Float*>(plane0 + gstride * (j + 1) + off) = kb * w;
+      if (!COMBINE) {
+        *reinterpret_cast<Float*>(plane0 + gstride * j + off) = ka * w;
+        *reinterpret_cast<Float*>(plane0 + gstride * (j + 1) + off) = kb * w;
+      } else {
+        // combine_abs_and_rayleigh (2-stream branch, mo_gas_optics_rrtmgp.F90:1983-2002) on the value just formed:
+        // tau = tau_abs + tau_rayleigh, ssa = tau_rayleigh / tau, g = 0 -- tau_rayleigh never goes to memory
+#ifdef RTE_USE_SP
+        const Float tiny2 = (Float)2 * 1.17549435e-38f;
+#else
+        const Float tiny2 = (Float)2 * 2.2250738585072014e-308;
+#endif
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const size_t po = (size_t)ncl * (g0 + j + u) * sizeof(Float) + off;
+          const Float tr = (u == 0 ? ka : kb) * w;
+          const Float t = ta[j + u] + tr;
+          if (icol < ncol) {  // tau may alias tau_abs: the clamped lanes past the last column must not update it again
+            *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.ssa) + po) = t > tiny2 ? tr / t : (Float)0;
+            *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.tau) + po) = t;
+            *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.g) + po) = (Float)0;
+          }
+        }
+      }
     }
   }
 }
@@ -2450,18 +2502,16 @@ void rrtmgp_compute_tau_absorption(
   }
 }
 
-void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* nbnd_,
-                                 const int* ngpt_, const int* ngas_, const int* nflav_,
-                                 const int* neta_, const int* npres_, const int* ntemp_,
-                                 const int* gpoint_flavor, const int* band_lims_gpt,
-                                 const Float* krayl, const int* idx_h2o_, const Float* col_dry,
-                                 const Float* col_gas, const Float* fminor, const int* jeta,
-                                 const Bool* tropo, const int* jtemp, Float* tau_rayleigh) {
-  const int ncol = *ncol_, nlay = *nlay_, nbnd = *nbnd_, ngpt = *ngpt_, ngas = *ngas_,
-            nflav = *nflav_, neta = *neta_, ntemp = *ntemp_;
-  (void)npres_;
+}  // extern "C"
+// compute_tau_rayleigh, optionally fused with combine_abs_and_rayleigh (tau_abs != nullptr: tau_rayleigh is not written)
+static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta,
+                              int ntemp, const int* gpoint_flavor, const int* band_lims_gpt, const Float* krayl,
+                              int idx_h2o, const Float* col_dry, const Float* col_gas, const Float* fminor,
+                              const int* jeta, const Bool* tropo, const int* jtemp, Float* tau_rayleigh,
+                              const Float* tau_abs, Float* tau, Float* ssa, Float* g) {
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
-  rte::Call c("rrtmgp_compute_tau_rayleigh");
+  rte::Call c(api_name);
+  const bool combine = tau_abs != nullptr;
   const size_t ncl = (size_t)ncol * nlay;
   const int* d_gpoint_flavor = c.in(gpoint_flavor, (size_t)2 * ngpt);
   const int* d_band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
@@ -2472,7 +2522,14 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
   const int* d_jeta = c.in(jeta, 2 * ncl * nflav);
   const Bool* d_tropo = c.in(tropo, ncl);
   const int* d_jtemp = c.in(jtemp, ncl);
-  Float* d_tau = c.out(tau_rayleigh, ncl * ngpt);
+  Float* d_tau = combine ? nullptr : c.out(tau_rayleigh, ncl * ngpt);
+  RaylCombine cb{nullptr, nullptr, nullptr, nullptr};
+  if (combine) {
+    if (tau == tau_abs) { cb.tau = c.inout(tau, ncl * ngpt); cb.tau_abs = cb.tau; }
+    else { cb.tau_abs = c.in(tau_abs, ncl * ngpt); cb.tau = c.out(tau, ncl * ngpt); }
+    cb.ssa = c.out(ssa, ncl * ngpt);
+    cb.g = c.out(g, ncl * ngpt);
+  }
   stale_poll();
   // production kernel: 16-aligned whole-chunk bands (checked once per table pointer), aligned inputs
   static const void* bl_key = nullptr;
@@ -2507,23 +2564,54 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
     hipLaunchKernelGGL(bands_guard_kernel, dim3(1), dim3(64), 0, st, nbnd, ngpt, d_band_lims, bl_gw, guard, stale_flag());
     RaylArgs q;
     q.skip_if = guard;
-    q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.neta = neta; q.ntemp = ntemp; q.idx_h2o = *idx_h2o_;
+    q.cb = cb;
+    q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.neta = neta; q.ntemp = ntemp; q.idx_h2o = idx_h2o;
     q.gpoint_flavor = d_gpoint_flavor; q.jeta = d_jeta; q.jtemp = d_jtemp; q.krayl = d_krayl; q.col_dry = d_col_dry;
     q.col_gas = d_col_gas; q.fminor = d_fminor; q.tropo = d_tropo; q.tau_rayleigh = d_tau;
-    rte::ProfScope p("tau_rayleigh_kernel");
-    if (bl_gw == 16)
-      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 16>), dim3(ngpt / 16, cdiv(ncol, 256)), dim3(256), slab_bytes, st, q);
-    else
-      hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 8>), dim3(ngpt / 8, cdiv(ncol, 256)), dim3(256), slab_bytes, st, q);
+    rte::ProfScope p(combine ? "tau_rayleigh_combine_kernel" : "tau_rayleigh_kernel");
+    const dim3 g16(ngpt / 16, cdiv(ncol, 256)), g8(ngpt / 8, cdiv(ncol, 256));
+    if (bl_gw == 16) {
+      if (combine) hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 16, true>), g16, dim3(256), slab_bytes, st, q);
+      else hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 16, false>), g16, dim3(256), slab_bytes, st, q);
+    } else {
+      if (combine) hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 8, true>), g8, dim3(256), slab_bytes, st, q);
+      else hipLaunchKernelGGL((tau_rayleigh_slab_kernel<256, 8, false>), g8, dim3(256), slab_bytes, st, q);
+    }
   }
   {
     // the direct kernel: the whole call when the production kernel does not apply, otherwise only if the guard fired
-    rte::ProfScope p(fast ? "tau_rayleigh_fallback" : "tau_rayleigh_kernel");
-    dim3 grid(cdiv(ncol, 256), nlay, nbnd), block(256);
-    hipLaunchKernelGGL(tau_rayleigh_kernel, grid, block, 0, st, ncol, nlay, ngpt, neta, ntemp,
-                       *idx_h2o_, d_gpoint_flavor, d_band_lims, d_krayl, d_col_dry, d_col_gas, d_fminor, d_jeta,
-                       d_tropo, d_jtemp, d_tau, (const int*)guard);
+    rte::ProfScope p(fast ? "tau_rayleigh_fallback" : (combine ? "tau_rayleigh_combine_kernel" : "tau_rayleigh_kernel"));
+    const size_t items = (size_t)cdiv(ncol, 256) * nlay * nbnd;
+    const unsigned blocks = (unsigned)(fast ? (items < 2048 ? items : 2048) : (items < 262144 ? items : 262144));
+    hipLaunchKernelGGL(tau_rayleigh_kernel, dim3(blocks), dim3(256), 0, st, ncol, nlay, nbnd, ngpt, neta, ntemp,
+                       idx_h2o, d_gpoint_flavor, d_band_lims, d_krayl, d_col_dry, d_col_gas, d_fminor, d_jeta,
+                       d_tropo, d_jtemp, d_tau, cb, (const int*)guard);
   }
+}
+extern "C" {
+void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* nbnd_,
+                                 const int* ngpt_, const int* ngas_, const int* nflav_,
+                                 const int* neta_, const int* npres_, const int* ntemp_,
+                                 const int* gpoint_flavor, const int* band_lims_gpt,
+                                 const Float* krayl, const int* idx_h2o_, const Float* col_dry,
+                                 const Float* col_gas, const Float* fminor, const int* jeta,
+                                 const Bool* tropo, const int* jtemp, Float* tau_rayleigh) {
+  (void)npres_;
+  tau_rayleigh_impl("rrtmgp_compute_tau_rayleigh", *ncol_, *nlay_, *nbnd_, *ngpt_, *ngas_, *nflav_, *neta_, *ntemp_,
+                    gpoint_flavor, band_lims_gpt, krayl, *idx_h2o_, col_dry, col_gas, fminor, jeta, tropo, jtemp,
+                    tau_rayleigh, nullptr, nullptr, nullptr, nullptr);
+}
+// Library extension (scalars by value): compute_tau_rayleigh FUSED with the 2-stream branch of the frontend's
+// combine_abs_and_rayleigh (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:666-678, :1983-2002): tau = tau_abs + tau_rayleigh,
+// ssa = tau_rayleigh / tau, g = 0, without the tau_rayleigh array's round trip through memory.  tau may be tau_abs.
+int rte_hip_tau_rayleigh_combine_2str(int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int ntemp,
+                                      const int* gpoint_flavor, const int* band_lims_gpt, const Float* krayl, int idx_h2o,
+                                      const Float* col_dry, const Float* col_gas, const Float* fminor, const int* jeta,
+                                      const Bool* tropo, const int* jtemp, const Float* tau_abs, Float* tau, Float* ssa,
+                                      Float* g) {
+  tau_rayleigh_impl("rte_hip_tau_rayleigh_combine_2str", ncol, nlay, nbnd, ngpt, ngas, nflav, neta, ntemp, gpoint_flavor,
+                    band_lims_gpt, krayl, idx_h2o, col_dry, col_gas, fminor, jeta, tropo, jtemp, nullptr, tau_abs, tau, ssa, g);
+  return 0;
 }
 
 void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int* nbnd_,

@@ -793,22 +793,22 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         const Float tau_s = x.tau[i], w0_s = x.ssa[i], g_s = x.g[i];
         const Float gamma1 = ((Float)8 - w0_s * ((Float)5 + (Float)3 * g_s)) * (Float).25;
         const Float gamma2 = (Float)3 * (w0_s * ((Float)1 - g_s)) * (Float).25;
-        const Float kk = sqrt(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
-        const Float e1 = exp(-tau_s * kk);
+        const Float kk = rte::sqrt_nr(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
+        const Float e1 = rte::exp_nonpos(-tau_s * kk);
         const Float e2 = e1 * e1;
-        Float RT = (Float)1 / (kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
+        Float RT = rte::rcp_nr(kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
         R[i] = RT * gamma2 * ((Float)1 - e2);
         T[i] = RT * (Float)2 * kk * e1;
         const Float mu0_s = fmax(min_mu0, mu0r[i * 64]);
         const Float k_mu = kk * mu0_s;
         const Float om = (Float)1 - k_mu * k_mu;
-        RT = w0_s * RT / (fabs(om) >= (Float)RTE_EPS ? om : (Float)RTE_EPS);
+        RT = rte::div_nr(w0_s * RT, fabs(om) >= (Float)RTE_EPS ? om : (Float)RTE_EPS);
         const Float gamma3 = ((Float)2 - (Float)3 * mu0_s * g_s) * (Float).25;
         const Float gamma4 = (Float)1 - gamma3;
         const Float alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
         const Float alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
         const Float k_gamma3 = kk * gamma3, k_gamma4 = kk * gamma4;
-        const Float Tnoscat = exp(-tau_s / mu0_s);
+        const Float Tnoscat = rte::exp_nonpos(-rte::div_nr(tau_s, mu0_s));
         Float Rdir = RT * (((Float)1 - k_mu) * (alpha2 + k_gamma3) - ((Float)1 + k_mu) * (alpha2 - k_gamma3) * e2 -
                            (Float)2.0 * (k_gamma3 - alpha2 * k_mu) * e1 * Tnoscat);
         Float Tdir = -RT * (((Float)1 + k_mu) * (alpha1 + k_gamma4) * Tnoscat -
@@ -868,7 +868,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         const Float c10 = X1[(3 * SMAX + q) * 64 + lane] * dq[q], c11 = X1[(4 * SMAX + q) * 64 + lane];
         const Float c12 = X1[(5 * SMAX + q) * 64 + lane] * dq[q];
         const Float c20 = X1[(6 * SMAX + q) * 64 + lane], c22 = X1[(7 * SMAX + q) * 64 + lane];
-        const Float w = (Float)1 / (c20 * alb + c22);
+        const Float w = rte::rcp_nr(c20 * alb + c22);
         const Float a_new = (c00 * alb + c02) * w;
         const Float s_new = (c10 * alb + c11 * src + c12) * w;
         alb = a_new; src = s_new;
@@ -882,7 +882,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) {
       const Float sui = su[i] * dir_in, sdi = sd[i] * dir_in;
-      const Float denom = (Float)1 / ((Float)1 - R[i] * alb);
+      const Float denom = rte::rcp_nr((Float)1 - R[i] * alb);
       const Float src_new = sui + T[i] * denom * (src + alb * sdi);
       const Float alb_new = R[i] + T[i] * T[i] * alb * denom;
       fa[i] = T[i] * denom;
@@ -996,16 +996,16 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
         const Float t = x.tau[i], w0 = x.ssa[i], g = x.g[i];
         const Float gamma1 = LW_diff_sec * ((Float)1 - (Float)0.5 * w0 * ((Float)1 + g));
         const Float gamma2 = LW_diff_sec * (Float)0.5 * w0 * ((Float)1 - g);
-        const Float kk = sqrt(fmax((gamma1 - gamma2) * (gamma1 + gamma2), (Float)1.e-12));
-        const Float e1 = exp(-t * kk);
+        const Float kk = rte::sqrt_nr(fmax((gamma1 - gamma2) * (gamma1 + gamma2), (Float)1.e-12));
+        const Float e1 = rte::exp_nonpos(-t * kk);
         const Float e2 = e1 * e1;
-        const Float RT = (Float)1 / (kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
+        const Float RT = rte::rcp_nr(kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
         const Float Rdif = RT * gamma2 * ((Float)1 - e2);
         const Float Tdif = RT * (Float)2 * kk * e1;
         const Float lev_top = x.lev[i], lev_bot = x.lev[i + 1];
         Float s_up = 0, s_dn = 0;
         if (t > (Float)1.0e-8) {
-          const Float Z = (lev_bot - lev_top) / (t * (gamma1 + gamma2));
+          const Float Z = rte::div_nr(lev_bot - lev_top, t * (gamma1 + gamma2));
           const Float Zup_top = Z + lev_top, Zup_bottom = Z + lev_bot;
           const Float Zdn_top = -Z + lev_top, Zdn_bottom = -Z + lev_bot;
           s_up = kPi * (Zup_top - Rdif * Zdn_top - Tdif * Zup_bottom);
@@ -1047,7 +1047,7 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
         const Float c10 = X1[(2 * SMAX + q) * 64 + lane], c11 = X1[(3 * SMAX + q) * 64 + lane];
         const Float c12 = X1[(4 * SMAX + q) * 64 + lane];
         const Float c20 = X1[(5 * SMAX + q) * 64 + lane], c22 = X1[(6 * SMAX + q) * 64 + lane];
-        const Float w = (Float)1 / (c20 * alb + c22);
+        const Float w = rte::rcp_nr(c20 * alb + c22);
         const Float a_new = (c00 * alb + c02) * w;
         const Float s_new = (c10 * alb + c11 * src + c12) * w;
         alb = a_new; src = s_new;
@@ -1057,7 +1057,7 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
     al[L] = alb; sr[L] = src;
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) {  // :1174-1186 / :1214-1226
-      const Float denom = (Float)1 / ((Float)1 - R[i] * alb);
+      const Float denom = rte::rcp_nr((Float)1 - R[i] * alb);
       const Float src_new = su[i] + T[i] * denom * (src + alb * sd[i]);
       const Float alb_new = R[i] + T[i] * T[i] * alb * denom;
       fa[i] = T[i] * denom;
@@ -1167,10 +1167,10 @@ __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArg
         const Float ssal = x.ssa[i];
         const Float wb = ssal * ((Float)1 - x.g[i]) * (Float)0.5;
         const Float scaleTau = ((Float)1 - ssal + wb);
-        Cn[i] = (Float)0.4 * wb / scaleTau;
+        Cn[i] = rte::div_nr((Float)0.4 * wb, scaleTau);
         const Float tau_loc = x.tau[i] * x.D * scaleTau;
-        const Float tr = exp(-tau_loc);
-        lw_source_layer(tau_loc, tr, x.lay[i], x.lev[i], x.lev[i + 1], sd[i], su[i]);
+        const Float tr = rte::exp_nonpos(-tau_loc);
+        lw_source_layer_fast(tau_loc, tr, x.lay[i], x.lev[i], x.lev[i + 1], sd[i], su[i]);
         t[i] = tr;
       } else {  // neutral layer
         t[i] = 1; sd[i] = 0; su[i] = 0; Cn[i] = 0;

@@ -241,7 +241,7 @@ class GasOptics:
 
     # -- gas_optics_ext: SW, returns 2str optical props + toa source
     def gas_optics_sw(self, ncol, nlay, play, plev, tlay, col_gas, col_dry,
-                      buffers: Optional[Dict[str, object]] = None, glue=None):
+                      buffers: Optional[Dict[str, object]] = None, glue=None, fuse_rayleigh: bool = False):
         xp = self.xp
         b = buffers if buffers is not None else {}
 
@@ -252,16 +252,26 @@ class GasOptics:
 
         st = self.interpolation(ncol, nlay, play, tlay, col_gas, b.get("interp"))
         b["interp"] = st
-        tau_abs = buf("tau_abs", (ncol, nlay, self.ngpt))
-        tau_ray = buf("tau_rayleigh", (ncol, nlay, self.ngpt))
+        gl = glue or default_glue(self.lib, xp)
+        fused = fuse_rayleigh and hasattr(gl, "tau_rayleigh_combine_2str")
+        # fused: the absorption optical depth is computed straight into `tau`, which the fused kernel updates in place
+        tau_abs = buf("tau" if fused else "tau_abs", (ncol, nlay, self.ngpt))
         self.lib.zero_array_3D(ncol, nlay, self.ngpt, tau_abs)  # :637
         self.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau_abs)
-        self.compute_tau_rayleigh(ncol, nlay, st, col_dry, col_gas, tau_ray)
-        tau, ssa, g = (buf(n, (ncol, nlay, self.ngpt)) for n in ("tau", "ssa", "g"))
-        (glue or default_glue(self.lib, xp)).combine_abs_and_rayleigh_2str(
-            ncol, nlay, self.ngpt, tau_abs, tau_ray, tau, ssa, g)
+        if fused:
+            # compute_tau_rayleigh + combine_abs_and_rayleigh (:666-678) in one pass: tau_rayleigh never goes to memory
+            ssa, g = (buf(n, (ncol, nlay, self.ngpt)) for n in ("ssa", "g"))
+            t = self.t
+            gl.tau_rayleigh_combine_2str(ncol, nlay, self.nbnd, self.ngpt, self.ngas, self.nflav, self.neta, self.ntemp,
+                                         t["gpoint_flavor"], t["band_lims_gpt"], t["krayl"], self.kd.idx_h2o, col_dry,
+                                         col_gas, st.fminor, st.jeta, st.tropo, st.jtemp, tau_abs, tau_abs, ssa, g)
+        else:
+            tau_ray = buf("tau_rayleigh", (ncol, nlay, self.ngpt))
+            self.compute_tau_rayleigh(ncol, nlay, st, col_dry, col_gas, tau_ray)
+            tau, ssa, g = (buf(n, (ncol, nlay, self.ngpt)) for n in ("tau", "ssa", "g"))
+            gl.combine_abs_and_rayleigh_2str(ncol, nlay, self.ngpt, tau_abs, tau_ray, tau, ssa, g)
         toa = buf("toa_src", (ncol, self.ngpt))
-        (glue or default_glue(self.lib, xp)).broadcast_gpt(ncol, self.ngpt, self.t["solar_source"], toa)
+        gl.broadcast_gpt(ncol, self.ngpt, self.t["solar_source"], toa)
         return b
 
 
@@ -317,6 +327,15 @@ class HipGlue:
         from .hiplib import ext_call
 
         ext_call(self.lib, "rte_hip_broadcast_gpt", ["i", "i", "a", "a"], ncol, ngpt, per_gpt, out)
+
+    # compute_tau_rayleigh fused with the 2-stream combine (csrc/gas_optics.hip: rte_hip_tau_rayleigh_combine_2str)
+    def tau_rayleigh_combine_2str(self, ncol, nlay, nbnd, ngpt, ngas, nflav, neta, ntemp, gpoint_flavor, band_lims_gpt, krayl,
+                                  idx_h2o, col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_abs, tau, ssa, g):
+        from .hiplib import ext_call
+
+        ext_call(self.lib, "rte_hip_tau_rayleigh_combine_2str", ["i"] * 8 + ["a", "a", "a", "i"] + ["a"] * 10,
+                 ncol, nlay, nbnd, ngpt, ngas, nflav, neta, ntemp, gpoint_flavor, band_lims_gpt, krayl, idx_h2o,
+                 col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_abs, tau, ssa, g)
 
     def cloud_masks(self, ncol, nlay, clwp, ciwp, liqmsk, icemsk):
         from .hiplib import ext_call
@@ -384,9 +403,12 @@ def allsky_lw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds
     return gb, cb, rb
 
 
-def allsky_sw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds, mu0, sfc_alb_gpt, gb=None, cb=None, rb=None):
-    """SW half (:382-404): two-stream clouds, delta-scaled, added to the gas optical properties band by band."""
-    gb = go.gas_optics_sw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["col_gas"], atm["col_dry"], buffers=gb)
+def allsky_sw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds, mu0, sfc_alb_gpt, gb=None, cb=None, rb=None,
+              fuse: bool = True):
+    """SW half (:382-404): two-stream clouds, delta-scaled, added to the gas optical properties band by band.
+    ``fuse``: use the library's fused extension kernels where the array container is device-resident."""
+    gb = go.gas_optics_sw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["col_gas"], atm["col_dry"], buffers=gb,
+                          fuse_rayleigh=fuse)
     cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], True, buffers=cb)
     lib.rte_delta_scale_2str_k(ncol, nlay, co.nbnd, cb["cld_tau"], cb["cld_ssa"], cb["cld_g"])                       # :394
     lib.rte_inc_2stream_by_2stream_bybnd(ncol, nlay, go.ngpt, gb["tau"], gb["ssa"], gb["g"], cb["cld_tau"], cb["cld_ssa"],

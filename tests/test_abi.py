@@ -36,7 +36,8 @@ def test_library_builds_and_exports_every_header_symbol():
                 "rte_hip_col_gas_fill", "rte_hip_tlev_interp", "rte_hip_compute_optimal_angles",
                 "rte_hip_combine_abs_and_rayleigh_1scl", "rte_hip_combine_abs_and_rayleigh_nstr",
                 "rte_hip_expand_and_transpose", "rte_hip_secants_fill", "rte_hip_rfmip_sw_toa_renorm",
-                "rte_hip_rfmip_sw_mu0", "rte_hip_broadcast_cols", "rte_hip_mask_columns"):
+                "rte_hip_rfmip_sw_mu0", "rte_hip_broadcast_cols", "rte_hip_mask_columns",
+                "rte_hip_tau_rayleigh_combine_2str"):
         assert hasattr(dll, ext)
 
 

@@ -368,6 +368,31 @@ def test_pinned_host_arrays_are_synchronous(hip, oracle_c):
     assert cases.rel_err(got_up, ru) <= RTOL_FLUX
 
 
+def test_fused_rayleigh_combine_matches_unfused(hip, oracle_c):
+    """rte_hip_tau_rayleigh_combine_2str (compute_tau_rayleigh + the 2-stream branch of combine_abs_and_rayleigh in one
+    pass, in place on the absorption optical depth) against the unfused ABI calls -- bit-identical -- and the oracle;
+    production kernel (1100 columns, 16- and 8-wide bands) and the direct kernel (small call)."""
+    from rte_rrtmgp_amd import synth
+
+    xp, xn = frontend.TorchArrays("cuda:0"), frontend.NumpyArrays()
+    A = xp.asarray
+    for ncol, nbnd, ngpt in ((1100, 4, 64), (1100, 8, 64), (90, 4, 64)):
+        kd = synth.make_kdist("sw", ngpt=ngpt, nbnd=nbnd)
+        nlay = 22
+        atm = synth.make_atmosphere(ncol, nlay, seed=13, kdist=kd)
+        go = frontend.GasOptics(hip, kd, xp)
+        args = [A(getattr(atm, k)) for k in ("play", "plev", "tlay", "col_gas", "col_dry")]
+        un = go.gas_optics_sw(ncol, nlay, *args)
+        fu = go.gas_optics_sw(ncol, nlay, *args, fuse_rayleigh=True)
+        assert "tau_rayleigh" not in fu
+        for k in ("tau", "ssa", "g"):
+            assert np.array_equal(xp.to_numpy(fu[k]), xp.to_numpy(un[k])), (ncol, nbnd, k)
+        bn = frontend.GasOptics(oracle_c, kd, xn).gas_optics_sw(ncol, nlay, atm.play, atm.plev, atm.tlay, atm.col_gas, atm.col_dry)
+        for k in ("tau", "ssa", "g"):
+            assert cases.rel_err(xp.to_numpy(fu[k]), bn[k]) <= RTOL_GAS, (ncol, nbnd, k)
+            assert cases.elem_err(xp.to_numpy(fu[k]), bn[k]) <= ETOL_GAS, (ncol, nbnd, k)
+
+
 
 def test_tau_rayleigh_paths_agree(hip, oracle_c):
     """The production Rayleigh kernel (whole (T, eta) plane of a band staged in LDS, layers walked by the
