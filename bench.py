@@ -72,13 +72,18 @@ def allsky_bytes_per_collay(kd_lw, kd_sw, nlay):
     N1, N2, b1, b2 = kd_lw.ngpt, kd_sw.ngpt, kd_lw.nbnd, kd_sw.nbnd
     return {
         "interpolation_kernel": lw["interpolation_kernel"] + sw["interpolation_kernel"],
-        "tau_absorption_kernel": lw["tau_absorption_kernel"] + sw["tau_absorption_kernel"],
+        # LW: the absorbing clouds' band-wise increment is applied inside compute_tau_absorption (+ one band array read)
+        "tau_absorption_kernel": lw["tau_absorption_kernel"] + 8 * b1 + sw["tau_absorption_kernel"],
         "planck_source_kernel": lw["planck_source_kernel"],
         "lw_noscat_seg_kernel": lw["lw_noscat_seg_kernel"],
+        # SW: Rayleigh + combine + the two-stream clouds' band-wise increment in one pass (library extension)
+        "tau_rayleigh_combine_kernel": sw["tau_rayleigh_combine_kernel"] + 24 * b2,
+        "sw_2stream_seg_kernel": sw["sw_2stream_seg_kernel"],
+        # cloud optics in one pass each (look-ups, liquid + ice, delta scaling): 4 inputs, 1 (LW) or 3 (SW) band arrays out
+        "cloud_optics_fused_kernel": (32 + 8 * b1) + (32 + 24 * b2),
+        # the unfused kernels (only launched with host containers / fuse=False)
         "tau_rayleigh_kernel": sw["tau_rayleigh_kernel"],
         "combine_2str_kernel": sw["combine_2str_kernel"],
-        "tau_rayleigh_combine_kernel": sw["tau_rayleigh_combine_kernel"],
-        "sw_2stream_seg_kernel": sw["sw_2stream_seg_kernel"],
         "cld_from_table_kernel": 2 * (17 + 24 * b1) + 2 * (17 + 24 * b2),
         "cloud_combine_kernel": (32 * b1 + 8 * b1) + (48 * b2 + 24 * b2),
         "delta_scale_kernel": 48 * b2,

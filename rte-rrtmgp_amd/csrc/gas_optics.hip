@@ -310,6 +310,7 @@ struct TauArgs {
   const Float *col_mix, *fmajor, *fminor, *play, *tlay, *col_gas;
   const int *jeta, *jtemp, *jpress;
   Float* tau;
+  const Float* add_bybnd;  // (ncol, nlay, nbnd) or nullptr: added to every g-point of its band after the gas terms
 };
 
 // direct-gather version for one (column, layer, band): reads the native tables through L1/L2
@@ -362,6 +363,11 @@ __device__ __forceinline__ void tau_direct_column(const TauArgs& a, int icol, in
     if (in_upper)
       minor_chunk(a.upper, 1, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, a.idx_h2o, P, T, jT, a.col_gas, a.fminor,
                   a.jeta, a.gpoint_flavor, acc);
+    if (a.add_bybnd) {  // increment_1scalar_by_1scalar_bybnd fused in: tau = tau_gas + tau_2(band)
+      const Float addv = a.add_bybnd[cl + ncl * (size_t)ibnd];
+#pragma unroll
+      for (int j = 0; j < GC; ++j) acc[j] = acc[j] + addv;
+    }
 #pragma unroll
     for (int j = 0; j < GC; ++j)
       if (g0 + j <= gptE) a.tau[cl + ncl * (size_t)(g0 + j)] = acc[j];
@@ -452,6 +458,7 @@ struct TauV5 {
   const int* skip_if;  // device flag: some column has overlapping regimes -> the fallback kernel does the call
   int* worklist;       // [0] = count, then (tile, layer, band) triples for tau_absorption_worklist_kernel
   bool overwrite;      // tau is known to be zero (deferred zero_array): do not read it
+  const Float* add_bybnd;  // (ncol, nlay, nbnd) or nullptr: see TauArgs
 #ifdef EXP_CLOCKS
   unsigned long long* clocks;
 #endif
@@ -1110,8 +1117,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     x.je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
   };
   // minor column amounts, weights and eta indices of one stage
-  struct Minor { Float sc[MM], cgs[MM]; Float2 fn0, fn1; int2 em; };
+  struct Minor { Float sc[MM], cgs[MM]; Float2 fn0, fn1; int2 em; Float addv; };
   auto load_minor = [&](int b, int n, Minor& x) {
+    x.addv = a.add_bybnd ? a.add_bybnd[cl + (size_t)ncl * b] : (Float)0;  // block-uniform condition
 #pragma unroll
     for (int k = 0; k < MM; ++k) {
       x.sc[k] = 0; x.cgs[k] = 0;
@@ -1157,6 +1165,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     for (int k = 0; k < MM; ++k) { sc[k] = mn.sc[k]; cgs[k] = mn.cgs[k]; }
     const Float2 fn0 = mn.fn0, fn1 = mn.fn1;
     const int2 em = mn.em;
+    const Float addv = mn.addv;
     // this stage's major weights into locals (col_mix folded in)
     const Float w0 = mj.cm.x * mj.fm[0].x, w1 = mj.cm.x * mj.fm[0].y, w2 = mj.cm.x * mj.fm[1].x, w3 = mj.cm.x * mj.fm[1].y,
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
@@ -1273,6 +1282,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     if (a.ncol < 0)
 #endif
     if (OVERWRITE) {
+      if (a.add_bybnd) {  // by-band increment fused in (tau = tau_gas + tau_2 of the band)
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
+      }
       // lanes past the last column repeat it (ic is clamped): same values to the same addresses.  Unconditional
       // stores keep the count of outstanding memory operations static (counted waits instead of drains).
 #pragma unroll
@@ -1283,6 +1296,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       // otherwise the same terms in a different order (1 ulp)
 #pragma unroll
       for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
+      if (a.add_bybnd) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
+      }
 #pragma unroll
       for (int j = 0; j < G; ++j) *tau_at(j) = acc[j];
     }
@@ -1308,22 +1325,45 @@ __global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a,
 // -------------------------------------------------------------------------------------------
 // compute_tau_rayleigh: reference :506-565
 // -------------------------------------------------------------------------------------------
-// combine_abs_and_rayleigh, 2-stream branch (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:1983-2002), applied to one value
+// combine_abs_and_rayleigh, 2-stream branch (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:1983-2002), applied to one value,
+// optionally followed by increment_2stream_by_2stream_bybnd (rte/kernels/mo_optical_props_kernels.F90: the by-band
+// form of :159-181) with a second set of 2-stream properties given per band (clouds): the same operations in the same
+// order as the separate kernels, on values that are doubles in registers instead of doubles in memory -- bit-identical.
 struct RaylCombine {
   const Float* tau_abs;  // nullptr: plain compute_tau_rayleigh
   Float *tau, *ssa, *g;  // tau may alias tau_abs
+  const Float *cld_tau, *cld_ssa, *cld_g;  // (ncol, nlay, nbnd) or nullptr
 };
-__device__ __forceinline__ void rayl_store(const RaylCombine& cb, Float* tau_rayleigh, size_t idx, Float tr) {
-  if (cb.tau_abs == nullptr) { tau_rayleigh[idx] = tr; return; }
 #ifdef RTE_USE_SP
-  const Float tiny2 = (Float)2 * 1.17549435e-38f;
+#define RTE_TINY 1.17549435e-38f
 #else
-  const Float tiny2 = (Float)2 * 2.2250738585072014e-308;
+#define RTE_TINY 2.2250738585072014e-308
 #endif
-  const Float t = cb.tau_abs[idx] + tr;
-  cb.ssa[idx] = t > tiny2 ? tr / t : (Float)0;
+__device__ __forceinline__ void rayl_finish(Float ta, Float tr, bool cld, Float t2, Float s2, Float g2, Float& tau, Float& ssa,
+                                            Float& g) {
+  const Float tiny2 = (Float)2 * (Float)RTE_TINY;
+  const Float t = ta + tr;
+  ssa = t > tiny2 ? tr / t : (Float)0;
+  tau = t;
+  g = (Float)0;
+  if (cld) {
+    const Float eps = (Float)3 * (Float)RTE_TINY;  // mo_optical_props_kernels.F90:38
+    const Float tau12 = tau + t2;
+    const Float tauscat12 = tau * ssa + t2 * s2;
+    g = (tau * ssa * g + t2 * s2 * g2) / fmax(eps, tauscat12);
+    ssa = tauscat12 / fmax(eps, tau12);
+    tau = tau12;
+  }
+}
+__device__ __forceinline__ void rayl_store(const RaylCombine& cb, Float* tau_rayleigh, size_t idx, size_t idx_bnd, Float tr) {
+  if (cb.tau_abs == nullptr) { tau_rayleigh[idx] = tr; return; }
+  const bool cld = cb.cld_tau != nullptr;
+  Float t, s_, g_;
+  rayl_finish(cb.tau_abs[idx], tr, cld, cld ? cb.cld_tau[idx_bnd] : (Float)0, cld ? cb.cld_ssa[idx_bnd] : (Float)0,
+              cld ? cb.cld_g[idx_bnd] : (Float)0, t, s_, g_);
+  cb.ssa[idx] = s_;
   cb.tau[idx] = t;
-  cb.g[idx] = (Float)0;
+  cb.g[idx] = g_;
 }
 
 // direct kernel: work items (column tile, layer, band) in grid stride (a small grid when it only stands by for the plan guard)
@@ -1359,7 +1399,7 @@ tau_rayleigh_kernel(int ncol, int nlay, int nbnd, int ngpt, int neta, int ntemp,
     for (int g = gptS; g <= gptE; ++g) {
       const Float* kk = kr + tn * (size_t)g;
       const Float k = f0 * kk[o1] + f1 * kk[o1 + ntemp] + f2 * kk[o2] + f3 * kk[o2 + ntemp];
-      rayl_store(cb, tau_rayleigh, cl + ncl * (size_t)g, k * w);
+      rayl_store(cb, tau_rayleigh, cl + ncl * (size_t)g, cl + ncl * (size_t)ibnd, k * w);
     }
   }
 }
@@ -1964,6 +2004,8 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
 struct RaylArgs {
   const int* skip_if;  // plan guard raised: the direct kernel does the call
   RaylCombine cb;      // cb.tau_abs != nullptr: fused with combine_abs_and_rayleigh (2-stream)
+  int nbnd;
+  const int* band_lims;
   int ncol, nlay, ngpt, neta, ntemp, idx_h2o;
   const int *gpoint_flavor, *jeta, *jtemp;
   const Float *krayl, *col_dry, *col_gas, *fminor;
@@ -1992,6 +2034,11 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
   const unsigned icol = blockIdx.y * BS + tid;
   const unsigned ic = min(icol, ncol - 1);  // lanes past the last column repeat it (same values, same addresses)
   const int flav0 = a.gpoint_flavor[2 * g0] - 1, flav1 = a.gpoint_flavor[1 + 2 * g0] - 1;
+  const bool cld = COMBINE && a.cb.cld_tau != nullptr;
+  int ibnd_blk = 0;  // band of this block's g-point chunk (by-band cloud operand)
+  if (cld)
+    for (int b = 0; b < a.nbnd; ++b)
+      if (g0 + 1 >= a.band_lims[2 * b] && g0 + 1 <= a.band_lims[2 * b + 1]) ibnd_blk = b;
   struct In { Bool tropo; int jT; Float h2o, dry; };
   struct Wt { Float2 f01, f23; int2 je; };
   auto load_in = [&](unsigned l, In& x) {
@@ -2025,6 +2072,11 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
     unsigned off = (ic + ncol * l) * (unsigned)sizeof(Float);
     asm volatile("" : "+v"(off));  // keep 64-bit store addresses out of the loop-invariant registers
     Float ta[COMBINE ? G : 1];
+    Float ct = 0, cs = 0, cg = 0;
+    if (COMBINE && cld) {  // the band's cloud properties of this (column, layer)
+      const size_t ob = (size_t)ic + (size_t)ncol * l + (size_t)ncl * ibnd_blk;
+      ct = a.cb.cld_tau[ob]; cs = a.cb.cld_ssa[ob]; cg = a.cb.cld_g[ob];
+    }
     if (COMBINE) {  // this layer's absorption optical depths, requested before the table arithmetic
 #pragma unroll
       for (int j = 0; j < G; ++j)
@@ -2041,21 +2093,17 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
         *reinterpret_cast<Float*>(plane0 + gstride * (j + 1) + off) = kb * w;
       } else {
         // combine_abs_and_rayleigh (2-stream branch, mo_gas_optics_rrtmgp.F90:1983-2002) on the value just formed:
-        // tau = tau_abs + tau_rayleigh, ssa = tau_rayleigh / tau, g = 0 -- tau_rayleigh never goes to memory
-#ifdef RTE_USE_SP
-        const Float tiny2 = (Float)2 * 1.17549435e-38f;
-#else
-        const Float tiny2 = (Float)2 * 2.2250738585072014e-308;
-#endif
+        // tau = tau_abs + tau_rayleigh, ssa = tau_rayleigh / tau, g = 0 -- tau_rayleigh never goes to memory -- and,
+        // with clouds given by band, their increment_2stream_by_2stream_bybnd
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const size_t po = (size_t)ncl * (g0 + j + u) * sizeof(Float) + off;
-          const Float tr = (u == 0 ? ka : kb) * w;
-          const Float t = ta[j + u] + tr;
+          Float t, s_, g_;
+          rayl_finish(ta[j + u], (u == 0 ? ka : kb) * w, cld, ct, cs, cg, t, s_, g_);
           if (icol < ncol) {  // tau may alias tau_abs: the clamped lanes past the last column must not update it again
-            *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.ssa) + po) = t > tiny2 ? tr / t : (Float)0;
+            *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.ssa) + po) = s_;
             *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.tau) + po) = t;
-            *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.g) + po) = (Float)0;
+            *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.g) + po) = g_;
           }
         }
       }
@@ -2168,11 +2216,12 @@ void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, 
                      d_tlay, d_col_gas, d_jtemp, d_fmajor, d_fminor, d_col_mix, d_tropo, d_jeta, d_jpress);
 }
 
-void rrtmgp_compute_tau_absorption(
-    const int* ncol_, const int* nlay_, const int* nbnd_, const int* ngpt_, const int* ngas_,
-    const int* nflav_, const int* neta_, const int* npres_, const int* ntemp_,
-    const int* nminorlower_, const int* nminorklower_, const int* nminorupper_,
-    const int* nminorkupper_, const int* idx_h2o_, const int* gpoint_flavor,
+}  // extern "C"
+// compute_tau_absorption; add_bybnd != nullptr: the band-wise increment of the result by a second optical depth given
+// per band (clouds as absorbers) is applied in the same pass
+static void tau_absorption_impl(
+    const char* api_name, int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp,
+    int nlo, int nkl_, int nup, int nku_, int idx_h2o, const int* gpoint_flavor,
     const int* band_lims_gpt, const Float* kmajor, const Float* kminor_lower,
     const Float* kminor_upper, const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper,
     const Bool* minor_scales_with_density_lower, const Bool* minor_scales_with_density_upper,
@@ -2181,16 +2230,17 @@ void rrtmgp_compute_tau_absorption(
     const int* idx_minor_scaling_upper, const int* kminor_start_lower, const int* kminor_start_upper,
     const Bool* tropo, const Float* col_mix, const Float* fmajor, const Float* fminor,
     const Float* play, const Float* tlay, const Float* col_gas, const int* jeta, const int* jtemp,
-    const int* jpress, Float* tau) {
-  const int ncol = *ncol_, nlay = *nlay_, nbnd = *nbnd_, ngpt = *ngpt_, ngas = *ngas_,
-            nflav = *nflav_, neta = *neta_, npres = *npres_, ntemp = *ntemp_;
-  const int nlo = *nminorlower_, nup = *nminorupper_;
+    const int* jpress, Float* tau, const Float* add_bybnd) {
+  const int* nminorklower_ = &nkl_;
+  const int* nminorkupper_ = &nku_;
+  const int* idx_h2o_ = &idx_h2o;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
   // a deferred zero_array on exactly this buffer turns the accumulate into an overwrite
   const bool overwrite = rte::take_pending_zero(tau, sizeof(Float) * (size_t)ncol * nlay * ngpt);
-  rte::Call c("rrtmgp_compute_tau_absorption");
+  rte::Call c(api_name);
   const size_t ncl = (size_t)ncol * nlay;
   const size_t tn = (size_t)ntemp * neta;
+  const Float* d_add = add_bybnd ? c.in(add_bybnd, ncl * nbnd) : nullptr;
   const int* d_gpoint_flavor = c.in(gpoint_flavor, (size_t)2 * ngpt);
   const int* d_band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
   const Float* d_kmajor = c.in(kmajor, tn * (npres + 1) * ngpt);
@@ -2365,7 +2415,7 @@ void rrtmgp_compute_tau_absorption(
   a.kmajor = d_kmajor; a.lower = lo; a.upper = up;
   a.lim = lim; a.tropo = d_tropo; a.col_mix = d_col_mix; a.fmajor = d_fmajor; a.fminor = d_fminor;
   a.play = d_play; a.tlay = d_tlay; a.col_gas = d_col_gas; a.jeta = d_jeta; a.jtemp = d_jtemp; a.jpress = d_jpress;
-  a.tau = d_tau; a.overwrite = overwrite_ok;
+  a.tau = d_tau; a.overwrite = overwrite_ok; a.add_bybnd = d_add;
   a.run_if = fast ? overlap : nullptr;
   {
     rte::ProfScope p(fast ? "tau_absorption_fallback" : "tau_absorption_kernel");
@@ -2426,7 +2476,7 @@ void rrtmgp_compute_tau_absorption(
   v.kmaj = kmaj_g; v.klo = klo_g; v.kup = kup_g;
   v.lim = lim; v.jeta = d_jeta; v.jtemp = d_jtemp; v.jpress = d_jpress; v.tropo = d_tropo;
   v.col_mix = d_col_mix; v.fmajor = d_fmajor; v.fminor = d_fminor; v.play = d_play; v.tlay = d_tlay;
-  v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap; v.overwrite = overwrite_ok;
+  v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap; v.overwrite = overwrite_ok; v.add_bybnd = d_add;
 #ifndef V7_BS
 #define V7_BS 256
 #define V7_MINW 2
@@ -2437,7 +2487,7 @@ void rrtmgp_compute_tau_absorption(
   const size_t wl_cap = (size_t)cdiv(ncol, 256) * nlay * nbnd;  // tiles are at least 256 columns wide
   v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
   HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
-  const bool use_v9 = g_tau_variant == 9 || cache.gw != 16;  // the single-role kernel exists for 16-wide stages only
+  const bool use_v9 = g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr;  // the single-role kernel exists for 16-wide stages only
   if (use_v9) {
 #ifdef EXP_CLOCKS
     v.clocks = (unsigned long long*)rte::scratch(64);
@@ -2502,13 +2552,61 @@ void rrtmgp_compute_tau_absorption(
   }
 }
 
+extern "C" {
+void rrtmgp_compute_tau_absorption(
+    const int* ncol_, const int* nlay_, const int* nbnd_, const int* ngpt_, const int* ngas_,
+    const int* nflav_, const int* neta_, const int* npres_, const int* ntemp_,
+    const int* nminorlower_, const int* nminorklower_, const int* nminorupper_,
+    const int* nminorkupper_, const int* idx_h2o_, const int* gpoint_flavor,
+    const int* band_lims_gpt, const Float* kmajor, const Float* kminor_lower,
+    const Float* kminor_upper, const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper,
+    const Bool* minor_scales_with_density_lower, const Bool* minor_scales_with_density_upper,
+    const Bool* scale_by_complement_lower, const Bool* scale_by_complement_upper,
+    const int* idx_minor_lower, const int* idx_minor_upper, const int* idx_minor_scaling_lower,
+    const int* idx_minor_scaling_upper, const int* kminor_start_lower, const int* kminor_start_upper,
+    const Bool* tropo, const Float* col_mix, const Float* fmajor, const Float* fminor,
+    const Float* play, const Float* tlay, const Float* col_gas, const int* jeta, const int* jtemp,
+    const int* jpress, Float* tau) {
+  tau_absorption_impl("rrtmgp_compute_tau_absorption", *ncol_, *nlay_, *nbnd_, *ngpt_, *ngas_, *nflav_, *neta_, *npres_,
+                      *ntemp_, *nminorlower_, *nminorklower_, *nminorupper_, *nminorkupper_, *idx_h2o_, gpoint_flavor,
+                      band_lims_gpt, kmajor, kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                      minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower,
+                      scale_by_complement_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
+                      idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, tropo, col_mix, fmajor, fminor, play,
+                      tlay, col_gas, jeta, jtemp, jpress, tau, nullptr);
+}
+// Library extension (scalars by value): compute_tau_absorption followed, in the same pass, by the band-wise increment
+// tau(:,:,g) += tau_bybnd(:,:,band(g)) -- rte_inc_1scalar_by_1scalar_bybnd (rte/kernels/mo_optical_props_kernels.F90), what
+// the all-sky driver does with its absorbing clouds (examples/all-sky/rrtmgp_allsky.F90:374); saves a read and a write of tau.
+int rte_hip_compute_tau_absorption_inc_bybnd(
+    int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nminorlower,
+    int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, const int* gpoint_flavor,
+    const int* band_lims_gpt, const Float* kmajor, const Float* kminor_lower,
+    const Float* kminor_upper, const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper,
+    const Bool* minor_scales_with_density_lower, const Bool* minor_scales_with_density_upper,
+    const Bool* scale_by_complement_lower, const Bool* scale_by_complement_upper,
+    const int* idx_minor_lower, const int* idx_minor_upper, const int* idx_minor_scaling_lower,
+    const int* idx_minor_scaling_upper, const int* kminor_start_lower, const int* kminor_start_upper,
+    const Bool* tropo, const Float* col_mix, const Float* fmajor, const Float* fminor,
+    const Float* play, const Float* tlay, const Float* col_gas, const int* jeta, const int* jtemp,
+    const int* jpress, Float* tau, const Float* tau_bybnd) {
+  tau_absorption_impl("rte_hip_compute_tau_absorption_inc_bybnd", ncol, nlay, nbnd, ngpt, ngas, nflav, neta, npres, ntemp,
+                      nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, kmajor,
+                      kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                      minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower,
+                      scale_by_complement_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
+                      idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, tropo, col_mix, fmajor, fminor, play,
+                      tlay, col_gas, jeta, jtemp, jpress, tau, tau_bybnd);
+  return 0;
+}
 }  // extern "C"
 // compute_tau_rayleigh, optionally fused with combine_abs_and_rayleigh (tau_abs != nullptr: tau_rayleigh is not written)
 static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta,
                               int ntemp, const int* gpoint_flavor, const int* band_lims_gpt, const Float* krayl,
                               int idx_h2o, const Float* col_dry, const Float* col_gas, const Float* fminor,
                               const int* jeta, const Bool* tropo, const int* jtemp, Float* tau_rayleigh,
-                              const Float* tau_abs, Float* tau, Float* ssa, Float* g) {
+                              const Float* tau_abs, Float* tau, Float* ssa, Float* g, const Float* cld_tau = nullptr,
+                              const Float* cld_ssa = nullptr, const Float* cld_g = nullptr) {
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
   rte::Call c(api_name);
   const bool combine = tau_abs != nullptr;
@@ -2523,7 +2621,10 @@ static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd
   const Bool* d_tropo = c.in(tropo, ncl);
   const int* d_jtemp = c.in(jtemp, ncl);
   Float* d_tau = combine ? nullptr : c.out(tau_rayleigh, ncl * ngpt);
-  RaylCombine cb{nullptr, nullptr, nullptr, nullptr};
+  RaylCombine cb{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (combine && cld_tau) {
+    cb.cld_tau = c.in(cld_tau, ncl * nbnd); cb.cld_ssa = c.in(cld_ssa, ncl * nbnd); cb.cld_g = c.in(cld_g, ncl * nbnd);
+  }
   if (combine) {
     if (tau == tau_abs) { cb.tau = c.inout(tau, ncl * ngpt); cb.tau_abs = cb.tau; }
     else { cb.tau_abs = c.in(tau_abs, ncl * ngpt); cb.tau = c.out(tau, ncl * ngpt); }
@@ -2565,6 +2666,7 @@ static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd
     RaylArgs q;
     q.skip_if = guard;
     q.cb = cb;
+    q.nbnd = nbnd; q.band_lims = d_band_lims;
     q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.neta = neta; q.ntemp = ntemp; q.idx_h2o = idx_h2o;
     q.gpoint_flavor = d_gpoint_flavor; q.jeta = d_jeta; q.jtemp = d_jtemp; q.krayl = d_krayl; q.col_dry = d_col_dry;
     q.col_gas = d_col_gas; q.fminor = d_fminor; q.tropo = d_tropo; q.tau_rayleigh = d_tau;
@@ -2604,13 +2706,17 @@ void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* 
 // Library extension (scalars by value): compute_tau_rayleigh FUSED with the 2-stream branch of the frontend's
 // combine_abs_and_rayleigh (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:666-678, :1983-2002): tau = tau_abs + tau_rayleigh,
 // ssa = tau_rayleigh / tau, g = 0, without the tau_rayleigh array's round trip through memory.  tau may be tau_abs.
+// With cloud properties by band it also performs the all-sky driver's band-wise increment
+// (examples/all-sky/rrtmgp_allsky.F90:395), saving a read and a write of the three gas arrays.
 int rte_hip_tau_rayleigh_combine_2str(int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int ntemp,
                                       const int* gpoint_flavor, const int* band_lims_gpt, const Float* krayl, int idx_h2o,
                                       const Float* col_dry, const Float* col_gas, const Float* fminor, const int* jeta,
                                       const Bool* tropo, const int* jtemp, const Float* tau_abs, Float* tau, Float* ssa,
-                                      Float* g) {
+                                      Float* g, const Float* cld_tau, const Float* cld_ssa, const Float* cld_g) {
+  // cld_* (ncol, nlay, nbnd), all three or none: additionally increment_2stream_by_2stream_bybnd with these properties
   tau_rayleigh_impl("rte_hip_tau_rayleigh_combine_2str", ncol, nlay, nbnd, ngpt, ngas, nflav, neta, ntemp, gpoint_flavor,
-                    band_lims_gpt, krayl, idx_h2o, col_dry, col_gas, fminor, jeta, tropo, jtemp, nullptr, tau_abs, tau, ssa, g);
+                    band_lims_gpt, krayl, idx_h2o, col_dry, col_gas, fminor, jeta, tropo, jtemp, nullptr, tau_abs, tau, ssa, g,
+                    cld_tau, cld_tau ? cld_ssa : nullptr, cld_tau ? cld_g : nullptr);
   return 0;
 }
 

@@ -194,6 +194,69 @@ cld_from_table_kernel(int ncl, int nsteps, Float step_size, Float offset, const 
     taussag[i] = 0;
   }
 }
+
+// ---- fused cloud optics (library extension): cloud_optics of ty_cloud_optics_rrtmgp, look-up-table branch
+// (rrtmgp/frontend/mo_cloud_optics_rrtmgp.F90:334-425) = masks, compute_cld_from_table for liquid and for ice, their
+// combination, and optionally the all-sky driver's delta scaling (rte_delta_scale_2str_k), in ONE pass: the six
+// (ncol, nlay, nbnd) intermediates of the separate kernels never go to memory.  Every value is formed by the same
+// operations in the same order as in those kernels (cld_from_table_kernel, cloud_combine_kernel, delta_scale_kernel).
+struct CldFused {
+  int ncl, nbnd, liq_nsteps, ice_nsteps;
+  Float liq_step, liq_off, ice_step, ice_off;
+  const Float *clwp, *ciwp, *reliq, *deice;
+  const Float *lext, *lssa, *lasy, *iext, *issa, *iasy;  // (nsteps, nbnd)
+  Float *tau, *ssa, *g;
+};
+__device__ __forceinline__ void cld_lookup(bool on, Float wp, Float re, Float offset, Float step_size, int nsteps, int ibnd,
+                                           const Float* __restrict__ te, const Float* __restrict__ ts_, const Float* __restrict__ ta,
+                                           Float& tau, Float& taussa, Float& taussag) {
+  tau = 0; taussa = 0; taussag = 0;
+  if (on) {
+    const Float x = (re - offset) / step_size;
+    const int index = min((int)floor(x) + 1, nsteps - 1);  // 1-based
+    const Float fint = x - (Float)(index - 1);
+    const size_t o = (size_t)nsteps * ibnd + (index - 1);
+    const Float t = wp * (te[o] + fint * (te[o + 1] - te[o]));
+    const Float ts = t * (ts_[o] + fint * (ts_[o + 1] - ts_[o]));
+    taussag = ts * (ta[o] + fint * (ta[o + 1] - ta[o]));
+    taussa = ts;
+    tau = t;
+  }
+}
+template <bool TWOSTR, bool DELTA>
+__global__ void __launch_bounds__(256) cloud_optics_fused_kernel(CldFused a) {
+  const int cl = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ibnd = blockIdx.y;
+  if (cl >= a.ncl) return;
+  const Float lwp = a.clwp[cl], iwp = a.ciwp[cl];
+  Float lt, lts, ltsg, it, its, itsg;
+  cld_lookup(lwp > (Float)0, lwp, a.reliq[cl], a.liq_off, a.liq_step, a.liq_nsteps, ibnd, a.lext, a.lssa, a.lasy, lt, lts, ltsg);
+  cld_lookup(iwp > (Float)0, iwp, a.deice[cl], a.ice_off, a.ice_step, a.ice_nsteps, ibnd, a.iext, a.issa, a.iasy, it, its, itsg);
+  const size_t i = (size_t)cl + (size_t)a.ncl * ibnd;
+  if (!TWOSTR) {
+    a.tau[i] = (lt - lts) + (it - its);
+    return;
+  }
+  const Float t = lt + it;
+  const Float ts = lts + its;
+#ifdef RTE_USE_SP
+  const Float eps = 1.1920929e-07f;  // epsilon(tau)
+#else
+  const Float eps = 2.220446049250313e-16;
+#endif
+  Float g = (ltsg + itsg) / fmax(eps, ts);
+  Float ssa = ts / fmax(eps, t);
+  Float tau = t;
+  if (DELTA) {  // delta_scale_2str_k, rte/kernels/mo_optical_props_kernels.F90:76-98
+    const Float f = g * g;
+    const Float wf = ssa * f;
+    tau = ((Float)1 - wf) * tau;
+    const Float ssa_new = (ssa - wf) / fmax(kEps, ((Float)1 - wf));
+    g = (g - f) / fmax(kEps, ((Float)1 - f));
+    ssa = ssa_new;
+  }
+  a.tau[i] = tau; a.ssa[i] = ssa; a.g[i] = g;
+}
 }  // namespace
 
 extern "C" {
@@ -313,4 +376,30 @@ void rrtmgp_compute_cld_from_table(const int* ncol_, const int* nlay_, const int
   hipLaunchKernelGGL(cld_from_table_kernel, dim3(cdiv(ncl, 256), ngpt), dim3(256), 0, rte::stream(), (int)ncl, nsteps,
                      *step_size, *offset, d_mask, d_lwp, d_re, d_tt, d_st, d_at, d_tau, d_ts, d_tsg);
 }
-}  // extern "C"
+// cloud_optics (look-up tables) in one pass; twostr = 0: absorption optical depth only (tau); delta_scale != 0: the
+// two-stream result is delta-scaled with f = g^2.  Tables are (nsteps, nbnd); outputs (ncol, nlay, nbnd).
+int rte_hip_cloud_optics_fused(int ncol, int nlay, int nbnd, int twostr, int delta_scale, const Float* clwp, const Float* ciwp,
+                               const Float* reliq, const Float* deice, int liq_nsteps, double liq_step_size, double radliq_lwr,
+                               const Float* extliq, const Float* ssaliq, const Float* asyliq, int ice_nsteps,
+                               double ice_step_size, double diamice_lwr, const Float* extice, const Float* ssaice,
+                               const Float* asyice, Float* tau, Float* ssa, Float* g) {
+  const size_t ncl = (size_t)ncol * nlay;
+  if (ncl == 0 || nbnd <= 0) return 0;
+  rte::Call c("rte_hip_cloud_optics_fused");
+  CldFused a;
+  a.ncl = (int)ncl; a.nbnd = nbnd; a.liq_nsteps = liq_nsteps; a.ice_nsteps = ice_nsteps;
+  a.liq_step = (Float)liq_step_size; a.liq_off = (Float)radliq_lwr; a.ice_step = (Float)ice_step_size; a.ice_off = (Float)diamice_lwr;
+  a.clwp = c.in(clwp, ncl); a.ciwp = c.in(ciwp, ncl); a.reliq = c.in(reliq, ncl); a.deice = c.in(deice, ncl);
+  a.lext = c.in(extliq, (size_t)liq_nsteps * nbnd); a.lssa = c.in(ssaliq, (size_t)liq_nsteps * nbnd); a.lasy = c.in(asyliq, (size_t)liq_nsteps * nbnd);
+  a.iext = c.in(extice, (size_t)ice_nsteps * nbnd); a.issa = c.in(ssaice, (size_t)ice_nsteps * nbnd); a.iasy = c.in(asyice, (size_t)ice_nsteps * nbnd);
+  a.tau = c.out(tau, ncl * nbnd);
+  a.ssa = twostr ? c.out(ssa, ncl * nbnd) : nullptr;
+  a.g = twostr ? c.out(g, ncl * nbnd) : nullptr;
+  rte::ProfScope p("cloud_optics_fused_kernel");
+  const dim3 grid(cdiv(ncl, 256), nbnd), blk(256);
+  if (!twostr) hipLaunchKernelGGL((cloud_optics_fused_kernel<false, false>), grid, blk, 0, rte::stream(), a);
+  else if (delta_scale) hipLaunchKernelGGL((cloud_optics_fused_kernel<true, true>), grid, blk, 0, rte::stream(), a);
+  else hipLaunchKernelGGL((cloud_optics_fused_kernel<true, false>), grid, blk, 0, rte::stream(), a);
+  return 0;
+}
+}

@@ -185,8 +185,23 @@ class GasOptics:
         return out
 
     # -- compute_tau_absorption (mo_gas_optics_rrtmgp.F90:638-665 / 680-707); tau is ACCUMULATED
-    def compute_tau_absorption(self, ncol, nlay, st: InterpState, play, tlay, col_gas, tau):
+    def compute_tau_absorption(self, ncol, nlay, st: InterpState, play, tlay, col_gas, tau, tau_bybnd=None):
         t = self.t
+        if tau_bybnd is not None:
+            # library extension: the band-wise increment by `tau_bybnd` (ncol, nlay, nbnd) in the same pass
+            from .hiplib import ext_call
+
+            ext_call(self.lib, "rte_hip_compute_tau_absorption_inc_bybnd", ["i"] * 14 + ["a"] * 29,
+                     ncol, nlay, self.nbnd, self.ngpt, self.ngas, self.nflav, self.neta, self.npres,
+                     self.ntemp, self.nminorlower, self.nminorklower, self.nminorupper, self.nminorkupper,
+                     self.kd.idx_h2o, t["gpoint_flavor"], t["band_lims_gpt"], t["kmajor"], t["kminor_lower"],
+                     t["kminor_upper"], t["minor_limits_gpt_lower"], t["minor_limits_gpt_upper"],
+                     t["minor_scales_with_density_lower"], t["minor_scales_with_density_upper"],
+                     t["scale_by_complement_lower"], t["scale_by_complement_upper"], t["idx_minor_lower"],
+                     t["idx_minor_upper"], t["idx_minor_scaling_lower"], t["idx_minor_scaling_upper"],
+                     t["kminor_start_lower"], t["kminor_start_upper"], st.tropo, st.col_mix, st.fmajor,
+                     st.fminor, play, tlay, col_gas, st.jeta, st.jtemp, st.jpress, tau, tau_bybnd)
+            return
         self.lib.rrtmgp_compute_tau_absorption(
             ncol, nlay, self.nbnd, self.ngpt, self.ngas, self.nflav, self.neta, self.npres,
             self.ntemp, self.nminorlower, self.nminorklower, self.nminorupper, self.nminorkupper,
@@ -218,7 +233,7 @@ class GasOptics:
 
     # -- gas_optics_int: LW, returns 1scl optical props + sources
     def gas_optics_lw(self, ncol, nlay, play, plev, tlay, tsfc, col_gas, tlev, top_at_1,
-                      buffers: Optional[Dict[str, object]] = None):
+                      buffers: Optional[Dict[str, object]] = None, tau_bybnd=None):
         xp = self.xp
         b = buffers if buffers is not None else {}
 
@@ -231,7 +246,7 @@ class GasOptics:
         b["interp"] = st
         tau = buf("tau", (ncol, nlay, self.ngpt))
         self.lib.zero_array_3D(ncol, nlay, self.ngpt, tau)  # :679
-        self.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau)
+        self.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau, tau_bybnd=tau_bybnd)
         lay_src = buf("lay_src", (ncol, nlay, self.ngpt))
         lev_src = buf("lev_src", (ncol, nlay + 1, self.ngpt))
         sfc_src = buf("sfc_src", (ncol, self.ngpt))
@@ -241,7 +256,7 @@ class GasOptics:
 
     # -- gas_optics_ext: SW, returns 2str optical props + toa source
     def gas_optics_sw(self, ncol, nlay, play, plev, tlay, col_gas, col_dry,
-                      buffers: Optional[Dict[str, object]] = None, glue=None, fuse_rayleigh: bool = False):
+                      buffers: Optional[Dict[str, object]] = None, glue=None, fuse_rayleigh: bool = False, clouds_bybnd=None):
         xp = self.xp
         b = buffers if buffers is not None else {}
 
@@ -254,6 +269,7 @@ class GasOptics:
         b["interp"] = st
         gl = glue or default_glue(self.lib, xp)
         fused = fuse_rayleigh and hasattr(gl, "tau_rayleigh_combine_2str")
+        assert clouds_bybnd is None or fused, "the by-band cloud increment is part of the fused kernel"
         # fused: the absorption optical depth is computed straight into `tau`, which the fused kernel updates in place
         tau_abs = buf("tau" if fused else "tau_abs", (ncol, nlay, self.ngpt))
         self.lib.zero_array_3D(ncol, nlay, self.ngpt, tau_abs)  # :637
@@ -264,7 +280,8 @@ class GasOptics:
             t = self.t
             gl.tau_rayleigh_combine_2str(ncol, nlay, self.nbnd, self.ngpt, self.ngas, self.nflav, self.neta, self.ntemp,
                                          t["gpoint_flavor"], t["band_lims_gpt"], t["krayl"], self.kd.idx_h2o, col_dry,
-                                         col_gas, st.fminor, st.jeta, st.tropo, st.jtemp, tau_abs, tau_abs, ssa, g)
+                                         col_gas, st.fminor, st.jeta, st.tropo, st.jtemp, tau_abs, tau_abs, ssa, g,
+                                         clouds_bybnd)
         else:
             tau_ray = buf("tau_rayleigh", (ncol, nlay, self.ngpt))
             self.compute_tau_rayleigh(ncol, nlay, st, col_dry, col_gas, tau_ray)
@@ -330,12 +347,23 @@ class HipGlue:
 
     # compute_tau_rayleigh fused with the 2-stream combine (csrc/gas_optics.hip: rte_hip_tau_rayleigh_combine_2str)
     def tau_rayleigh_combine_2str(self, ncol, nlay, nbnd, ngpt, ngas, nflav, neta, ntemp, gpoint_flavor, band_lims_gpt, krayl,
-                                  idx_h2o, col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_abs, tau, ssa, g):
+                                  idx_h2o, col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_abs, tau, ssa, g, clouds_bybnd=None):
         from .hiplib import ext_call
 
-        ext_call(self.lib, "rte_hip_tau_rayleigh_combine_2str", ["i"] * 8 + ["a", "a", "a", "i"] + ["a"] * 10,
+        ct, cs, cg = clouds_bybnd if clouds_bybnd is not None else (None, None, None)
+        ext_call(self.lib, "rte_hip_tau_rayleigh_combine_2str", ["i"] * 8 + ["a", "a", "a", "i"] + ["a"] * 13,
                  ncol, nlay, nbnd, ngpt, ngas, nflav, neta, ntemp, gpoint_flavor, band_lims_gpt, krayl, idx_h2o,
-                 col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_abs, tau, ssa, g)
+                 col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_abs, tau, ssa, g, ct, cs, cg)
+
+    # masks + both table look-ups + liquid/ice combination (+ delta scaling) in one pass (csrc/optical_props.hip)
+    def cloud_optics_fused(self, ncol, nlay, nbnd, twostr, delta_scale, clwp, ciwp, reliq, deice, tb, t, tau, ssa, g):
+        from .hiplib import ext_call
+
+        ext_call(self.lib, "rte_hip_cloud_optics_fused", ["i"] * 5 + ["a"] * 4 + ["i", "d", "d", "a", "a", "a"] * 2 + ["a"] * 3,
+                 ncol, nlay, nbnd, 1 if twostr else 0, 1 if delta_scale else 0, clwp, ciwp, reliq, deice,
+                 int(tb["liq_nsteps"]), float(tb["liq_step_size"]), float(tb["radliq_lwr"]), t["extliq"], t["ssaliq"], t["asyliq"],
+                 int(tb["ice_nsteps"]), float(tb["ice_step_size"]), float(tb["diamice_lwr"]), t["extice"], t["ssaice"], t["asyice"],
+                 tau, ssa if twostr else tau, g if twostr else tau)
 
     def cloud_masks(self, ncol, nlay, clwp, ciwp, liqmsk, icemsk):
         from .hiplib import ext_call
@@ -365,7 +393,10 @@ class CloudOptics:
         self.nbnd = tables["extliq"].shape[1]
         self.t = {k: arrays.asarray(v) for k, v in tables.items() if hasattr(v, "shape")}
 
-    def cloud_optics(self, ncol, nlay, clwp, ciwp, reliq, deice, twostr, buffers=None, glue=None):
+    def cloud_optics(self, ncol, nlay, clwp, ciwp, reliq, deice, twostr, buffers=None, glue=None, fused=False,
+                     delta_scale=False):
+        """``fused`` (device containers): one extension kernel instead of masks + 2 look-ups + combination, optionally with
+        the delta scaling the all-sky driver applies next (``delta_scale``; without ``fused`` the caller does it)."""
         xp, tb, nb = self.xp, self.tb, self.nbnd
         b = buffers if buffers is not None else {}
 
@@ -375,6 +406,14 @@ class CloudOptics:
             return b[name]
 
         gl = glue or default_glue(self.lib, xp)
+        if fused and hasattr(gl, "cloud_optics_fused"):
+            tau = buf("cld_tau", (ncol, nlay, nb))
+            ssa = buf("cld_ssa", (ncol, nlay, nb)) if twostr else None
+            g = buf("cld_g", (ncol, nlay, nb)) if twostr else None
+            gl.cloud_optics_fused(ncol, nlay, nb, twostr, delta_scale, clwp, ciwp, reliq, deice, tb, self.t, tau, ssa, g)
+            b["delta_scaled"] = bool(delta_scale)
+            return b
+        b["delta_scaled"] = False
         liqmsk, icemsk = buf("liqmsk", (ncol, nlay), "b"), buf("icemsk", (ncol, nlay), "b")
         gl.cloud_masks(ncol, nlay, clwp, ciwp, liqmsk, icemsk)
         liq = [buf(n, (ncol, nlay, nb)) for n in ("ltau", "ltaussa", "ltaussag")]
@@ -391,13 +430,22 @@ class CloudOptics:
         return b
 
 
-def allsky_lw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds, sfc_emis_gpt, gb=None, cb=None, rb=None):
+def allsky_lw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds, sfc_emis_gpt, gb=None, cb=None, rb=None,
+              fuse: bool = True):
     """LW half of examples/all-sky/rrtmgp_allsky.F90:362-380: clouds as absorbers (1scl) added to the gas optical
-    depth band by band, then rte_lw without scattering."""
-    gb = go.gas_optics_lw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["tsfc"], atm["col_gas"], atm["tlev"],
-                          atm["top_at_1"], buffers=gb)
-    cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], False, buffers=cb)
-    lib.rte_inc_1scalar_by_1scalar_bybnd(ncol, nlay, go.ngpt, gb["tau"], cb["cld_tau"], go.nbnd, go.t["band_lims_gpt"])  # :374
+    depth band by band, then rte_lw without scattering.  ``fuse`` (device containers only): the library's fused
+    extension kernels -- cloud optics in one pass, and the band-wise increment applied inside compute_tau_absorption;
+    same values, each 3-D array written once."""
+    fuse = fuse and not isinstance(xp, NumpyArrays)
+    if fuse:
+        cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], False, buffers=cb, fused=True)
+        gb = go.gas_optics_lw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["tsfc"], atm["col_gas"], atm["tlev"],
+                              atm["top_at_1"], buffers=gb, tau_bybnd=cb["cld_tau"])                                 # :374 fused in
+    else:
+        gb = go.gas_optics_lw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["tsfc"], atm["col_gas"], atm["tlev"],
+                              atm["top_at_1"], buffers=gb)
+        cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], False, buffers=cb)
+        lib.rte_inc_1scalar_by_1scalar_bybnd(ncol, nlay, go.ngpt, gb["tau"], cb["cld_tau"], go.nbnd, go.t["band_lims_gpt"])  # :374
     rb = rte_lw(lib, xp, ncol, nlay, go.ngpt, atm["top_at_1"], gb["tau"], gb["lay_src"], gb["lev_src"], sfc_emis_gpt,
                 gb["sfc_src"], buffers=rb)
     return gb, cb, rb
@@ -406,13 +454,20 @@ def allsky_lw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds
 def allsky_sw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds, mu0, sfc_alb_gpt, gb=None, cb=None, rb=None,
               fuse: bool = True):
     """SW half (:382-404): two-stream clouds, delta-scaled, added to the gas optical properties band by band.
-    ``fuse``: use the library's fused extension kernels where the array container is device-resident."""
-    gb = go.gas_optics_sw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["col_gas"], atm["col_dry"], buffers=gb,
-                          fuse_rayleigh=fuse)
-    cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], True, buffers=cb)
-    lib.rte_delta_scale_2str_k(ncol, nlay, co.nbnd, cb["cld_tau"], cb["cld_ssa"], cb["cld_g"])                       # :394
-    lib.rte_inc_2stream_by_2stream_bybnd(ncol, nlay, go.ngpt, gb["tau"], gb["ssa"], gb["g"], cb["cld_tau"], cb["cld_ssa"],
-                                         cb["cld_g"], go.nbnd, go.t["band_lims_gpt"])                               # :395
+    ``fuse`` (device containers only): cloud optics + delta scaling in one pass, and compute_tau_rayleigh +
+    combine_abs_and_rayleigh + the band-wise increment in one pass over the gas arrays."""
+    fuse = fuse and not isinstance(xp, NumpyArrays)
+    if fuse:
+        cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], True, buffers=cb, fused=True,
+                             delta_scale=True)                                                                      # :394 fused in
+        gb = go.gas_optics_sw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["col_gas"], atm["col_dry"], buffers=gb,
+                              fuse_rayleigh=True, clouds_bybnd=(cb["cld_tau"], cb["cld_ssa"], cb["cld_g"]))         # :395 fused in
+    else:
+        gb = go.gas_optics_sw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["col_gas"], atm["col_dry"], buffers=gb)
+        cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], True, buffers=cb)
+        lib.rte_delta_scale_2str_k(ncol, nlay, co.nbnd, cb["cld_tau"], cb["cld_ssa"], cb["cld_g"])                   # :394
+        lib.rte_inc_2stream_by_2stream_bybnd(ncol, nlay, go.ngpt, gb["tau"], gb["ssa"], gb["g"], cb["cld_tau"], cb["cld_ssa"],
+                                             cb["cld_g"], go.nbnd, go.t["band_lims_gpt"])                           # :395
     rb = rte_sw(lib, xp, ncol, nlay, go.ngpt, atm["top_at_1"], gb["tau"], gb["ssa"], gb["g"], mu0, gb["toa_src"],
                 sfc_alb_gpt, sfc_alb_gpt, buffers=rb)
     return gb, cb, rb

@@ -17,18 +17,18 @@ def _setup(kind, ncol, nlay, top_at_1=False):
     return kd, atm, tb, cl
 
 
-def _run(lib, xp, kind, kd, atm, tb, cl, ncol, nlay):
+def _run(lib, xp, kind, kd, atm, tb, cl, ncol, nlay, fuse=True):
     A = xp.asarray
     go, co = frontend.GasOptics(lib, kd, xp), frontend.CloudOptics(lib, tb, xp)
     a = {k: A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry")}
     a["top_at_1"] = atm.top_at_1
     c = {k: A(v) for k, v in cl.items()}
     if kind == "lw":
-        gb, cb, rb = frontend.allsky_lw(lib, xp, go, co, ncol, nlay, a, c, xp.full((ncol, kd.ngpt), 0.98))
+        gb, cb, rb = frontend.allsky_lw(lib, xp, go, co, ncol, nlay, a, c, xp.full((ncol, kd.ngpt), 0.98), fuse=fuse)
         keys = [("cld_tau", cb), ("tau", gb), ("flux_up", rb), ("flux_dn", rb)]
     else:
         mu0, alb = xp.full((ncol, nlay), 0.86), xp.full((ncol, kd.ngpt), 0.06)
-        gb, cb, rb = frontend.allsky_sw(lib, xp, go, co, ncol, nlay, a, c, mu0, alb)
+        gb, cb, rb = frontend.allsky_sw(lib, xp, go, co, ncol, nlay, a, c, mu0, alb, fuse=fuse)
         keys = [("cld_tau", cb), ("cld_ssa", cb), ("cld_g", cb), ("tau", gb), ("ssa", gb), ("g", gb), ("flux_up", rb),
                 ("flux_dn", rb), ("flux_dir", rb)]
     return {k: np.array(xp.to_numpy(d[k])) for k, d in keys}
@@ -70,6 +70,25 @@ def test_hip_matches_oracle(kind, top_at_1):
     out = _run(hip, frontend.TorchArrays("cuda:0"), kind, kd, atm, tb, cl, ncol, nlay)
     for k in ref:
         assert _rel(out[k], ref[k]) <= 1e-12, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,ncol", [("lw", 70), ("sw", 70), ("lw", 1200), ("sw", 1200)])
+def test_fused_extension_kernels_match_the_unfused_chain(kind, ncol):
+    """The library's fused extension kernels (cloud optics in one pass; band-wise cloud increment inside
+    compute_tau_absorption; Rayleigh + combine + increment in one pass) give exactly the arrays of the chain of
+    reference-ABI kernels they replace -- same operations in the same order on the same doubles: bit-identical.
+    70 columns run the direct kernels, 1200 the production ones."""
+    from rte_rrtmgp_amd import hiplib
+
+    hip = hiplib.load()
+    nlay = 24
+    kd, atm, tb, cl = _setup(kind, ncol, nlay)
+    xp = frontend.TorchArrays("cuda:0")
+    fused = _run(hip, xp, kind, kd, atm, tb, cl, ncol, nlay, fuse=True)
+    unfused = _run(hip, xp, kind, kd, atm, tb, cl, ncol, nlay, fuse=False)
+    for k in unfused:
+        assert np.array_equal(fused[k], unfused[k]), k
 
 
 def _golden():
