@@ -248,6 +248,10 @@ def main():
     ap.add_argument("--workload", choices=("lw", "sw", "allsky"), default="lw",
                     help="lw: the headline chain (default); sw: SW gas optics + sw_solver_2stream (BASELINE configs[2]); "
                          "allsky: LW + SW with cloud optics at 72 layers (BASELINE configs[3])")
+    ap.add_argument("--atmosphere", choices=("rce", "sites", "sites-shuffled"), default="rce",
+                    help="rce: one RCE-like climate, every column a random perturbation (default, the headline); "
+                         "sites: 100 distinct RFMIP-like sites (polar to tropical, sea level to plateaus), each repeated in a "
+                         "contiguous run; sites-shuffled: the same columns in random order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
     args = ap.parse_args()
@@ -279,7 +283,16 @@ def main():
     ncol = args.ncol
     nlay_w = 72 if args.workload == "allsky" else NLAY
     kd = synth.make_kdist("lw" if args.workload == "allsky" else args.workload)
-    atm = synth.make_atmosphere(ncol, nlay_w, seed=42 + rank, kdist=kd)  # each rank owns different columns
+    if args.atmosphere == "rce":
+        atm = synth.make_atmosphere(ncol, nlay_w, seed=42 + rank, kdist=kd)  # each rank owns different columns
+    else:
+        # 100 distinct sites tiled to ncol columns: in runs of ncol/100 copies ("sites") or in random order
+        sites = synth.make_atmosphere(100, nlay_w, seed=42 + rank, kdist=kd, climate="sites")
+        idx = np.repeat(np.arange(100), -(-ncol // 100))[:ncol]
+        if args.atmosphere == "sites-shuffled":
+            idx = np.random.default_rng(7 + rank).permutation(idx)
+        atm = synth.Atmosphere(ncol, nlay_w, sites.top_at_1, *(np.asfortranarray(getattr(sites, k)[idx]) for k in
+                               ("play", "plev", "tlay", "tlev", "tsfc", "vmr", "col_dry", "col_gas")))
     go = frontend.GasOptics(lib, kd, xp)
     A = xp.asarray
     play, plev, tlay, tlev, tsfc, col_gas = (A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas"))
@@ -346,6 +359,40 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(rb["flux_up"]).all() and float(rb["flux_up"].max()) > 0
+    # work the production gas-optics kernels handed to the direct-gather worklists in the last step
+    wl_tau = hiplib.ext_call(lib, "rte_hip_stat", ["i"], 0)
+    wl_planck = hiplib.ext_call(lib, "rte_hip_stat", ["i"], 1)
+    tiles = -(-ncol // 512)
+
+    def timed_ms(fn, reps=5):
+        fn()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        fence()
+        return (time.perf_counter() - t1) / reps * 1e3
+
+    # the frontend glue that produces the step's inputs (timed separately): col_dry, col_gas from
+    # volume mixing ratios, tlev from tlay, secants -- device kernels (csrc/glue.hip), outside the timed region
+    glue_ms = None
+    if args.workload == "lw":
+        vmr_d, col_dry_d = A(atm.vmr), xp.empty((ncol, nlay_w))
+        col_gas_d, tlev_d, sec_d = xp.empty((ncol, nlay_w, kd.ngas + 1)), xp.empty((ncol, nlay_w + 1)), xp.empty((ncol, kd.ngpt, 1))
+        h2o_d, ds_d = A(np.asfortranarray(atm.vmr[:, :, kd.idx_h2o - 1])), A(np.array([frontend.GAUSS_DS[0][0]]))
+
+        def glue():
+            hiplib.ext_call(lib, "rte_hip_get_layer_number", "iiaadda", ncol, nlay_w, h2o_d, plev, 0.028964, 9.80665, col_dry_d)
+            hiplib.ext_call(lib, "rte_hip_col_gas_fill", "iiiaaa", ncol, nlay_w, kd.ngas, vmr_d, col_dry_d, col_gas_d)
+            hiplib.ext_call(lib, "rte_hip_tlev_interp", "iiaaaa", ncol, nlay_w, play, plev, tlay, tlev_d)
+            hiplib.ext_call(lib, "rte_hip_secants_fill", "iiiaa", ncol, kd.ngpt, 1, ds_d, sec_d)
+
+        glue_ms = timed_ms(glue)
+    # assembling the global broadband field on every rank (all-gather of the per-rank slabs), outside the timed region
+    allgather_ms = None
+    if dist is not None:
+        allgather_ms = timed_ms(lambda: (sharding.allgather_fluxes(rb["flux_up"], ncol * world),
+                                         sharding.allgather_fluxes(rb["flux_dn"], ncol * world)))
 
     # per-kernel HIP-event timings collected inside the timed region
     kern = {}
@@ -414,7 +461,15 @@ def main():
                                     f"all-sky LW (clouds as absorbers) + SW (two-stream clouds, delta-scaled), {ncol} synthetic "
                                     f"columns per GPU x {nlay_w} layers, 256 + 224 g-points (BASELINE configs[3] shape), "
                                     f"synthetic k-distributions and cloud tables, cloud field of examples/all-sky"),
-                       "columns_per_gpu": ncol, "nlay": nlay_w, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero},
+                       "columns_per_gpu": ncol, "nlay": nlay_w, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero,
+                       "atmosphere": args.atmosphere,
+                       "direct_gather_worklist": {"tau_tile_layer_bands": wl_tau, "of": tiles * nlay_w * kd.nbnd,
+                                                  "planck_tile_bands": wl_planck, "of_planck": tiles * kd.nbnd},
+                       "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
+                       "device": torch.cuda.get_device_name(local_rank),
+                       "glue_ms_per_step_outside_timed_region": (round(glue_ms, 4) if glue_ms is not None else None),
+                       "allgather_global_fluxes_ms_outside_timed_region": (round(allgather_ms, 4) if allgather_ms is not None else None),
+                       "scaling_note": "weak scaling: columns_per_gpu per rank; no multi-GPU curve has been measured by the builder"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -2126,6 +2126,15 @@ static int g_plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget ca
 // drops the cached plans, so that they are rebuilt instead of the direct kernels doing every later call.
 static volatile int* g_stale_host = nullptr;
 static int* g_stale_dev = nullptr;
+// diagnostics: entries handed to the direct-gather worklists by the last tau / Planck call (rte_hip_stat)
+static int* g_stats_dev = nullptr;
+static int* stats_dev() {
+  if (!g_stats_dev) {
+    HIP_CHECK(hipMalloc((void**)&g_stats_dev, 4 * sizeof(int)));
+    HIP_CHECK(hipMemset(g_stats_dev, 0, 4 * sizeof(int)));
+  }
+  return g_stats_dev;
+}
 static int* stale_flag() {
   if (!g_stale_dev) {
     HIP_CHECK(hipHostMalloc((void**)&g_stale_host, sizeof(int), hipHostMallocMapped));
@@ -2175,6 +2184,15 @@ int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
 int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
 int rte_hip_invalidate_plans(void) { ++g_plan_epoch; return 0; }
 int rte_hip_geom_variant(int v) { g_geom_variant = v; return 0; }
+// diagnostics (synchronises): 0 = (column tile, layer, band) triples the last compute_tau_absorption call handed to the
+// direct-gather worklist, 1 = (column tile, band) pairs of the last compute_Planck_source call
+int rte_hip_stat(int which) {
+  if (which < 0 || which > 3) return -1;
+  int v = 0;
+  HIP_CHECK(hipStreamSynchronize(rte::stream()));
+  HIP_CHECK(hipMemcpy(&v, stats_dev() + which, sizeof(int), hipMemcpyDeviceToHost));
+  return v;
+}
 
 
 void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, const int* nflav_,
@@ -2549,6 +2567,7 @@ static void tau_absorption_impl(
     aw.run_if = nullptr;
     hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(4096), dim3(256), 0, st, aw, (const int*)v.worklist,
                        use_v9 ? V9_NCW * 64 : BS);
+    HIP_CHECK(hipMemcpyAsync(stats_dev() + 0, v.worklist, sizeof(int), hipMemcpyDeviceToDevice, st));
   }
 }
 
@@ -2874,6 +2893,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     hipLaunchKernelGGL(planck_source_worklist_kernel, dim3(1024), dim3(256), 0, st, q, (const int*)v.worklist, wl_tile);
     // the whole call on the direct kernel if the guard fired
     hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)guard);
+    HIP_CHECK(hipMemcpyAsync(stats_dev() + 1, v.worklist, sizeof(int), hipMemcpyDeviceToDevice, st));
   }
 }
 

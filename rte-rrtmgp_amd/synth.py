@@ -207,18 +207,24 @@ def col_dry_from_plev(vmr_h2o: np.ndarray, plev: np.ndarray) -> np.ndarray:
 
 
 def make_atmosphere(ncol: int, nlay: int = 60, seed: int = 42, top_at_1: bool = False,
-                    ngas: int = 8, kdist: KDist | None = None) -> Atmosphere:
+                    ngas: int = 8, kdist: KDist | None = None, climate: str = "rce") -> Atmosphere:
     """RCEMIP-flavoured columns: surface ~300 K, 6.7 K/km lapse rate to a ~15 km tropopause,
     warming stratosphere, exponential pressure up to ~70 km; each column gets a seeded, vertically
-    smooth temperature/humidity/surface-pressure perturbation."""
+    smooth temperature/humidity/surface-pressure perturbation.
+    ``climate="sites"``: columns spread like the RFMIP sites instead -- polar to tropical surfaces (235 ... 305 K),
+    sea level to high plateaus (650 ... 1030 hPa), tropopause height and humidity following the surface temperature."""
     rng = np.random.default_rng(seed)
     z_lev = np.linspace(0.0, 70.0, nlay + 1)  # km, index 0 = surface
     z_lay = 0.5 * (z_lev[:-1] + z_lev[1:])
-    ps = 100000.0 * (1.0 + 0.03 * rng.standard_normal(ncol))
-    sst = 300.0 + 4.0 * rng.standard_normal(ncol)
+    if climate == "sites":
+        ps = rng.uniform(65000.0, 103000.0, ncol)
+        sst = rng.uniform(235.0, 305.0, ncol)
+    else:
+        ps = 100000.0 * (1.0 + 0.03 * rng.standard_normal(ncol))
+        sst = 300.0 + 4.0 * rng.standard_normal(ncol)
 
     def temperature(z, c):
-        ztrop = 15.0 + 1.0 * c["a"]
+        ztrop = (8.0 + 8.0 * (c["sst"] - 235.0) / 70.0 if climate == "sites" else 15.0) + 1.0 * c["a"]
         t_trop = c["sst"][:, None] - 6.7 * np.minimum(z[None, :], ztrop[:, None])
         strat = np.clip((z[None, :] - ztrop[:, None]), 0.0, None)
         t = t_trop + 2.2 * np.minimum(strat, 33.0) - 2.8 * np.clip(strat - 33.0, 0.0, None)
@@ -238,6 +244,8 @@ def make_atmosphere(ncol: int, nlay: int = 60, seed: int = 42, top_at_1: bool = 
         play = np.clip(play, kdist.press_ref_min * 1.0002, kdist.press_ref_max * 0.9998)
     vmr = np.zeros((ncol, nlay, ngas))
     q0 = 0.018 * np.exp(0.3 * rng.standard_normal(ncol))
+    if climate == "sites":
+        q0 = q0 * np.exp(0.065 * (sst - 300.0))  # saturation humidity falls ~6.5 % per kelvin
     h2o = q0[:, None] * np.exp(-z_lay[None, :] / 2.6) * np.exp(-(z_lay[None, :] / 11.0) ** 2)
     vmr[:, :, 0] = np.maximum(h2o, 3.0e-6)
     consts = {1: 348e-6, 3: 306e-9, 4: 0.12e-6, 5: 1650e-9, 6: 0.2095, 7: 0.7808}
