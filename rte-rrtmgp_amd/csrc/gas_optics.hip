@@ -41,8 +41,11 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
                      int* __restrict__ jtemp, Float* __restrict__ fmajor, Float* __restrict__ fminor,
                      Float* __restrict__ col_mix, Bool* __restrict__ tropo, int* __restrict__ jeta,
                      int* __restrict__ jpress) {
+  // block = (256 columns, one layer); the flavors are walked INSIDE the block: pressure / temperature terms (one log)
+  // are formed once per (column, layer), and play, tlay and the column amounts are read once instead of once per flavor
+  // (as a grid dimension the flavors' blocks ran far apart: 1.9 GB of reads for 0.5 GB of inputs)
   const int icol_raw = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ilay = blockIdx.y, iflav = blockIdx.z;
+  const int ilay = blockIdx.y;
   const bool in_range = icol_raw < ncol;
   const int icol = in_range ? icol_raw : ncol - 1;  // ragged last block: compute on a valid column, store nothing
   const size_t ncl = (size_t)ncol * nlay;
@@ -58,78 +61,85 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
   const Float jpress_aint = fmin((Float)(npres - 1), fmax((Float)1, trunc(locpress)));
   const Float fpress = locpress - jpress_aint;
   const bool trop = P > press_ref_trop;  // :117
-  if (iflav == 0 && in_range) {
+  if (in_range) {
     jtemp[cl] = jt;
     jpress[cl] = (int)jpress_aint;
     tropo[cl] = trop;
   }
-  // :121-168
   const int itropo = trop ? 0 : 1;
-  const int igas_1 = flavor[2 * iflav], igas_2 = flavor[2 * iflav + 1];
-  const Float cg1 = col_gas[cl + ncl * igas_1], cg2 = col_gas[cl + ncl * igas_2];
-  Float fmn[4], fmj[8], cm[2];
-  int je[2];
-#pragma unroll
-  for (int itemp = 0; itemp < 2; ++itemp) {
-    const int t = jt + itemp;  // 1-based
-    const size_t v = (size_t)itropo + 2 * ((size_t)0 + (size_t)(ngas + 1) * (t - 1));
-    const Float ratio_eta_half = vmr_ref[v + 2 * (size_t)igas_1] / vmr_ref[v + 2 * (size_t)igas_2];
-    const Float c = cg1 + ratio_eta_half * cg2;
-    cm[itemp] = c;
-    Float eta;
-#ifdef RTE_USE_SP
-    if (c > (Float)2 * (Float)1.17549435e-38f)
-#else
-    if (c > (Float)2 * (Float)2.2250738585072014e-308)
-#endif
-      eta = cg1 / c;
-    else
-      eta = (Float)0.5;
-    const Float loceta = eta * (Float)(neta - 1);
-    je[itemp] = min((int)loceta + 1, neta - 1);
-    const Float feta = loceta - trunc(loceta);
-    const Float ftemp_term = ((Float)(1 - itemp) + (Float)(2 * itemp - 1) * ftemp);
-    const Float f1 = ((Float)1 - feta) * ftemp_term;
-    const Float f2 = feta * ftemp_term;
-    fmn[0 + 2 * itemp] = f1;
-    fmn[1 + 2 * itemp] = f2;
-    fmj[0 + 4 * itemp] = ((Float)1 - fpress) * f1;
-    fmj[1 + 4 * itemp] = ((Float)1 - fpress) * f2;
-    fmj[2 + 4 * itemp] = fpress * f1;
-    fmj[3 + 4 * itemp] = fpress * f2;
-  }
+  // this column's amounts of every gas, parked in LDS (lane-private slots; the flavor's two gases are block-uniform indices)
+  extern __shared__ Float s_cg[];  // [ngas + 1][256]
+  const int t = threadIdx.x;
+  for (int ig = 0; ig <= ngas; ++ig) s_cg[ig * 256 + t] = col_gas[cl + ncl * ig];
   // The outputs are interleaved records per column (8, 4, 2, 2 values): written straight from the
   // registers every store instruction would scatter 8-16 bytes per lane over kilobytes.  Transpose
   // through LDS instead, so each store instruction of the block writes one contiguous 2-4 KB run.
   __shared__ Float s_fmj[256 * 9], s_fmn[256 * 5], s_cm[256 * 3];
   __shared__ int s_je[256 * 3];
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s_fmj[t * 9 + i] = fmj[i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) s_fmn[t * 5 + i] = fmn[i];
-  s_cm[t * 3] = cm[0]; s_cm[t * 3 + 1] = cm[1];
-  s_je[t * 3] = je[0]; s_je[t * 3 + 1] = je[1];
-  __syncthreads();
   const int c0 = blockIdx.x * blockDim.x;
   const int nc = min((int)blockDim.x, ncol - c0);  // columns of this block
-  const size_t rec0 = (size_t)c0 + (size_t)ncol * ilay + ncl * iflav;  // record index of the block's first column
+#pragma unroll 1
+  for (int iflav = 0; iflav < nflav; ++iflav) {
+    // :121-168
+    const int igas_1 = flavor[2 * iflav], igas_2 = flavor[2 * iflav + 1];
+    const Float cg1 = s_cg[igas_1 * 256 + t], cg2 = s_cg[igas_2 * 256 + t];
+    Float fmn[4], fmj[8], cm[2];
+    int je[2];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int e = t + 256 * k;
-    if (e < 8 * nc) fmajor[8 * rec0 + e] = s_fmj[(e >> 3) * 9 + (e & 7)];
-  }
+    for (int itemp = 0; itemp < 2; ++itemp) {
+      const int tt = jt + itemp;  // 1-based
+      const size_t v = (size_t)itropo + 2 * ((size_t)0 + (size_t)(ngas + 1) * (tt - 1));
+      const Float ratio_eta_half = vmr_ref[v + 2 * (size_t)igas_1] / vmr_ref[v + 2 * (size_t)igas_2];
+      const Float c = cg1 + ratio_eta_half * cg2;
+      cm[itemp] = c;
+      Float eta;
+#ifdef RTE_USE_SP
+      if (c > (Float)2 * (Float)1.17549435e-38f)
+#else
+      if (c > (Float)2 * (Float)2.2250738585072014e-308)
+#endif
+        eta = cg1 / c;
+      else
+        eta = (Float)0.5;
+      const Float loceta = eta * (Float)(neta - 1);
+      je[itemp] = min((int)loceta + 1, neta - 1);
+      const Float feta = loceta - trunc(loceta);
+      const Float ftemp_term = ((Float)(1 - itemp) + (Float)(2 * itemp - 1) * ftemp);
+      const Float f1 = ((Float)1 - feta) * ftemp_term;
+      const Float f2 = feta * ftemp_term;
+      fmn[0 + 2 * itemp] = f1;
+      fmn[1 + 2 * itemp] = f2;
+      fmj[0 + 4 * itemp] = ((Float)1 - fpress) * f1;
+      fmj[1 + 4 * itemp] = ((Float)1 - fpress) * f2;
+      fmj[2 + 4 * itemp] = fpress * f1;
+      fmj[3 + 4 * itemp] = fpress * f2;
+    }
+    __syncthreads();  // the previous flavor's records have been stored
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int e = t + 256 * k;
-    if (e < 4 * nc) fminor[4 * rec0 + e] = s_fmn[(e >> 2) * 5 + (e & 3)];
-  }
+    for (int i = 0; i < 8; ++i) s_fmj[t * 9 + i] = fmj[i];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int e = t + 256 * k;
-    if (e < 2 * nc) {
-      col_mix[2 * rec0 + e] = s_cm[(e >> 1) * 3 + (e & 1)];
-      jeta[2 * rec0 + e] = s_je[(e >> 1) * 3 + (e & 1)];
+    for (int i = 0; i < 4; ++i) s_fmn[t * 5 + i] = fmn[i];
+    s_cm[t * 3] = cm[0]; s_cm[t * 3 + 1] = cm[1];
+    s_je[t * 3] = je[0]; s_je[t * 3 + 1] = je[1];
+    __syncthreads();
+    const size_t rec0 = (size_t)c0 + (size_t)ncol * ilay + ncl * iflav;  // record index of the block's first column
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int e = t + 256 * k;
+      if (e < 8 * nc) fmajor[8 * rec0 + e] = s_fmj[(e >> 3) * 9 + (e & 7)];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = t + 256 * k;
+      if (e < 4 * nc) fminor[4 * rec0 + e] = s_fmn[(e >> 2) * 5 + (e & 3)];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = t + 256 * k;
+      if (e < 2 * nc) {
+        col_mix[2 * rec0 + e] = s_cm[(e >> 1) * 3 + (e & 1)];
+        jeta[2 * rec0 + e] = s_je[(e >> 1) * 3 + (e & 1)];
+      }
     }
   }
 }
@@ -2227,8 +2237,8 @@ void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, 
   int* d_jeta = c.out(jeta, 2 * ncl * nflav);
   int* d_jpress = c.out(jpress, ncl);
   rte::ProfScope p("interpolation_kernel");
-  dim3 grid(cdiv(ncol, 256), nlay, nflav), block(256);
-  hipLaunchKernelGGL(interpolation_kernel, grid, block, 0, rte::stream(), ncol, nlay, ngas, nflav, neta,
+  dim3 grid(cdiv(ncol, 256), nlay), block(256);
+  hipLaunchKernelGGL(interpolation_kernel, grid, block, sizeof(Float) * 256 * (ngas + 1), rte::stream(), ncol, nlay, ngas, nflav, neta,
                      npres, ntemp, d_flavor, d_temp_ref, d_press_ref_log, press_ref_log_delta_inv,
                      *temp_ref_min, *temp_ref_delta, temp_ref_delta_inv, press_ref_trop, d_vmr_ref, d_play,
                      d_tlay, d_col_gas, d_jtemp, d_fmajor, d_fminor, d_col_mix, d_tropo, d_jeta, d_jpress);
