@@ -269,7 +269,7 @@ __device__ __forceinline__ void seg_offsets(SegOffsets<L>& o, int c, int ncol, i
   asm volatile("" : "+v"(o.cg));
 }
 
-template <int L, bool do_jac>
+template <int L, bool do_jac, bool SFC = true>
 __device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, int igpt, int ncol, int nlay, int np,
                                          const Float* __restrict__ Dsec,
                                          const Float* __restrict__ tau_, const Float* __restrict__ lay_source_,
@@ -295,18 +295,20 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, 
   }
 #pragma unroll
   for (int i = 0; i <= L; ++i) t.lev[i] = at(lev, o.lev[i]);
-#ifdef LWX_NOSFC
-  t.D = 1.5; t.emis = 0.9; t.ssrc = 1; t.inc = 0; (void)ncg;
-#else
-  t.D = at(Dsec + ncg, o.cg);
-  t.emis = at(sfc_emis + ncg, o.cg);
-  t.ssrc = at(sfc_src + ncg, o.cg);
-  t.inc = at(inc_flux + ncg, o.cg);
-#endif
-  t.sjac = do_jac ? at(sfc_srcJac + ncg, o.cg) : (Float)0;
+  if (SFC) {
+    t.D = at(Dsec + ncg, o.cg);
+    t.emis = at(sfc_emis + ncg, o.cg);
+    t.ssrc = at(sfc_src + ncg, o.cg);
+    t.inc = at(inc_flux + ncg, o.cg);
+    t.sjac = do_jac ? at(sfc_srcJac + ncg, o.cg) : (Float)0;
+  }
 }
 
-template <int L, bool do_jac>
+// SFCLDS (8-wave blocks only): the per-(column, g-point) arrays -- secant, surface emissivity and source, incident flux
+// [, surface source Jacobian] -- are fetched ONCE per block in chunks of 16 g-points, each wave loading two g-points'
+// worth a chunk ahead, and handed to all waves through LDS; otherwise every wave loads all of them for every g-point
+// (8 waves x 4 arrays of the same 512 bytes: 32 of the block's 232 load instructions per g-point, 28 of them redundant).
+template <int L, bool do_jac, bool SFCLDS>
 __global__ void __launch_bounds__(64 * 8)
 lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
                      const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
@@ -333,6 +335,8 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   const int g_begin = blockIdx.y * g_per_block;
   const int g_end = min(ngpt, g_begin + g_per_block);
   constexpr int MAXS = 8;  // waves per block at most
+  constexpr int CH = 16, NA = do_jac ? 5 : 4, RPW = 2 * NA;  // chunk of g-points, arrays, rows loaded per wave and chunk
+  Float* const SFCB = lds + 2 * 3 * MAXS * 64;  // [2 buffers][CH][NA][64]
   // neutral composites (Td, Sd, Su) = (1, 0, 0) for the segment slots no wave owns (read after the first barrier)
   for (int i = threadIdx.x; i < 2 * 3 * MAXS * 64; i += blockDim.x) {
     const int q = (i >> 6) % MAXS, k = (i >> 6) / MAXS % 3;
@@ -345,14 +349,21 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 
   // One g-point of work on tile `cur` (FULL: the segment has all L layers, no predication needed)
   // One g-point of work on tile `cur` (padded slots are neutral, see seg_load: no predication)
-  auto process = [&](const SegTile<L>& cur, int buf) {
+  auto process = [&](const SegTile<L>& cur_, int buf, int gl, int cbuf) {
 #pragma clang fp contract(fast)
+    struct Sfc { Float D, emis, ssrc, inc, sjac; } cur;
+    if (SFCLDS) {
+      const Float* q = SFCB + ((size_t)(cbuf * CH + gl) * NA) * 64 + lane;
+      cur.D = q[0]; cur.emis = q[64]; cur.ssrc = q[128]; cur.inc = q[192]; cur.sjac = do_jac ? q[(NA - 1) * 64] : (Float)0;
+    } else {
+      cur.D = cur_.D; cur.emis = cur_.emis; cur.ssrc = cur_.ssrc; cur.inc = cur_.inc; cur.sjac = cur_.sjac;
+    }
     Float t[L], sd[L], su[L];
     // ---- pass 1: layer transmissivities and sources (:180-190), segment composites
     Float Td = 1, Sd = 0;
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-      const Float tau_loc = cur.tau[i] * cur.D;
+      const Float tau_loc = cur_.tau[i] * cur.D;
 #ifdef LWX_NOEXP
       const Float tr = (Float)1 - tau_loc * (Float)0.001;
 #else
@@ -361,9 +372,9 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo): "toward bottom" uses the
       // bottom level source, "toward top" the top level source
 #ifdef LWX_NOSRC
-      sd[i] = tr * cur.lev[i + 1] + cur.lay[i]; su[i] = tr * cur.lev[i] + cur.lay[i];
+      sd[i] = tr * cur_.lev[i + 1] + cur_.lay[i]; su[i] = tr * cur_.lev[i] + cur_.lay[i];
 #else
-      lw_source_layer_fast(tau_loc, tr, cur.lay[i], cur.lev[i], cur.lev[i + 1], sd[i], su[i]);
+      lw_source_layer_fast(tau_loc, tr, cur_.lay[i], cur_.lev[i], cur_.lev[i + 1], sd[i], su[i]);
 #endif
       t[i] = tr;
       Sd = tr * Sd + sd[i];
@@ -443,19 +454,43 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   SegOffsets<L> offs;
   seg_offsets<L>(offs, c, ncol, nlay, p0, np, top_at_1);
   auto load = [&](SegTile<L>& tile, int igpt) {
-    seg_load<L, do_jac>(tile, offs, min(igpt, g_end - 1), ncol, nlay, np, Dsec, tau_, lay_source_, lev_source_,
-                        sfc_emis, sfc_src, inc_flux, sfc_srcJac);
+    seg_load<L, do_jac, !SFCLDS>(tile, offs, min(igpt, g_end - 1), ncol, nlay, np, Dsec, tau_, lay_source_, lev_source_,
+                                 sfc_emis, sfc_src, inc_flux, sfc_srcJac);
   };
+  // surface-array chunks: wave s fetches g-points 2s, 2s+1 of a chunk (row i: array i % NA of g-point 2s + i / NA)
+  Float sfcpf[RPW];
+  auto sfc_fetch = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int g = min(g_begin + chunk * CH + 2 * s + i / NA, g_end - 1);
+      const Float* base = (i % NA) == 0 ? Dsec : (i % NA) == 1 ? sfc_emis : (i % NA) == 2 ? sfc_src : (i % NA) == 3 ? inc_flux : sfc_srcJac;
+      unsigned off = offs.cg;
+      asm volatile("" : "+v"(off));
+      sfcpf[i] = *reinterpret_cast<const Float*>(reinterpret_cast<const char*>(base + (size_t)ncol * g) + off);
+    }
+  };
+  auto sfc_publish = [&](int cbuf) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) SFCB[((size_t)(cbuf * CH + 2 * s + i / NA) * NA + (i % NA)) * 64 + lane] = sfcpf[i];
+  };
+  if (SFCLDS) {
+    sfc_fetch(0);
+    sfc_publish(0);
+    __syncthreads();
+  }
   // software prefetch: the next g-point's loads are in flight while this one is computed.  (A ring of tiles
   // unrolled so that no tile is copied measures the same and needs 45 more registers; two g-points ahead spill.)
   SegTile<L> cur;
   load(cur, g_begin);
-  int buf = 0;
+  int buf = 0, gl = 0, chunk = 0;
   for (int igpt = g_begin; igpt < g_end; ++igpt, buf ^= 1) {
     SegTile<L> nxt;
+    if (SFCLDS && gl == 0) sfc_fetch(chunk + 1);           // a chunk ahead, behind this g-point's barrier ...
     load(nxt, igpt + 1);
-    process(cur, buf);
+    if (SFCLDS && gl == 1) sfc_publish((chunk + 1) & 1);   // ... written an iteration later, read 14 barriers later
+    process(cur, buf, gl, chunk & 1);
     cur = nxt;
+    if (++gl == CH) { gl = 0; ++chunk; }
   }
   // ---- partial broadband for this g-group: (ncol, nlev, ngroups)
   if (active) {
@@ -1295,6 +1330,7 @@ size_t pick_gchunk(size_t bytes_per_g, int ngpt) {
 static int g_lw2str_gpt1_levsource = 0;
 static int g_lw_force_generic = 0;
 static int g_sw_force_generic = 0;
+static int g_lw_sfc_lds = 1;  // surface arrays of the LW segmented solver through LDS chunks (rte_hip_lw_sfc_lds)
 static int g_seg_groups = 0;  // > 0: g-point groups per column tile of the segmented solvers (rte_hip_seg_groups; 0 = automatic)
 
 extern "C" {
@@ -1303,6 +1339,7 @@ int rte_hip_set_lw2str_bugcompat(int on) { g_lw2str_gpt1_levsource = on; return 
 int rte_hip_force_generic_lw(int on) { g_lw_force_generic = on; return 0; }
 int rte_hip_force_generic_sw(int on) { g_sw_force_generic = on; return 0; }
 int rte_hip_seg_groups(int n) { g_seg_groups = n; return 0; }
+int rte_hip_lw_sfc_lds(int on) { g_lw_sfc_lds = on; return 0; }
 
 void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
                           const int* nmus_, const Float* Ds, const Float* weights, const Float* tau,
@@ -1388,14 +1425,22 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     Float* part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
     Float* part_dn = part_up + nclv * ngroups;
     Float* part_jac = do_jac ? part_dn + nclv * ngroups : nullptr;
-    const size_t lds_bytes = sizeof(Float) * 2 * 3 * 8 * 64;
+    const bool sfclds = g_lw_sfc_lds && S == 8 && (L == 8 || !do_jac);  // (the wider variants with Jacobians run out of registers)
+    const size_t lds_bytes = sizeof(Float) * (2 * 3 * 8 * 64 + (sfclds ? 2 * 16 * (do_jac ? 5 : 4) * 64 : 0));
     for (int imu = 0; imu < nmus; ++imu) {
       {
         rte::ProfScope p("lw_noscat_seg_kernel");
 #define RTE_LAUNCH_SEG(LL, JJ)                                                                                  \
-  hipLaunchKernelGGL((lw_noscat_seg_kernel<LL, JJ>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st, ncol, \
-                     nlay, ngpt, S, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev, \
-                     d_emis, d_sfc, d_inc, d_srcJac, part_up, part_dn, part_jac)
+  do {                                                                                                          \
+    if (sfclds)                                                                                                 \
+      hipLaunchKernelGGL((lw_noscat_seg_kernel<LL, JJ, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st, ncol, \
+                         nlay, ngpt, S, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev, \
+                         d_emis, d_sfc, d_inc, d_srcJac, part_up, part_dn, part_jac);                           \
+    else                                                                                                        \
+      hipLaunchKernelGGL((lw_noscat_seg_kernel<LL, JJ, false>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st, ncol, \
+                         nlay, ngpt, S, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev, \
+                         d_emis, d_sfc, d_inc, d_srcJac, part_up, part_dn, part_jac);                           \
+  } while (0)
         if (L == 8) { if (do_jac) RTE_LAUNCH_SEG(8, true); else RTE_LAUNCH_SEG(8, false); }
         else if (L == 9) { if (do_jac) RTE_LAUNCH_SEG(9, true); else RTE_LAUNCH_SEG(9, false); }
         else { if (do_jac) RTE_LAUNCH_SEG(10, true); else RTE_LAUNCH_SEG(10, false); }
