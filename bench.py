@@ -91,7 +91,22 @@ def allsky_bytes_per_collay(kd_lw, kd_sw, nlay):
     }
 
 
-def _cpu_chain(workload, seed, ncol_block):
+def _shared_kdist(kind, shm_dir):
+    """The synthetic k-distribution with its arrays mapped read-only from files under `shm_dir` (written once by the
+    parent): all worker processes then share ONE physical copy of the 33 MB of tables, as the threads of an OpenMP
+    driver would, instead of evicting each other's private copies from the last-level cache."""
+    from rte_rrtmgp_amd import synth
+
+    kd = synth.make_kdist(kind)
+    if shm_dir:
+        for name in list(kd.arrays):
+            path = os.path.join(shm_dir, f"{kind}_{name}.npy")
+            if os.path.exists(path):
+                kd.arrays[name] = np.load(path, mmap_mode="r")
+    return kd
+
+
+def _cpu_chain(workload, seed, ncol_block, shm_dir=None):
     """One closure that runs the workload's kernel chain once on a block of columns with the CPU kernels
     (reference build if present, else the C restatement).  Returns (run, kind, gpt-description, nlay)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -108,7 +123,7 @@ def _cpu_chain(workload, seed, ncol_block):
     xp = frontend.NumpyArrays()
     nlay_b = 72 if workload == "allsky" else NLAY
     if workload == "allsky":
-        kdl, kds = synth.make_kdist("lw"), synth.make_kdist("sw")
+        kdl, kds = _shared_kdist("lw", shm_dir), _shared_kdist("sw", shm_dir)
         atm = synth.make_atmosphere(ncol_block, nlay_b, seed=seed, kdist=kdl)
         a = {k: getattr(atm, k) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry")}
         a["top_at_1"] = atm.top_at_1
@@ -125,7 +140,7 @@ def _cpu_chain(workload, seed, ncol_block):
             st["s"] = frontend.allsky_sw(lib, xp, gos, cos_, ncol_block, nlay_b, a, cl, mu0, alb, *st.get("s", (None, None, None)))
 
         return run, kind, "256 + 224", nlay_b
-    kd = synth.make_kdist(workload)
+    kd = _shared_kdist(workload, shm_dir)
     atm = synth.make_atmosphere(ncol_block, NLAY, seed=seed, kdist=kd)
     go = frontend.GasOptics(lib, kd, xp)
     emis = xp.full((ncol_block, kd.ngpt), 0.98)
@@ -146,7 +161,7 @@ def _cpu_chain(workload, seed, ncol_block):
     return (run_sw if workload == "sw" else run_lw), kind, str(kd.ngpt), NLAY
 
 
-def cpu_worker(workload, seed, ncol_block):
+def cpu_worker(workload, seed, ncol_block, shm_dir=None):
     """Body of one `bench.py --cpu-worker` process: ONE single-threaded process per core (no GIL shared
     between cores).  Protocol on stdin/stdout: prints "ready <kind> <gpt> <nlay>" after set-up and one
     untimed block, then for every line "go <seconds>" runs whole blocks until the time is up and prints
@@ -156,7 +171,7 @@ def cpu_worker(workload, seed, ncol_block):
     threading.stack_size(1 << 30)  # flang keeps automatic arrays such as pfrac(ncol,nlay,ngpt) on the stack
 
     def body():
-        run, kind, gpt, nlay_b = _cpu_chain(workload, seed, ncol_block)
+        run, kind, gpt, nlay_b = _cpu_chain(workload, seed, ncol_block, shm_dir)
         run()
         print(f"ready {kind} {gpt.replace(' ', '')} {nlay_b}", flush=True)
         for line in sys.stdin:
@@ -178,6 +193,31 @@ def cpu_worker(workload, seed, ncol_block):
     t.join()
 
 
+def _usable_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the container's CPU-time quota (cgroup cpu.max /
+    cfs_quota_us) -- a box can show 256 logical CPUs and grant the time of 16; more single-threaded workers than that only
+    throttle each other."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} logical CPUs in the affinity mask"
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        note += f", CPU-time quota of the container {quota:g} CPUs"
+        n = max(1, int(quota))
+    return n, note
+
+
 def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw"):
     """Reference (or port) CPU kernels on the host cores, bounded sample of the same workload: one
     single-threaded PROCESS per core, each looping over blocks of `ncol_block` columns (the reference's own
@@ -185,10 +225,20 @@ def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw")
     (`value_1core`, one process running alone)."""
     import subprocess
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    import shutil
+    import tempfile
+
+    from rte_rrtmgp_amd import synth
+
+    cores, cores_note = _usable_cores()
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    # the k-distribution tables once, in shared memory, mapped read-only by every worker
+    shm_dir = tempfile.mkdtemp(prefix="rte_kdist_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    for kind in (("lw", "sw") if workload == "allsky" else (workload,)):
+        for name, arr in synth.make_kdist(kind).arrays.items():
+            np.save(os.path.join(shm_dir, f"{kind}_{name}.npy"), np.asfortranarray(arr))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", workload, str(1000 + i),
-                               str(ncol_block)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
+                               str(ncol_block), shm_dir], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
              for i in range(cores)]
     try:
         ready = [p.stdout.readline().split() for p in procs]
@@ -220,6 +270,7 @@ def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw")
                 p.wait(timeout=30)
             except Exception:
                 p.kill()
+        shutil.rmtree(shm_dir, ignore_errors=True)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -230,15 +281,16 @@ def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw")
         pass
     gpt = gpt.replace("+", " + ")
     return {"value": rate, "unit": "columns/s", "cores": cores, "kind": kind,
-            "value_1core": rate1, "per_core_at_full_load": rate / cores, "cpu_model": model,
+            "value_1core": rate1, "per_core_at_full_load": rate / cores, "cpu_model": model, "cores_note": cores_note,
             "sample": f"{blocks * ncol_block} columns in {dt:.1f} s ({cores} single-threaded processes, one per core, "
-                      f"{blocks} blocks of {ncol_block} columns x {nlay_b} lay x {gpt} gpt), same kernel chain; "
+                      f"{blocks} blocks of {ncol_block} columns x {nlay_b} lay x {gpt} gpt, k-distribution tables shared read-only), "
+                      f"same kernel chain; "
                       f"1-core figure: {blocks1 * ncol_block} columns in {dt1:.1f} s by one process alone"}
 
 
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":  # internal: one process of cpu_baseline()
-        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+        cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else None)
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

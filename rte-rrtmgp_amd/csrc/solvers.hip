@@ -1383,7 +1383,7 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     const int Sr = (nlay + Lr - 1) / Lr;
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
-    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 6144 && ngroups < 16) ngroups *= 2;  // >= 24 blocks per CU: a short tail
     if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
     const int g_per_block = (ngpt + ngroups - 1) / ngroups;
     ngroups = (ngpt + g_per_block - 1) / g_per_block;
@@ -1418,7 +1418,7 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     // g-points per block: enough blocks to fill the chip several times over, few enough partial slabs
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
-    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 6144 && ngroups < 16) ngroups *= 2;  // >= 24 blocks per CU: a short tail
     if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
     const int g_per_block = (ngpt + ngroups - 1) / ngroups;
     ngroups = (ngpt + g_per_block - 1) / g_per_block;
@@ -1544,7 +1544,7 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const int S = (nlay + L - 1) / L;
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
-    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 6144 && ngroups < 16) ngroups *= 2;  // >= 24 blocks per CU: a short tail
     if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
     const int g_per_block = (ngpt + ngroups - 1) / ngroups;
     ngroups = (ngpt + g_per_block - 1) / g_per_block;
@@ -1620,7 +1620,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const int S = (nlay + L - 1) / L;
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
-    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 2048 && ngroups < 16) ngroups *= 2;
+    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 6144 && ngroups < 16) ngroups *= 2;  // >= 24 blocks per CU: a short tail
     if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
     const int g_per_block = (ngpt + ngroups - 1) / ngroups;
     ngroups = (ngpt + g_per_block - 1) / g_per_block;

@@ -65,7 +65,7 @@ class NumpyArrays:
     def asarray(self, a):
         a = np.asarray(a)
         if a.dtype.kind == "f":
-            a = a.astype(self.ftype)
+            a = a.astype(self.ftype, copy=False)  # no copy when already right: read-only shared (mmap) tables stay shared
         return np.asfortranarray(a)
 
     def to_numpy(self, a):
