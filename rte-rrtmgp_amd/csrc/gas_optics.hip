@@ -1299,7 +1299,13 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       // lanes past the last column repeat it (ic is clamped): same values to the same addresses.  Unconditional
       // stores keep the count of outstanding memory operations static (counted waits instead of drains).
 #pragma unroll
-      for (int j = 0; j < G; ++j) *tau_at(j) = acc[j];
+      for (int j = 0; j < G; ++j) {
+#ifdef X9_NT
+        __builtin_nontemporal_store(acc[j], tau_at(j));
+#else
+        *tau_at(j) = acc[j];
+#endif
+      }
     } else if (valid) {
       // tau is inout (the reference accumulates onto it, :637,:679).  The stage's sum is added to the incoming
       // value at the end: identical to the reference when tau comes in as zero (always, in the frontend),
@@ -1950,8 +1956,13 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
           // lanes past the last column repeat it (ic is clamped) and store the same values to the same
           // addresses: unconditional stores keep the number of outstanding memory operations static, so the
           // wait for the next layer's weights is a counted one instead of a drain of these stores
+#ifdef PLX_NT
+          __builtin_nontemporal_store(vlay, reinterpret_cast<Float*>(play_ + slay * j + olay));
+          __builtin_nontemporal_store(vlev, reinterpret_cast<Float*>(plev_ + slev * j + olay));
+#else
           *reinterpret_cast<Float*>(play_ + slay * j + olay) = vlay;
           *reinterpret_cast<Float*>(plev_ + slev * j + olay) = vlev;  // level l of (ncol, nlay+1): same column offset
+#endif
           prev[j] = pf;
         }
         asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));  // keep the pair's arithmetic here

@@ -769,6 +769,7 @@ struct Sw2SegArgs {
 
 template <int L>
 __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
+#pragma clang fp contract(fast)  // VALU-bound: fuse a*b+c (the segment composites already differ from the reference's rounding)
   constexpr int SMAX = 8, NC1 = 8, NC2 = 2;
   extern __shared__ Float lds[];  // X1[NC1][SMAX][64] (P, m00, m02, m10, m11, m12, m20, m22), X2[NC2][SMAX][64] (A, B)
   Float* const X1 = lds;
@@ -818,6 +819,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   };
 
   auto process = [&](In& x, int igpt_next) {
+#pragma clang fp contract(fast)
     Float R[L], T[L], su[L], sd[L];  // Rdif, Tdif, source up / down (relative to the beam entering the segment)
     Float Tn[L];                      // direct-beam transmission of the layer
     Float P = 1;                      // direct-beam transmission of the layers above layer i in this segment
@@ -1023,6 +1025,7 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
   };
 
   auto process = [&](In& x, int igpt, int igpt_next) {
+    // (no FMA contraction here: lw_two_stream's differences of nearly equal terms move by 4e-10 relative when fused)
     Float R[L], T[L], su[L], sd[L];
     // ---- (1) two-stream coefficients and sources of this segment's layers (slot i: top level i, bottom i+1)
 #pragma unroll
