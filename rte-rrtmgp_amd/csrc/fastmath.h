@@ -25,9 +25,8 @@ __device__ __forceinline__ float sqrt_nr(float x) { return sqrtf(x); }
 // Horner step with the coefficient as the addend; the constant sits in a register pair of its own (VGPRs: these kernels have no scalar registers to spare),
 // so a step is ONE v_fma_f64 instead of the v_mov_b64 + v_fmac_f64 pair the generic code gets
 __device__ __forceinline__ double fma_c(double p, double r, double c) {
-  double o;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
-  return o;
+  asm("" : "+s"(c));  // the constant in a scalar register pair: the FMA takes it as its SGPR operand
+  return __builtin_fma(p, r, c);
 }
 
 __device__ __forceinline__ double exp_nonpos(double x) {

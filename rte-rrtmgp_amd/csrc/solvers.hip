@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   extern __shared__ Float lds[];  // X1[NC1][SMAX][64] (P, m00, m02, m10, m11, m12, m20, m22), X2[NC2][SMAX][64] (A, B)
   Float* const X1 = lds;
   Float* const X2 = lds + NC1 * SMAX * 64;
-  Float* const MU = X2 + NC2 * SMAX * 64;  // mu0 of this wave's layers: [SMAX][L][64]
+  Float* const MU = X2 + NC2 * SMAX * 64;  // of this wave's layers: max(min_mu0, mu0) and its reciprocal, [SMAX][2][L][64]
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int S = a.S, ncol = a.ncol, nlay = a.nlay;
@@ -794,28 +794,54 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     return a.top_at_1 ? p : nlay - 1 - p;
   };
 
-  // per-layer cosine of the solar zenith angle: independent of the g-point, parked in LDS (lane-private slots)
-  Float* const mu0r = MU + (size_t)s * L * 64 + lane;  // element i at mu0r[i * 64]
+  constexpr bool DIRLDS = L <= 9;  // the direct-flux accumulators in LDS (ds_add_f64 on the thread's own slots): 2L+2 registers
+  Float* const dirs = MU + (size_t)SMAX * 2 * L * 64 + (size_t)s * (L + 1) * 64 + lane;  // acc_dir slot i at dirs[i * 64]
+  // per-layer cosine of the solar zenith angle and what depends on it alone: independent of the g-point, parked in
+  // LDS (lane-private slots) -- the clamped value (:1046) and its reciprocal (tau / mu0 becomes a product), the
+  // reciprocal carrying "mu0 > 0" (:1122) in its sign
+  Float* const mu0s = MU + (size_t)s * 2 * L * 64 + lane;  // element i at mu0s[i * 64]
+  Float* const mu0i = mu0s + L * 64;
 #pragma unroll
-  for (int i = 0; i < L; ++i) mu0r[i * 64] = a.mu0[c + (size_t)ncol * layer_of(i)];
+  for (int i = 0; i < L; ++i) {
+    const Float m = a.mu0[c + (size_t)ncol * layer_of(i)];
+    const Float ms = fmax(min_mu0, m);
+    mu0s[i * 64] = ms;
+    mu0i[i * 64] = m > (Float)0 ? rte::rcp_nr(ms) : -rte::rcp_nr(ms);
+  }
   const Float mu0_top = a.mu0[c + (size_t)ncol * (a.top_at_1 ? 0 : nlay - 1)];
   const Float mu0_sfc = a.mu0[c + (size_t)ncol * (a.top_at_1 ? nlay - 1 : 0)];
 
-  Float acc_up[L + 1], acc_dn[L + 1], acc_dir[L + 1];
+  Float acc_up[L + 1], acc_dn[L + 1], acc_dir[DIRLDS ? 1 : L + 1];
 #pragma unroll
-  for (int i = 0; i <= L; ++i) { acc_up[i] = 0; acc_dn[i] = 0; acc_dir[i] = 0; }
+  for (int i = 0; i <= L; ++i) {
+    acc_up[i] = 0; acc_dn[i] = 0;
+    if constexpr (DIRLDS) dirs[i * 64] = 0; else acc_dir[i] = 0;
+  }
+  auto add_dir = [&](int i, Float v) { if constexpr (DIRLDS) atomicAdd(&dirs[i * 64], v); else acc_dir[i] += v; };
 
   struct In { Float tau[L], ssa[L], g[L], inc_dir, alb_dir, alb_dif, inc_dif; };
+  // loads as (wave-uniform plane base, advanced per g-point) + (32-bit byte offset of the lane's row): the saddr form
+  // of global_load, no 64-bit address arithmetic per load (the host guarantees 8 * ncol * nlay < 2^32)
+  unsigned orow[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    orow[i] = ((unsigned)c + (unsigned)ncol * (unsigned)layer_of(i)) * (unsigned)sizeof(Float);
+    asm volatile("" : "+v"(orow[i]));
+  }
+  unsigned ocg = (unsigned)c * (unsigned)sizeof(Float);
+  asm volatile("" : "+v"(ocg));
+  auto at = [](const Float* plane, unsigned off) {  // plane is wave-uniform
+    asm volatile("" : "+v"(off));  // opaque inside the g-point loop: its 64-bit extension cannot be hoisted
+    return *reinterpret_cast<const Float*>(reinterpret_cast<const char*>(plane) + off);
+  };
   auto load = [&](In& x, int igpt_) {
     const int igpt = min(igpt_, g_end - 1);
-    const size_t cg = c + (size_t)ncol * igpt;
+    const Float *ptau = a.tau + ncl * igpt, *pssa = a.ssa + ncl * igpt, *pg = a.g + ncl * igpt;
 #pragma unroll
-    for (int i = 0; i < L; ++i) {
-      const size_t o = c + (size_t)ncol * layer_of(i) + ncl * igpt;
-      x.tau[i] = a.tau[o]; x.ssa[i] = a.ssa[o]; x.g[i] = a.g[o];
-    }
-    x.inc_dir = a.inc_flux_dir[cg]; x.alb_dir = a.sfc_alb_dir[cg]; x.alb_dif = a.sfc_alb_dif[cg];
-    x.inc_dif = a.has_dif_bc ? a.inc_flux_dif[cg] : (Float)0;  // :579-583
+    for (int i = 0; i < L; ++i) { x.tau[i] = at(ptau, orow[i]); x.ssa[i] = at(pssa, orow[i]); x.g[i] = at(pg, orow[i]); }
+    const size_t cg = (size_t)ncol * igpt;
+    x.inc_dir = at(a.inc_flux_dir + cg, ocg); x.alb_dir = at(a.sfc_alb_dir + cg, ocg); x.alb_dif = at(a.sfc_alb_dif + cg, ocg);
+    x.inc_dif = a.has_dif_bc ? at(a.inc_flux_dif + cg, ocg) : (Float)0;  // :579-583
   };
 
   auto process = [&](In& x, int igpt_next) {
@@ -826,26 +852,34 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     // ---- (1) two-stream coefficients and relative sources, top -> bottom (:1015-1114)
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-      if (i < np) {  // wave-uniform
-        const Float tau_s = x.tau[i], w0_s = x.ssa[i], g_s = x.g[i];
+      {
+        // a slot past the segment's last layer (partial last segment only) is made NEUTRAL by tau = 0: e1 = e2 =
+        // Tnoscat = 1, so Rdif = 0, the clamps give Rdir = Tdir = 0 exactly, and Tdif (1 up to rounding) is set to 1
+        // -- the identity in every recurrence, without a branch around the layer
+        const Float tau_s = i < np ? x.tau[i] : (Float)0, w0_s = x.ssa[i], g_s = x.g[i];
         const Float gamma1 = ((Float)8 - w0_s * ((Float)5 + (Float)3 * g_s)) * (Float).25;
         const Float gamma2 = (Float)3 * (w0_s * ((Float)1 - g_s)) * (Float).25;
         const Float kk = rte::sqrt_nr(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
         const Float e1 = rte::exp_nonpos(-tau_s * kk);
         const Float e2 = e1 * e1;
-        Float RT = rte::rcp_nr(kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
-        R[i] = RT * gamma2 * ((Float)1 - e2);
-        T[i] = RT * (Float)2 * kk * e1;
-        const Float mu0_s = fmax(min_mu0, mu0r[i * 64]);
+        // RT = 1 / x (:1031) and w0 RT / om (:1054) from ONE reciprocal, of x om
+        const Float xden = kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2);
+        const Float mu0_s = mu0s[i * 64];
         const Float k_mu = kk * mu0_s;
         const Float om = (Float)1 - k_mu * k_mu;
-        RT = rte::div_nr(w0_s * RT, fabs(om) >= (Float)RTE_EPS ? om : (Float)RTE_EPS);
+        const Float om_s = fabs(om) >= (Float)RTE_EPS ? om : (Float)RTE_EPS;
+        const Float inv = rte::rcp_nr(xden * om_s);
+        Float RT = om_s * inv;
+        R[i] = RT * gamma2 * ((Float)1 - e2);
+        T[i] = i < np ? RT * (Float)2 * kk * e1 : (Float)1;
+        RT = w0_s * inv;
         const Float gamma3 = ((Float)2 - (Float)3 * mu0_s * g_s) * (Float).25;
         const Float gamma4 = (Float)1 - gamma3;
         const Float alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
         const Float alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
         const Float k_gamma3 = kk * gamma3, k_gamma4 = kk * gamma4;
-        const Float Tnoscat = rte::exp_nonpos(-rte::div_nr(tau_s, mu0_s));
+        const Float imu = mu0i[i * 64];
+        const Float Tnoscat = rte::exp_nonpos(-tau_s * fabs(imu));
         Float Rdir = RT * (((Float)1 - k_mu) * (alpha2 + k_gamma3) - ((Float)1 + k_mu) * (alpha2 - k_gamma3) * e2 -
                            (Float)2.0 * (k_gamma3 - alpha2 * k_mu) * e1 * Tnoscat);
         Float Tdir = -RT * (((Float)1 + k_mu) * (alpha1 + k_gamma4) * Tnoscat -
@@ -853,13 +887,11 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
                             (Float)2.0 * (k_gamma4 + alpha1 * k_mu) * e1);
         Rdir = fmax((Float)0, fmin(Rdir, ((Float)1 - Tnoscat)));
         Tdir = fmax((Float)0, fmin(Tdir, ((Float)1 - Tnoscat - Rdir)));
-        const bool sun = mu0r[i * 64] > (Float)0;  // :1122-1125
+        const bool sun = imu > (Float)0;  // :1122-1125
         su[i] = sun ? Rdir * P : (Float)0;
         sd[i] = sun ? Tdir * P : (Float)0;
         Tn[i] = Tnoscat;
         P = Tnoscat * P;
-      } else {  // neutral layer: identity in every recurrence
-        R[i] = 0; T[i] = 1; su[i] = 0; sd[i] = 0; Tn[i] = 1;
       }
     }
     // ---- segment composite of the adding recurrence (bottom -> top product of the per-layer maps)
@@ -873,7 +905,8 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
       const Float n20 = q20 * m00 + m20, n22 = q20 * m02 + m22;
       m00 = n00; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m22 = n22;
     }
-    // the layer inputs are dead: request the next g-point's into the same registers (in flight during (2), (3))
+    // the layer inputs are dead: request the next g-point's into the same registers (in flight during (2), (3);
+    // spreading the requests over pass (1), layer by layer, was tried: the register allocator spills)
     const Float inc_dir = x.inc_dir, alb_dir = x.alb_dir, alb_dif = x.alb_dif, inc_dif = x.inc_dif;
     load(x, igpt_next);
     X1[(0 * SMAX + s) * 64 + lane] = P;
@@ -943,13 +976,13 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     for (int i = 0; i < L; ++i) {
       acc_up[i] += fd * al[i] + sr[i];
       acc_dn[i] += fd + dirl;
-      acc_dir[i] += dirl;
+      add_dir(i, dirl);
       fd = fa[i] * fd + fb[i];
       dirl = Tn[i] * dirl;
     }
     acc_up[L] += fd * al[L] + sr[L];
     acc_dn[L] += fd + dirl;
-    acc_dir[L] += dirl;
+    add_dir(L, dirl);
   };
 
   In cur;
@@ -964,7 +997,8 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         const int ilev = a.top_at_1 ? p : nlay - p;
         a.part_up[base + (size_t)ncol * ilev] = acc_up[i];
         a.part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
-        a.part_dir[base + (size_t)ncol * ilev] = acc_dir[i];
+        if constexpr (DIRLDS) a.part_dir[base + (size_t)ncol * ilev] = dirs[i * 64];
+        else a.part_dir[base + (size_t)ncol * ilev] = acc_dir[i];
       }
     }
   }
@@ -1617,7 +1651,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
   }
   hipStream_t st0 = rte::stream();
   // ------------------------------------------------------------------ production path (broadband, nlay <= 64)
-  if (do_broadband && nlay <= 80 && !g_sw_force_generic) {
+  if (do_broadband && nlay <= 80 && !g_sw_force_generic && ncl < ((size_t)1 << 29)) {  // 32-bit in-plane byte offsets
     // layers per wave: 8 up to 64 layers, then 9 (72 layers: the all-sky configuration) or 10 -- always 8 waves
     const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);
     const int S = (nlay + L - 1) / L;
@@ -1635,7 +1669,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     q.part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * 3);
     q.part_dn = q.part_up + nclv * ngroups;
     q.part_dir = q.part_dn + nclv * ngroups;
-    const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 8 * L);
+    const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 2 * 8 * L + (L <= 9 ? 8 * (L + 1) : 0));  // composites, flux maps, mu0 (clamped, reciprocal), direct-flux accumulators
     {
       rte::ProfScope p("sw_2stream_seg_kernel");
       if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
