@@ -1324,11 +1324,22 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   if (all_run) run_stages(std::true_type{}); else run_stages(std::false_type{});
 }
 
+// the few flag / counter words a call needs zeroed, in ONE launch (each hipMemsetAsync is a launch of its own)
+__global__ void __launch_bounds__(256) zero_words_kernel(int* a, unsigned na, int* b, unsigned nb, int* c, unsigned nc) {
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < na + nb + nc; i += gridDim.x * 256) {
+    if (i < na) a[i] = 0;
+    else if (i < na + nb) b[i - na] = 0;
+    else c[i - na - nb] = 0;
+  }
+}
+
 // (tile, layer, band) triples the slab kernel could not hold, done by the direct-gather code
 // (work item = one entry x one 64-column chunk, taken by waves in grid stride: the few hundred entries of a call
 // spread over all CUs instead of one block walking an entry's 512 columns)
-__global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a, const int* __restrict__ worklist, int tile) {
+__global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a, const int* __restrict__ worklist, int tile,
+                                                                      int* __restrict__ stat) {
   const int n = worklist[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *stat = n;  // rte_hip_stat(0)
   const int chunks = tile / 64;
   const int items = n * chunks;
   for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += gridDim.x * 4) {
@@ -1519,8 +1530,9 @@ __global__ void __launch_bounds__(256) planck_source_kernel(PlanckArgs q, const 
 
 // (tile, band) pairs the slab kernel handed over (worklist[0] = count)
 __global__ void __launch_bounds__(256)
-planck_source_worklist_kernel(PlanckArgs q, const int* __restrict__ worklist, int tile) {
+planck_source_worklist_kernel(PlanckArgs q, const int* __restrict__ worklist, int tile, int* __restrict__ stat) {
   const int n = worklist[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *stat = n;  // rte_hip_stat(1)
   for (int w = blockIdx.x; w < n; w += gridDim.x)
     for (int c = threadIdx.x; c < tile; c += 256) {
       const int icol = worklist[1 + 2 * w] * tile + c;
@@ -2306,9 +2318,11 @@ static void tau_absorption_impl(
   // layer limits of the two regimes per column (:274-285) + "regimes overlap somewhere" flag
   int* lim = (int*)rte::scratch(sizeof(int) * (4 * (size_t)ncol + 1));
   int* overlap = lim + 4 * (size_t)ncol;
+  const size_t wl_cap = (size_t)cdiv(ncol, 256) * nlay * nbnd;  // tiles are at least 256 columns wide
+  int* const worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
   {
     rte::ProfScope p("tau_absorption_setup");
-    HIP_CHECK(hipMemsetAsync(overlap, 0, sizeof(int), st));
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, overlap, 1u, worklist, 1u, (int*)nullptr, 0u);
     hipLaunchKernelGGL(tropo_limits_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, st, ncol, nlay, d_play, d_tropo, lim,
                        overlap);
   }
@@ -2523,9 +2537,7 @@ static void tau_absorption_impl(
 #define V7_SLAB SLAB_FLOATS
 #endif
   constexpr int BS = V7_BS;
-  const size_t wl_cap = (size_t)cdiv(ncol, 256) * nlay * nbnd;  // tiles are at least 256 columns wide
-  v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
-  HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
+  v.worklist = worklist;
   const bool use_v9 = g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr;  // the single-role kernel exists for 16-wide stages only
   if (use_v9) {
 #ifdef EXP_CLOCKS
@@ -2587,8 +2599,7 @@ static void tau_absorption_impl(
     TauArgs aw = a;
     aw.run_if = nullptr;
     hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(4096), dim3(256), 0, st, aw, (const int*)v.worklist,
-                       use_v9 ? V9_NCW * 64 : BS);
-    HIP_CHECK(hipMemcpyAsync(stats_dev() + 0, v.worklist, sizeof(int), hipMemcpyDeviceToDevice, st));
+                       use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
   }
 }
 
@@ -2835,7 +2846,11 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   }
   // plan guard: the band limits on the device must have the alignment the cached stage width assumes
   int* guard = (int*)rte::scratch(sizeof(int));
-  HIP_CHECK(hipMemsetAsync(guard, 0, sizeof(int), st));
+  constexpr int BS = 256;
+  int* const worklist = (int*)rte::scratch(sizeof(int) * (1 + 2 * (size_t)cdiv(ncol, BS) * nbnd));
+  const unsigned nflags = cdiv(ncol, 512) * (unsigned)nbnd;  // (512-column tile, band) flags of the specialised-wave kernel
+  int* const d_flags = (int*)rte::scratch(sizeof(int) * (size_t)nflags);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(cdiv(nflags + 2, 256)), dim3(256), 0, st, guard, 1u, worklist, 1u, d_flags, nflags);
   hipLaunchKernelGGL(bands_guard_kernel, dim3(1), dim3(64), 0, st, nbnd, ngpt, d_band_lims, bl_gw, guard, d_stale);
   const int TE = ntemp * neta;
   Float* pf_g = (Float*)rte::scratch(sizeof(Float) * (size_t)TE * (npres + 1) * ngpt);
@@ -2852,9 +2867,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   v.tlay = d_tlay; v.tlev = d_tlev; v.tsfc = d_tsfc;
   v.sfc_src = d_sfc_src; v.lay_src = d_lay_src; v.lev_src = d_lev_src; v.sfc_jac = d_sfc_jac;
   v.skip_if = guard;
-  constexpr int BS = 256;
-  v.worklist = (int*)rte::scratch(sizeof(int) * (1 + 2 * (size_t)cdiv(ncol, BS) * nbnd));
-  HIP_CHECK(hipMemsetAsync(v.worklist, 0, sizeof(int), st));
+  v.worklist = worklist;
   int wl_tile = BS;
   const bool planck9 = (g_planck_variant == 9 || bl_gw != 16) && nlay <= 256 && nbnd <= MAXB &&
                        (size_t)ncol * (nlay + 1) < ((size_t)1 << 29);
@@ -2868,8 +2881,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     wl_tile = NCW * 64;
     const unsigned tiles = cdiv(ncol, NCW * 64);
     TileGeom* d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
-    int* d_flags = (int*)rte::scratch(sizeof(int) * (size_t)tiles * nbnd);
-    HIP_CHECK(hipMemsetAsync(d_flags, 0, sizeof(int) * (size_t)tiles * nbnd, st));
+    static_assert(NCW * 64 == 512, "d_flags is sized for 512-column tiles");
 #ifdef EXP_CLOCKS
     v.clocks = (unsigned long long*)rte::scratch(64);
     HIP_CHECK(hipMemsetAsync(v.clocks, 0, 64, st));
@@ -2911,10 +2923,10 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   {
     // (tile, band) pairs whose pfrac bounding box exceeded the LDS slab at some layer
     rte::ProfScope p("planck_source_fallback");
-    hipLaunchKernelGGL(planck_source_worklist_kernel, dim3(1024), dim3(256), 0, st, q, (const int*)v.worklist, wl_tile);
+    hipLaunchKernelGGL(planck_source_worklist_kernel, dim3(1024), dim3(256), 0, st, q, (const int*)v.worklist, wl_tile,
+                       stats_dev() + 1);
     // the whole call on the direct kernel if the guard fired
     hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)guard);
-    HIP_CHECK(hipMemcpyAsync(stats_dev() + 1, v.worklist, sizeof(int), hipMemcpyDeviceToDevice, st));
   }
 }
 

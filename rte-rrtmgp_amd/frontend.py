@@ -515,7 +515,9 @@ def rte_lw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, lay_src, lev_src, sfc_emis_
             for imu in range(nmus):
                 sec[:, :, imu] = GAUSS_DS[nmus - 1][imu]
             b[key] = xp.asarray(sec)
-        b[("weights", nmus)] = xp.asarray(np.array(GAUSS_WTS[nmus - 1] if lw_Ds is None else [1.0]))
+        # the quadrature weights stay on the HOST, as in the reference (gauss_wts is a host table, mo_rte_lw.F90:367):
+        # the library reads them on the host, and a device copy would cost a device-to-host copy + sync per call
+        b[("weights", nmus)] = np.array(GAUSS_WTS[nmus - 1] if lw_Ds is None else [1.0], dtype=xp.ftype)
     secants, weights = b[key], b[("weights", nmus)]
     do_rescaling = ssa is not None and g is not None
     decoy2 = buf("decoy2D", (ncol, nlay + 1))
