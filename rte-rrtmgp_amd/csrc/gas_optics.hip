@@ -2186,7 +2186,7 @@ static void stale_poll() {
 
 namespace {
 struct TauPlanCache {
-  const void* key[13] = {};
+  const void* key[14] = {};
   int dims[7] = {};
   int epoch = -1;
   bool fast_ok = false;
@@ -2196,14 +2196,14 @@ struct TauPlanCache {
   std::vector<BandMeta> bands;
   bool matches(const void* const* k, const int* d, int e) const {
     if (e != epoch) return false;
-    for (int i = 0; i < 13; ++i)
+    for (int i = 0; i < 14; ++i)
       if (k[i] != key[i]) return false;
     for (int i = 0; i < 7; ++i)
       if (d[i] != dims[i]) return false;
     return true;
   }
   void set(const void* const* k, const int* d, int e) {
-    for (int i = 0; i < 13; ++i) key[i] = k[i];
+    for (int i = 0; i < 14; ++i) key[i] = k[i];
     for (int i = 0; i < 7; ++i) dims[i] = d[i];
     epoch = e;
   }
@@ -2334,10 +2334,10 @@ static void tau_absorption_impl(
   constexpr int NPLAN = 4;
   static TauPlanCache plans[NPLAN];
   static int plan_next = 0;
-  const void* key[13] = {gpoint_flavor, band_lims_gpt, minor_limits_gpt_lower, minor_limits_gpt_upper, kminor_start_lower,
+  const void* key[14] = {gpoint_flavor, band_lims_gpt, minor_limits_gpt_lower, minor_limits_gpt_upper, kminor_start_lower,
                          kminor_start_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
-                         idx_minor_scaling_upper, minor_scales_with_density_lower, scale_by_complement_lower,
-                         scale_by_complement_upper};
+                         idx_minor_scaling_upper, minor_scales_with_density_lower, minor_scales_with_density_upper,
+                         scale_by_complement_lower, scale_by_complement_upper};
   // Tables in HOST memory (what the Fortran frontend passes) are fingerprinted, so a plan is never reused for
   // different contents at the same address.  Device-resident tables cannot be inspected without draining the
   // stream: their owner calls rte_hip_invalidate_plans() after (re)uploading tables (frontend.GasOptics does).
