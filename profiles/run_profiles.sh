@@ -18,4 +18,11 @@ for g in fetch write; do
     python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc/${TAG}_$g.log 2>&1
 done
 python profiles/pmc_summarize.py gpurun_out/pmc/${TAG}_fetch gpurun_out/pmc/${TAG}_write > gpurun_out/prof/${TAG}_pmc_summary.csv
+# SQ counters (issue / wait / LDS) and traffic of the LW chain, the SW chain (60 layers) and the 72-layer solvers
+PMC_GROUPS="a b" bash profiles/pmc_run.sh ${TAG}lwsq bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cp gpurun_out/pmc/${TAG}lwsq_summary.csv gpurun_out/prof/${TAG}_lw_sq_summary.csv
+PMC_GROUPS="a b fetch write" bash profiles/pmc_run.sh ${TAG}sw tools/time_sw.py > /dev/null 2>&1
+cp gpurun_out/pmc/${TAG}sw_summary.csv gpurun_out/prof/${TAG}_sw_pmc_summary.csv
+PMC_GROUPS="a b fetch write" bash profiles/pmc_run.sh ${TAG}l72 tools/time_72_layers.py > /dev/null 2>&1
+cp gpurun_out/pmc/${TAG}l72_summary.csv gpurun_out/prof/${TAG}_72layers_pmc_summary.csv
 ls gpurun_out/prof | grep ${TAG}
