@@ -306,6 +306,11 @@ def main():
                          "contiguous run; sites-shuffled: the same columns in random order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
+    ap.add_argument("--overlap", action="store_true",
+                    help="compute_Planck_source concurrently with compute_tau_absorption on the library's second stream "
+                         "(rte_hip_overlap_planck; measured -0.12 ms per LW step: together the two kernels sit at the "
+                         "HBM ceiling).  Off by default: the per-kernel event and rocprof durations of the pair then "
+                         "overlap and no longer describe the kernels themselves")
     args = ap.parse_args()
 
     import torch
@@ -330,6 +335,8 @@ def main():
     # this driver touches tau only through the library between zero_array and compute_tau_absorption, so
     # the zero fill can be folded into the kernel that overwrites it (see csrc/runtime.hip)
     hiplib.ext_call(lib, "rte_hip_defer_zero", ["i"], 0 if args.no_defer_zero else 1)
+    overlap = args.overlap and args.workload in ("lw", "allsky")  # (the SW chain has no Planck source)
+    hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1 if overlap else 0)
     dev = f"cuda:{local_rank}"
     xp = frontend.TorchArrays(dev)
     ncol = args.ncol
@@ -447,14 +454,33 @@ def main():
                                          sharding.allgather_fluxes(rb["flux_dn"], ncol * world)))
 
     # per-kernel HIP-event timings collected inside the timed region
-    kern = {}
-    n = hiplib.ext_call(lib, "rte_hip_profile_count", [])
-    for i in range(n):
-        buf = ctypes.create_string_buffer(128)
-        cnt, ms = ctypes.c_longlong(0), ctypes.c_double(0)
-        lib.raw("rte_hip_profile_get")(ctypes.c_int(i), buf, ctypes.c_int(128), ctypes.byref(cnt), ctypes.byref(ms))
-        # several launches of one kernel per step (all-sky) count together: time per STEP
-        kern[buf.value.decode()] = {"launches": int(cnt.value), "avg_ms": ms.value / max(1, args.steps)}
+    def read_profile(nsteps):
+        out = {}
+        for i in range(hiplib.ext_call(lib, "rte_hip_profile_count", [])):
+            buf = ctypes.create_string_buffer(128)
+            cnt, ms = ctypes.c_longlong(0), ctypes.c_double(0)
+            lib.raw("rte_hip_profile_get")(ctypes.c_int(i), buf, ctypes.c_int(128), ctypes.byref(cnt), ctypes.byref(ms))
+            # several launches of one kernel per step (all-sky) count together: time per STEP
+            out[buf.value.decode()] = {"launches": int(cnt.value), "avg_ms": ms.value / max(1, nsteps)}
+        return out
+
+    kern = read_profile(args.steps)
+    # With the overlap on, compute_tau_absorption and compute_Planck_source run at the same time: their event
+    # durations in the timed region overlap (each is stretched by the other).  A short pass outside the timed region
+    # with the overlap off gives the kernels' own durations for the per-kernel roofline table.
+    kern_serial = None
+    if overlap:
+        hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 0)
+        step()
+        fence()
+        hiplib.ext_call(lib, "rte_hip_profile_reset", [])
+        hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
+        for _ in range(3):
+            step()
+        fence()
+        hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 0)
+        kern_serial = read_profile(3)
+        hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1)
 
     if rank == 0:
         if args.workload == "allsky":
@@ -462,16 +488,28 @@ def main():
         else:
             ab = algorithmic_bytes_per_collay(kd.nflav, kd.ngas, kd.ngpt, NLAY, defer_zero=not args.no_defer_zero)
         per_kernel = {}
+        concurrent = ("tau_absorption", "planck_source") if overlap else ()
         for name, bytes_cl in ab.items():
             if name in kern:
                 gb = bytes_cl * ncol * nlay_w / 1e9
                 ms = kern[name]["avg_ms"]
                 per_kernel[name] = {"avg_ms": round(ms, 4), "alg_GB": round(gb, 3),
                                     "GBps": round(gb / (ms * 1e-3), 1), "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
+                if kern_serial and name.startswith(concurrent) and name in kern_serial:
+                    # timed-region duration = while the other kernel shares the chip; the kernel's own duration:
+                    sm = kern_serial[name]["avg_ms"]
+                    per_kernel[name].update({"avg_ms_concurrent": round(ms, 4), "avg_ms": round(sm, 4),
+                                             "GBps": round(gb / (sm * 1e-3), 1),
+                                             "frac": round(gb / (sm * 1e-3) / HBM_PEAK_GBS, 4)})
         others = {k: round(v["avg_ms"], 4) for k, v in kern.items() if k not in per_kernel}
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
+        # the dominant kernel is chosen among those whose timed-region duration is their own (not the concurrent pair)
+        cand = [k for k in per_kernel if not k.startswith(concurrent)] or list(per_kernel)
+        dom = max(cand, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
         chain_gb = sum(v["alg_GB"] for v in per_kernel.values())
-        chain_ms = sum(v["avg_ms"] for v in per_kernel.values()) + sum(others.values())
+        if overlap:  # event durations of concurrent kernels double-count: the chain is the wall clock of a step
+            chain_ms = dt / args.steps * 1e3
+        else:
+            chain_ms = sum(v["avg_ms"] for v in per_kernel.values()) + sum(others.values())
         traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if dom and args.workload == "lw" and os.path.exists(pmc_path):  # the counters were collected on the LW chain
@@ -494,6 +532,8 @@ def main():
                     "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic, "traffic_unit": "GB per launch (PMC)",
                     "traffic_source": traffic_source,
                     "chain": {"alg_GB_per_step": round(chain_gb, 3), "kernel_ms_per_step": round(chain_ms, 4),
+                              "kernel_ms_is": ("wall clock of a step (tau_absorption and planck_source run concurrently)"
+                                               if overlap else "sum of the kernels' event durations"),
                               "GBps": round(chain_gb / (chain_ms * 1e-3), 1),
                               "frac": round(chain_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4)},
                     "per_kernel": per_kernel, "other_kernels_avg_ms": others}
@@ -514,6 +554,7 @@ def main():
                                     f"columns per GPU x {nlay_w} layers, 256 + 224 g-points (BASELINE configs[3] shape), "
                                     f"synthetic k-distributions and cloud tables, cloud field of examples/all-sky"),
                        "columns_per_gpu": ncol, "nlay": nlay_w, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero,
+                       "overlap_tau_planck": overlap,
                        "atmosphere": args.atmosphere,
                        "direct_gather_worklist": {"tau_tile_layer_bands": wl_tau, "of": tiles * nlay_w * kd.nbnd,
                                                   "planck_tile_bands": wl_planck, "of_planck": tiles * kd.nbnd},

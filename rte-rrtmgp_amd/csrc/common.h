@@ -49,6 +49,8 @@ class Call {
   // small host-side copy of an input array that may live on the device (index tables etc.)
   template <class T> const T* host(const T* p, size_t n) { return (const T*)to_host((const void*)p, n * sizeof(T)); }
   bool any_host() const { return n_back_ > 0 || staged_in_; }
+  // opt-in overlap of independent calls (runtime.hip, rte_hip_overlap_planck): run the rest of this call on the side stream
+  bool try_fork(const void* const* outs, const size_t* bytes, int n);
   const char* name;
 
  private:
@@ -61,7 +63,9 @@ class Call {
   bool host_visible_ = false;  // some array is pinned / registered / managed host memory used in place
   void* host_tmp_[24];
   int n_host_tmp_ = 0;
+  bool fork_candidate_ = false, forked_ = false;
 };
+void fork_point(const void* out, size_t bytes);  // marks "everything queued so far" at the start of a call others may overlap
 
 bool is_device_pointer(const void* p);  // a kernel can address it (device, or pinned / registered / managed host memory)
 bool is_device_memory(const void* p);   // device memory proper: calls on it are asynchronous

@@ -2315,6 +2315,7 @@ static void tau_absorption_impl(
   const int* d_jpress = c.in(jpress, ncl);
   Float* d_tau = c.inout(tau, ncl * ngpt);
   hipStream_t st = rte::stream();
+  if (!c.any_host() && rte::is_device_memory(d_tau)) rte::fork_point(d_tau, sizeof(Float) * ncl * ngpt);
   // layer limits of the two regimes per column (:274-285) + "regimes overlap somewhere" flag
   int* lim = (int*)rte::scratch(sizeof(int) * (4 * (size_t)ncol + 1));
   int* overlap = lim + 4 * (size_t)ncol;
@@ -2805,6 +2806,12 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   Float* d_lev_src = c.out(lev_src, (size_t)ncol * (nlay + 1) * ngpt);
   Float* d_sfc_jac = c.out(sfc_source_Jac, (size_t)ncol * ngpt);
   const Float totplnk_delta_r = (Float)1 / *totplnk_delta;  // :636
+  {
+    const void* outs[4] = {d_sfc_src, d_lay_src, d_lev_src, d_sfc_jac};
+    const size_t ob[4] = {sizeof(Float) * (size_t)ncol * ngpt, sizeof(Float) * ncl * ngpt,
+                          sizeof(Float) * (size_t)ncol * (nlay + 1) * ngpt, sizeof(Float) * (size_t)ncol * ngpt};
+    c.try_fork(outs, ob, 4);  // opt-in: concurrently with the compute_tau_absorption call this one follows
+  }
   hipStream_t st = rte::stream();
   int* d_stale = stale_flag();
   stale_poll();

@@ -17,16 +17,32 @@ namespace rte {
 static std::recursive_mutex g_mutex;  // entry points are serialised: stateless for the caller
 static hipStream_t g_stream = nullptr;
 
-hipStream_t stream() { return g_stream; }
+// ---- side stream (opt-in, rte_hip_overlap_planck) ------------------------------------------------
+// compute_tau_absorption and compute_Planck_source of one gas-optics step are independent of each other (both read
+// the interpolation state; one writes tau, the other the sources), one is bound by LDS gathers and latency, the other
+// by HBM stores, and each leaves a tail of idle CUs.  With the option on, a compute_Planck_source call that directly
+// follows a compute_tau_absorption call -- both on device memory, disjoint outputs -- runs on a second stream that
+// waits only for the work queued BEFORE the tau call; the library stream then waits for it, so every later call (and
+// anything the caller queues afterwards) sees its results.  Like the deferred zero fill: only for callers that queue
+// nothing of their own on the library stream between the two calls that writes compute_Planck_source's inputs.
+static bool g_overlap = false;
+static hipStream_t g_side = nullptr;
+static bool g_on_side = false;
+static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+static bool g_fork_valid = false;       // g_ev_fork marks the start of the immediately preceding library call
+static const char* g_fork_lo = nullptr; // that call's output range
+static const char* g_fork_hi = nullptr;
 
-// ---- scratch arena -----------------------------------------------------------------------
+hipStream_t stream() { return g_on_side ? g_side : g_stream; }
+
+// ---- scratch arena (one per stream) --------------------------------------------------------
 struct Block { char* base; size_t size; size_t used; };
-static std::vector<Block> g_blocks;
-static size_t g_call_total = 0;
+static std::vector<Block> g_blocks_main, g_blocks_side;
+static std::vector<Block>& blocks() { return g_on_side ? g_blocks_side : g_blocks_main; }
 
 void* scratch(size_t bytes) {
   bytes = (bytes + 255) & ~size_t(255);
-  g_call_total += bytes;
+  auto& g_blocks = blocks();
   for (auto& b : g_blocks)
     if (b.size - b.used >= bytes) {
       void* p = b.base + b.used;
@@ -41,9 +57,10 @@ void* scratch(size_t bytes) {
 }
 
 static void scratch_reset() {
+  auto& g_blocks = blocks();
   // keep one block big enough for the largest call seen so far; drop fragmentation
   if (g_blocks.size() > 1) {
-    HIP_CHECK(hipStreamSynchronize(g_stream));
+    HIP_CHECK(hipStreamSynchronize(stream()));
     size_t total = 0;
     for (auto& b : g_blocks) { total += b.size; HIP_CHECK(hipFree(b.base)); }
     g_blocks.clear();
@@ -52,7 +69,21 @@ static void scratch_reset() {
     g_blocks.push_back(nb);
   }
   for (auto& b : g_blocks) b.used = 0;
-  g_call_total = 0;
+}
+
+// compute_tau_absorption, before its first launch: everything queued so far is what a following
+// compute_Planck_source may depend on
+void fork_point(const void* out, size_t bytes) {
+  if (!g_overlap) return;
+  if (!g_ev_fork) {
+    HIP_CHECK(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
+    HIP_CHECK(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));  // no implicit ordering with the null stream
+  }
+  HIP_CHECK(hipEventRecord(g_ev_fork, g_stream));
+  g_fork_lo = (const char*)out;
+  g_fork_hi = g_fork_lo + bytes;
+  g_fork_valid = true;
 }
 
 // ---- persistent slots ----------------------------------------------------------------------
@@ -131,8 +162,27 @@ void flush_pending_zeros() {
 // ---- Call ---------------------------------------------------------------------------------------
 Call::Call(const char* n) : name(n) {
   g_mutex.lock();
+  fork_candidate_ = g_fork_valid;  // the previous call left a fork point (it is consumed or dropped by this call)
+  g_fork_valid = false;
   if (!g_pending.empty()) flush_pending_zeros();
   scratch_reset();
+}
+
+// Move the rest of this call (launches, scratch, timing events) to the side stream if that is safe: nothing of this
+// call has been staged or queued yet, all its arrays are device memory, and its outputs do not touch the range the
+// previous call writes.  Must be called after the in()/out() conversions and before the first launch.
+bool Call::try_fork(const void* const* outs, const size_t* bytes, int n) {
+  if (!g_overlap || !fork_candidate_ || n_back_ > 0 || staged_in_ || host_visible_ || n_host_tmp_ > 0) return false;
+  for (int i = 0; i < n; ++i) {
+    const char* lo = (const char*)outs[i];
+    if (!lo || !is_device_memory(lo)) return false;
+    if (lo < g_fork_hi && lo + bytes[i] > g_fork_lo) return false;
+  }
+  HIP_CHECK(hipStreamWaitEvent(g_side, g_ev_fork, 0));
+  g_on_side = true;
+  forked_ = true;
+  scratch_reset();  // the side arena: its previous user was the previous forked call, which the library stream has joined
+  return true;
 }
 
 void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out) {
@@ -160,8 +210,8 @@ const void* Call::to_host(const void* p, size_t bytes) {
     abort();
   }
   void* h = malloc(bytes);
-  HIP_CHECK(hipMemcpyAsync(h, p, bytes, hipMemcpyDeviceToHost, g_stream));
-  HIP_CHECK(hipStreamSynchronize(g_stream));
+  HIP_CHECK(hipMemcpyAsync(h, p, bytes, hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
   host_tmp_[n_host_tmp_++] = h;
   return h;
 }
@@ -172,6 +222,11 @@ Call::~Call() {
   // host arrays (staged, or host-visible memory used in place): the caller owns them again when the call returns
   if (n_back_ > 0 || staged_in_ || host_visible_) HIP_CHECK(hipStreamSynchronize(g_stream));
   for (int i = 0; i < n_host_tmp_; ++i) free(host_tmp_[i]);
+  if (forked_) {  // join: the library stream (and whatever is queued on it from now on) waits for this call
+    HIP_CHECK(hipEventRecord(g_ev_join, g_side));
+    HIP_CHECK(hipStreamWaitEvent(g_stream, g_ev_join, 0));
+    g_on_side = false;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fprintf(stderr, "rte_rrtmgp_hip: %s: launch error: %s\n", name, hipGetErrorString(e));
@@ -197,13 +252,13 @@ void prof_begin(const char* kernel) {
     g_cur = &g_prof.back();
   }
   HIP_CHECK(hipEventCreate(&g_cur_start));
-  HIP_CHECK(hipEventRecord(g_cur_start, g_stream));
+  HIP_CHECK(hipEventRecord(g_cur_start, stream()));
 }
 void prof_end() {
   if (!g_prof_on || !g_cur) return;
   hipEvent_t stop;
   HIP_CHECK(hipEventCreate(&stop));
-  HIP_CHECK(hipEventRecord(stop, g_stream));
+  HIP_CHECK(hipEventRecord(stop, stream()));
   g_cur->ev.emplace_back(g_cur_start, stop);
   g_cur = nullptr;
 }
@@ -233,7 +288,8 @@ int rte_hip_set_stream(void* s) {
   // work queued on the old stream still uses the scratch arena, the persistent slots and recorded zero fills:
   // materialise the fills there and drain it before anything is launched on the new stream
   rte::flush_pending_zeros();
-  HIP_CHECK(hipStreamSynchronize(rte::g_stream));
+  HIP_CHECK(hipStreamSynchronize(rte::g_stream));  // (forked calls have been joined into it)
+  rte::g_fork_valid = false;
   rte::g_stream = (hipStream_t)s;
   return 0;
 }
@@ -246,6 +302,13 @@ int rte_hip_sync(void) {
 int rte_hip_defer_zero(int on) {
   rte::flush_pending_zeros();
   rte::g_defer_zero = on != 0;
+  return 0;
+}
+// run compute_Planck_source concurrently with the compute_tau_absorption call it directly follows (see runtime.hip)
+int rte_hip_overlap_planck(int on) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::g_overlap = on != 0;
+  rte::g_fork_valid = false;
   return 0;
 }
 int rte_hip_device_count(void) {
@@ -283,8 +346,11 @@ int rte_hip_release(void) {
   std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
   rte::flush_pending_zeros();
   HIP_CHECK(hipStreamSynchronize(rte::g_stream));
-  for (auto& b : rte::g_blocks) HIP_CHECK(hipFree(b.base));
-  rte::g_blocks.clear();
+  if (rte::g_side) HIP_CHECK(hipStreamSynchronize(rte::g_side));
+  for (auto* v : {&rte::g_blocks_main, &rte::g_blocks_side}) {
+    for (auto& b : *v) HIP_CHECK(hipFree(b.base));
+    v->clear();
+  }
   for (auto& s : rte::g_slots) {
     if (s.p) HIP_CHECK(hipFree(s.p));
     s = rte::Slot{};

@@ -155,3 +155,41 @@ def test_32bit_offset_guard_falls_back():
             a, b = rb[k][..., sl], rs[k]
             assert float(((a - b).abs() / b.abs().clamp_min(1e-300)).max()) <= 1e-13, (k, c0)
     torch.cuda.synchronize()
+
+
+def test_planck_on_the_side_stream_gives_the_same_arrays():
+    """``rte_hip_overlap_planck(1)``: compute_Planck_source runs on a second stream concurrently with the
+    compute_tau_absorption call it follows (waiting only for what was queued before that call), and the library stream
+    joins it.  Same kernels on the same inputs: every array of the LW chain must be bit-identical to the serial run,
+    repeatedly (a missing dependency would show as a race), at a size where both kernels fill the chip."""
+    import torch
+
+    hip = hiplib.load()
+    xp = frontend.TorchArrays("cuda:0")
+    kd = synth.make_kdist("lw")
+    ncol = 40000
+    atm = synth.make_atmosphere(ncol, NLAY, seed=5, kdist=kd)
+    inp = {k: getattr(atm, k) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas")}
+
+    def run(overlap, reps):
+        hiplib.ext_call(hip, "rte_hip_overlap_planck", ["i"], overlap)
+        hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 1)
+        try:
+            bufs, rb, out = {}, {}, None
+            for _ in range(reps):
+                b, r = _lw_chain(hip, xp, kd, inp, ncol, atm.top_at_1, bufs=bufs, rb=rb)
+                # something of the caller's queued right behind the call, on the library stream, must see the sources
+                chk = b["lay_src"].sum() + b["lev_src"].sum() + b["sfc_src"].sum()
+                out = {k: b[k].clone() for k in ("tau", "lay_src", "lev_src", "sfc_src", "sfc_src_jac")}
+                out["flux_up"], out["flux_dn"], out["chk"] = r["flux_up"].clone(), r["flux_dn"].clone(), chk.clone()
+            torch.cuda.synchronize()
+            return out
+        finally:
+            hiplib.ext_call(hip, "rte_hip_overlap_planck", ["i"], 0)
+            hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 0)
+
+    serial = run(0, 1)
+    for _ in range(3):
+        forked = run(1, 3)
+        for k, v in serial.items():
+            assert torch.equal(v, forked[k]), k
