@@ -1009,7 +1009,10 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
 
 // MM = minor intervals per (band, regime) kept in registers (column amounts of the current and of the next stage):
 // 4 when no band of the table has more (saves 16 VGPRs and their selects), else MAXM
-template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G, int MM>
+// ADDB: a band-wise operand is added (rte_hip_compute_tau_absorption_inc_bybnd) -- a template parameter, not a run-time
+// test: a conditional load changes the number of outstanding memory operations from path to path, and the compiler
+// then waits for (nearly) all of them, i.e. for the previous stage's stores, at the top of every stage.
+template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G, int MM, bool ADDB>
 __global__ void __launch_bounds__((NCW + NLW) * 64, V9_MINW)
 tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
@@ -1129,7 +1132,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // minor column amounts, weights and eta indices of one stage
   struct Minor { Float sc[MM], cgs[MM]; Float2 fn0, fn1; int2 em; Float addv; };
   auto load_minor = [&](int b, int n, Minor& x) {
-    x.addv = a.add_bybnd ? a.add_bybnd[cl + (size_t)ncl * b] : (Float)0;  // block-uniform condition
+    x.addv = ADDB ? a.add_bybnd[cl + (size_t)ncl * b] : (Float)0;
 #pragma unroll
     for (int k = 0; k < MM; ++k) {
       x.sc[k] = 0; x.cgs[k] = 0;
@@ -1160,6 +1163,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   Minor mn;
   load_major(0, mj);
   load_minor(0, n_minor(0), mn);
+  // Nothing outstanding when the loop is entered: the wait counts inside it are then those of the steady state
+  // (requests of stage s+1, then the stores of stage s) and not the merge with this prologue, which made every stage
+  // wait for all but three of the previous stage's stores.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   int ibnd = 0;
 #pragma unroll 1
   for (int s = 0; s < nstage; ++s) {
@@ -1292,7 +1299,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     if (a.ncol < 0)
 #endif
     if (OVERWRITE) {
-      if (a.add_bybnd) {  // by-band increment fused in (tau = tau_gas + tau_2 of the band)
+      if (ADDB) {  // by-band increment fused in (tau = tau_gas + tau_2 of the band)
 #pragma unroll
         for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
       }
@@ -1312,7 +1319,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       // otherwise the same terms in a different order (1 ulp)
 #pragma unroll
       for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
-      if (a.add_bybnd) {
+      if (ADDB) {
 #pragma unroll
         for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
       }
@@ -2558,6 +2565,16 @@ static void tau_absorption_impl(
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = false;
     ga.lim = lim; ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.bmeta = d_bm;
     ga.skip_if = overlap; ga.worklist = v.worklist;
+#define RTE_LAUNCH_TAU9_(GW, AB)                                                                                  \
+  do {                                                                                                            \
+    if (mm4) {                                                                                                    \
+      if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
+      else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
+    } else {                                                                                                      \
+      if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MAXM, AB>), grid, blk, dyn, st, v, cg); \
+      else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, MAXM, AB>), grid, blk, dyn, st, v, cg); \
+    }                                                                                                             \
+  } while (0)
 #define RTE_LAUNCH_TAU9(GW)                                                                                       \
   do {                                                                                                            \
     {                                                                                                             \
@@ -2566,16 +2583,11 @@ static void tau_absorption_impl(
       else hipLaunchKernelGGL((tau_geom_kernel<NCW * 64, GW>), grid, dim3(NCW * 64), 0, st, v, d_geom, SLAB9);    \
     }                                                                                                             \
     rte::ProfScope p("tau_absorption_kernel");                                                                    \
-    if (mm4) {                                                                                                    \
-      if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4>), grid, blk, dyn, st, v, cg); \
-      else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4>), grid, blk, dyn, st, v, cg); \
-    } else {                                                                                                      \
-      if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MAXM>), grid, blk, dyn, st, v, cg); \
-      else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, MAXM>), grid, blk, dyn, st, v, cg); \
-    }                                                                                                             \
+    if (d_add) RTE_LAUNCH_TAU9_(GW, true); else RTE_LAUNCH_TAU9_(GW, false);                                      \
   } while (0)
     if (cache.gw == 16) RTE_LAUNCH_TAU9(16); else RTE_LAUNCH_TAU9(8);
 #undef RTE_LAUNCH_TAU9
+#undef RTE_LAUNCH_TAU9_
   } else {
     rte::ProfScope p("tau_absorption_kernel");
     // <min waves per SIMD, g-points per register chunk>: measured best of {2,3} x {4,8,16} on MI355X

@@ -20,6 +20,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 ROOT = os.path.dirname(PKG_DIR)
 LIB_NAMES = {"dp": "librte_rrtmgp_hip.so", "sp": "librte_rrtmgp_hip_sp.so"}
+if os.environ.get("RTE_HIP_VARIANT"):  # experiment builds of tools/variants.py (librte_rrtmgp_hip_x<tag>.so), A/B timing only
+    LIB_NAMES["dp"] = f"librte_rrtmgp_hip_x{os.environ['RTE_HIP_VARIANT']}.so"
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function"]
 
