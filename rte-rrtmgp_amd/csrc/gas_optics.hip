@@ -1121,8 +1121,8 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 
   // major weights + eta indices of band b (requested one stage ahead)
   struct Major { Float2 fm[4], cm; int2 je; };
-  auto load_major = [&](int b, Major& x) {
-    const size_t clf = cl + (size_t)ncl * bm[b].flav[itropo];
+  auto load_major = [&](int flav, Major& x) {
+    const size_t clf = cl + (size_t)ncl * flav;
     const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
 #pragma unroll
     for (int i = 0; i < 4; ++i) x.fm[i] = fmp[i];
@@ -1131,18 +1131,38 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   };
   // minor column amounts, weights and eta indices of one stage
   struct Minor { Float sc[MM], cgs[MM]; Float2 fn0, fn1; int2 em; Float addv; };
-  auto load_minor = [&](int b, int n, Minor& x) {
+  // What the requests of a stage's minor inputs need from the band table in LDS: which gases, which flavor.  Read at
+  // the TOP of the stage before (peek_minor), so that at its end the requests go out back to back: looked up there,
+  // each request waited for its own LDS round trip -- eleven in a row, with nothing else left to issue (0.8 ms).
+  struct MinorIdx { int idx[MM], isc[MM], flav, flav_major, n; };
+  auto peek_minor = [&](int b, int n, MinorIdx& q) {
+    q.n = n;
+#pragma unroll
+    for (int k = 0; k < MM; ++k) {
+      const MinorMeta& m = bm[b].m[rsel][k];  // (slots past the band's count are zero-filled: never used)
+      q.idx[k] = m.idx_minor;
+      q.isc[k] = ((m.flags & 1) && m.idx_scaling > 0) ? m.idx_scaling : -1;
+      asm volatile("" : "+v"(q.idx[k]), "+v"(q.isc[k]));  // looked up here, not where they are used
+    }
+    q.flav = bm[b].flav[rsel];  // minor absorbers use THEIR regime's flavor (:487)
+    q.flav_major = bm[b].flav[itropo];
+    asm volatile("" : "+v"(q.flav), "+v"(q.flav_major));
+  };
+  auto load_minor = [&](int b, const MinorIdx& q, Minor& x) {
     x.addv = ADDB ? a.add_bybnd[cl + (size_t)ncl * b] : (Float)0;
 #pragma unroll
     for (int k = 0; k < MM; ++k) {
       x.sc[k] = 0; x.cgs[k] = 0;
-      if (k < n) {
-        const MinorMeta& m = bm[b].m[rsel][k];
-        x.sc[k] = a.col_gas[cl + (size_t)ncl * m.idx_minor];
-        if ((m.flags & 1) && m.idx_scaling > 0) x.cgs[k] = a.col_gas[cl + (size_t)ncl * m.idx_scaling];
+      if (k < q.n) {
+        x.sc[k] = a.col_gas[cl + (size_t)ncl * q.idx[k]];
+        if (q.isc[k] >= 0) x.cgs[k] = a.col_gas[cl + (size_t)ncl * q.isc[k]];
       }
     }
-    const size_t clm = cl + (size_t)ncl * bm[b].flav[rsel];  // minor absorbers use THEIR regime's flavor (:487)
+  };
+  // the minor interpolation weights and eta indices go with the major ones (after the major pass), into registers of
+  // their own: left to the end of the stage with the column amounts they were on the stage's critical path
+  auto load_minor_w = [&](const MinorIdx& q, Minor& x) {
+    const size_t clm = cl + (size_t)ncl * q.flav;
     const Float2* fnp = reinterpret_cast<const Float2*>(a.fminor + 4 * clm);
     x.fn0 = fnp[0]; x.fn1 = fnp[1];
     x.em = *reinterpret_cast<const int2*>(a.jeta + 2 * clm);
@@ -1161,8 +1181,12 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr bool ALLRUN = decltype(allrun_tag)::value;
   Major mj;
   Minor mn;
-  load_major(0, mj);
-  load_minor(0, n_minor(0), mn);
+  MinorIdx nq;
+  Minor mw;  // (only fn0, fn1, em are used: the next stage's)
+  peek_minor(0, n_minor(0), nq);
+  load_major(nq.flav_major, mj);
+  load_minor(0, nq, mn);
+  load_minor_w(nq, mw);
   // Nothing outstanding when the loop is entered: the wait counts inside it are then those of the steady state
   // (requests of stage s+1, then the stores of stage s) and not the merge with this prologue, which made every stage
   // wait for all but three of the previous stage's stores.
@@ -1180,17 +1204,19 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     Float sc[MM], cgs[MM];
 #pragma unroll
     for (int k = 0; k < MM; ++k) { sc[k] = mn.sc[k]; cgs[k] = mn.cgs[k]; }
-    const Float2 fn0 = mn.fn0, fn1 = mn.fn1;
-    const int2 em = mn.em;
+    const Float2 fn0 = mw.fn0, fn1 = mw.fn1;
+    const int2 em = mw.em;
     const Float addv = mn.addv;
     // this stage's major weights into locals (col_mix folded in)
     const Float w0 = mj.cm.x * mj.fm[0].x, w1 = mj.cm.x * mj.fm[0].y, w2 = mj.cm.x * mj.fm[1].x, w3 = mj.cm.x * mj.fm[1].y,
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
     const int je1 = mj.je.x, je2 = mj.je.y;
     __syncthreads();  // B(s): slab(s) is complete
+    peek_minor(ibnd_n, n_minor(ibnd_n), nq);
     if (!ALLRUN && !run) {
-      load_major(ibnd_n, mj);
-      load_minor(ibnd_n, n_minor(ibnd_n), mn);
+      load_major(nq.flav_major, mj);
+      load_minor_w(nq, mw);
+      load_minor(ibnd_n, nq, mn);
       continue;
     }
     const Float* sl = slab[s & 1];
@@ -1237,7 +1263,11 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #ifdef X9_NOLOAD
     if (a.ncol < 0)
 #endif
-    load_major(ibnd_n, mj);
+    load_major(nq.flav_major, mj);
+#if defined(X9_NOLOAD) || defined(X9_NOLOAD_MIN)
+    if (a.ncol < 0)
+#endif
+    load_minor_w(nq, mw);
     __builtin_amdgcn_sched_barrier(0);
     // ---- minor absorbers of this regime; scalings (:461-480)
 #pragma unroll
@@ -1255,6 +1285,13 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         }
       }
     }
+#ifdef X9_EARLY_SC
+#if defined(X9_NOLOAD) || defined(X9_NOLOAD_MIN)
+    if (a.ncol < 0)
+#endif
+    load_minor(ibnd_n, nq, mn);  // this stage's amounts are scaled copies by now
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const Float f0 = fn0.x, f1 = fn0.y, f2 = fn1.x, f3 = fn1.y;
 #pragma unroll 1
     for (int k = 0; k < n_my; ++k) {
@@ -1284,10 +1321,12 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         if ((j & 6) == 6) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads in flight
       }
     }
-#ifdef X9_NOLOAD
+#ifndef X9_EARLY_SC
+#if defined(X9_NOLOAD) || defined(X9_NOLOAD_MIN)
     if (a.ncol < 0)
 #endif
-    load_minor(ibnd_n, n_minor(ibnd_n), mn);
+    load_minor(ibnd_n, nq, mn);
+#endif
     __builtin_amdgcn_sched_barrier(0);  // keep these requests ahead of the stores that follow
 #ifdef X9_NOSTORE
     {
