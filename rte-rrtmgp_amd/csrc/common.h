@@ -51,6 +51,7 @@ class Call {
   bool any_host() const { return n_back_ > 0 || staged_in_; }
   // opt-in overlap of independent calls (runtime.hip, rte_hip_overlap_planck): run the rest of this call on the side stream
   bool try_fork(const void* const* outs, const size_t* bytes, int n);
+  bool forked() const { return forked_; }
   const char* name;
 
  private:
@@ -65,6 +66,7 @@ class Call {
   int n_host_tmp_ = 0;
   bool fork_candidate_ = false, forked_ = false;
 };
+long call_seq();  // sequence number of the API call in progress (every entry point counts)
 void fork_point(const void* out, size_t bytes);  // marks "everything queued so far" at the start of a call others may overlap
 
 bool is_device_pointer(const void* p);  // a kernel can address it (device, or pinned / registered / managed host memory)

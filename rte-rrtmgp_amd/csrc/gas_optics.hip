@@ -903,6 +903,8 @@ struct Geom2Args {
   const BandMeta* bmeta;     // tau: band flavors and minor counts
   const int *band_lims, *gpoint_flavor;  // Planck: band flavors
   const int* skip_if;        // tau: the direct kernel does the whole call
+  const int* skip_if2;       // Planck: the geometry left by the compute_tau_absorption call before is valid (shared)
+  int* valid_out;            // tau: set to 1 once this geometry is (being) written, for a Planck call that shares it
   int* worklist;             // tau: (tile, layer, band) triples; Planck: (tile, band) pairs
   int* flags;                // Planck: one worklist entry per (tile, band)
 };
@@ -914,10 +916,12 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
   __shared__ unsigned mE[MAXFLAV][2];
   __shared__ int flav[MAXB][2], cnt[MAXB][2];
   if (a.skip_if && *a.skip_if) return;
+  if (a.skip_if2 && *a.skip_if2) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
   const unsigned ncl = ncol * nlay;
   const int nbnd = a.nbnd, nflav = a.nflav;
+  if (a.valid_out && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *a.valid_out = 1;  // (read by later launches only)
   if (tid == 0) { mT = 0; mP[0] = 0; mP[1] = 0; mReg = 0; }
   if (tid < 2 * MAXFLAV) mE[tid >> 1][tid & 1] = 0;
   if (tid < 2 * nbnd) {
@@ -1002,7 +1006,8 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
         const int w = atomicAdd(&a.worklist[0], 1);
         a.worklist[1 + 3 * w] = blockIdx.x; a.worklist[2 + 3 * w] = ilay; a.worklist[3 + 3 * w] = tid;
       }
-      out->eg[tid] = make_int2(emin, fits ? nE : 0);
+      // (nE <= 0: not a stage of the slab kernel; the magnitude is kept for a Planck call that shares this geometry)
+      out->eg[tid] = make_int2(emin, fits ? nE : -nE);
     }
   }
 }
@@ -1839,6 +1844,28 @@ __global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd,
   }
 }
 
+// Planck on a geometry left by compute_tau_absorption (rte_hip_share_geometry): which (tile, band) pairs do not fit
+// the slab at some layer.  One thread per pair.
+__global__ void __launch_bounds__(256)
+planck_flags_kernel(const TileGeom* __restrict__ geom, int tiles, int nlay, int nbnd, int slab_floats, int RS,
+                    int* __restrict__ flags, int* __restrict__ worklist, const int* __restrict__ valid,
+                    const int* __restrict__ guard) {
+  if (!*valid || *guard) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= tiles * nbnd) return;
+  const int tile = i / nbnd, b = i - tile * nbnd;
+  bool fits = true;
+  for (int l = 0; l < nlay; ++l) {
+    const TileGeom* g = geom + (tile + (size_t)tiles * l);
+    fits = fits && g->nP * g->nT * abs(g->eg[b].y) * RS <= slab_floats;
+  }
+  if (!fits) {
+    flags[i] = 1;
+    const int w = atomicAdd(&worklist[0], 1);
+    worklist[1 + 2 * w] = tile; worklist[2 + 2 * w] = b;
+  }
+}
+
 template <int NCW, int NLW, int SLAB, int G>
 __global__ void __launch_bounds__((NCW + NLW) * 64, (NCW + NLW + 3) / 4)
 planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* __restrict__ geom,
@@ -1868,7 +1895,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
   for (int l = tid; l < (int)nlay; l += NT) {
     const TileGeom* g = geom + (tile + (size_t)ntiles * l);
     gl[l][0] = g->Tmin; gl[l][1] = g->nT; gl[l][2] = g->Pmin; gl[l][3] = g->nP;
-    gl[l][4] = g->eg[ibnd].x; gl[l][5] = g->eg[ibnd].y;
+    gl[l][4] = g->eg[ibnd].x; gl[l][5] = abs(g->eg[ibnd].y);  // (negative in a geometry shared with compute_tau_absorption)
   }
   __syncthreads();
   const int nchunk = (gptE - gptS + 1) / G;  // host guarantees whole, 16-aligned chunks
@@ -2256,8 +2283,25 @@ struct TauPlanCache {
 };
 }  // namespace
 
+// Geometry shared between compute_tau_absorption and the compute_Planck_source call that directly follows it
+// (opt-in, rte_hip_share_geometry): both derive the same per-(tile, layer) bounding boxes from the same interpolation
+// indices, each by reading all of jeta (0.13 ms).  Like the deferred zero fill, for callers that touch the
+// interpolation arrays only through this library between the two calls; keyed by the arrays' addresses, the
+// dimensions and the library's call sequence (the Planck call must be the very next one).
+static int g_share_geom = 0;
+struct SharedGeom {
+  const void *jeta = nullptr, *jtemp = nullptr, *jpress = nullptr, *tropo = nullptr;
+  int ncol = 0, nlay = 0, nflav = 0, nbnd = 0, gw = 0;
+  long seq = -1;            // call sequence number of the compute_tau_absorption call that wrote it
+  TileGeom* geom = nullptr;  // persistent: lives across calls
+  int* valid = nullptr;      // device word: 1 once that call's geometry kernel ran (it does not when the call is rerouted)
+  size_t cap = 0;
+};
+static SharedGeom g_shared;
+
 extern "C" {
 
+int rte_hip_share_geometry(int on) { g_share_geom = on; g_shared.seq = -1; return 0; }
 int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
 int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
 int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
@@ -2593,17 +2637,36 @@ static void tau_absorption_impl(
 #endif
     constexpr int NCW = V9_NCW, NLW = V9_NLW, SLAB9 = V9_SLAB;  // compute + loader waves, 2 x 68 KB slab: one block per CU
     const unsigned tiles = cdiv(ncol, NCW * 64);
-    TileGeom* d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
+    const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
+    const bool share = g_share_geom && geom2 && NCW * 64 == 512 && !c.any_host();
+    TileGeom* d_geom;
+    g_shared.seq = -1;
+    if (share) {  // the geometry outlives this call: a compute_Planck_source call right behind it may use it
+      const size_t need = sizeof(TileGeom) * (size_t)tiles * nlay;
+      if (g_shared.cap < need) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (g_shared.geom) HIP_CHECK(hipFree(g_shared.geom));
+        HIP_CHECK(hipMalloc((void**)&g_shared.geom, need));
+        if (!g_shared.valid) HIP_CHECK(hipMalloc((void**)&g_shared.valid, sizeof(int)));
+        g_shared.cap = need;
+      }
+      d_geom = g_shared.geom;
+      hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, g_shared.valid, 1u, (int*)nullptr, 0u, (int*)nullptr, 0u);
+      g_shared.jeta = jeta; g_shared.jtemp = jtemp; g_shared.jpress = jpress; g_shared.tropo = tropo;
+      g_shared.ncol = ncol; g_shared.nlay = nlay; g_shared.nflav = nflav; g_shared.nbnd = nbnd; g_shared.gw = cache.gw;
+      g_shared.seq = rte::call_seq();
+    } else {
+      d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
+    }
     const dim3 grid(tiles, nlay), blk((NCW + NLW) * 64);
     const size_t dyn = sizeof(BandMeta) * nbnd;
     const TileGeom* cg = d_geom;
     bool mm4 = true;
     for (const BandMeta& bmh : cache.bands) mm4 = mm4 && bmh.cnt[0] <= 4 && bmh.cnt[1] <= 4;
-    const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
     Geom2Args ga{};
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = false;
     ga.lim = lim; ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.bmeta = d_bm;
-    ga.skip_if = overlap; ga.worklist = v.worklist;
+    ga.skip_if = overlap; ga.worklist = v.worklist; ga.valid_out = share ? g_shared.valid : nullptr;
 #define RTE_LAUNCH_TAU9_(GW, AB)                                                                                  \
   do {                                                                                                            \
     if (mm4) {                                                                                                    \
@@ -2938,7 +3001,14 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     constexpr int NCW = 8, NLW = 2, SLAB9 = 8704;  // 8 compute + 2 loader waves, 2 x 68 KB slab: one block per CU
     wl_tile = NCW * 64;
     const unsigned tiles = cdiv(ncol, NCW * 64);
-    TileGeom* d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
+    // the geometry of the compute_tau_absorption call immediately before this one, if it is for the same arrays
+    const bool shared = g_share_geom && g_shared.seq >= 0 && g_shared.seq + 1 == rte::call_seq() && g_shared.jeta == jeta &&
+                        g_shared.jtemp == jtemp && g_shared.jpress == jpress && g_shared.tropo == tropo &&
+                        g_shared.ncol == ncol && g_shared.nlay == nlay && g_shared.nflav == nflav &&
+                        g_shared.nbnd == nbnd && g_shared.gw == bl_gw && !c.any_host() &&
+                        !c.forked();  // (on the side stream this call does not wait for that call's kernels)
+    g_shared.seq = -1;
+    TileGeom* d_geom = shared ? g_shared.geom : (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
     static_assert(NCW * 64 == 512, "d_flags is sized for 512-column tiles");
 #ifdef EXP_CLOCKS
     v.clocks = (unsigned long long*)rte::scratch(64);
@@ -2949,10 +3019,14 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = true;
     ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.band_lims = d_band_lims;
     ga.gpoint_flavor = d_gpoint_flavor; ga.worklist = v.worklist; ga.flags = d_flags; ga.skip_if = guard;
+    ga.skip_if2 = shared ? g_shared.valid : nullptr;  // (set on the device by that call's geometry kernel, if it ran)
 #define RTE_LAUNCH_PLANCK9(GW)                                                                                    \
   do {                                                                                                            \
     {                                                                                                             \
       rte::ProfScope p("planck_source_setup");                                                                    \
+      if (shared) hipLaunchKernelGGL(planck_flags_kernel, dim3(cdiv(tiles * nbnd, 256)), dim3(256), 0, st, (const TileGeom*)d_geom, \
+                                     (int)tiles, nlay, nbnd, SLAB9, GW + 2, d_flags, v.worklist, (const int*)g_shared.valid, \
+                                     (const int*)guard);                                                          \
       if (geom2) hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, ga, d_geom); \
       else hipLaunchKernelGGL((planck_geom_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, \
                               d_flags, SLAB9);                                                                    \

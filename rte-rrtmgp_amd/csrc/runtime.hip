@@ -160,8 +160,12 @@ void flush_pending_zeros() {
 }
 
 // ---- Call ---------------------------------------------------------------------------------------
+static long g_seq = 0;
+long call_seq() { return g_seq; }  // number of the current (innermost) API call
+
 Call::Call(const char* n) : name(n) {
   g_mutex.lock();
+  ++g_seq;
   fork_candidate_ = g_fork_valid;  // the previous call left a fork point (it is consumed or dropped by this call)
   g_fork_valid = false;
   if (!g_pending.empty()) flush_pending_zeros();

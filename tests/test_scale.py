@@ -193,3 +193,56 @@ def test_planck_on_the_side_stream_gives_the_same_arrays():
         forked = run(1, 3)
         for k, v in serial.items():
             assert torch.equal(v, forked[k]), k
+
+
+def test_planck_on_the_geometry_of_tau_gives_the_same_arrays():
+    """``rte_hip_share_geometry(1)``: compute_Planck_source takes the per-(tile, layer) bounding boxes left by the
+    compute_tau_absorption call right before it instead of deriving them again.  The boxes only say which table rows
+    are staged: every array must be bit-identical to the run without sharing -- on the benchmark atmosphere, and on a
+    shuffled site-like one whose wide boxes send work to the direct-gather worklists; a call in between (here: a
+    zero_array on an unrelated buffer) must switch the sharing off for that step, not break it."""
+    import torch
+
+    hip = hiplib.load()
+    xp = frontend.TorchArrays("cuda:0")
+    kd = synth.make_kdist("lw")
+    ncol = 20000
+    for climate, seed in (("rce", 3), ("sites", 4)):
+        atm = synth.make_atmosphere(ncol, NLAY, seed=seed, kdist=kd, climate=climate)
+        inp = {k: getattr(atm, k) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas")}
+        if climate == "sites":  # random column order: every tile spans the whole climatological range
+            perm = np.random.default_rng(1).permutation(ncol)
+            inp = {k: np.asfortranarray(v[perm]) for k, v in inp.items()}
+
+        def run(share):
+            hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], share)
+            try:
+                b, r = _lw_chain(hip, xp, kd, inp, ncol, atm.top_at_1)
+                torch.cuda.synchronize()
+                out = {k: b[k].clone() for k in ("tau", "lay_src", "lev_src", "sfc_src", "sfc_src_jac")}
+                out["flux_up"], out["flux_dn"] = r["flux_up"].clone(), r["flux_dn"].clone()
+                return out
+            finally:
+                hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 0)
+
+        plain = run(0)
+        shared = run(1)
+        for k, v in plain.items():
+            assert torch.equal(v, shared[k]), (climate, k)
+    # a foreign library call between the two: the Planck call must fall back to its own geometry
+    hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 1)
+    try:
+        go = frontend.GasOptics(hip, kd, xp)
+        A = xp.asarray
+        st = go.interpolation(ncol, NLAY, A(inp["play"]), A(inp["tlay"]), A(inp["col_gas"]), None)
+        tau = xp.empty((ncol, NLAY, kd.ngpt))
+        hip.zero_array_3D(ncol, NLAY, kd.ngpt, tau)
+        go.compute_tau_absorption(ncol, NLAY, st, A(inp["play"]), A(inp["tlay"]), A(inp["col_gas"]), tau)
+        other = xp.empty((ncol, 4))
+        hip.zero_array_2D(ncol, 4, other)  # <- in between
+        bufs = [xp.empty((ncol, kd.ngpt)), xp.empty((ncol, NLAY, kd.ngpt)), xp.empty((ncol, NLAY + 1, kd.ngpt)), xp.empty((ncol, kd.ngpt))]
+        go.source(ncol, NLAY, st, A(inp["tlay"]), A(inp["tlev"]), A(inp["tsfc"]), atm.top_at_1, bufs[0], bufs[1], bufs[2], bufs[3])
+        torch.cuda.synchronize()
+        assert torch.equal(bufs[1], plain["lay_src"]) and torch.equal(bufs[2], plain["lev_src"])
+    finally:
+        hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 0)
