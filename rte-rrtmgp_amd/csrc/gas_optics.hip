@@ -2299,6 +2299,14 @@ struct SharedGeom {
 };
 static SharedGeom g_shared;
 
+namespace rte {
+void release_gas_optics_buffers() {  // rte_hip_release()
+  if (g_shared.geom) HIP_CHECK(hipFree(g_shared.geom));
+  if (g_shared.valid) HIP_CHECK(hipFree(g_shared.valid));
+  g_shared = SharedGeom{};
+}
+}  // namespace rte
+
 extern "C" {
 
 int rte_hip_share_geometry(int on) { g_share_geom = on; g_shared.seq = -1; return 0; }

@@ -283,6 +283,8 @@ static void prof_resolve() {
 
 }  // namespace rte
 
+namespace rte { void release_gas_optics_buffers(); }  // gas_optics.hip
+
 // ---- library-extension entry points (not part of the reference interface) ------------------------
 extern "C" {
 
@@ -351,6 +353,7 @@ int rte_hip_release(void) {
   rte::flush_pending_zeros();
   HIP_CHECK(hipStreamSynchronize(rte::g_stream));
   if (rte::g_side) HIP_CHECK(hipStreamSynchronize(rte::g_side));
+  rte::release_gas_optics_buffers();
   for (auto* v : {&rte::g_blocks_main, &rte::g_blocks_side}) {
     for (auto& b : *v) HIP_CHECK(hipFree(b.base));
     v->clear();
