@@ -1203,9 +1203,13 @@ __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArg
   const int g_begin = blockIdx.y * a.g_per_block;
   const int g_end = min(a.ngpt, g_begin + a.g_per_block);
 
-  Float acc_dn[L + 1], acc_up[L + 1], acc_j[do_jac ? L + 1 : 1];
+  // the level accumulators live in LDS (ds_add_f64 on the thread's own slots): 4L+4 registers the three sweeps need
+  Float* const ACC = lds + 2 * 4 * SMAX * 64 + (size_t)s * (L + 1) * 2 * 64 + lane;  // [wave][slot][dn, up][64]
+  Float acc_j[do_jac ? L + 1 : 1];
+  auto add_dn = [&](int i, Float v) { atomicAdd(&ACC[(2 * i) * 64], v); };
+  auto add_up = [&](int i, Float v) { atomicAdd(&ACC[(2 * i + 1) * 64], v); };
 #pragma unroll
-  for (int i = 0; i <= L; ++i) { acc_dn[i] = 0; acc_up[i] = 0; if (do_jac) acc_j[i] = 0; }
+  for (int i = 0; i <= L; ++i) { ACC[(2 * i) * 64] = 0; ACC[(2 * i + 1) * 64] = 0; if (do_jac) acc_j[i] = 0; }
 
   struct In { Float tau[L], ssa[L], g[L], lay[L], lev[L + 1], D, emis, ssrc, inc, sjac; };
   auto load = [&](In& x, int igpt_) {
@@ -1288,13 +1292,13 @@ __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArg
     }
     Float ul[L + 1];
     ul[L] = u;
-    acc_up[L] += u;
+    add_up(L, u);
     if (do_jac) acc_j[L] += jv;
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) {
       u = t[i] * u + su2[i];
       ul[i] = u;
-      acc_up[i] += u;
+      add_up(i, u);
       if (do_jac) { jv = t[i] * jv; acc_j[i] += jv; }
     }
     // adjusted downward sources of sweep 3 (:787-791 / :822-826): the upward radiance at the layer's top level
@@ -1313,10 +1317,10 @@ __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArg
     for (int q = 0; q < s; ++q) r = X(0, q) * r + X(3, q);
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-      acc_dn[i] += r;
+      add_dn(i, r);
       r = t[i] * r + su2[i];
     }
-    acc_dn[L] += r;
+    add_dn(L, r);
   };
 
   In cur;
@@ -1329,8 +1333,8 @@ __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArg
       if (i < np || (last && i == np)) {
         const int p = p0 + i;
         const int ilev = a.top_at_1 ? p : nlay - p;
-        a.part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
-        a.part_up[base + (size_t)ncol * ilev] = acc_up[i];
+        a.part_dn[base + (size_t)ncol * ilev] = ACC[(2 * i) * 64];
+        a.part_up[base + (size_t)ncol * ilev] = ACC[(2 * i + 1) * 64];
         if (do_jac) a.part_jac[base + (size_t)ncol * ilev] = acc_j[i];
       }
     }
@@ -1431,7 +1435,7 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     q.part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
     q.part_dn = q.part_up + nclv * ngroups;
     q.part_jac = do_jac ? q.part_dn + nclv * ngroups : nullptr;
-    const size_t lds_bytes = sizeof(Float) * 2 * 4 * 8 * 64;
+    const size_t lds_bytes = sizeof(Float) * (2 * 4 * 8 * 64 + 8 * (Lr + 1) * 2 * 64);  // composites + level accumulators
     for (int imu = 0; imu < nmus; ++imu) {
       q.weight = w_h[imu]; q.D = d_Ds + ncg * imu;
       {
