@@ -377,7 +377,8 @@ def main():
 
     def step_allsky():
         st_as["l"] = frontend.allsky_lw(lib, xp, go, col, ncol, nlay_w, a_dev, clouds, emis, *st_as.get("l", (None, None, None)))
-        st_as["s"] = frontend.allsky_sw(lib, xp, gos, cos_, ncol, nlay_w, a_dev, clouds, mu0, alb, *st_as.get("s", (None, None, None)))
+        st_as["s"] = frontend.allsky_sw(lib, xp, gos, cos_, ncol, nlay_w, a_dev, clouds, mu0, alb, *st_as.get("s", (None, None, None)),
+                                        fuse="all")
         rb.update(st_as["l"][2])
         if dist is not None:
             mean_profile.copy_(sharding.allreduce_mean_profile(rb["flux_up"], rb["flux_dn"], ncol * world))
@@ -387,7 +388,8 @@ def main():
         mu0, alb = xp.full((ncol, NLAY), 0.86), xp.full((ncol, kd.ngpt), 0.06)
 
     def step_sw():
-        go.gas_optics_sw(ncol, NLAY, play, plev, tlay, col_gas, col_dry, buffers=bufs, fuse_rayleigh=True)
+        # one-pass SW gas optics (library extension rte_hip_gas_optics_sw_2str): absorption + Rayleigh + combine
+        go.gas_optics_sw(ncol, NLAY, play, plev, tlay, col_gas, col_dry, buffers=bufs, fuse_rayleigh="all")
         frontend.rte_sw(lib, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["ssa"], bufs["g"], mu0,
                         bufs["toa_src"], alb, alb, buffers=rb)
         if dist is not None:
@@ -493,6 +495,11 @@ def main():
             ab = allsky_bytes_per_collay(kd, kds, nlay_w)
         else:
             ab = algorithmic_bytes_per_collay(kd.nflav, kd.ngas, kd.ngpt, NLAY, defer_zero=not args.no_defer_zero)
+        # the one-pass SW gas optics runs under the name of compute_tau_absorption: it stands for the bytes of the two
+        # ABI calls it replaces (the chain's algorithmic bytes stay those of the reference-ABI chain)
+        if (args.workload in ("sw", "allsky") and "tau_rayleigh_combine_kernel" in ab and "tau_rayleigh_combine_kernel" not in kern
+                and "tau_absorption_kernel" in kern):
+            ab["tau_absorption_kernel"] += ab.pop("tau_rayleigh_combine_kernel")
         per_kernel = {}
         concurrent = ("tau_absorption", "planck_source") if overlap else ()
         for name, bytes_cl in ab.items():

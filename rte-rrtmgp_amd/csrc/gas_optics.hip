@@ -455,6 +455,45 @@ struct BandMeta {  // built on the host from the small index tables, uploaded pe
   MinorMeta m[2][MAXM];  // [0]: lower-regime intervals of the band, [1]: upper
 };
 
+// combine_abs_and_rayleigh, 2-stream branch (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:1983-2002), applied to one value,
+// optionally followed by increment_2stream_by_2stream_bybnd (rte/kernels/mo_optical_props_kernels.F90: the by-band
+// form of :159-181) with a second set of 2-stream properties given per band (clouds): the same operations in the same
+// order as the separate kernels, on values that are doubles in registers instead of doubles in memory -- bit-identical.
+struct RaylCombine {
+  const Float* tau_abs;  // nullptr: plain compute_tau_rayleigh
+  Float *tau, *ssa, *g;  // tau may alias tau_abs
+  const Float *cld_tau, *cld_ssa, *cld_g;  // (ncol, nlay, nbnd) or nullptr
+};
+#ifdef RTE_USE_SP
+#define RTE_TINY 1.17549435e-38f
+#else
+#define RTE_TINY 2.2250738585072014e-308
+#endif
+__device__ __forceinline__ void rayl_finish(Float ta, Float tr, bool cld, Float t2, Float s2, Float g2, Float& tau, Float& ssa,
+                                            Float& g) {
+  const Float tiny2 = (Float)2 * (Float)RTE_TINY;
+  const Float t = ta + tr;
+  ssa = t > tiny2 ? tr / t : (Float)0;
+  tau = t;
+  g = (Float)0;
+  if (cld) {
+    const Float eps = (Float)3 * (Float)RTE_TINY;  // mo_optical_props_kernels.F90:38
+    const Float tau12 = tau + t2;
+    const Float tauscat12 = tau * ssa + t2 * s2;
+    g = (tau * ssa * g + t2 * s2 * g2) / fmax(eps, tauscat12);
+    ssa = tauscat12 / fmax(eps, tau12);
+    tau = tau12;
+  }
+}
+// compute_tau_absorption fused with compute_tau_rayleigh and the 2-stream combine (rte_hip_gas_optics_sw_2str): the
+// Rayleigh table rows are staged like one more pair of minor planes, and a stage writes tau, ssa, g instead of tau_abs
+struct RaylFuse {
+  const Float* krayl_g[2];  // g-fastest copies of krayl(:, :, :, regime)
+  const Float* col_dry;
+  const Float *cld_tau, *cld_ssa, *cld_g;  // (ncol, nlay, nbnd) or nullptr: increment by band-wise 2-stream properties
+  Float *ssa, *g;           // (tau goes to TauV5::tau)
+};
+
 struct TauV5 {
   int ncol, nlay, ngpt, nbnd, ntemp, TE, idx_h2o, nk_lo, nk_up;
   const int* band_lims;      // (2,nbnd)
@@ -469,6 +508,7 @@ struct TauV5 {
   int* worklist;       // [0] = count, then (tile, layer, band) triples for tau_absorption_worklist_kernel
   bool overwrite;      // tau is known to be zero (deferred zero_array): do not read it
   const Float* add_bybnd;  // (ncol, nlay, nbnd) or nullptr: see TauArgs
+  RaylFuse rf;             // used by the RAYL instantiations only
 #ifdef EXP_CLOCKS
   unsigned long long* clocks;
 #endif
@@ -905,6 +945,7 @@ struct Geom2Args {
   const int* skip_if;        // tau: the direct kernel does the whole call
   const int* skip_if2;       // Planck: the geometry left by the compute_tau_absorption call before is valid (shared)
   int* valid_out;            // tau: set to 1 once this geometry is (being) written, for a Planck call that shares it
+  int extra_planes;          // tau: more (T, eta) planes staged per stage (2 with the fused Rayleigh rows)
   int* worklist;             // tau: (tile, layer, band) triples; Planck: (tile, band) pairs
   int* flags;                // Planck: one worklist entry per (tile, band)
 };
@@ -993,7 +1034,7 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
     const unsigned me = mE[flav[tid][0]][0] | mE[flav[tid][1]][1];
     const int emin = me ? __ffs(me) - 1 : 1, nE = me ? (32 - __clz(me)) - emin : 0;
     const int n_lo = has_lo ? cnt[tid][0] : 0, n_up = has_up ? cnt[tid][1] : 0;
-    const int rows = (nP + n_lo + n_up) * nT * nE;
+    const int rows = (nP + n_lo + n_up + (a.planck ? 0 : a.extra_planes)) * nT * nE;
     const bool fits = rows * RS <= a.slab_floats;
     if (a.planck) {
       if (!fits && atomicCAS(&a.flags[blockIdx.x * nbnd + tid], 0, 1) == 0) {  // once per (tile, band)
@@ -1017,7 +1058,8 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
 // ADDB: a band-wise operand is added (rte_hip_compute_tau_absorption_inc_bybnd) -- a template parameter, not a run-time
 // test: a conditional load changes the number of outstanding memory operations from path to path, and the compiler
 // then waits for (nearly) all of them, i.e. for the previous stage's stores, at the top of every stage.
-template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G, int MM, bool ADDB>
+// RAYL: fused with compute_tau_rayleigh + combine_abs_and_rayleigh (2-stream) [+ by-band 2-stream increment]: see RaylFuse
+template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G, int MM, bool ADDB, int RAYL = 0 /* 1: fused, 2: + by-band clouds */>
 __global__ void __launch_bounds__((NCW + NLW) * 64, V9_MINW)
 tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
@@ -1059,7 +1101,8 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         const float inv_nE = 1.0f / (float)nE;
         const int n_lo = has_lo ? bm[ibnd].cnt[0] : 0, n_up = has_up ? bm[ibnd].cnt[1] : 0;
         const int rowsMaj = nP * nT * nE, rowsLo = n_lo * nT * nE, rowsUp = n_up * nT * nE;
-        const int nAll = (rowsMaj + rowsLo + rowsUp) * (G / 2);
+        const int rowsRay = RAYL ? 2 * nT * nE : 0;  // [regime][t][eta] rows of the Rayleigh table, behind the minor planes
+        const int nAll = (rowsMaj + rowsLo + rowsUp + rowsRay) * (G / 2);
         Float* sl = slab[s & 1];
         // rows ordered [p][t][eta] (+ minor: [interval][t][eta]); piece = 16 bytes of a 128-byte row chunk
         auto piece = [&](int idx) -> Float2 {
@@ -1071,6 +1114,13 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
                 a.kmaj + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
           }
           const int rm = r - rowsMaj;
+          if (RAYL && rm >= rowsLo + rowsUp) {
+            const int rr = rm - rowsLo - rowsUp;
+            const int rest = (int)(((float)rr + 0.5f) * inv_nE), e = rr - rest * nE;
+            const int k = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - k * nT;  // k: regime
+            return *reinterpret_cast<const Float2*>(
+                a.rf.krayl_g[k] + ((size_t)((emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
+          }
           const bool up = rm >= rowsLo;
           const int rr = up ? rm - rowsLo : rm;
           const int rest = (int)(((float)rr + 0.5f) * inv_nE), e = rr - rest * nE;
@@ -1123,9 +1173,11 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   const Float dens = (Float)0.01 * P / T;                                                             // :469
   const Float vmr_fact = (Float)1 / a.col_gas[cl];                                                    // :471
   const Float dry_fact = (Float)1 / ((Float)1 + a.col_gas[cl + (size_t)ncl * a.idx_h2o] * vmr_fact);  // :472
+  Float wray = 0;  // Rayleigh: column amount of moist air (:553)
+  if (RAYL) wray = a.col_gas[cl + (size_t)ncl * a.idx_h2o] + a.rf.col_dry[cl];
 
   // major weights + eta indices of band b (requested one stage ahead)
-  struct Major { Float2 fm[4], cm; int2 je; };
+  struct Major { Float2 fm[4], cm; int2 je; Float2 fr[RAYL ? 2 : 1]; };
   auto load_major = [&](int flav, Major& x) {
     const size_t clf = cl + (size_t)ncl * flav;
     const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
@@ -1133,9 +1185,13 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     for (int i = 0; i < 4; ++i) x.fm[i] = fmp[i];
     x.cm = *reinterpret_cast<const Float2*>(a.col_mix + 2 * clf);
     x.je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
+    if (RAYL) {  // compute_tau_rayleigh interpolates with fminor of the MAJOR species' flavor (:548-551)
+      const Float2* frp = reinterpret_cast<const Float2*>(a.fminor + 4 * clf);
+      x.fr[0] = frp[0]; x.fr[1] = frp[1];
+    }
   };
   // minor column amounts, weights and eta indices of one stage
-  struct Minor { Float sc[MM], cgs[MM]; Float2 fn0, fn1; int2 em; Float addv; };
+  struct Minor { Float sc[MM], cgs[MM]; Float2 fn0, fn1; int2 em; Float addv; Float cld[RAYL == 2 ? 3 : 1]; };
   // What the requests of a stage's minor inputs need from the band table in LDS: which gases, which flavor.  Read at
   // the TOP of the stage before (peek_minor), so that at its end the requests go out back to back: looked up there,
   // each request waited for its own LDS round trip -- eleven in a row, with nothing else left to issue (0.8 ms).
@@ -1155,6 +1211,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   };
   auto load_minor = [&](int b, const MinorIdx& q, Minor& x) {
     x.addv = ADDB ? a.add_bybnd[cl + (size_t)ncl * b] : (Float)0;
+    if (RAYL == 2) {  // the band's cloud properties of this (column, layer)
+      x.cld[0] = a.rf.cld_tau[cl + (size_t)ncl * b]; x.cld[1] = a.rf.cld_ssa[cl + (size_t)ncl * b];
+      x.cld[2] = a.rf.cld_g[cl + (size_t)ncl * b];
+    }
 #pragma unroll
     for (int k = 0; k < MM; ++k) {
       x.sc[k] = 0; x.cgs[k] = 0;
@@ -1212,6 +1272,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const Float2 fn0 = mw.fn0, fn1 = mw.fn1;
     const int2 em = mw.em;
     const Float addv = mn.addv;
+    Float2 fr0{}, fr1{};
+    Float cld_t = 0, cld_s = 0, cld_g = 0;
+    if (RAYL) { fr0 = mj.fr[0]; fr1 = mj.fr[1]; }
+    if (RAYL == 2) { cld_t = mn.cld[0]; cld_s = mn.cld[1]; cld_g = mn.cld[2]; }
     // this stage's major weights into locals (col_mix folded in)
     const Float w0 = mj.cm.x * mj.fm[0].x, w1 = mj.cm.x * mj.fm[0].y, w2 = mj.cm.x * mj.fm[1].x, w3 = mj.cm.x * mj.fm[1].y,
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
@@ -1342,7 +1406,30 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     }
     if (a.ncol < 0)
 #endif
-    if (OVERWRITE) {
+    if constexpr (RAYL != 0) {
+      // compute_tau_rayleigh (:548-555: interpolate2D with the reference's association) on the staged table rows,
+      // combine_abs_and_rayleigh and the optional by-band increment on the values in registers (rayl_finish), and
+      // the stage's 3 x G stores.  Rows [regime][t][eta] behind the minor planes; unconditional stores as below.
+      const int rowsUp_ = (has_up ? bm[ibnd].cnt[1] : 0) * nT * nE;
+      const Float* R1 = sl + (rowsMaj + rowsLo + rowsUp_ + ((itropo * nT + (jT - Tmin)) * nE + (je1 - emin))) * RS;
+      const Float* R2 = sl + (rowsMaj + rowsLo + rowsUp_ + ((itropo * nT + (jT + 1 - Tmin)) * nE + (je2 - emin))) * RS;
+      char* const splane = reinterpret_cast<char*>(a.rf.ssa + (size_t)ncl * g0);
+      char* const gplane = reinterpret_cast<char*>(a.rf.g + (size_t)ncl * g0);
+#pragma unroll
+      for (int j = 0; j < G; j += 2) {
+        const Float2 a0 = ld2(R1 + j), a1 = ld2(R1 + RS + j), b0 = ld2(R2 + j), b1 = ld2(R2 + RS + j);
+        const Float ka = fr0.x * a0.x + fr0.y * a1.x + fr1.x * b0.x + fr1.y * b1.x;
+        const Float kb = fr0.x * a0.y + fr0.y * a1.y + fr1.x * b0.y + fr1.y * b1.y;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          Float t_, s_, g_;
+          rayl_finish(acc[j + u], (u == 0 ? ka : kb) * wray, RAYL == 2, cld_t, cld_s, cld_g, t_, s_, g_);
+          *tau_at(j + u) = t_;
+          *reinterpret_cast<Float*>(splane + gstride * (j + u) + toff) = s_;
+          *reinterpret_cast<Float*>(gplane + gstride * (j + u) + toff) = g_;
+        }
+      }
+    } else if (OVERWRITE) {
       if (ADDB) {  // by-band increment fused in (tau = tau_gas + tau_2 of the band)
 #pragma unroll
         for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
@@ -1403,36 +1490,6 @@ __global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a,
 // -------------------------------------------------------------------------------------------
 // compute_tau_rayleigh: reference :506-565
 // -------------------------------------------------------------------------------------------
-// combine_abs_and_rayleigh, 2-stream branch (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:1983-2002), applied to one value,
-// optionally followed by increment_2stream_by_2stream_bybnd (rte/kernels/mo_optical_props_kernels.F90: the by-band
-// form of :159-181) with a second set of 2-stream properties given per band (clouds): the same operations in the same
-// order as the separate kernels, on values that are doubles in registers instead of doubles in memory -- bit-identical.
-struct RaylCombine {
-  const Float* tau_abs;  // nullptr: plain compute_tau_rayleigh
-  Float *tau, *ssa, *g;  // tau may alias tau_abs
-  const Float *cld_tau, *cld_ssa, *cld_g;  // (ncol, nlay, nbnd) or nullptr
-};
-#ifdef RTE_USE_SP
-#define RTE_TINY 1.17549435e-38f
-#else
-#define RTE_TINY 2.2250738585072014e-308
-#endif
-__device__ __forceinline__ void rayl_finish(Float ta, Float tr, bool cld, Float t2, Float s2, Float g2, Float& tau, Float& ssa,
-                                            Float& g) {
-  const Float tiny2 = (Float)2 * (Float)RTE_TINY;
-  const Float t = ta + tr;
-  ssa = t > tiny2 ? tr / t : (Float)0;
-  tau = t;
-  g = (Float)0;
-  if (cld) {
-    const Float eps = (Float)3 * (Float)RTE_TINY;  // mo_optical_props_kernels.F90:38
-    const Float tau12 = tau + t2;
-    const Float tauscat12 = tau * ssa + t2 * s2;
-    g = (tau * ssa * g + t2 * s2 * g2) / fmax(eps, tauscat12);
-    ssa = tauscat12 / fmax(eps, tau12);
-    tau = tau12;
-  }
-}
 __device__ __forceinline__ void rayl_store(const RaylCombine& cb, Float* tau_rayleigh, size_t idx, size_t idx_bnd, Float tr) {
   if (cb.tau_abs == nullptr) { tau_rayleigh[idx] = tr; return; }
   const bool cld = cb.cld_tau != nullptr;
@@ -1452,13 +1509,23 @@ tau_rayleigh_kernel(int ncol, int nlay, int nbnd, int ngpt, int neta, int ntemp,
                     const Float* __restrict__ col_gas, const Float* __restrict__ fminor,
                     const int* __restrict__ jeta, const Bool* __restrict__ tropo,
                     const int* __restrict__ jtemp, Float* __restrict__ tau_rayleigh, RaylCombine cb,
-                    const int* __restrict__ run_if) {
+                    const int* __restrict__ run_if, const int* __restrict__ worklist = nullptr, int wl_tile = 0) {
   if (run_if && *run_if == 0) return;
   const unsigned tiles_x = (ncol + 255) / 256;
-  const size_t total = (size_t)tiles_x * nlay * nbnd;
+  // worklist != nullptr: only the (tile of wl_tile columns, layer, band) triples listed (the entries the fused gas-optics
+  // kernel left to the direct-gather code)
+  const int chunks = worklist ? wl_tile / 256 : 1;
+  const size_t total = worklist ? (size_t)worklist[0] * chunks : (size_t)tiles_x * nlay * nbnd;
   for (size_t wi = blockIdx.x; wi < total; wi += gridDim.x) {
-    const int icol = (int)(wi % tiles_x) * 256 + threadIdx.x;
-    const int ilay = (int)((wi / tiles_x) % nlay), ibnd = (int)(wi / ((size_t)tiles_x * nlay));
+    int icol, ilay, ibnd;
+    if (worklist) {
+      const size_t w = wi / chunks;
+      icol = worklist[1 + 3 * w] * wl_tile + (int)(wi - w * chunks) * 256 + threadIdx.x;
+      ilay = worklist[2 + 3 * w]; ibnd = worklist[3 + 3 * w];
+    } else {
+      icol = (int)(wi % tiles_x) * 256 + threadIdx.x;
+      ilay = (int)((wi / tiles_x) % nlay); ibnd = (int)(wi / ((size_t)tiles_x * nlay));
+    }
     if (icol >= ncol) continue;
     const size_t ncl = (size_t)ncol * nlay;
     const size_t cl = icol + (size_t)ncol * ilay;
@@ -2368,6 +2435,12 @@ void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, 
 }  // extern "C"
 // compute_tau_absorption; add_bybnd != nullptr: the band-wise increment of the result by a second optical depth given
 // per band (clouds as absorbers) is applied in the same pass
+// fused SW gas optics (rte_hip_gas_optics_sw_2str): what compute_tau_rayleigh and the combine need besides the
+// arguments of compute_tau_absorption; tau is then an output only
+struct RaylHost {
+  const Float *krayl, *col_dry, *cld_tau, *cld_ssa, *cld_g;
+  Float *ssa, *g;
+};
 static void tau_absorption_impl(
     const char* api_name, int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp,
     int nlo, int nkl_, int nup, int nku_, int idx_h2o, const int* gpoint_flavor,
@@ -2379,13 +2452,13 @@ static void tau_absorption_impl(
     const int* idx_minor_scaling_upper, const int* kminor_start_lower, const int* kminor_start_upper,
     const Bool* tropo, const Float* col_mix, const Float* fmajor, const Float* fminor,
     const Float* play, const Float* tlay, const Float* col_gas, const int* jeta, const int* jtemp,
-    const int* jpress, Float* tau, const Float* add_bybnd) {
+    const int* jpress, Float* tau, const Float* add_bybnd, const RaylHost* rh = nullptr) {
   const int* nminorklower_ = &nkl_;
   const int* nminorkupper_ = &nku_;
   const int* idx_h2o_ = &idx_h2o;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
   // a deferred zero_array on exactly this buffer turns the accumulate into an overwrite
-  const bool overwrite = rte::take_pending_zero(tau, sizeof(Float) * (size_t)ncol * nlay * ngpt);
+  const bool overwrite = rh ? true : rte::take_pending_zero(tau, sizeof(Float) * (size_t)ncol * nlay * ngpt);
   rte::Call c(api_name);
   const size_t ncl = (size_t)ncol * nlay;
   const size_t tn = (size_t)ntemp * neta;
@@ -2411,9 +2484,19 @@ static void tau_absorption_impl(
   const int* d_jeta = c.in(jeta, 2 * ncl * nflav);
   const int* d_jtemp = c.in(jtemp, ncl);
   const int* d_jpress = c.in(jpress, ncl);
-  Float* d_tau = c.inout(tau, ncl * ngpt);
+  Float* d_tau = rh ? c.out(tau, ncl * ngpt) : c.inout(tau, ncl * ngpt);
+  RaylCombine cb{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const Float *d_krayl = nullptr, *d_col_dry = nullptr;
+  if (rh) {
+    d_krayl = c.in(rh->krayl, (size_t)ntemp * neta * ngpt * 2);
+    d_col_dry = c.in(rh->col_dry, ncl);
+    if (rh->cld_tau) { cb.cld_tau = c.in(rh->cld_tau, ncl * nbnd); cb.cld_ssa = c.in(rh->cld_ssa, ncl * nbnd); cb.cld_g = c.in(rh->cld_g, ncl * nbnd); }
+    cb.tau_abs = d_tau; cb.tau = d_tau;  // the direct kernels combine in place
+    cb.ssa = c.out(rh->ssa, ncl * ngpt);
+    cb.g = c.out(rh->g, ncl * ngpt);
+  }
   hipStream_t st = rte::stream();
-  if (!c.any_host() && rte::is_device_memory(d_tau)) rte::fork_point(d_tau, sizeof(Float) * ncl * ngpt);
+  if (!rh && !c.any_host() && rte::is_device_memory(d_tau)) rte::fork_point(d_tau, sizeof(Float) * ncl * ngpt);
   // layer limits of the two regimes per column (:274-285) + "regimes overlap somewhere" flag
   int* lim = (int*)rte::scratch(sizeof(int) * (4 * (size_t)ncol + 1));
   int* overlap = lim + 4 * (size_t)ncol;
@@ -2553,7 +2636,19 @@ static void tau_absorption_impl(
   }
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
   const bool fast = cache.fast_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) &&
-                    al(d_fmajor, 16) && al(d_fminor, 16) && al(d_col_mix, 16) && al(d_jeta, 8);
+                    al(d_fmajor, 16) && al(d_fminor, 16) && al(d_col_mix, 16) && al(d_jeta, 8) &&
+                    (!rh || (overwrite_ok && g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 &&
+                             npres + 1 < 63));  // (fused: the bands tile the g-points -- else tau was zero-filled above --
+                                                //  and the bit-mask geometry, which counts the Rayleigh rows)
+  // the direct Rayleigh + combine kernel of the fused entry: everything (run_if == nullptr), only when the guard
+  // fired (run_if = the flag), or the worklist entries
+  auto rayleigh_direct = [&](const int* run_if, const int* wl, int wl_tile) {
+    const size_t items = (size_t)cdiv(ncol, 256) * nlay * nbnd;
+    const unsigned blocks = (unsigned)((run_if || wl) ? (items < 2048 ? items : 2048) : (items < 262144 ? items : 262144));
+    hipLaunchKernelGGL(tau_rayleigh_kernel, dim3(blocks), dim3(256), 0, st, ncol, nlay, nbnd, ngpt, neta, ntemp,
+                       *idx_h2o_, d_gpoint_flavor, d_band_lims, d_krayl, d_col_dry, d_col_gas, d_fminor, d_jeta,
+                       d_tropo, d_jtemp, (Float*)nullptr, cb, run_if, wl, wl_tile);
+  };
 
   // native-layout direct kernel: always correct; the whole call when the fast path does not apply,
   // otherwise armed only if some column has overlapping regimes (device-side flag)
@@ -2581,6 +2676,7 @@ static void tau_absorption_impl(
     const size_t tiles = (size_t)cdiv(ncol, 256) * nlay * nbnd;
     hipLaunchKernelGGL(tau_absorption_kernel, dim3((unsigned)(tiles < 1048576 ? tiles : 1048576)), dim3(256), 0, st, a,
                        nbnd);
+    if (rh) rayleigh_direct(nullptr, nullptr, 0);
     return;
   }
   // ---- production path: g-fastest copies of the three tables (scratch, this call only)
@@ -2588,6 +2684,7 @@ static void tau_absorption_impl(
   Float* kmaj_g = (Float*)rte::scratch(sizeof(Float) * tn * (npres + 1) * ngpt);
   Float* klo_g = (Float*)rte::scratch(sizeof(Float) * tn * (nkl > 0 ? nkl : 1));
   Float* kup_g = (Float*)rte::scratch(sizeof(Float) * tn * (nku > 0 ? nku : 1));
+  Float* kray_g = nullptr;
   // band metadata lives in a persistent device buffer and is uploaded only when the host plan was rebuilt
   // (a per-call copy from pageable host memory stalls the submitting thread)
   bool bm_fresh = false;
@@ -2608,6 +2705,12 @@ static void tau_absorption_impl(
     if (nku > 0)
       hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(nku, 32), 1), dim3(256), tile_bytes, st, TE, 1, nku, up.kminor,
                          kup_g);
+    if (rh) {  // the Rayleigh table (ntemp, neta, ngpt, 2): one g-fastest copy per regime
+      kray_g = (Float*)rte::scratch(sizeof(Float) * tn * ngpt * 2);
+      for (int r = 0; r < 2; ++r)
+        hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(ngpt, 32), 1), dim3(256), tile_bytes, st, TE, 1, ngpt,
+                           d_krayl + tn * ngpt * r, kray_g + tn * ngpt * r);
+    }
   }
   {  // plan guard: the tables on the device must be the ones the cached plan was built from
     GuardTables gt{};
@@ -2629,6 +2732,11 @@ static void tau_absorption_impl(
   v.lim = lim; v.jeta = d_jeta; v.jtemp = d_jtemp; v.jpress = d_jpress; v.tropo = d_tropo;
   v.col_mix = d_col_mix; v.fmajor = d_fmajor; v.fminor = d_fminor; v.play = d_play; v.tlay = d_tlay;
   v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap; v.overwrite = overwrite_ok; v.add_bybnd = d_add;
+  v.rf = RaylFuse{};
+  if (rh) {
+    v.rf.krayl_g[0] = kray_g; v.rf.krayl_g[1] = kray_g + tn * ngpt; v.rf.col_dry = d_col_dry;
+    v.rf.cld_tau = cb.cld_tau; v.rf.cld_ssa = cb.cld_ssa; v.rf.cld_g = cb.cld_g; v.rf.ssa = cb.ssa; v.rf.g = cb.g;
+  }
 #ifndef V7_BS
 #define V7_BS 256
 #define V7_MINW 2
@@ -2637,7 +2745,7 @@ static void tau_absorption_impl(
 #endif
   constexpr int BS = V7_BS;
   v.worklist = worklist;
-  const bool use_v9 = g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr;  // the single-role kernel exists for 16-wide stages only
+  const bool use_v9 = g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr || rh != nullptr;  // the single-role kernel exists for 16-wide stages only
   if (use_v9) {
 #ifdef EXP_CLOCKS
     v.clocks = (unsigned long long*)rte::scratch(64);
@@ -2646,7 +2754,7 @@ static void tau_absorption_impl(
     constexpr int NCW = V9_NCW, NLW = V9_NLW, SLAB9 = V9_SLAB;  // compute + loader waves, 2 x 68 KB slab: one block per CU
     const unsigned tiles = cdiv(ncol, NCW * 64);
     const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
-    const bool share = g_share_geom && geom2 && NCW * 64 == 512 && !c.any_host();
+    const bool share = g_share_geom && geom2 && NCW * 64 == 512 && !c.any_host() && !rh;
     TileGeom* d_geom;
     g_shared.seq = -1;
     if (share) {  // the geometry outlives this call: a compute_Planck_source call right behind it may use it
@@ -2675,6 +2783,9 @@ static void tau_absorption_impl(
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = false;
     ga.lim = lim; ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.bmeta = d_bm;
     ga.skip_if = overlap; ga.worklist = v.worklist; ga.valid_out = share ? g_shared.valid : nullptr;
+    ga.extra_planes = rh ? 2 : 0;
+#define RTE_LAUNCH_TAU9R_(GW, MMV, RV) \
+  hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MMV, false, RV>), grid, blk, dyn, st, v, cg)
 #define RTE_LAUNCH_TAU9_(GW, AB)                                                                                  \
   do {                                                                                                            \
     if (mm4) {                                                                                                    \
@@ -2693,11 +2804,15 @@ static void tau_absorption_impl(
       else hipLaunchKernelGGL((tau_geom_kernel<NCW * 64, GW>), grid, dim3(NCW * 64), 0, st, v, d_geom, SLAB9);    \
     }                                                                                                             \
     rte::ProfScope p("tau_absorption_kernel");                                                                    \
-    if (d_add) RTE_LAUNCH_TAU9_(GW, true); else RTE_LAUNCH_TAU9_(GW, false);                                      \
+    if (rh) {                                                                                                     \
+      if (cb.cld_tau) { if (mm4) RTE_LAUNCH_TAU9R_(GW, 4, 2); else RTE_LAUNCH_TAU9R_(GW, MAXM, 2); }              \
+      else            { if (mm4) RTE_LAUNCH_TAU9R_(GW, 4, 1); else RTE_LAUNCH_TAU9R_(GW, MAXM, 1); }              \
+    } else if (d_add) RTE_LAUNCH_TAU9_(GW, true); else RTE_LAUNCH_TAU9_(GW, false);                               \
   } while (0)
     if (cache.gw == 16) RTE_LAUNCH_TAU9(16); else RTE_LAUNCH_TAU9(8);
 #undef RTE_LAUNCH_TAU9
 #undef RTE_LAUNCH_TAU9_
+#undef RTE_LAUNCH_TAU9R_
   } else {
     rte::ProfScope p("tau_absorption_kernel");
     // <min waves per SIMD, g-points per register chunk>: measured best of {2,3} x {4,8,16} on MI355X
@@ -2723,6 +2838,10 @@ static void tau_absorption_impl(
     aw.run_if = nullptr;
     hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(4096), dim3(256), 0, st, aw, (const int*)v.worklist,
                        use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
+    if (rh) {  // the same two sets of (column, layer, band) hold tau_abs in tau: Rayleigh + combine in place
+      rayleigh_direct(overlap, nullptr, 0);
+      rayleigh_direct(nullptr, (const int*)v.worklist, V9_NCW * 64);
+    }
   }
 }
 
@@ -2771,6 +2890,34 @@ int rte_hip_compute_tau_absorption_inc_bybnd(
                       scale_by_complement_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
                       idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, tropo, col_mix, fmajor, fminor, play,
                       tlay, col_gas, jeta, jtemp, jpress, tau, tau_bybnd);
+  return 0;
+}
+// Library extension (scalars by value): the SW gas optics of one call -- compute_tau_absorption, compute_tau_rayleigh and
+// combine_abs_and_rayleigh (2-stream branch, mo_gas_optics_rrtmgp.F90:1983-2002), optionally followed by the band-wise
+// increment by 2-stream cloud properties -- in ONE pass over (column, layer, g-point): the absorption optical depth
+// never goes to memory (-21.5 GB per step at 1e5 x 60 x 224).  Same operations in the same order on the same doubles
+// as the chain compute_tau_absorption -> rte_hip_tau_rayleigh_combine_2str: bit-identical tau, ssa, g.
+int rte_hip_gas_optics_sw_2str(
+    int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nminorlower,
+    int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, const int* gpoint_flavor,
+    const int* band_lims_gpt, const Float* kmajor, const Float* kminor_lower,
+    const Float* kminor_upper, const int* minor_limits_gpt_lower, const int* minor_limits_gpt_upper,
+    const Bool* minor_scales_with_density_lower, const Bool* minor_scales_with_density_upper,
+    const Bool* scale_by_complement_lower, const Bool* scale_by_complement_upper,
+    const int* idx_minor_lower, const int* idx_minor_upper, const int* idx_minor_scaling_lower,
+    const int* idx_minor_scaling_upper, const int* kminor_start_lower, const int* kminor_start_upper,
+    const Bool* tropo, const Float* col_mix, const Float* fmajor, const Float* fminor,
+    const Float* play, const Float* tlay, const Float* col_gas, const int* jeta, const int* jtemp,
+    const int* jpress, const Float* krayl, const Float* col_dry, Float* tau, Float* ssa, Float* g,
+    const Float* cld_tau, const Float* cld_ssa, const Float* cld_g) {
+  RaylHost rh{krayl, col_dry, cld_tau, cld_ssa, cld_g, ssa, g};
+  tau_absorption_impl("rte_hip_gas_optics_sw_2str", ncol, nlay, nbnd, ngpt, ngas, nflav, neta, npres, ntemp,
+                      nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, kmajor,
+                      kminor_lower, kminor_upper, minor_limits_gpt_lower, minor_limits_gpt_upper,
+                      minor_scales_with_density_lower, minor_scales_with_density_upper, scale_by_complement_lower,
+                      scale_by_complement_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
+                      idx_minor_scaling_upper, kminor_start_lower, kminor_start_upper, tropo, col_mix, fmajor, fminor, play,
+                      tlay, col_gas, jeta, jtemp, jpress, tau, nullptr, &rh);
   return 0;
 }
 }  // extern "C"

@@ -270,6 +270,13 @@ class GasOptics:
         gl = glue or default_glue(self.lib, xp)
         fused = fuse_rayleigh and hasattr(gl, "tau_rayleigh_combine_2str")
         assert clouds_bybnd is None or fused, "the by-band cloud increment is part of the fused kernel"
+        if fused and fuse_rayleigh == "all" and hasattr(gl, "gas_optics_sw_2str"):
+            # absorption, Rayleigh, combine (and the by-band cloud increment) in ONE pass: tau_abs never goes to memory
+            tau, ssa, g = (buf(n, (ncol, nlay, self.ngpt)) for n in ("tau", "ssa", "g"))
+            gl.gas_optics_sw_2str(self, ncol, nlay, st, play, tlay, col_gas, col_dry, tau, ssa, g, clouds_bybnd)
+            toa = buf("toa_src", (ncol, self.ngpt))
+            gl.broadcast_gpt(ncol, self.ngpt, self.t["solar_source"], toa)
+            return b
         # fused: the absorption optical depth is computed straight into `tau`, which the fused kernel updates in place
         tau_abs = buf("tau" if fused else "tau_abs", (ncol, nlay, self.ngpt))
         self.lib.zero_array_3D(ncol, nlay, self.ngpt, tau_abs)  # :637
@@ -354,6 +361,22 @@ class HipGlue:
         ext_call(self.lib, "rte_hip_tau_rayleigh_combine_2str", ["i"] * 8 + ["a", "a", "a", "i"] + ["a"] * 13,
                  ncol, nlay, nbnd, ngpt, ngas, nflav, neta, ntemp, gpoint_flavor, band_lims_gpt, krayl, idx_h2o,
                  col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_abs, tau, ssa, g, ct, cs, cg)
+
+    # the whole SW gas optics in one pass (csrc/gas_optics.hip: rte_hip_gas_optics_sw_2str)
+    def gas_optics_sw_2str(self, go, ncol, nlay, st, play, tlay, col_gas, col_dry, tau, ssa, g, clouds_bybnd=None):
+        from .hiplib import ext_call
+
+        t = go.t
+        ct, cs, cg = clouds_bybnd if clouds_bybnd is not None else (None, None, None)
+        ext_call(self.lib, "rte_hip_gas_optics_sw_2str", ["i"] * 14 + ["a"] * 36,
+                 ncol, nlay, go.nbnd, go.ngpt, go.ngas, go.nflav, go.neta, go.npres, go.ntemp, go.nminorlower,
+                 go.nminorklower, go.nminorupper, go.nminorkupper, go.kd.idx_h2o, t["gpoint_flavor"], t["band_lims_gpt"],
+                 t["kmajor"], t["kminor_lower"], t["kminor_upper"], t["minor_limits_gpt_lower"], t["minor_limits_gpt_upper"],
+                 t["minor_scales_with_density_lower"], t["minor_scales_with_density_upper"], t["scale_by_complement_lower"],
+                 t["scale_by_complement_upper"], t["idx_minor_lower"], t["idx_minor_upper"], t["idx_minor_scaling_lower"],
+                 t["idx_minor_scaling_upper"], t["kminor_start_lower"], t["kminor_start_upper"], st.tropo, st.col_mix,
+                 st.fmajor, st.fminor, play, tlay, col_gas, st.jeta, st.jtemp, st.jpress, t["krayl"], col_dry, tau, ssa, g,
+                 ct, cs, cg)
 
     # masks + both table look-ups + liquid/ice combination (+ delta scaling) in one pass (csrc/optical_props.hip)
     def cloud_optics_fused(self, ncol, nlay, nbnd, twostr, delta_scale, clwp, ciwp, reliq, deice, tb, t, tau, ssa, g):
@@ -452,16 +475,19 @@ def allsky_lw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds
 
 
 def allsky_sw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds, mu0, sfc_alb_gpt, gb=None, cb=None, rb=None,
-              fuse: bool = True):
+              fuse=True):
     """SW half (:382-404): two-stream clouds, delta-scaled, added to the gas optical properties band by band.
     ``fuse`` (device containers only): cloud optics + delta scaling in one pass, and compute_tau_rayleigh +
-    combine_abs_and_rayleigh + the band-wise increment in one pass over the gas arrays."""
-    fuse = fuse and not isinstance(xp, NumpyArrays)
+    combine_abs_and_rayleigh + the band-wise increment in one pass over the gas arrays; ``fuse="all"``: that pass is
+    compute_tau_absorption's as well (the absorption optical depth never goes to memory)."""
+    if isinstance(xp, NumpyArrays):
+        fuse = False
     if fuse:
         cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], True, buffers=cb, fused=True,
                              delta_scale=True)                                                                      # :394 fused in
         gb = go.gas_optics_sw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["col_gas"], atm["col_dry"], buffers=gb,
-                              fuse_rayleigh=True, clouds_bybnd=(cb["cld_tau"], cb["cld_ssa"], cb["cld_g"]))         # :395 fused in
+                              fuse_rayleigh=("all" if fuse == "all" else True),
+                              clouds_bybnd=(cb["cld_tau"], cb["cld_ssa"], cb["cld_g"]))                             # :395 fused in
     else:
         gb = go.gas_optics_sw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["col_gas"], atm["col_dry"], buffers=gb)
         cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], True, buffers=cb)

@@ -91,6 +91,41 @@ def test_fused_extension_kernels_match_the_unfused_chain(kind, ncol):
         assert np.array_equal(fused[k], unfused[k]), k
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncol", [70, 1200, 5003])
+def test_one_pass_sw_gas_optics_matches_the_chain(ncol):
+    """``fuse="all"`` (rte_hip_gas_optics_sw_2str): compute_tau_absorption + compute_tau_rayleigh + combine + the band-wise
+    cloud increment in one pass.  The same operations on the same doubles as the chain of kernels, so the arrays are
+    bit-identical wherever both run the slab kernel; the Rayleigh rows make the staged box a little larger, so a few
+    (tile, layer, band) entries more go to the direct-gather code, whose sums of the same terms differ by rounding:
+    1e-14 elementwise, and most values exactly equal.  Clear sky (the SW bench chain) and with clouds."""
+    import torch
+
+    from rte_rrtmgp_amd import hiplib
+
+    hip = hiplib.load()
+    nlay = 24
+    kd, atm, tb, cl = _setup("sw", ncol, nlay)
+    xp = frontend.TorchArrays("cuda:0")
+    chain = _run(hip, xp, "sw", kd, atm, tb, cl, ncol, nlay, fuse=True)
+    one = _run(hip, xp, "sw", kd, atm, tb, cl, ncol, nlay, fuse="all")
+    for k in chain:
+        err = np.max(np.abs(one[k] - chain[k]) / np.maximum(np.abs(chain[k]), 1e-300))
+        assert err <= 1e-14, (k, err)
+        assert np.mean(one[k] == chain[k]) > 0.98, k
+    # clear sky: GasOptics alone
+    go = frontend.GasOptics(hip, kd, xp)
+    A = xp.asarray
+    args = [A(getattr(atm, k)) for k in ("play", "plev", "tlay", "col_gas", "col_dry")]
+    a = {k: v.clone() for k, v in go.gas_optics_sw(ncol, nlay, *args, fuse_rayleigh=True).items() if k in ("tau", "ssa", "g")}
+    b = go.gas_optics_sw(ncol, nlay, *args, fuse_rayleigh="all")
+    torch.cuda.synchronize()
+    for k in a:
+        err = float(((b[k] - a[k]).abs() / a[k].abs().clamp_min(1e-300)).max())
+        assert err <= 1e-14, (k, err)
+        assert float((b[k] == a[k]).double().mean()) > 0.98, k
+
+
 def _golden():
     import importlib.util
     import os

@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, ".")
 from rte_rrtmgp_amd import frontend, hiplib, synth
 lib = hiplib.load(); hiplib.ext_call(lib, "rte_hip_defer_zero", ["i"], 1); xp = frontend.TorchArrays("cuda:0")
-ncol = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+ncol = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100000
 nlay = 60
 kd = synth.make_kdist("sw"); atm = synth.make_atmosphere(ncol, nlay, seed=42, kdist=kd)
 go = frontend.GasOptics(lib, kd, xp); A = xp.asarray
@@ -12,7 +12,7 @@ play, plev, tlay, col_gas, col_dry = (A(getattr(atm, k)) for k in ("play", "plev
 mu0 = xp.full((ncol, nlay), 0.86); alb = xp.full((ncol, kd.ngpt), 0.06)
 bufs, rb = {}, {}
 def step():
-    go.gas_optics_sw(ncol, nlay, play, plev, tlay, col_gas, col_dry, buffers=bufs, fuse_rayleigh=True)
+    go.gas_optics_sw(ncol, nlay, play, plev, tlay, col_gas, col_dry, buffers=bufs, fuse_rayleigh=(True if "--chain" in sys.argv else "all"))
     frontend.rte_sw(lib, xp, ncol, nlay, kd.ngpt, False, bufs["tau"], bufs["ssa"], bufs["g"], mu0, bufs["toa_src"], alb, alb, buffers=rb)
 step(); step(); step(); torch.cuda.synchronize()
 hiplib.ext_call(lib, "rte_hip_profile_reset", []); hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
