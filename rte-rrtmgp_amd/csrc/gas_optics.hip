@@ -1177,7 +1177,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   if (RAYL) wray = a.col_gas[cl + (size_t)ncl * a.idx_h2o] + a.rf.col_dry[cl];
 
   // major weights + eta indices of band b (requested one stage ahead)
-  struct Major { Float2 fm[4], cm; int2 je; Float2 fr[RAYL ? 2 : 1]; };
+  struct Major { Float2 fm[4], cm; int2 je; };
   auto load_major = [&](int flav, Major& x) {
     const size_t clf = cl + (size_t)ncl * flav;
     const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
@@ -1185,13 +1185,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     for (int i = 0; i < 4; ++i) x.fm[i] = fmp[i];
     x.cm = *reinterpret_cast<const Float2*>(a.col_mix + 2 * clf);
     x.je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
-    if (RAYL) {  // compute_tau_rayleigh interpolates with fminor of the MAJOR species' flavor (:548-551)
-      const Float2* frp = reinterpret_cast<const Float2*>(a.fminor + 4 * clf);
-      x.fr[0] = frp[0]; x.fr[1] = frp[1];
-    }
   };
   // minor column amounts, weights and eta indices of one stage
-  struct Minor { Float sc[MM], cgs[MM]; Float2 fn0, fn1; int2 em; Float addv; Float cld[RAYL == 2 ? 3 : 1]; };
+  struct Minor { Float sc[MM], cgs[MM]; Float2 fn0, fn1; int2 em; Float addv; };
   // What the requests of a stage's minor inputs need from the band table in LDS: which gases, which flavor.  Read at
   // the TOP of the stage before (peek_minor), so that at its end the requests go out back to back: looked up there,
   // each request waited for its own LDS round trip -- eleven in a row, with nothing else left to issue (0.8 ms).
@@ -1211,10 +1207,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   };
   auto load_minor = [&](int b, const MinorIdx& q, Minor& x) {
     x.addv = ADDB ? a.add_bybnd[cl + (size_t)ncl * b] : (Float)0;
-    if (RAYL == 2) {  // the band's cloud properties of this (column, layer)
-      x.cld[0] = a.rf.cld_tau[cl + (size_t)ncl * b]; x.cld[1] = a.rf.cld_ssa[cl + (size_t)ncl * b];
-      x.cld[2] = a.rf.cld_g[cl + (size_t)ncl * b];
-    }
+
 #pragma unroll
     for (int k = 0; k < MM; ++k) {
       x.sc[k] = 0; x.cgs[k] = 0;
@@ -1272,10 +1265,19 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const Float2 fn0 = mw.fn0, fn1 = mw.fn1;
     const int2 em = mw.em;
     const Float addv = mn.addv;
+    // RAYL: what only the end of the stage needs -- the Rayleigh interpolation weights (fminor of the MAJOR species'
+    // flavor, :548-551) and the band's cloud properties -- is requested here, at the top of its own stage
     Float2 fr0{}, fr1{};
     Float cld_t = 0, cld_s = 0, cld_g = 0;
-    if (RAYL) { fr0 = mj.fr[0]; fr1 = mj.fr[1]; }
-    if (RAYL == 2) { cld_t = mn.cld[0]; cld_s = mn.cld[1]; cld_g = mn.cld[2]; }
+    if (RAYL) {
+      const int flav_cur = bm[ibnd].flav[itropo];
+      const Float2* frp = reinterpret_cast<const Float2*>(a.fminor + 4 * (cl + (size_t)ncl * flav_cur));
+      fr0 = frp[0]; fr1 = frp[1];
+    }
+    if (RAYL == 2) {
+      cld_t = a.rf.cld_tau[cl + (size_t)ncl * ibnd]; cld_s = a.rf.cld_ssa[cl + (size_t)ncl * ibnd];
+      cld_g = a.rf.cld_g[cl + (size_t)ncl * ibnd];
+    }
     // this stage's major weights into locals (col_mix folded in)
     const Float w0 = mj.cm.x * mj.fm[0].x, w1 = mj.cm.x * mj.fm[0].y, w2 = mj.cm.x * mj.fm[1].x, w3 = mj.cm.x * mj.fm[1].y,
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
