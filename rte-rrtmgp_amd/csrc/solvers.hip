@@ -795,29 +795,40 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   };
 
   constexpr bool DIRLDS = L <= 9;  // the direct-flux accumulators in LDS (ds_add_f64 on the thread's own slots): 2L+2 registers
-  Float* const dirs = MU + (size_t)SMAX * 2 * L * 64 + (size_t)s * (L + 1) * 64 + lane;  // acc_dir slot i at dirs[i * 64]
+  // L == 9 (72 layers) is 15 registers over: the upward-flux accumulators go to LDS as well, and to make room there
+  // only ONE value per layer is parked (the reciprocal is formed again per g-point, 6 instructions per layer)
+  constexpr bool UPLDS = L == 9;
+  constexpr int NMU = UPLDS ? 1 : 2;
+  Float* const dirs = MU + (size_t)SMAX * NMU * L * 64 + (size_t)s * (L + 1) * 64 + lane;  // acc_dir slot i at dirs[i * 64]
+  Float* const ups = MU + (size_t)SMAX * NMU * L * 64 + (size_t)SMAX * (L + 1) * 64 + (size_t)s * (L + 1) * 64 + lane;
   // per-layer cosine of the solar zenith angle and what depends on it alone: independent of the g-point, parked in
   // LDS (lane-private slots) -- the clamped value (:1046) and its reciprocal (tau / mu0 becomes a product), the
-  // reciprocal carrying "mu0 > 0" (:1122) in its sign
-  Float* const mu0s = MU + (size_t)s * 2 * L * 64 + lane;  // element i at mu0s[i * 64]
+  // reciprocal (UPLDS: the clamped value) carrying "mu0 > 0" (:1122) in its sign
+  Float* const mu0s = MU + (size_t)s * NMU * L * 64 + lane;  // element i at mu0s[i * 64]
   Float* const mu0i = mu0s + L * 64;
 #pragma unroll
   for (int i = 0; i < L; ++i) {
     const Float m = a.mu0[c + (size_t)ncol * layer_of(i)];
     const Float ms = fmax(min_mu0, m);
-    mu0s[i * 64] = ms;
-    mu0i[i * 64] = m > (Float)0 ? rte::rcp_nr(ms) : -rte::rcp_nr(ms);
+    if constexpr (UPLDS) {
+      mu0s[i * 64] = m > (Float)0 ? ms : -ms;
+    } else {
+      mu0s[i * 64] = ms;
+      mu0i[i * 64] = m > (Float)0 ? rte::rcp_nr(ms) : -rte::rcp_nr(ms);
+    }
   }
   const Float mu0_top = a.mu0[c + (size_t)ncol * (a.top_at_1 ? 0 : nlay - 1)];
   const Float mu0_sfc = a.mu0[c + (size_t)ncol * (a.top_at_1 ? nlay - 1 : 0)];
 
-  Float acc_up[L + 1], acc_dn[L + 1], acc_dir[DIRLDS ? 1 : L + 1];
+  Float acc_up[UPLDS ? 1 : L + 1], acc_dn[L + 1], acc_dir[DIRLDS ? 1 : L + 1];
 #pragma unroll
   for (int i = 0; i <= L; ++i) {
-    acc_up[i] = 0; acc_dn[i] = 0;
+    acc_dn[i] = 0;
+    if constexpr (UPLDS) ups[i * 64] = 0; else acc_up[i] = 0;
     if constexpr (DIRLDS) dirs[i * 64] = 0; else acc_dir[i] = 0;
   }
   auto add_dir = [&](int i, Float v) { if constexpr (DIRLDS) atomicAdd(&dirs[i * 64], v); else acc_dir[i] += v; };
+  auto add_up = [&](int i, Float v) { if constexpr (UPLDS) atomicAdd(&ups[i * 64], v); else acc_up[i] += v; };
 
   struct In { Float tau[L], ssa[L], g[L], inc_dir, alb_dir, alb_dif, inc_dif; };
   // loads as (wave-uniform plane base, advanced per g-point) + (32-bit byte offset of the lane's row): the saddr form
@@ -864,7 +875,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         const Float e2 = e1 * e1;
         // RT = 1 / x (:1031) and w0 RT / om (:1054) from ONE reciprocal, of x om
         const Float xden = kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2);
-        const Float mu0_s = mu0s[i * 64];
+        const Float mu0_s = UPLDS ? fabs(mu0s[i * 64]) : mu0s[i * 64];
         const Float k_mu = kk * mu0_s;
         const Float om = (Float)1 - k_mu * k_mu;
         const Float om_s = fabs(om) >= (Float)RTE_EPS ? om : (Float)RTE_EPS;
@@ -878,7 +889,9 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         const Float alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
         const Float alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
         const Float k_gamma3 = kk * gamma3, k_gamma4 = kk * gamma4;
-        const Float imu = mu0i[i * 64];
+        Float imu;
+        if constexpr (UPLDS) { const Float r_ = rte::rcp_nr(mu0_s); imu = mu0s[i * 64] > (Float)0 ? r_ : -r_; }
+        else imu = mu0i[i * 64];
         const Float Tnoscat = rte::exp_nonpos(-tau_s * fabs(imu));
         Float Rdir = RT * (((Float)1 - k_mu) * (alpha2 + k_gamma3) - ((Float)1 + k_mu) * (alpha2 - k_gamma3) * e2 -
                            (Float)2.0 * (k_gamma3 - alpha2 * k_mu) * e1 * Tnoscat);
@@ -974,13 +987,13 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     Float dirl = dir_in;  // beam at the segment's levels
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-      acc_up[i] += fd * al[i] + sr[i];
+      add_up(i, fd * al[i] + sr[i]);
       acc_dn[i] += fd + dirl;
       add_dir(i, dirl);
       fd = fa[i] * fd + fb[i];
       dirl = Tn[i] * dirl;
     }
-    acc_up[L] += fd * al[L] + sr[L];
+    add_up(L, fd * al[L] + sr[L]);
     acc_dn[L] += fd + dirl;
     add_dir(L, dirl);
   };
@@ -995,7 +1008,8 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
       if (i < np || (last && i == np)) {
         const int p = p0 + i;  // level position from the top
         const int ilev = a.top_at_1 ? p : nlay - p;
-        a.part_up[base + (size_t)ncol * ilev] = acc_up[i];
+        if constexpr (UPLDS) a.part_up[base + (size_t)ncol * ilev] = ups[i * 64];
+        else a.part_up[base + (size_t)ncol * ilev] = acc_up[i];
         a.part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
         if constexpr (DIRLDS) a.part_dir[base + (size_t)ncol * ilev] = dirs[i * 64];
         else a.part_dir[base + (size_t)ncol * ilev] = acc_dir[i];
@@ -1673,7 +1687,8 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     q.part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * 3);
     q.part_dn = q.part_up + nclv * ngroups;
     q.part_dir = q.part_dn + nclv * ngroups;
-    const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 2 * 8 * L + (L <= 9 ? 8 * (L + 1) : 0));  // composites, flux maps, mu0 (clamped, reciprocal), direct-flux accumulators
+    // composites, flux maps, mu0 (clamped, reciprocal; L == 9: one value), direct-flux (L == 9: and upward-flux) accumulators
+    const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + (L == 9 ? 1 : 2) * 8 * L + (L <= 9 ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
     {
       rte::ProfScope p("sw_2stream_seg_kernel");
       if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
