@@ -2061,6 +2061,9 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
     load_wts(0, x0, w0);
 #pragma unroll
     for (int j = 0; j < G; ++j) prev[j] = 0;
+    // nothing outstanding at loop entry: the wait counts inside are then those of the steady state (requests of
+    // the following layers, then this layer's 32 stores), not their merge with this prologue
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll 1
     for (unsigned l = 0; l < nlay; ++l, ++s) {
       TICK(0);
@@ -2070,8 +2073,11 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
       const int je1 = w0.je1, je2 = w0.je2, jT = x0.jT, jp = x0.jpress + (x0.tropo ? 0 : 1) + 1;  // levels jp-1, jp
       const Float tl = x0.tlay, tv = x0.tlev;
       x0 = x1;
-      if (l + 1 < nlay) load_wts(l + 1, x0, w0);
-      if (l + 2 < nlay) load_idx(l + 2, x1);
+      // unconditional (the last layers repeat the last one): a request made on some paths only makes the number of
+      // outstanding memory operations path-dependent, and the compiler then drains them all -- this layer's requests
+      // and the previous layer's 32 stores -- in front of every barrier
+      load_wts(min(l + 1, nlay - 1), x0, w0);
+      load_idx(min(l + 2, nlay - 1), x1);
       const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], emin = gl[l][4], nE = gl[l][5];
       const Float pl_lay = planck(tl), pl_lev = planck(tv);
       TICK(1);
