@@ -306,6 +306,11 @@ def main():
                          "contiguous run; sites-shuffled: the same columns in random order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
+    ap.add_argument("--no-aux-stream", action="store_true",
+                    help="run compute_tau_absorption's direct-gather worklist after the slab kernel instead of beside it "
+                         "(rte_hip_aux_stream(0); A/B)")
+    ap.add_argument("--share-geometry-mode", type=int, default=1, choices=[1, 2, 3],
+                    help="A/B: 2 = only compute_tau_absorption -> compute_Planck_source, 3 = only interpolation -> compute_tau_absorption")
     ap.add_argument("--no-share-geometry", action="store_true",
                     help="compute_Planck_source derives its own tile geometry instead of re-using compute_tau_absorption's")
     ap.add_argument("--overlap", action="store_true",
@@ -341,7 +346,8 @@ def main():
     # compute_Planck_source re-uses the tile geometry of the compute_tau_absorption call right before it (same promise as
     # the deferred zero fill: the driver touches the interpolation arrays only through the library in between)
     share_geom = not args.no_share_geometry
-    hiplib.ext_call(lib, "rte_hip_share_geometry", ["i"], 1 if share_geom else 0)
+    hiplib.ext_call(lib, "rte_hip_share_geometry", ["i"], (args.share_geometry_mode if share_geom else 0))
+    hiplib.ext_call(lib, "rte_hip_aux_stream", ["i"], 0 if args.no_aux_stream else 1)
     hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1 if overlap else 0)
     dev = f"cuda:{local_rank}"
     xp = frontend.TorchArrays(dev)
@@ -567,7 +573,7 @@ def main():
                                     f"columns per GPU x {nlay_w} layers, 256 + 224 g-points (BASELINE configs[3] shape), "
                                     f"synthetic k-distributions and cloud tables, cloud field of examples/all-sky"),
                        "columns_per_gpu": ncol, "nlay": nlay_w, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero,
-                       "overlap_tau_planck": overlap, "share_geometry": share_geom,
+                       "overlap_tau_planck": overlap, "share_geometry": share_geom, "worklist_beside_slab_kernel": not args.no_aux_stream,
                        "atmosphere": args.atmosphere,
                        "direct_gather_worklist": {"tau_tile_layer_bands": wl_tau, "of": tiles * nlay_w * kd.nbnd,
                                                   "planck_tile_bands": wl_planck, "of_planck": tiles * kd.nbnd},

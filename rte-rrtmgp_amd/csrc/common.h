@@ -67,6 +67,8 @@ class Call {
   bool fork_candidate_ = false, forked_ = false;
 };
 long call_seq();  // sequence number of the API call in progress (every entry point counts)
+hipStream_t aux_fork();  // second stream inside one call, ordered after everything the call has queued so far (nullptr: off)
+void aux_join();         // the call's stream waits for it
 void fork_point(const void* out, size_t bytes);  // marks "everything queued so far" at the start of a call others may overlap
 
 bool is_device_pointer(const void* p);  // a kernel can address it (device, or pinned / registered / managed host memory)

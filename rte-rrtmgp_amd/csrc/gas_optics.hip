@@ -28,6 +28,22 @@ using rte::cdiv;
 
 constexpr int GC = 16;  // g-points held in registers per chunk
 
+// OR over the 64 lanes of a wave, result returned as a wave-uniform value: inclusive scan inside each row of 16
+// lanes (row_shr 1, 2, 4, 8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15), then rows 0-1 -> rows 2-3
+// (row_bcast:31); lane 63 holds the total
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+
+constexpr int MAXFLAV = 32;
+
 // -------------------------------------------------------------------------------------------
 // interpolation: reference mo_gas_optics_rrtmgp_kernels.F90:37-170
 // -------------------------------------------------------------------------------------------
@@ -40,7 +56,7 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
                      const Float* __restrict__ tlay, const Float* __restrict__ col_gas,
                      int* __restrict__ jtemp, Float* __restrict__ fmajor, Float* __restrict__ fminor,
                      Float* __restrict__ col_mix, Bool* __restrict__ tropo, int* __restrict__ jeta,
-                     int* __restrict__ jpress) {
+                     int* __restrict__ jpress, unsigned* __restrict__ masks) {
   // block = (256 columns, one layer); the flavors are walked INSIDE the block: pressure / temperature terms (one log)
   // are formed once per (column, layer), and play, tlay and the column amounts are read once instead of once per flavor
   // (as a grid dimension the flavors' blocks ran far apart: 1.9 GB of reads for 0.5 GB of inputs)
@@ -67,6 +83,21 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
     tropo[cl] = trop;
   }
   const int itropo = trop ? 0 : 1;
+  // masks != nullptr: the block also leaves bit masks of the LUT rows its columns touch (temperature, pressure, regime,
+  // and per flavor and regime the eta rows) -- what tile_geom2_kernel would otherwise derive by reading jtemp, jpress,
+  // tropo and all of jeta again in the compute_tau_absorption call that follows (InterpMasks below)
+  __shared__ unsigned s_mask[4 + 2 * MAXFLAV];
+  const int mask_w = 4 + 2 * nflav;
+  if (masks) {
+    if ((int)threadIdx.x < mask_w) s_mask[threadIdx.x] = 0;
+    __syncthreads();
+    const int jp = (int)jpress_aint + itropo + 1;
+    const unsigned long long pm = in_range ? (3ull << (jp - 1)) : 0ull;
+    const unsigned tm = wave_or(in_range ? (3u << jt) : 0u);
+    const unsigned p0 = wave_or((unsigned)pm), p1 = wave_or((unsigned)(pm >> 32));
+    const unsigned rg = wave_or(in_range ? (trop ? 1u : 2u) : 0u);
+    if ((threadIdx.x & 63) == 0) { atomicOr(&s_mask[0], tm); atomicOr(&s_mask[1], p0); atomicOr(&s_mask[2], p1); atomicOr(&s_mask[3], rg); }
+  }
   // this column's amounts of every gas, parked in LDS (lane-private slots; the flavor's two gases are block-uniform indices)
   extern __shared__ Float s_cg[];  // [ngas + 1][256]
   const int t = threadIdx.x;
@@ -114,6 +145,11 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
       fmj[2 + 4 * itemp] = fpress * f1;
       fmj[3 + 4 * itemp] = fpress * f2;
     }
+    if (masks) {
+      const unsigned m = (3u << je[0]) | (3u << je[1]);  // rows eta, eta + 1 of both temperature corners
+      const unsigned w0 = wave_or(in_range && trop ? m : 0u), w1 = wave_or(in_range && !trop ? m : 0u);
+      if ((t & 63) == 0) { atomicOr(&s_mask[4 + 2 * iflav], w0); atomicOr(&s_mask[5 + 2 * iflav], w1); }
+    }
     __syncthreads();  // the previous flavor's records have been stored
 #pragma unroll
     for (int i = 0; i < 8; ++i) s_fmj[t * 9 + i] = fmj[i];
@@ -141,6 +177,10 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
         jeta[2 * rec0 + e] = s_je[(e >> 1) * 3 + (e & 1)];
       }
     }
+  }
+  if (masks) {
+    __syncthreads();
+    if (t < mask_w) masks[((size_t)blockIdx.x + (size_t)gridDim.x * ilay) * mask_w + t] = s_mask[t];
   }
 }
 
@@ -194,19 +234,38 @@ __global__ void bands_guard_kernel(int nbnd, int ngpt, const int* __restrict__ b
 // -------------------------------------------------------------------------------------------
 __global__ void tropo_limits_kernel(int ncol, int nlay, const Float* __restrict__ play,
                                     const Bool* __restrict__ tropo, int* __restrict__ lim /*(ncol,4)*/,
-                                    int* __restrict__ overlap) {
+                                    int* __restrict__ overlap, int* __restrict__ irregular) {
   const int icol = blockIdx.x * blockDim.x + threadIdx.x;
   if (icol >= ncol) return;
   const bool top_at_1 = play[0] < play[(size_t)ncol * (nlay - 1)];
   int minloc_t = 0, maxloc_n = 0;
+  int first_t = 0, last_t = 0, first_n = 0, last_n = 0;  // first / last layer (1-based) with / without the tropo flag
   Float pmin = 0, pmax = 0;
-  for (int ilay = 0; ilay < nlay; ++ilay) {
-    const size_t cl = icol + (size_t)ncol * ilay;
-    const Float p = play[cl];
-    if (tropo[cl]) {
-      if (minloc_t == 0 || p < pmin) { minloc_t = ilay + 1; pmin = p; }
-    } else {
-      if (maxloc_n == 0 || p > pmax) { maxloc_n = ilay + 1; pmax = p; }
+  // twelve layers requested at a time (one load after the other, the 60 layers of a column were 60 memory latencies)
+  constexpr int B = 12;
+  for (int l0 = 0; l0 < nlay; l0 += B) {
+    Float pb[B];
+    bool tb[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      const size_t cl = icol + (size_t)ncol * min(l0 + k, nlay - 1);
+      pb[k] = play[cl];
+      tb[k] = tropo[cl];
+    }
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+      const int ilay = l0 + k;
+      if (ilay >= nlay) break;
+      const Float p = pb[k];
+      if (tb[k]) {
+        if (minloc_t == 0 || p < pmin) { minloc_t = ilay + 1; pmin = p; }
+        if (first_t == 0) first_t = ilay + 1;
+        last_t = ilay + 1;
+      } else {
+        if (maxloc_n == 0 || p > pmax) { maxloc_n = ilay + 1; pmax = p; }
+        if (first_n == 0) first_n = ilay + 1;
+        last_n = ilay + 1;
+      }
     }
   }
   int lo1, lo2, up1, up2;
@@ -220,6 +279,13 @@ __global__ void tropo_limits_kernel(int ncol, int nlay, const Float* __restrict_
   // a layer that lies in BOTH ranges gets both regimes' minor absorbers in the reference (possible
   // only for non-monotone pressure profiles); the production kernel does not handle that
   if (lo1 > 0 && up1 > 0 && max(lo1, up1) <= min(lo2, up2)) *overlap = 1;
+  // "regular": every layer lies in exactly the range of its own flag (lower <=> tropo), which is what a pressure
+  // profile monotone in the layer index gives.  Only then are masks keyed by the tropo flag alone (those the
+  // interpolation call leaves, InterpMasks) the masks tile_geom2_kernel derives from these limits.
+  bool regular;
+  if (top_at_1) regular = (first_t == 0 || first_t == minloc_t) && (last_n == 0 || last_n == maxloc_n) && (first_t == 0 || last_n == 0 || last_n < first_t);
+  else          regular = (last_t == 0 || last_t == minloc_t) && (first_n == 0 || first_n == maxloc_n) && (last_t == 0 || first_n == 0 || last_t < first_n);
+  if (!regular) *irregular = 1;
 }
 
 // Per band, the ordered list of minor intervals whose g-point range intersects the band
@@ -918,22 +984,6 @@ __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __res
 // A band's eta range is then the span of the masks of its two flavors, keyed by the regime of the columns
 // that use them -- the same box as before.
 // -------------------------------------------------------------------------------------------
-// OR over the 64 lanes of a wave, result returned as a wave-uniform value: inclusive scan inside each row of 16
-// lanes (row_shr 1, 2, 4, 8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15), then rows 0-1 -> rows 2-3
-// (row_bcast:31); lane 63 holds the total
-__device__ __forceinline__ unsigned wave_or(unsigned v) {
-  int x = (int)v;
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-  return (unsigned)__builtin_amdgcn_readlane(x, 63);
-}
-
-constexpr int MAXFLAV = 32;
-
 struct Geom2Args {
   int ncol, nlay, nbnd, nflav, slab_floats;
   bool planck;               // Planck: box = pressure x temperature x eta of pfrac; no minor rows, no regime ranges
@@ -948,6 +998,10 @@ struct Geom2Args {
   int extra_planes;          // tau: more (T, eta) planes staged per stage (2 with the fused Rayleigh rows)
   int* worklist;             // tau: (tile, layer, band) triples; Planck: (tile, band) pairs
   int* flags;                // Planck: one worklist entry per (tile, band)
+  const unsigned* imask;     // tau: masks per (256-column block, layer) left by the interpolation call (InterpMasks), or nullptr
+  int imask_nblk;            //      blocks per layer
+  const int* irregular;      //      != 0: some column's layer ranges are not those of its tropo flags -> derive the masks here
+  int* stat;                 //      rte_hip_stat(2): 1 = masks taken from the interpolation call, 2 = derived here
 };
 
 template <int TILE, int G>
@@ -976,6 +1030,24 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
     }
   }
   __syncthreads();
+  static_assert(TILE % 256 == 0, "the interpolation kernel leaves one mask record per 256 columns");
+  const bool pre = a.imask != nullptr && *a.irregular == 0;
+  if (a.stat && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *a.stat = pre ? 1 : 2;
+  if (pre) {
+    const int W = 4 + 2 * nflav;
+    if (tid < W) {
+      unsigned m = 0;
+      for (int k = 0; k < TILE / 256; ++k) {
+        const unsigned blk = blockIdx.x * (TILE / 256) + k;
+        if (blk < (unsigned)a.imask_nblk) m |= a.imask[((size_t)blk + (size_t)a.imask_nblk * ilay) * W + tid];
+      }
+      if (tid == 0) mT = m;
+      else if (tid == 1) mP[0] = m;
+      else if (tid == 2) mP[1] = m;
+      else if (tid == 3) mReg = m;
+      else mE[(tid - 4) >> 1][(tid - 4) & 1] = m;
+    }
+  } else {
   const unsigned icol = blockIdx.x * TILE + tid;
   const bool valid = icol < ncol;
   const unsigned ic = min(icol, ncol - 1);
@@ -1020,6 +1092,7 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
         if (f0 + k < nflav) { atomicOr(&mE[f0 + k][0], w[k][0]); atomicOr(&mE[f0 + k][1], w[k][1]); }
     }
   }
+  }  // !pre
   __syncthreads();
   TileGeom* out = geom + (blockIdx.x + (size_t)gridDim.x * ilay);
   const int Tmin = __ffs(mT) - 1, nT = (32 - __clz(mT)) - Tmin;
@@ -1482,7 +1555,8 @@ __global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a,
   if (blockIdx.x == 0 && threadIdx.x == 0) *stat = n;  // rte_hip_stat(0)
   const int chunks = tile / 64;
   const int items = n * chunks;
-  for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += gridDim.x * 4) {
+  const int wpb = blockDim.x >> 6;  // 4 waves per block after the slab kernel, 1 beside it (to fit next to its blocks)
+  for (int it = blockIdx.x * wpb + (threadIdx.x >> 6); it < items; it += gridDim.x * wpb) {
     const int w = it / chunks, ch = it - w * chunks;
     const int icol = worklist[1 + 3 * w] * tile + ch * 64 + (threadIdx.x & 63);
     if (icol < a.ncol) tau_direct_column(a, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
@@ -2363,7 +2437,9 @@ struct TauPlanCache {
 // indices, each by reading all of jeta (0.13 ms).  Like the deferred zero fill, for callers that touch the
 // interpolation arrays only through this library between the two calls; keyed by the arrays' addresses, the
 // dimensions and the library's call sequence (the Planck call must be the very next one).
-static int g_share_geom = 0;
+static int g_share_geom = 0;  // 0 off, 1 on; 2 = tau -> Planck only, 3 = interpolation -> tau only (A/B)
+static bool share_boxes() { return g_share_geom == 1 || g_share_geom == 2; }
+static bool share_masks() { return g_share_geom == 1 || g_share_geom == 3; }
 struct SharedGeom {
   const void *jeta = nullptr, *jtemp = nullptr, *jpress = nullptr, *tropo = nullptr;
   int ncol = 0, nlay = 0, nflav = 0, nbnd = 0, gw = 0;
@@ -2374,17 +2450,34 @@ struct SharedGeom {
 };
 static SharedGeom g_shared;
 
+// The same option also lets rrtmgp_interpolation leave, per (256-column block, layer), the bit masks of the LUT rows
+// its columns touch (it has every index in registers), and the compute_tau_absorption call that is the very next
+// library call on the same interpolation arrays builds its tile geometry from these few megabytes instead of reading
+// jtemp, jpress, tropo and all of jeta again (0.13 ms).  Masks are keyed by the tropo flag; the geometry kernel's own
+// are keyed by the layer ranges derived from it, which is the same thing unless a column's pressure is not monotone in
+// the layer index -- tropo_limits_kernel raises `irregular` then and the geometry kernel derives its masks itself.
+struct InterpMasks {
+  const void *jeta = nullptr, *jtemp = nullptr, *jpress = nullptr, *tropo = nullptr;
+  int ncol = 0, nlay = 0, nflav = 0;
+  long seq = -1;             // call sequence number of the interpolation call that wrote them
+  unsigned* buf = nullptr;   // persistent
+  size_t cap = 0;
+};
+static InterpMasks g_imask;
+
 namespace rte {
 void release_gas_optics_buffers() {  // rte_hip_release()
   if (g_shared.geom) HIP_CHECK(hipFree(g_shared.geom));
   if (g_shared.valid) HIP_CHECK(hipFree(g_shared.valid));
   g_shared = SharedGeom{};
+  if (g_imask.buf) HIP_CHECK(hipFree(g_imask.buf));
+  g_imask = InterpMasks{};
 }
 }  // namespace rte
 
 extern "C" {
 
-int rte_hip_share_geometry(int on) { g_share_geom = on; g_shared.seq = -1; return 0; }
+int rte_hip_share_geometry(int on) { g_share_geom = on; g_shared.seq = -1; g_imask.seq = -1; return 0; }
 int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
 int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
 int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
@@ -2432,12 +2525,28 @@ void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, 
   Bool* d_tropo = c.out(tropo, ncl);
   int* d_jeta = c.out(jeta, 2 * ncl * nflav);
   int* d_jpress = c.out(jpress, ncl);
-  rte::ProfScope p("interpolation_kernel");
   dim3 grid(cdiv(ncol, 256), nlay), block(256);
+  // masks for the compute_tau_absorption call that follows (InterpMasks): row numbers must fit the mask words
+  unsigned* d_masks = nullptr;
+  g_imask.seq = -1;
+  if (share_masks() && !c.any_host() && rte::is_device_memory(jeta) && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63) {
+    const size_t need = sizeof(unsigned) * (size_t)grid.x * nlay * (4 + 2 * nflav);
+    if (g_imask.cap < need) {
+      HIP_CHECK(hipStreamSynchronize(rte::stream()));
+      if (g_imask.buf) HIP_CHECK(hipFree(g_imask.buf));
+      HIP_CHECK(hipMalloc((void**)&g_imask.buf, need));
+      g_imask.cap = need;
+    }
+    d_masks = g_imask.buf;
+    g_imask.jeta = jeta; g_imask.jtemp = jtemp; g_imask.jpress = jpress; g_imask.tropo = tropo;
+    g_imask.ncol = ncol; g_imask.nlay = nlay; g_imask.nflav = nflav;
+    g_imask.seq = rte::call_seq();
+  }
+  rte::ProfScope p("interpolation_kernel");
   hipLaunchKernelGGL(interpolation_kernel, grid, block, sizeof(Float) * 256 * (ngas + 1), rte::stream(), ncol, nlay, ngas, nflav, neta,
                      npres, ntemp, d_flavor, d_temp_ref, d_press_ref_log, press_ref_log_delta_inv,
                      *temp_ref_min, *temp_ref_delta, temp_ref_delta_inv, press_ref_trop, d_vmr_ref, d_play,
-                     d_tlay, d_col_gas, d_jtemp, d_fmajor, d_fminor, d_col_mix, d_tropo, d_jeta, d_jpress);
+                     d_tlay, d_col_gas, d_jtemp, d_fmajor, d_fminor, d_col_mix, d_tropo, d_jeta, d_jpress, d_masks);
 }
 
 }  // extern "C"
@@ -2506,15 +2615,16 @@ static void tau_absorption_impl(
   hipStream_t st = rte::stream();
   if (!rh && !c.any_host() && rte::is_device_memory(d_tau)) rte::fork_point(d_tau, sizeof(Float) * ncl * ngpt);
   // layer limits of the two regimes per column (:274-285) + "regimes overlap somewhere" flag
-  int* lim = (int*)rte::scratch(sizeof(int) * (4 * (size_t)ncol + 1));
+  int* lim = (int*)rte::scratch(sizeof(int) * (4 * (size_t)ncol + 2));
   int* overlap = lim + 4 * (size_t)ncol;
+  int* irregular = overlap + 1;  // some column's layer ranges are not those of its tropo flags (see tropo_limits_kernel)
   const size_t wl_cap = (size_t)cdiv(ncol, 256) * nlay * nbnd;  // tiles are at least 256 columns wide
   int* const worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
   {
     rte::ProfScope p("tau_absorption_setup");
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, overlap, 1u, worklist, 1u, (int*)nullptr, 0u);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, overlap, 2u, worklist, 1u, (int*)nullptr, 0u);
     hipLaunchKernelGGL(tropo_limits_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, st, ncol, nlay, d_play, d_tropo, lim,
-                       overlap);
+                       overlap, irregular);
   }
   int* d_stale = stale_flag();
   stale_poll();
@@ -2753,6 +2863,7 @@ static void tau_absorption_impl(
 #endif
   constexpr int BS = V7_BS;
   v.worklist = worklist;
+  hipStream_t aux = nullptr;
   const bool use_v9 = g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr || rh != nullptr;  // the single-role kernel exists for 16-wide stages only
   if (use_v9) {
 #ifdef EXP_CLOCKS
@@ -2762,7 +2873,7 @@ static void tau_absorption_impl(
     constexpr int NCW = V9_NCW, NLW = V9_NLW, SLAB9 = V9_SLAB;  // compute + loader waves, 2 x 68 KB slab: one block per CU
     const unsigned tiles = cdiv(ncol, NCW * 64);
     const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
-    const bool share = g_share_geom && geom2 && NCW * 64 == 512 && !c.any_host() && !rh;
+    const bool share = share_boxes() && geom2 && NCW * 64 == 512 && !c.any_host() && !rh;
     TileGeom* d_geom;
     g_shared.seq = -1;
     if (share) {  // the geometry outlives this call: a compute_Planck_source call right behind it may use it
@@ -2792,6 +2903,14 @@ static void tau_absorption_impl(
     ga.lim = lim; ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.bmeta = d_bm;
     ga.skip_if = overlap; ga.worklist = v.worklist; ga.valid_out = share ? g_shared.valid : nullptr;
     ga.extra_planes = rh ? 2 : 0;
+    ga.irregular = irregular;
+    ga.stat = stats_dev() + 2;
+    if (share_masks() && g_imask.seq >= 0 && g_imask.seq + 1 == rte::call_seq() && g_imask.jeta == jeta && g_imask.jtemp == jtemp &&
+        g_imask.jpress == jpress && g_imask.tropo == tropo && g_imask.ncol == ncol && g_imask.nlay == nlay &&
+        g_imask.nflav == nflav && !c.any_host()) {
+      ga.imask = g_imask.buf;
+      ga.imask_nblk = cdiv(ncol, 256);
+    }
 #define RTE_LAUNCH_TAU9R_(GW, MMV, RV) \
   hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MMV, false, RV>), grid, blk, dyn, st, v, cg)
 #define RTE_LAUNCH_TAU9_(GW, AB)                                                                                  \
@@ -2811,6 +2930,7 @@ static void tau_absorption_impl(
       if (geom2) hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), grid, dim3(NCW * 64), 0, st, ga, d_geom);  \
       else hipLaunchKernelGGL((tau_geom_kernel<NCW * 64, GW>), grid, dim3(NCW * 64), 0, st, v, d_geom, SLAB9);    \
     }                                                                                                             \
+    aux = rte::aux_fork(); /* the worklist is complete: its kernel may run beside the slab kernel */             \
     rte::ProfScope p("tau_absorption_kernel");                                                                    \
     if (rh) {                                                                                                     \
       if (cb.cld_tau) { if (mm4) RTE_LAUNCH_TAU9R_(GW, 4, 2); else RTE_LAUNCH_TAU9R_(GW, MAXM, 2); }              \
@@ -2844,12 +2964,14 @@ static void tau_absorption_impl(
     // tiles whose LUT bounding box exceeded the LDS slab
     TauArgs aw = a;
     aw.run_if = nullptr;
-    hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(4096), dim3(256), 0, st, aw, (const int*)v.worklist,
-                       use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
-    if (rh) {  // the same two sets of (column, layer, band) hold tau_abs in tau: Rayleigh + combine in place
-      rayleigh_direct(overlap, nullptr, 0);
-      rayleigh_direct(nullptr, (const int*)v.worklist, V9_NCW * 64);
-    }
+    if (rh) rayleigh_direct(overlap, nullptr, 0);  // the same (column, layer, band) hold tau_abs in tau: Rayleigh + combine in place
+    hipStream_t main_st = st;
+    if (aux) st = aux;
+    hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw,
+                       (const int*)v.worklist, use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
+    if (rh) rayleigh_direct(nullptr, (const int*)v.worklist, V9_NCW * 64);  // (lambda launches on st)
+    st = main_st;
+    if (aux) rte::aux_join();
   }
 }
 
@@ -3165,7 +3287,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     wl_tile = NCW * 64;
     const unsigned tiles = cdiv(ncol, NCW * 64);
     // the geometry of the compute_tau_absorption call immediately before this one, if it is for the same arrays
-    const bool shared = g_share_geom && g_shared.seq >= 0 && g_shared.seq + 1 == rte::call_seq() && g_shared.jeta == jeta &&
+    const bool shared = share_boxes() && g_shared.seq >= 0 && g_shared.seq + 1 == rte::call_seq() && g_shared.jeta == jeta &&
                         g_shared.jtemp == jtemp && g_shared.jpress == jpress && g_shared.tropo == tropo &&
                         g_shared.ncol == ncol && g_shared.nlay == nlay && g_shared.nflav == nflav &&
                         g_shared.nbnd == nbnd && g_shared.gw == bl_gw && !c.any_host() &&

@@ -86,6 +86,32 @@ void fork_point(const void* out, size_t bytes) {
   g_fork_valid = true;
 }
 
+// ---- auxiliary stream inside one call --------------------------------------------------------
+// compute_tau_absorption's direct-gather worklist (§4.0) is bound by the texture addresser and touches entries the slab
+// kernel skips; on a second stream, forked after the geometry pre-pass and joined before the call returns, its single-wave
+// blocks run in the register space the slab kernel's 10-wave blocks leave free instead of after it.  Internal to one
+// call: whatever follows on the library stream sees both kernels' results.  rte_hip_aux_stream(0) switches it off.
+static bool g_aux_on = true;
+static hipStream_t g_aux = nullptr;
+static hipEvent_t g_ev_aux_fork = nullptr, g_ev_aux_join = nullptr;
+
+hipStream_t aux_fork() {
+  if (!g_aux_on) return nullptr;
+  if (!g_aux) {
+    HIP_CHECK(hipEventCreateWithFlags(&g_ev_aux_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&g_ev_aux_join, hipEventDisableTiming));
+    HIP_CHECK(hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking));
+  }
+  HIP_CHECK(hipEventRecord(g_ev_aux_fork, stream()));
+  HIP_CHECK(hipStreamWaitEvent(g_aux, g_ev_aux_fork, 0));
+  return g_aux;
+}
+
+void aux_join() {
+  HIP_CHECK(hipEventRecord(g_ev_aux_join, g_aux));
+  HIP_CHECK(hipStreamWaitEvent(stream(), g_ev_aux_join, 0));
+}
+
 // ---- persistent slots ----------------------------------------------------------------------
 struct Slot { void* p = nullptr; size_t bytes = 0; };
 static Slot g_slots[16];
@@ -317,6 +343,12 @@ int rte_hip_overlap_planck(int on) {
   rte::g_fork_valid = false;
   return 0;
 }
+// run the direct-gather worklist of compute_tau_absorption on a second stream inside the call (default on)
+int rte_hip_aux_stream(int on) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::g_aux_on = on != 0;
+  return 0;
+}
 int rte_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -353,6 +385,7 @@ int rte_hip_release(void) {
   rte::flush_pending_zeros();
   HIP_CHECK(hipStreamSynchronize(rte::g_stream));
   if (rte::g_side) HIP_CHECK(hipStreamSynchronize(rte::g_side));
+  if (rte::g_aux) HIP_CHECK(hipStreamSynchronize(rte::g_aux));
   rte::release_gas_optics_buffers();
   for (auto* v : {&rte::g_blocks_main, &rte::g_blocks_side}) {
     for (auto& b : *v) HIP_CHECK(hipFree(b.base));

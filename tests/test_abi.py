@@ -38,7 +38,8 @@ def test_library_builds_and_exports_every_header_symbol():
                 "rte_hip_expand_and_transpose", "rte_hip_secants_fill", "rte_hip_rfmip_sw_toa_renorm",
                 "rte_hip_rfmip_sw_mu0", "rte_hip_broadcast_cols", "rte_hip_mask_columns",
                 "rte_hip_tau_rayleigh_combine_2str", "rte_hip_compute_tau_absorption_inc_bybnd",
-                "rte_hip_cloud_optics_fused", "rte_hip_lw_sfc_lds", "rte_hip_stat", "rte_hip_overlap_planck", "rte_hip_share_geometry", "rte_hip_gas_optics_sw_2str"):
+                "rte_hip_cloud_optics_fused", "rte_hip_lw_sfc_lds", "rte_hip_stat", "rte_hip_overlap_planck", "rte_hip_share_geometry", "rte_hip_gas_optics_sw_2str",
+                "rte_hip_aux_stream"):
         assert hasattr(dll, ext)
 
 

@@ -246,3 +246,57 @@ def test_planck_on_the_geometry_of_tau_gives_the_same_arrays():
         assert torch.equal(bufs[1], plain["lay_src"]) and torch.equal(bufs[2], plain["lev_src"])
     finally:
         hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 0)
+
+
+def test_tau_on_the_masks_of_interpolation_gives_the_same_arrays():
+    """``rte_hip_share_geometry(1)``, first half of the step: rrtmgp_interpolation leaves per (256-column block, layer)
+    the bit masks of the table rows its columns touch, and the compute_tau_absorption call that directly follows builds
+    its tile geometry from them instead of reading the index arrays again.  Masks only say which rows are staged:
+    every array and the size of the direct-gather worklist must be those of the run without sharing -- on the benchmark
+    atmosphere, on a shuffled site-like one, and on columns whose pressure is not monotone in the layer index (the
+    interpolation's masks are keyed by the tropo flag, the geometry kernel's by the layer ranges: there the kernel must
+    notice and derive its own)."""
+    import torch
+
+    hip = hiplib.load()
+    xp = frontend.TorchArrays("cuda:0")
+    kd = synth.make_kdist("lw")
+    ncol = 20000
+    ptrop = float(np.exp(kd.press_ref_trop_log))
+    for case, seed in (("rce", 5), ("sites", 6), ("kinked", 7)):
+        atm = synth.make_atmosphere(ncol, NLAY, seed=seed, kdist=kd, climate="sites" if case == "sites" else "rce")
+        inp = {k: np.array(getattr(atm, k), order="F") for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas")}
+        if case == "sites":
+            perm = np.random.default_rng(2).permutation(ncol)
+            inp = {k: np.asfortranarray(v[perm]) for k, v in inp.items()}
+        if case == "kinked":
+            # every 7th column: exchange the pressures of the two tropospheric layers nearest the tropopause -- the layer
+            # of lowest tropospheric pressure is then not the first tropospheric layer, so that layer lies in neither range
+            play = inp["play"]
+            trop = play > ptrop
+            for c in range(0, ncol, 7):
+                idx = np.nonzero(trop[c])[0]
+                a, b = (idx[0], idx[1]) if play[c, idx[0]] < play[c, idx[1]] else (idx[-1], idx[-2])
+                play[c, a], play[c, b] = play[c, b], play[c, a]
+            assert ((play > ptrop) == trop).all()
+
+        def run(share):
+            hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], share)
+            hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 1)
+            try:
+                b, r = _lw_chain(hip, xp, kd, inp, ncol, atm.top_at_1)
+                torch.cuda.synchronize()
+                out = {k: b[k].clone() for k in ("tau", "lay_src", "lev_src", "sfc_src")}
+                out["flux_up"], out["flux_dn"] = r["flux_up"].clone(), r["flux_dn"].clone()
+                return out, hiplib.ext_call(hip, "rte_hip_stat", ["i"], 0), hiplib.ext_call(hip, "rte_hip_stat", ["i"], 2)
+            finally:
+                hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 0)
+                hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 0)
+
+        plain, n_plain, src_plain = run(0)
+        shared, n_shared, src_shared = run(1)
+        assert src_plain == 2
+        assert src_shared == (2 if case == "kinked" else 1), case
+        assert n_plain == n_shared, (case, n_plain, n_shared)
+        for k, v in plain.items():
+            assert torch.equal(v, shared[k]), (case, k)
