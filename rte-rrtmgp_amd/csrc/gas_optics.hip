@@ -202,8 +202,8 @@ struct GuardTables {
   const Bool* bp[4];    // logical tables
   int bn[4];
 };
-__global__ void __launch_bounds__(256) tables_guard_kernel(GuardTables t, unsigned expected, int* __restrict__ flag,
-                                                           int* __restrict__ stale) {
+__device__ __forceinline__ void tables_guard_body(const GuardTables& t, unsigned expected, int* __restrict__ flag,
+                                                  int* __restrict__ stale) {
   __shared__ unsigned acc;
   if (threadIdx.x == 0) acc = 0;
   __syncthreads();
@@ -220,6 +220,10 @@ __global__ void __launch_bounds__(256) tables_guard_kernel(GuardTables t, unsign
   __syncthreads();
   if (threadIdx.x == 0 && acc != expected) { *flag = 1; *stale = 1; }
 }
+__global__ void __launch_bounds__(256) tables_guard_kernel(GuardTables t, unsigned expected, int* __restrict__ flag,
+                                                           int* __restrict__ stale) {
+  tables_guard_body(t, expected, flag, stale);
+}
 // band limits: whole chunks of gw g-points, ngpt a multiple of gw (what the stage loops of the production kernels assume)
 __global__ void bands_guard_kernel(int nbnd, int ngpt, const int* __restrict__ band_lims, int gw, int* __restrict__ flag,
                                    int* __restrict__ stale) {
@@ -232,10 +236,10 @@ __global__ void bands_guard_kernel(int nbnd, int ngpt, const int* __restrict__ b
 // layer limits of the lower / upper atmosphere: reference :274-285 (minloc/maxloc with mask,
 // first extremal location; 0 = no such layer)
 // -------------------------------------------------------------------------------------------
-__global__ void tropo_limits_kernel(int ncol, int nlay, const Float* __restrict__ play,
-                                    const Bool* __restrict__ tropo, int* __restrict__ lim /*(ncol,4)*/,
-                                    int* __restrict__ overlap, int* __restrict__ irregular) {
-  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void tropo_limits_body(unsigned bx, int ncol, int nlay, const Float* __restrict__ play,
+                                                  const Bool* __restrict__ tropo, int* __restrict__ lim /*(ncol,4)*/,
+                                                  int* __restrict__ overlap, int* __restrict__ irregular) {
+  const int icol = bx * blockDim.x + threadIdx.x;
   if (icol >= ncol) return;
   const bool top_at_1 = play[0] < play[(size_t)ncol * (nlay - 1)];
   int minloc_t = 0, maxloc_n = 0;
@@ -287,12 +291,18 @@ __global__ void tropo_limits_kernel(int ncol, int nlay, const Float* __restrict_
   else          regular = (last_t == 0 || last_t == minloc_t) && (first_n == 0 || first_n == maxloc_n) && (last_t == 0 || first_n == 0 || last_t < first_n);
   if (!regular) *irregular = 1;
 }
+__global__ void tropo_limits_kernel(int ncol, int nlay, const Float* __restrict__ play,
+                                    const Bool* __restrict__ tropo, int* __restrict__ lim /*(ncol,4)*/,
+                                    int* __restrict__ overlap, int* __restrict__ irregular) {
+  tropo_limits_body(blockIdx.x, ncol, nlay, play, tropo, lim, overlap, irregular);
+}
 
 // Per band, the ordered list of minor intervals whose g-point range intersects the band
 // (one wave; ordered compaction by ballot so the reference's interval order is preserved).
-__global__ void plan_minor_kernel(int nbnd, const int* __restrict__ band_lims_gpt, int nminor,
-                                  const int* __restrict__ minor_limits_gpt, int* __restrict__ cnt /*(nbnd)*/,
-                                  int* __restrict__ list /*(nminor,nbnd)*/) {
+__device__ __forceinline__ void plan_minor_body(int nbnd, const int* __restrict__ band_lims_gpt, int nminor,
+                                                const int* __restrict__ minor_limits_gpt, int* __restrict__ cnt /*(nbnd)*/,
+                                                int* __restrict__ list /*(nminor,nbnd)*/) {
+  if (threadIdx.x >= RTE_WAVE) return;  // one wave
   const int lane = threadIdx.x;
   for (int ibnd = 0; ibnd < nbnd; ++ibnd) {
     const int bS = band_lims_gpt[2 * ibnd], bE = band_lims_gpt[2 * ibnd + 1];
@@ -307,6 +317,11 @@ __global__ void plan_minor_kernel(int nbnd, const int* __restrict__ band_lims_gp
     }
     if (lane == 0) cnt[ibnd] = n;
   }
+}
+__global__ void plan_minor_kernel(int nbnd, const int* __restrict__ band_lims_gpt, int nminor,
+                                  const int* __restrict__ minor_limits_gpt, int* __restrict__ cnt /*(nbnd)*/,
+                                  int* __restrict__ list /*(nminor,nbnd)*/) {
+  plan_minor_body(nbnd, band_lims_gpt, nminor, minor_limits_gpt, cnt, list);
 }
 
 struct MinorTables {
@@ -470,10 +485,10 @@ __global__ void __launch_bounds__(256) tau_absorption_kernel(TauArgs a, int nbnd
 // A band's g-points of one (T, eta, p) corner become one contiguous 128-byte row, which is what
 // the LDS staging below copies.  ~35 MB moved per call (L2 / Infinity-Cache resident): ~10 us.
 // -------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, Float* __restrict__ out) {
+__device__ __forceinline__ void relayout_gfast_body(unsigned bx, unsigned by, int TE, int nouter, int ng,
+                                                    const Float* __restrict__ in, Float* __restrict__ out) {
   extern __shared__ Float tile[];  // [TE][33]
-  const int g0 = blockIdx.x * 32, o = blockIdx.y;
+  const int g0 = bx * 32, o = by;
   const int ngc = min(32, ng - g0);
   for (int idx = threadIdx.x; idx < TE * ngc; idx += blockDim.x) {
     const int te = idx % TE, gg = idx / TE;
@@ -483,6 +498,42 @@ relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, 
   for (int idx = threadIdx.x; idx < TE * ngc; idx += blockDim.x) {
     const int gg = idx % ngc, te = idx / ngc;
     out[((size_t)o * TE + te) * ng + g0 + gg] = tile[te * 33 + gg];
+  }
+}
+__global__ void __launch_bounds__(256)
+relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, Float* __restrict__ out) {
+  relayout_gfast_body(blockIdx.x, blockIdx.y, TE, nouter, ng, in, out);
+}
+
+// Everything compute_tau_absorption's production path prepares before its geometry pre-pass, in ONE launch: the
+// blocks take roles by index -- layer limits per column, the two minor-interval plans of the stand-by direct kernel,
+// the g-fastest copies of up to five tables, the plan guard.  The roles do not depend on each other; as seven
+// launches of 5-40 us each they cost their sum (0.08 ms) plus the gaps between dependent launches.
+struct TauSetupArgs {
+  int ncol, nlay, nbnd, TE;
+  const Float* play; const Bool* tropo; int *lim, *overlap, *irregular;
+  const int* band_lims;
+  int nminor[2]; const int* minor_limits[2]; int* cnt[2]; int* list[2];
+  int ntab; int nouter[5], ng[5], first_block[6]; const Float* tin[5]; Float* tout[5];  // tables to re-lay out
+  GuardTables gt; unsigned guard_expected; int* stale;
+  unsigned b_plan, b_tab, b_guard;  // first block of each role after the layer limits
+};
+__global__ void __launch_bounds__(256) tau_setup_kernel(TauSetupArgs a) {
+  const unsigned b = blockIdx.x;
+  if (b < a.b_plan) {
+    tropo_limits_body(b, a.ncol, a.nlay, a.play, a.tropo, a.lim, a.overlap, a.irregular);
+  } else if (b < a.b_tab) {
+    const int r = b - a.b_plan;
+    plan_minor_body(a.nbnd, a.band_lims, a.nminor[r], a.minor_limits[r], a.cnt[r], a.list[r]);
+  } else if (b < a.b_guard) {
+    const unsigned q = b - a.b_tab;
+    int t = 0;
+    while (t + 1 < a.ntab && q >= (unsigned)a.first_block[t + 1]) ++t;
+    const unsigned local = q - a.first_block[t];
+    const unsigned nbx = (a.ng[t] + 31) / 32;
+    relayout_gfast_body(local % nbx, local / nbx, a.TE, a.nouter[t], a.ng[t], a.tin[t], a.tout[t]);
+  } else {
+    tables_guard_body(a.gt, a.guard_expected, a.overlap, a.stale);
   }
 }
 
@@ -1988,21 +2039,21 @@ __global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd,
 }
 
 // Planck on a geometry left by compute_tau_absorption (rte_hip_share_geometry): which (tile, band) pairs do not fit
-// the slab at some layer.  One thread per pair.
+// the slab at some layer.  One wave per pair, lanes = layers (one thread walking the layers was 60 dependent latencies).
 __global__ void __launch_bounds__(256)
 planck_flags_kernel(const TileGeom* __restrict__ geom, int tiles, int nlay, int nbnd, int slab_floats, int RS,
                     int* __restrict__ flags, int* __restrict__ worklist, const int* __restrict__ valid,
                     const int* __restrict__ guard) {
   if (!*valid || *guard) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= tiles * nbnd) return;
   const int tile = i / nbnd, b = i - tile * nbnd;
   bool fits = true;
-  for (int l = 0; l < nlay; ++l) {
+  for (int l = lane; l < nlay; l += 64) {
     const TileGeom* g = geom + (tile + (size_t)tiles * l);
     fits = fits && g->nP * g->nT * abs(g->eg[b].y) * RS <= slab_floats;
   }
-  if (!fits) {
+  if (__ballot(!fits) != 0ull && lane == 0) {
     flags[i] = 1;
     const int w = atomicAdd(&worklist[0], 1);
     worklist[1 + 2 * w] = tile; worklist[2 + 2 * w] = b;
@@ -2623,9 +2674,7 @@ static void tau_absorption_impl(
   {
     rte::ProfScope p("tau_absorption_setup");
     hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, overlap, 2u, worklist, 1u, (int*)nullptr, 0u);
-    hipLaunchKernelGGL(tropo_limits_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, st, ncol, nlay, d_play, d_tropo, lim,
-                       overlap, irregular);
-  }
+  }  // (layer limits: tropo_limits_kernel below, or a role of tau_setup_kernel on the production path)
   int* d_stale = stale_flag();
   stale_poll();
   // ---- host-side plan from the small index tables (cached while the caller's table pointers and
@@ -2782,15 +2831,14 @@ static void tau_absorption_impl(
   a.play = d_play; a.tlay = d_tlay; a.col_gas = d_col_gas; a.jeta = d_jeta; a.jtemp = d_jtemp; a.jpress = d_jpress;
   a.tau = d_tau; a.overwrite = overwrite_ok; a.add_bybnd = d_add;
   a.run_if = fast ? overlap : nullptr;
-  {
-    rte::ProfScope p(fast ? "tau_absorption_fallback" : "tau_absorption_kernel");
+  if (!fast) {
+    rte::ProfScope p("tau_absorption_kernel");
+    hipLaunchKernelGGL(tropo_limits_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, st, ncol, nlay, d_play, d_tropo, lim,
+                       overlap, irregular);
     hipLaunchKernelGGL(plan_minor_kernel, dim3(1), dim3(RTE_WAVE), 0, st, nbnd, d_band_lims, nlo, lo.limits,
                        (int*)lo.cnt, (int*)lo.list);
     hipLaunchKernelGGL(plan_minor_kernel, dim3(1), dim3(RTE_WAVE), 0, st, nbnd, d_band_lims, nup, up.limits,
                        (int*)up.cnt, (int*)up.list);
-  }
-  if (!fast) {
-    rte::ProfScope p("tau_absorption_kernel");
     const size_t tiles = (size_t)cdiv(ncol, 256) * nlay * nbnd;
     hipLaunchKernelGGL(tau_absorption_kernel, dim3((unsigned)(tiles < 1048576 ? tiles : 1048576)), dim3(256), 0, st, a,
                        nbnd);
@@ -2814,33 +2862,41 @@ static void tau_absorption_impl(
       HIP_CHECK(hipStreamSynchronize(st));  // cache.bands is host memory that the next rebuild overwrites
       cache.uploads_pending = false;
     }
-    const size_t tile_bytes = sizeof(Float) * TE * 33;
-    hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(ngpt, 32), npres + 1), dim3(256), tile_bytes, st, TE,
-                       npres + 1, ngpt, d_kmajor, kmaj_g);
-    if (nkl > 0)
-      hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(nkl, 32), 1), dim3(256), tile_bytes, st, TE, 1, nkl, lo.kminor,
-                         klo_g);
-    if (nku > 0)
-      hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(nku, 32), 1), dim3(256), tile_bytes, st, TE, 1, nku, up.kminor,
-                         kup_g);
+  }
+  {  // one launch: layer limits, minor-interval plans, g-fastest table copies, plan guard (tau_setup_kernel)
+    TauSetupArgs sa{};
+    sa.ncol = ncol; sa.nlay = nlay; sa.nbnd = nbnd; sa.TE = TE;
+    sa.play = d_play; sa.tropo = d_tropo; sa.lim = lim; sa.overlap = overlap; sa.irregular = irregular;
+    sa.band_lims = d_band_lims;
+    sa.nminor[0] = nlo; sa.minor_limits[0] = lo.limits; sa.cnt[0] = (int*)lo.cnt; sa.list[0] = (int*)lo.list;
+    sa.nminor[1] = nup; sa.minor_limits[1] = up.limits; sa.cnt[1] = (int*)up.cnt; sa.list[1] = (int*)up.list;
+    unsigned nb = 0;
+    auto table = [&](const Float* in, Float* out, int nouter, int ng) {
+      if (ng <= 0) return;
+      const int t = sa.ntab++;
+      sa.tin[t] = in; sa.tout[t] = out; sa.nouter[t] = nouter; sa.ng[t] = ng; sa.first_block[t] = (int)nb;
+      nb += (unsigned)cdiv(ng, 32) * nouter;
+    };
+    table(d_kmajor, kmaj_g, npres + 1, ngpt);
+    table(lo.kminor, klo_g, 1, nkl);
+    table(up.kminor, kup_g, 1, nku);
     if (rh) {  // the Rayleigh table (ntemp, neta, ngpt, 2): one g-fastest copy per regime
       kray_g = (Float*)rte::scratch(sizeof(Float) * tn * ngpt * 2);
-      for (int r = 0; r < 2; ++r)
-        hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(ngpt, 32), 1), dim3(256), tile_bytes, st, TE, 1, ngpt,
-                           d_krayl + tn * ngpt * r, kray_g + tn * ngpt * r);
+      for (int r = 0; r < 2; ++r) table(d_krayl + tn * ngpt * r, kray_g + tn * ngpt * r, 1, ngpt);
     }
-  }
-  {  // plan guard: the tables on the device must be the ones the cached plan was built from
-    GuardTables gt{};
+    sa.first_block[sa.ntab] = (int)nb;
+    // plan guard: the tables on the device must be the ones the cached plan was built from
     const int* ia[10] = {d_gpoint_flavor, d_band_lims, lo.limits, up.limits, lo.kminor_start, up.kminor_start,
                          lo.idx_minor, up.idx_minor, lo.idx_minor_scaling, up.idx_minor_scaling};
     const int in[10] = {2 * ngpt, 2 * nbnd, 2 * nlo, 2 * nup, nlo, nup, nlo, nup, nlo, nup};
     const Bool* ba[4] = {lo.scales_with_density, up.scales_with_density, lo.scale_by_complement, up.scale_by_complement};
     const int bn[4] = {nlo, nup, nlo, nup};
-    for (int i = 0; i < 10; ++i) { gt.ip[i] = ia[i]; gt.in[i] = in[i]; }
-    for (int i = 0; i < 4; ++i) { gt.bp[i] = ba[i]; gt.bn[i] = bn[i]; }
+    for (int i = 0; i < 10; ++i) { sa.gt.ip[i] = ia[i]; sa.gt.in[i] = in[i]; }
+    for (int i = 0; i < 4; ++i) { sa.gt.bp[i] = ba[i]; sa.gt.bn[i] = bn[i]; }
+    sa.guard_expected = cache.guard; sa.stale = d_stale;
+    sa.b_plan = (unsigned)cdiv(ncol, 256); sa.b_tab = sa.b_plan + 2; sa.b_guard = sa.b_tab + nb;
     rte::ProfScope p("tau_absorption_setup");
-    hipLaunchKernelGGL(tables_guard_kernel, dim3(1), dim3(256), 0, st, gt, cache.guard, overlap, d_stale);
+    hipLaunchKernelGGL(tau_setup_kernel, dim3(sa.b_guard + 1), dim3(256), sizeof(Float) * TE * 33, st, sa);
   }
   TauV5 v;
   v.ncol = ncol; v.nlay = nlay; v.ngpt = ngpt; v.nbnd = nbnd; v.ntemp = ntemp; v.TE = TE; v.idx_h2o = *idx_h2o_;
@@ -3309,7 +3365,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   do {                                                                                                            \
     {                                                                                                             \
       rte::ProfScope p("planck_source_setup");                                                                    \
-      if (shared) hipLaunchKernelGGL(planck_flags_kernel, dim3(cdiv(tiles * nbnd, 256)), dim3(256), 0, st, (const TileGeom*)d_geom, \
+      if (shared) hipLaunchKernelGGL(planck_flags_kernel, dim3(cdiv(tiles * nbnd, 4)), dim3(256), 0, st, (const TileGeom*)d_geom, \
                                      (int)tiles, nlay, nbnd, SLAB9, GW + 2, d_flags, v.worklist, (const int*)g_shared.valid, \
                                      (const int*)guard);                                                          \
       if (geom2) hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, ga, d_geom); \
