@@ -416,17 +416,56 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def read_profile(nsteps):
+        out = {}
+        for i in range(hiplib.ext_call(lib, "rte_hip_profile_count", [])):
+            buf = ctypes.create_string_buffer(128)
+            cnt, ms = ctypes.c_longlong(0), ctypes.c_double(0)
+            lib.raw("rte_hip_profile_get")(ctypes.c_int(i), buf, ctypes.c_int(128), ctypes.byref(cnt), ctypes.byref(ms))
+            # several launches of one kernel per step (all-sky) count together: time per STEP
+            out[buf.value.decode()] = {"launches": int(cnt.value), "avg_ms": ms.value / max(1, nsteps)}
+        return out
+
+    def profile_only(name):
+        lib.raw("rte_hip_profile_only")(ctypes.c_char_p(name.encode() if name else None))
+
+    if args.workload == "allsky":
+        ab = allsky_bytes_per_collay(kd, kds, nlay_w)
+    else:
+        ab = algorithmic_bytes_per_collay(kd.nflav, kd.ngas, kd.ngpt, NLAY, defer_zero=not args.no_defer_zero)
     for _ in range(args.warmup):
         step()
     fence()
+    # Every timed launch is bracketed by a pair of HIP events, and each pair costs microseconds on the GPU timeline
+    # (~30 pairs = 0.2 ms per LW step, measured).  So the per-kernel table comes from three fully instrumented steps
+    # here, OUTSIDE the timed region, and inside the timed region only the dominant kernel -- the one `roofline`
+    # reports -- carries events.
+    PRE = 3
+    profile_only(None)
     hiplib.ext_call(lib, "rte_hip_profile_reset", [])
     hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
+    for _ in range(PRE):
+        step()
+    fence()
+    hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 0)
+    kern = read_profile(PRE)
+    concurrent = ("tau_absorption", "planck_source") if overlap else ()
+    cand = [k for k in ab if k in kern and not k.startswith(concurrent)] or [k for k in ab if k in kern]
+    dom_scope = max(cand, key=lambda k: kern[k]["avg_ms"]) if cand else None
+    profile_only(dom_scope)
+    hiplib.ext_call(lib, "rte_hip_profile_reset", [])
+    hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1 if dom_scope else 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
     hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 0)
+    if dom_scope:
+        timed = read_profile(args.steps)
+        if dom_scope in timed:
+            kern[dom_scope] = dict(timed[dom_scope], timed_region=True)
+    profile_only(None)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -467,18 +506,6 @@ def main():
         allgather_ms = timed_ms(lambda: (sharding.allgather_fluxes(rb["flux_up"], ncol * world),
                                          sharding.allgather_fluxes(rb["flux_dn"], ncol * world)))
 
-    # per-kernel HIP-event timings collected inside the timed region
-    def read_profile(nsteps):
-        out = {}
-        for i in range(hiplib.ext_call(lib, "rte_hip_profile_count", [])):
-            buf = ctypes.create_string_buffer(128)
-            cnt, ms = ctypes.c_longlong(0), ctypes.c_double(0)
-            lib.raw("rte_hip_profile_get")(ctypes.c_int(i), buf, ctypes.c_int(128), ctypes.byref(cnt), ctypes.byref(ms))
-            # several launches of one kernel per step (all-sky) count together: time per STEP
-            out[buf.value.decode()] = {"launches": int(cnt.value), "avg_ms": ms.value / max(1, nsteps)}
-        return out
-
-    kern = read_profile(args.steps)
     # With the overlap on, compute_tau_absorption and compute_Planck_source run at the same time: their event
     # durations in the timed region overlap (each is stretched by the other).  A short pass outside the timed region
     # with the overlap off gives the kernels' own durations for the per-kernel roofline table.
@@ -497,23 +524,20 @@ def main():
         hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1)
 
     if rank == 0:
-        if args.workload == "allsky":
-            ab = allsky_bytes_per_collay(kd, kds, nlay_w)
-        else:
-            ab = algorithmic_bytes_per_collay(kd.nflav, kd.ngas, kd.ngpt, NLAY, defer_zero=not args.no_defer_zero)
         # the one-pass SW gas optics runs under the name of compute_tau_absorption: it stands for the bytes of the two
         # ABI calls it replaces (the chain's algorithmic bytes stay those of the reference-ABI chain)
         if (args.workload in ("sw", "allsky") and "tau_rayleigh_combine_kernel" in ab and "tau_rayleigh_combine_kernel" not in kern
                 and "tau_absorption_kernel" in kern):
             ab["tau_absorption_kernel"] += ab.pop("tau_rayleigh_combine_kernel")
         per_kernel = {}
-        concurrent = ("tau_absorption", "planck_source") if overlap else ()
         for name, bytes_cl in ab.items():
             if name in kern:
                 gb = bytes_cl * ncol * nlay_w / 1e9
                 ms = kern[name]["avg_ms"]
                 per_kernel[name] = {"avg_ms": round(ms, 4), "alg_GB": round(gb, 3),
-                                    "GBps": round(gb / (ms * 1e-3), 1), "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)}
+                                    "GBps": round(gb / (ms * 1e-3), 1), "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4),
+                                    "events": ("timed region" if kern[name].get("timed_region") else
+                                               f"{PRE} instrumented steps before the timed region")}
                 if kern_serial and name.startswith(concurrent) and name in kern_serial:
                     # timed-region duration = while the other kernel shares the chip; the kernel's own duration:
                     sm = kern_serial[name]["avg_ms"]
@@ -523,7 +547,7 @@ def main():
         others = {k: round(v["avg_ms"], 4) for k, v in kern.items() if k not in per_kernel}
         # the dominant kernel is chosen among those whose timed-region duration is their own (not the concurrent pair)
         cand = [k for k in per_kernel if not k.startswith(concurrent)] or list(per_kernel)
-        dom = max(cand, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
+        dom = dom_scope if dom_scope in per_kernel else (max(cand, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None)
         chain_gb = sum(v["alg_GB"] for v in per_kernel.values())
         if overlap:  # event durations of concurrent kernels double-count: the chain is the wall clock of a step
             chain_ms = dt / args.steps * 1e3
@@ -552,7 +576,8 @@ def main():
                     "traffic_source": traffic_source,
                     "chain": {"alg_GB_per_step": round(chain_gb, 3), "kernel_ms_per_step": round(chain_ms, 4),
                               "kernel_ms_is": ("wall clock of a step (tau_absorption and planck_source run concurrently)"
-                                               if overlap else "sum of the kernels' event durations"),
+                                               if overlap else "sum of the kernels' event durations (the dominant kernel's from the timed region, "
+                                               "the others' from the instrumented steps before it)"),
                               "GBps": round(chain_gb / (chain_ms * 1e-3), 1),
                               "frac": round(chain_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4)},
                     "per_kernel": per_kernel, "other_kernels_avg_ms": others}

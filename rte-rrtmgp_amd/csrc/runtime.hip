@@ -268,13 +268,15 @@ Call::~Call() {
 // ---- kernel timing ------------------------------------------------------------------------------
 struct ProfEntry { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms = 0; long n = 0; };
 static bool g_prof_on = false;
+static std::string g_prof_only;  // non-empty: only this scope is timed (every event pair costs microseconds on the GPU timeline)
 static std::vector<ProfEntry> g_prof;
 static ProfEntry* g_cur = nullptr;
 static hipEvent_t g_cur_start;
 
 void prof_begin(const char* kernel) {
-  if (!g_prof_on) return;
   g_cur = nullptr;
+  if (!g_prof_on) return;
+  if (!g_prof_only.empty() && g_prof_only != kernel) return;
   for (auto& e : g_prof)
     if (e.name == kernel) g_cur = &e;
   if (!g_cur) {
@@ -357,6 +359,12 @@ int rte_hip_device_count(void) {
 int rte_hip_profile_enable(int on) {
   std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
   rte::g_prof_on = on != 0;
+  return 0;
+}
+// time only the scope of this name (nullptr or "": all scopes)
+int rte_hip_profile_only(const char* name) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::g_prof_only = name ? name : "";
   return 0;
 }
 int rte_hip_profile_reset(void) {
