@@ -100,7 +100,10 @@ hipStream_t aux_fork() {
   if (!g_aux) {
     HIP_CHECK(hipEventCreateWithFlags(&g_ev_aux_fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&g_ev_aux_join, hipEventDisableTiming));
-    HIP_CHECK(hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking));
+    // lowest priority: its waves take what the library stream's kernel leaves free, not the other way round
+    int least = 0, greatest = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_CHECK(hipStreamCreateWithPriority(&g_aux, hipStreamNonBlocking, getenv("RTE_AUX_PRIO") ? atoi(getenv("RTE_AUX_PRIO")) : least));
   }
   HIP_CHECK(hipEventRecord(g_ev_aux_fork, stream()));
   HIP_CHECK(hipStreamWaitEvent(g_aux, g_ev_aux_fork, 0));
