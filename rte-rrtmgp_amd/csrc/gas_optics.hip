@@ -1299,6 +1299,28 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   const Float dry_fact = (Float)1 / ((Float)1 + a.col_gas[cl + (size_t)ncl * a.idx_h2o] * vmr_fact);  // :472
   Float wray = 0;  // Rayleigh: column amount of moist air (:553)
   if (RAYL) wray = a.col_gas[cl + (size_t)ncl * a.idx_h2o] + a.rf.col_dry[cl];
+  // The fused variants are a few registers over the budget, and a register spilled to scratch is reloaded with
+  // `s_waitcnt vmcnt(0)` -- in the middle of the minor pass that drains the previous stage's 48 stores (vector memory
+  // retires in order).  These three per-column factors are used a few times per stage only: park them in the thread's
+  // own LDS slots instead (a `ds_read` waits on lgkmcnt).  The unfused variants keep them in registers.
+  constexpr int NPARK = RAYL ? 3 : 0;
+  __shared__ Float s_park[NPARK ? NPARK : 1][NPARK ? TILE : 1];
+  unsigned park_at = 0;  // LDS byte address of this thread's first slot (the low half of the generic address)
+  if constexpr (RAYL != 0) {
+    s_park[0][tid] = dens; s_park[1][tid] = vmr_fact; s_park[2][tid] = dry_fact;
+    park_at = (unsigned)(uintptr_t)&s_park[0][tid];
+  }
+  // read back with an explicit ds_read (a volatile access from inside the stage lambdas becomes a flat load, and an
+  // ordinary one is hoisted back into a register)
+  auto parked = [](unsigned at, int i) -> Float {
+    Float v;
+    if constexpr (sizeof(Float) == 8)
+      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(at + (unsigned)(i * NCW * 64 * sizeof(Float))) : "memory");
+    else
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(at + (unsigned)(i * NCW * 64 * sizeof(Float))) : "memory");
+    return v;
+  };
+#define RTE_PARKED(i, in_register) (RAYL != 0 ? parked(park_at, i) : (in_register))
 
   // major weights + eta indices of band b (requested one stage ahead)
   struct Major { Float2 fm[4], cm; int2 je; };
@@ -1470,12 +1492,12 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       if (k < n_my) {
         const MinorMeta& m = bm[ibnd].m[rsel][k];
         if (m.flags & 1) {
-          sc[k] = sc[k] * dens;     // :469
-          if (m.idx_scaling > 0) {  // :470-478
+          sc[k] = sc[k] * RTE_PARKED(0, dens);  // :469
+          if (m.idx_scaling > 0) {          // :470-478
             if (m.flags & 2)
-              sc[k] = sc[k] * ((Float)1 - cgs[k] * vmr_fact * dry_fact);
+              sc[k] = sc[k] * ((Float)1 - cgs[k] * RTE_PARKED(1, vmr_fact) * RTE_PARKED(2, dry_fact));
             else
-              sc[k] = sc[k] * (cgs[k] * vmr_fact * dry_fact);
+              sc[k] = sc[k] * (cgs[k] * RTE_PARKED(1, vmr_fact) * RTE_PARKED(2, dry_fact));
           }
         }
       }
