@@ -1303,10 +1303,11 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // `s_waitcnt vmcnt(0)` -- in the middle of the minor pass that drains the previous stage's 48 stores (vector memory
   // retires in order).  These three per-column factors are used a few times per stage only: park them in the thread's
   // own LDS slots instead (a `ds_read` waits on lgkmcnt).  The unfused variants keep them in registers.
-  constexpr int NPARK = RAYL ? 3 : 0;
+  constexpr bool PARK = RAYL != 0 || MM > 4;  // (the variants that would otherwise spill)
+  constexpr int NPARK = PARK ? 3 : 0;
   __shared__ Float s_park[NPARK ? NPARK : 1][NPARK ? TILE : 1];
   unsigned park_at = 0;  // LDS byte address of this thread's first slot (the low half of the generic address)
-  if constexpr (RAYL != 0) {
+  if constexpr (PARK) {
     s_park[0][tid] = dens; s_park[1][tid] = vmr_fact; s_park[2][tid] = dry_fact;
     park_at = (unsigned)(uintptr_t)&s_park[0][tid];
   }
@@ -1320,7 +1321,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(at + (unsigned)(i * NCW * 64 * sizeof(Float))) : "memory");
     return v;
   };
-#define RTE_PARKED(i, in_register) (RAYL != 0 ? parked(park_at, i) : (in_register))
+#define RTE_PARKED(i, in_register) (PARK ? parked(park_at, i) : (in_register))
 
   // major weights + eta indices of band b (requested one stage ahead)
   struct Major { Float2 fm[4], cm; int2 je; };
@@ -2976,6 +2977,8 @@ static void tau_absorption_impl(
     const TileGeom* cg = d_geom;
     bool mm4 = true;
     for (const BandMeta& bmh : cache.bands) mm4 = mm4 && bmh.cnt[0] <= 4 && bmh.cnt[1] <= 4;
+    static const bool force_mm8 = getenv("RTE_FORCE_MM8") != nullptr;  // timing experiment: the variant for tables with more than
+    if (force_mm8) mm4 = false;                                           // 4 minor intervals per band and regime
     Geom2Args ga{};
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = false;
     ga.lim = lim; ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.bmeta = d_bm;
