@@ -306,6 +306,7 @@ def main():
                          "contiguous run; sites-shuffled: the same columns in random order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
+    ap.add_argument("--seg-groups", type=int, default=0, help="experiment: g-point groups per column tile of the segmented solvers (0 = automatic)")
     ap.add_argument("--no-aux-stream", action="store_true",
                     help="run compute_tau_absorption's direct-gather worklist after the slab kernel instead of beside it "
                          "(rte_hip_aux_stream(0); A/B)")
@@ -348,6 +349,7 @@ def main():
     share_geom = not args.no_share_geometry
     hiplib.ext_call(lib, "rte_hip_share_geometry", ["i"], (args.share_geometry_mode if share_geom else 0))
     hiplib.ext_call(lib, "rte_hip_aux_stream", ["i"], 0 if args.no_aux_stream else 1)
+    hiplib.ext_call(lib, "rte_hip_seg_groups", ["i"], args.seg_groups)
     hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1 if overlap else 0)
     dev = f"cuda:{local_rank}"
     xp = frontend.TorchArrays(dev)

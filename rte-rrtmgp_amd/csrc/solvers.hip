@@ -1473,7 +1473,9 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     // g-points per block: enough blocks to fill the chip several times over, few enough partial slabs
     const int col_tiles = cdiv(ncol, 64);
     int ngroups = 1;
-    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 6144 && ngroups < 16) ngroups *= 2;  // >= 24 blocks per CU: a short tail
+    // >= 18 blocks per CU keeps the tail short; one group fewer than the power of two is one partial slab less to
+    // reduce (1e5 columns: 3 groups, solver unchanged, reduction 0.090 -> 0.073 ms; the two-stream solvers lose with 3)
+    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 4608 && ngroups < 16) ngroups += 1;
     if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
     const int g_per_block = (ngpt + ngroups - 1) / ngroups;
     ngroups = (ngpt + g_per_block - 1) / g_per_block;
