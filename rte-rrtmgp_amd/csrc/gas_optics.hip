@@ -259,16 +259,17 @@ __device__ __forceinline__ void tropo_limits_body(unsigned bx, int ncol, int nla
 #pragma unroll
     for (int k = 0; k < B; ++k) {
       const int ilay = l0 + k;
-      if (ilay >= nlay) break;
       const Float p = pb[k];
-      if (tb[k]) {
-        if (minloc_t == 0 || p < pmin) { minloc_t = ilay + 1; pmin = p; }
-        if (first_t == 0) first_t = ilay + 1;
-        last_t = ilay + 1;
-      } else {
-        if (maxloc_n == 0 || p > pmax) { maxloc_n = ilay + 1; pmax = p; }
-        if (first_n == 0) first_n = ilay + 1;
-        last_n = ilay + 1;
+      if (ilay < nlay) {
+        if (tb[k]) {
+          if (minloc_t == 0 || p < pmin) { minloc_t = ilay + 1; pmin = p; }
+          if (first_t == 0) first_t = ilay + 1;
+          last_t = ilay + 1;
+        } else {
+          if (maxloc_n == 0 || p > pmax) { maxloc_n = ilay + 1; pmax = p; }
+          if (first_n == 0) first_n = ilay + 1;
+          last_n = ilay + 1;
+        }
       }
     }
   }
@@ -454,6 +455,136 @@ __device__ __forceinline__ void tau_direct_column(const TauArgs& a, int icol, in
     if (in_upper)
       minor_chunk(a.upper, 1, ibnd, g0, gptE, ncol, ncl, cl, ntemp, neta, a.idx_h2o, P, T, jT, a.col_gas, a.fminor,
                   a.jeta, a.gpoint_flavor, acc);
+    if (a.add_bybnd) {  // increment_1scalar_by_1scalar_bybnd fused in: tau = tau_gas + tau_2(band)
+      const Float addv = a.add_bybnd[cl + ncl * (size_t)ibnd];
+#pragma unroll
+      for (int j = 0; j < GC; ++j) acc[j] = acc[j] + addv;
+    }
+#pragma unroll
+    for (int j = 0; j < GC; ++j)
+      if (g0 + j <= gptE) a.tau[cl + ncl * (size_t)(g0 + j)] = acc[j];
+  }
+}
+
+// ---- the same column from the g-point-fastest table copies of the production path (worklist entries only) ----------
+// One 16-byte load brings a corner's coefficients for two g-points, and a band's 16 g-points of a corner share one
+// cache line: half the load instructions of the native layout and 1/16 of its cache lines (the worklist kernel is
+// bound by the texture addresser: one lane-private line per clock).  Valid where the production path runs: bands and
+// minor intervals are whole aligned chunks of 8 or 16 g-points, k-offsets and row lengths are even.  Every g-point
+// is formed by the same expression as in tau_direct_column: bit-identical results.
+struct GfastTabs { const Float *kmaj, *klo, *kup; int nkl, nku; };
+
+__device__ __forceinline__ void minor_chunk_g(const MinorTables& mt, const Float* __restrict__ kg, int nk, int flav_row, int ibnd,
+                                              int g0, int gEnd, size_t ncl, size_t cl, int ntemp, int idx_h2o, Float P, Float T,
+                                              int jT, const Float* __restrict__ col_gas, const Float* __restrict__ fminor,
+                                              const int* __restrict__ jeta, const int* __restrict__ gpoint_flavor,
+                                              Float (&acc)[GC]) {
+  const int n = mt.cnt[ibnd];
+  for (int k = 0; k < n; ++k) {
+    const int imnr = mt.list[(size_t)ibnd * mt.nminor + k];
+    const int mS = mt.limits[2 * imnr] - 1, mE = mt.limits[2 * imnr + 1] - 1;  // 0-based
+    if (mE < g0 || mS >= g0 + GC) continue;
+    // :461-480
+    Float scaling = col_gas[cl + ncl * mt.idx_minor[imnr]];
+    if (mt.scales_with_density[imnr]) {
+      scaling = scaling * ((Float)0.01 * P / T);
+      const int isc = mt.idx_minor_scaling[imnr];
+      if (isc > 0) {
+        const Float vmr_fact = (Float)1 / col_gas[cl];
+        const Float dry_fact = (Float)1 / ((Float)1 + col_gas[cl + ncl * idx_h2o] * vmr_fact);
+        const Float cgs = col_gas[cl + ncl * isc];
+        if (mt.scale_by_complement[imnr])
+          scaling = scaling * ((Float)1 - cgs * vmr_fact * dry_fact);
+        else
+          scaling = scaling * (cgs * vmr_fact * dry_fact);
+      }
+    }
+    // :485-494
+    const int iflav = gpoint_flavor[flav_row + 2 * mS] - 1;
+    const size_t clf = cl + ncl * iflav;
+    const Float f0 = fminor[4 * clf], f1 = fminor[4 * clf + 1], f2 = fminor[4 * clf + 2], f3 = fminor[4 * clf + 3];
+    const int je1 = jeta[2 * clf], je2 = jeta[2 * clf + 1];
+    const size_t kb = (size_t)(mt.kminor_start[imnr] - 1);
+    // rows (temperature, eta) of the g-fastest copy: [te][nk]
+    const Float* r0 = kg + ((size_t)(jT - 1) + (size_t)ntemp * (je1 - 1)) * nk + kb;
+    const Float* r1 = r0 + (size_t)ntemp * nk;
+    const Float* r2 = kg + ((size_t)jT + (size_t)ntemp * (je2 - 1)) * nk + kb;
+    const Float* r3 = r2 + (size_t)ntemp * nk;
+#pragma unroll
+    for (int j = 0; j < GC; j += 2) {
+      const int g = g0 + j;
+      if (g >= mS && g <= mE && g <= gEnd) {
+        const int c = g - mS;
+        const Float2 v0 = *reinterpret_cast<const Float2*>(r0 + c), v1 = *reinterpret_cast<const Float2*>(r1 + c);
+        const Float2 v2 = *reinterpret_cast<const Float2*>(r2 + c), v3 = *reinterpret_cast<const Float2*>(r3 + c);
+        const Float ta = f0 * v0.x + f1 * v1.x + f2 * v2.x + f3 * v3.x;
+        const Float tb = f0 * v0.y + f1 * v1.y + f2 * v2.y + f3 * v3.y;
+        acc[j] = acc[j] + scaling * ta;
+        acc[j + 1] = acc[j + 1] + scaling * tb;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void tau_direct_column_g(const TauArgs& a, const GfastTabs& t, int icol, int ilay, int ibnd) {
+  const int ncol = a.ncol, nlay = a.nlay, neta = a.neta, ntemp = a.ntemp, ngpt = a.ngpt;
+  const size_t ncl = (size_t)ncol * nlay;
+  const size_t cl = icol + (size_t)ncol * ilay;
+  const int gptS = a.band_lims_gpt[2 * ibnd] - 1, gptE = a.band_lims_gpt[2 * ibnd + 1] - 1;
+  const int itropo = a.tropo[cl] ? 0 : 1;
+  const int iflav = a.gpoint_flavor[itropo + 2 * gptS] - 1;
+  const size_t clf = cl + ncl * iflav;
+  const int jT = a.jtemp[cl];
+  const int jp = a.jpress[cl] + itropo + 1;  // "jpress + itropo": levels jp-1 and jp (1-based)
+  const int je1 = a.jeta[2 * clf], je2 = a.jeta[2 * clf + 1];
+  const Float cm1 = a.col_mix[2 * clf], cm2 = a.col_mix[2 * clf + 1];
+  Float fm[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fm[i] = a.fmajor[8 * clf + i];
+  const size_t TE = (size_t)ntemp * neta;
+  // rows [pressure level][eta][temperature] x ngpt of the g-fastest copy
+  const Float* A00 = t.kmaj + ((size_t)(jp - 2) * TE + (size_t)(jT - 1) + (size_t)ntemp * (je1 - 1)) * ngpt;
+  const Float* A01 = A00 + (size_t)ntemp * ngpt;
+  const Float* A10 = A00 + TE * ngpt;
+  const Float* A11 = A10 + (size_t)ntemp * ngpt;
+  const Float* B00 = t.kmaj + ((size_t)(jp - 2) * TE + (size_t)jT + (size_t)ntemp * (je2 - 1)) * ngpt;
+  const Float* B01 = B00 + (size_t)ntemp * ngpt;
+  const Float* B10 = B00 + TE * ngpt;
+  const Float* B11 = B10 + (size_t)ntemp * ngpt;
+  const Float P = a.play[cl], T = a.tlay[cl];
+  const int lay1 = ilay + 1;
+  const int lo1 = a.lim[icol], lo2 = a.lim[icol + ncol];
+  const int up1 = a.lim[icol + 2 * (size_t)ncol], up2 = a.lim[icol + 3 * (size_t)ncol];
+  const bool in_lower = lo1 > 0 && lay1 >= lo1 && lay1 <= lo2;
+  const bool in_upper = up1 > 0 && lay1 >= up1 && lay1 <= up2;
+
+  for (int g0 = gptS; g0 <= gptE; g0 += GC) {
+    Float acc[GC];
+#pragma unroll
+    for (int j = 0; j < GC; ++j) acc[j] = (g0 + j <= gptE && !a.overwrite) ? a.tau[cl + ncl * (size_t)(g0 + j)] : (Float)0;
+#pragma unroll
+    for (int j = 0; j < GC; j += 2) {
+      if (g0 + j <= gptE) {
+        const int g = g0 + j;
+        const Float2 a00 = *reinterpret_cast<const Float2*>(A00 + g), a01 = *reinterpret_cast<const Float2*>(A01 + g);
+        const Float2 a10 = *reinterpret_cast<const Float2*>(A10 + g), a11 = *reinterpret_cast<const Float2*>(A11 + g);
+        const Float2 b00 = *reinterpret_cast<const Float2*>(B00 + g), b01 = *reinterpret_cast<const Float2*>(B01 + g);
+        const Float2 b10 = *reinterpret_cast<const Float2*>(B10 + g), b11 = *reinterpret_cast<const Float2*>(B11 + g);
+        // :791-801
+        const Float ta = cm1 * (fm[0] * a00.x + fm[1] * a01.x + fm[2] * a10.x + fm[3] * a11.x) +
+                         cm2 * (fm[4] * b00.x + fm[5] * b01.x + fm[6] * b10.x + fm[7] * b11.x);
+        const Float tb = cm1 * (fm[0] * a00.y + fm[1] * a01.y + fm[2] * a10.y + fm[3] * a11.y) +
+                         cm2 * (fm[4] * b00.y + fm[5] * b01.y + fm[6] * b10.y + fm[7] * b11.y);
+        acc[j] = acc[j] + ta;
+        acc[j + 1] = acc[j + 1] + tb;
+      }
+    }
+    if (in_lower)
+      minor_chunk_g(a.lower, t.klo, t.nkl, 0, ibnd, g0, gptE, ncl, cl, ntemp, a.idx_h2o, P, T, jT, a.col_gas, a.fminor, a.jeta,
+                    a.gpoint_flavor, acc);
+    if (in_upper)
+      minor_chunk_g(a.upper, t.kup, t.nku, 1, ibnd, g0, gptE, ncl, cl, ntemp, a.idx_h2o, P, T, jT, a.col_gas, a.fminor, a.jeta,
+                    a.gpoint_flavor, acc);
     if (a.add_bybnd) {  // increment_1scalar_by_1scalar_bybnd fused in: tau = tau_gas + tau_2(band)
       const Float addv = a.add_bybnd[cl + ncl * (size_t)ibnd];
 #pragma unroll
@@ -1623,8 +1754,8 @@ __global__ void __launch_bounds__(256) zero_words_kernel(int* a, unsigned na, in
 // (tile, layer, band) triples the slab kernel could not hold, done by the direct-gather code
 // (work item = one entry x one 64-column chunk, taken by waves in grid stride: the few hundred entries of a call
 // spread over all CUs instead of one block walking an entry's 512 columns)
-__global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a, const int* __restrict__ worklist, int tile,
-                                                                      int* __restrict__ stat) {
+__global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a, GfastTabs gt, const int* __restrict__ worklist,
+                                                                      int tile, int* __restrict__ stat) {
   const int n = worklist[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) *stat = n;  // rte_hip_stat(0)
   const int chunks = tile / 64;
@@ -1633,7 +1764,9 @@ __global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a,
   for (int it = blockIdx.x * wpb + (threadIdx.x >> 6); it < items; it += gridDim.x * wpb) {
     const int w = it / chunks, ch = it - w * chunks;
     const int icol = worklist[1 + 3 * w] * tile + ch * 64 + (threadIdx.x & 63);
-    if (icol < a.ncol) tau_direct_column(a, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
+    if (icol >= a.ncol) continue;
+    if (gt.kmaj) tau_direct_column_g(a, gt, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
+    else tau_direct_column(a, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
   }
 }
 
@@ -2447,6 +2580,7 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
 // ===============================================================================================
 static int g_tau_force_direct = 0;
 static int g_tau_variant = 9;
+static const bool g_worklist_native = getenv("RTE_WORKLIST_NATIVE") != nullptr;  // A/B: worklist entries from the native-layout tables
 static int g_planck_variant = 9;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
 static int g_geom_variant = 2;  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
 static int g_plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget cached host-side plans
@@ -3048,7 +3182,9 @@ static void tau_absorption_impl(
     if (rh) rayleigh_direct(overlap, nullptr, 0);  // the same (column, layer, band) hold tau_abs in tau: Rayleigh + combine in place
     hipStream_t main_st = st;
     if (aux) st = aux;
-    hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw,
+    GfastTabs gft{};
+    if (!g_worklist_native) { gft.kmaj = kmaj_g; gft.klo = klo_g; gft.kup = kup_g; gft.nkl = nkl; gft.nku = nku; }
+    hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw, gft,
                        (const int*)v.worklist, use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
     if (rh) rayleigh_direct(nullptr, (const int*)v.worklist, V9_NCW * 64);  // (lambda launches on st)
     st = main_st;
