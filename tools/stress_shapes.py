@@ -5,12 +5,16 @@ sys.path.insert(0, ".")
 from rte_rrtmgp_amd import frontend, hiplib, synth
 hip = hiplib.load(); xp = frontend.TorchArrays("cuda:0"); A = xp.asarray
 worst = 0.0
+SHARE = "share" in sys.argv[1:]  # production runs with the opt-in driver modes: deferred zero fill + geometry sharing (masks
+                                 # from the interpolation call, ragged last blocks included)
 for kind, ncol, nlay, top in itertools.product(("lw", "sw"), (512, 513, 1023, 1537), (1, 2, 7, 33, 64, 65, 100), (False, True)):
     kd = synth.make_kdist(kind, ngpt=64, nbnd=4)
     atm = synth.make_atmosphere(ncol, nlay, seed=ncol + nlay, kdist=kd, top_at_1=top)
     outs = []
     for direct in (0, 1):
         hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], direct)
+        hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 1 if (SHARE and not direct) else 0)
+        hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 1 if (SHARE and not direct) else 0)
         go = frontend.GasOptics(hip, kd, xp)
         if kind == "lw":
             b = go.gas_optics_lw(ncol, nlay, A(atm.play), A(atm.plev), A(atm.tlay), A(atm.tsfc), A(atm.col_gas), A(atm.tlev), top)
@@ -20,6 +24,8 @@ for kind, ncol, nlay, top in itertools.product(("lw", "sw"), (512, 513, 1023, 15
             keys = ("tau_abs", "tau_rayleigh", "tau", "ssa")
         outs.append({k: np.array(xp.to_numpy(b[k])) for k in keys})
     hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 0)
+    hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 0)
+    hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 0)
     for k in outs[0]:
         den = np.max(np.abs(outs[1][k])); err = float(np.max(np.abs(outs[0][k] - outs[1][k])) / (den if den else 1))
         worst = max(worst, err)
