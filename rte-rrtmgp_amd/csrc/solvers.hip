@@ -1386,7 +1386,24 @@ static int g_lw2str_gpt1_levsource = 0;
 static int g_lw_force_generic = 0;
 static int g_sw_force_generic = 0;
 static int g_lw_sfc_lds = 1;  // surface arrays of the LW segmented solver through LDS chunks (rte_hip_lw_sfc_lds)
-static int g_seg_groups = 0;  // > 0: g-point groups per column tile of the segmented solvers (rte_hip_seg_groups; 0 = automatic)
+static int g_seg_groups = 0;  // > 0: g-point groups per column tile of the segmented solvers (rte_hip_seg_groups; 0 = automatic;
+                              // < 0: g-points per block given directly)
+// g-points per block of the segmented broadband solvers (grid = column tiles x groups, each block accumulates its
+// g-points into a partial slab).  A few LONG groups and one SHORT last group -- grid.y is the slow launch index, so the
+// short blocks run last: the long blocks keep the partial slabs few, the short ones fill the tail of the launch.
+// 1e5 columns: 120 + 120 + 16 of 256 g-points (lw_noscat: 6.96-7.03 ms against 7.10-7.17 for 86 + 86 + 84 and
+// 7.07-7.16 for 4 x 64), 104 + 104 + 16 of 224 (sw_2stream: 12.41-12.44 against 12.56-12.64 for 4 x 56); same results
+// (tools/sweep_seg_groups.py, bench.py --seg-groups).
+static int seg_g_per_block(int col_tiles, int ngpt) {
+  const int tail_g = ngpt >= 64 ? 16 : 0;
+  int nlong = 1;
+  while (nlong < 15 && (size_t)col_tiles * nlong < 3072 && (ngpt - tail_g) / (nlong + 1) >= 8) ++nlong;  // >= 12 long blocks per CU
+  int gpb = ((ngpt - tail_g + nlong - 1) / nlong + 7) / 8 * 8;
+  if (gpb > ngpt) gpb = ngpt;
+  if (g_seg_groups > 0) { const int n = g_seg_groups < ngpt ? g_seg_groups : ngpt; gpb = (ngpt + n - 1) / n; }
+  if (g_seg_groups < 0) gpb = -g_seg_groups < ngpt ? -g_seg_groups : ngpt;
+  return gpb;
+}
 
 extern "C" {
 
@@ -1437,11 +1454,8 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     const int Lr = nlay <= 64 ? 8 : 9;
     const int Sr = (nlay + Lr - 1) / Lr;
     const int col_tiles = cdiv(ncol, 64);
-    int ngroups = 1;
-    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 6144 && ngroups < 16) ngroups *= 2;  // >= 24 blocks per CU: a short tail
-    if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
-    const int g_per_block = (ngpt + ngroups - 1) / ngroups;
-    ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
     LwRescArgs q;
     q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = Sr; q.g_per_block = g_per_block; q.top_at_1 = *top_at_1; q.do_jac = do_jac;
     q.tau = d_tau; q.ssa = d_ssa; q.g = d_g; q.lay_source = d_lay; q.lev_source = d_lev; q.sfc_emis = d_emis; q.sfc_src = d_sfc;
@@ -1472,13 +1486,8 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
   if (do_broadband && !do_rescaling && nlay <= 80 && !g_lw_force_generic && nclv < ((size_t)1 << 29)) {  // 32-bit in-plane byte offsets
     // g-points per block: enough blocks to fill the chip several times over, few enough partial slabs
     const int col_tiles = cdiv(ncol, 64);
-    int ngroups = 1;
-    // >= 18 blocks per CU keeps the tail short; one group fewer than the power of two is one partial slab less to
-    // reduce (1e5 columns: 3 groups, solver unchanged, reduction 0.090 -> 0.073 ms; the two-stream solvers lose with 3)
-    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 4608 && ngroups < 16) ngroups += 1;
-    if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
-    const int g_per_block = (ngpt + ngroups - 1) / ngroups;
-    ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
     Float* part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
     Float* part_dn = part_up + nclv * ngroups;
     Float* part_jac = do_jac ? part_dn + nclv * ngroups : nullptr;
@@ -1600,11 +1609,8 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);  // layers per wave (always 8 waves), see rte_sw_solver_2stream
     const int S = (nlay + L - 1) / L;
     const int col_tiles = cdiv(ncol, 64);
-    int ngroups = 1;
-    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 6144 && ngroups < 16) ngroups *= 2;  // >= 24 blocks per CU: a short tail
-    if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
-    const int g_per_block = (ngpt + ngroups - 1) / ngroups;
-    ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
     Lw2SegArgs q;
     q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = S; q.g_per_block = g_per_block;
     q.top_at_1 = *top_at_1; q.lev_gpt1 = a.lev_gpt1;
@@ -1676,11 +1682,8 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);
     const int S = (nlay + L - 1) / L;
     const int col_tiles = cdiv(ncol, 64);
-    int ngroups = 1;
-    while (ngroups < ngpt && (size_t)col_tiles * ngroups < 6144 && ngroups < 16) ngroups *= 2;  // >= 24 blocks per CU: a short tail
-    if (g_seg_groups > 0) ngroups = g_seg_groups < ngpt ? g_seg_groups : ngpt;
-    const int g_per_block = (ngpt + ngroups - 1) / ngroups;
-    ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
     Sw2SegArgs q;
     q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = S; q.g_per_block = g_per_block;
     q.top_at_1 = *top_at_1; q.has_dif_bc = *has_dif_bc;

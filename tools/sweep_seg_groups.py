@@ -14,7 +14,7 @@ rb = {}
 f = lambda: frontend.rte_lw(lib, xp, ncol, nlay, ngpt, False, tau, lay, lev, emis, sfc, buffers=rb)
 for groups in [int(a) for a in sys.argv[1:]] or [0, 2, 4, 8, 16, 32]:
     hiplib.ext_call(lib, "rte_hip_lw_sfc_lds", ["i"], 0 if groups >= 100 else 1)
-    groups = groups % 100
+    groups = groups % 100 if groups >= 0 else groups  # negative: g-points per block given directly (uneven last group)
     hiplib.ext_call(lib, "rte_hip_seg_groups", ["i"], groups)
     f(); f(); torch.cuda.synchronize()
     hiplib.ext_call(lib, "rte_hip_profile_reset", []); hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
