@@ -300,3 +300,44 @@ def test_tau_on_the_masks_of_interpolation_gives_the_same_arrays():
         assert n_plain == n_shared, (case, n_plain, n_shared)
         for k, v in plain.items():
             assert torch.equal(v, shared[k]), (case, k)
+
+
+def test_worklist_beside_the_slab_kernel_gives_the_same_arrays():
+    """``rte_hip_aux_stream``: the direct-gather worklist of compute_tau_absorption runs on a second stream beside the
+    slab kernel (forked after the geometry pre-pass, joined before the call returns) -- or after it on the library
+    stream.  The two kernels write disjoint (tile, layer, band) entries: every array must be bit-identical, on an
+    atmosphere that actually fills the worklist (shuffled site-like columns), with the LW and the one-pass SW gas optics."""
+    import torch
+
+    hip = hiplib.load()
+    xp = frontend.TorchArrays("cuda:0")
+    ncol = 20000
+    A = xp.asarray
+    for kind in ("lw", "sw"):
+        kd = synth.make_kdist(kind)
+        atm = synth.make_atmosphere(ncol, NLAY, seed=8, kdist=kd, climate="sites")
+        perm = np.random.default_rng(3).permutation(ncol)
+        inp = {k: np.asfortranarray(getattr(atm, k)[perm]) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry")}
+
+        def run(beside):
+            hiplib.ext_call(hip, "rte_hip_aux_stream", ["i"], beside)
+            try:
+                go = frontend.GasOptics(hip, kd, xp)
+                if kind == "lw":
+                    b = go.gas_optics_lw(ncol, NLAY, A(inp["play"]), A(inp["plev"]), A(inp["tlay"]), A(inp["tsfc"]), A(inp["col_gas"]),
+                                         A(inp["tlev"]), atm.top_at_1)
+                    keys = ("tau", "lay_src", "lev_src")
+                else:
+                    b = go.gas_optics_sw(ncol, NLAY, A(inp["play"]), A(inp["plev"]), A(inp["tlay"]), A(inp["col_gas"]), A(inp["col_dry"]),
+                                         fuse_rayleigh="all")
+                    keys = ("tau", "ssa", "g")
+                torch.cuda.synchronize()
+                return {k: b[k].clone() for k in keys}, hiplib.ext_call(hip, "rte_hip_stat", ["i"], 0)
+            finally:
+                hiplib.ext_call(hip, "rte_hip_aux_stream", ["i"], 1)
+
+        after, n_after = run(0)
+        beside, n_beside = run(1)
+        assert n_after == n_beside and n_after > 0, (kind, n_after, n_beside)
+        for k, v in after.items():
+            assert torch.equal(v, beside[k]), (kind, k)
