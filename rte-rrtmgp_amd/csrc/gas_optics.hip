@@ -1738,14 +1738,23 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       // tau is inout (the reference accumulates onto it, :637,:679).  The stage's sum is added to the incoming
       // value at the end: identical to the reference when tau comes in as zero (always, in the frontend),
       // otherwise the same terms in a different order (1 ulp)
-#pragma unroll
-      for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
+      // ... as a hardware floating-point atomic add performed in L2 (global_atomic_add, no return value): the same
+      // single addition tau_in + sum, but the wave neither waits for tau_in nor holds it in registers (a load - add -
+      // store sequence needed `vmcnt(0)` 15 times per stage).  Every element is touched by exactly one thread of
+      // one block per call, so the result does not depend on any order.
       if (ADDB) {
 #pragma unroll
         for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
       }
+#ifdef X9_RMW
+#pragma unroll
+      for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
 #pragma unroll
       for (int j = 0; j < G; ++j) store_stream(tau_at(j), acc[j]);
+#else
+#pragma unroll
+      for (int j = 0; j < G; ++j) unsafeAtomicAdd(tau_at(j), acc[j]);
+#endif
     }
   }
   };
