@@ -769,6 +769,7 @@ struct TauV5 {
   const int* skip_if;  // device flag: some column has overlapping regimes -> the fallback kernel does the call
   int* worklist;       // [0] = count, then (tile, layer, band) triples for tau_absorption_worklist_kernel
   bool overwrite;      // tau is known to be zero (deferred zero_array): do not read it
+  bool atomic_ok;      // tau is device memory proper: hardware floating-point atomics are defined on it (not on host-visible memory)
   const Float* add_bybnd;  // (ncol, nlay, nbnd) or nullptr: see TauArgs
   RaylFuse rf;             // used by the RAYL instantiations only
 #ifdef EXP_CLOCKS
@@ -1747,14 +1748,19 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
       }
 #ifdef X9_RMW
-#pragma unroll
-      for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
-#pragma unroll
-      for (int j = 0; j < G; ++j) store_stream(tau_at(j), acc[j]);
+      const bool use_atomics = false;
 #else
-#pragma unroll
-      for (int j = 0; j < G; ++j) unsafeAtomicAdd(tau_at(j), acc[j]);
+      const bool use_atomics = a.atomic_ok;  // host-visible (pinned / managed) buffers: load - add - store
 #endif
+      if (use_atomics) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) unsafeAtomicAdd(tau_at(j), acc[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
+#pragma unroll
+        for (int j = 0; j < G; ++j) *tau_at(j) = acc[j];
+      }
     }
   }
   };
@@ -3077,6 +3083,7 @@ static void tau_absorption_impl(
   v.lim = lim; v.jeta = d_jeta; v.jtemp = d_jtemp; v.jpress = d_jpress; v.tropo = d_tropo;
   v.col_mix = d_col_mix; v.fmajor = d_fmajor; v.fminor = d_fminor; v.play = d_play; v.tlay = d_tlay;
   v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap; v.overwrite = overwrite_ok; v.add_bybnd = d_add;
+  v.atomic_ok = rte::is_device_memory(d_tau);
   v.rf = RaylFuse{};
   if (rh) {
     v.rf.krayl_g[0] = kray_g; v.rf.krayl_g[1] = kray_g + tn * ngpt; v.rf.col_dry = d_col_dry;

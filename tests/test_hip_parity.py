@@ -368,6 +368,44 @@ def test_pinned_host_arrays_are_synchronous(hip, oracle_c):
     assert cases.rel_err(got_up, ru) <= RTOL_FLUX
 
 
+def test_tau_accumulates_onto_device_and_pinned_buffers(hip):
+    """compute_tau_absorption is intent(inout): it adds to what `tau` holds.  On device memory the production kernel
+    does that with a hardware floating-point atomic add, on host-visible (pinned) memory -- where such atomics are not
+    defined -- with load, add, store.  Both must equal (incoming value + the optical depth computed onto zeros), bit for
+    bit: it is one addition of the same two numbers."""
+    import torch
+    from rte_rrtmgp_amd import synth
+
+    kd = synth.make_kdist("lw", ngpt=64, nbnd=4)
+    ncol, nlay = 1100, 24  # >= 512 columns: the production kernel
+    atm = synth.make_atmosphere(ncol, nlay, seed=19, kdist=kd)
+    xn, xp = frontend.NumpyArrays(), frontend.TorchArrays("cuda:0")
+    rng = np.random.default_rng(4)
+    incoming = np.asfortranarray(rng.uniform(0.0, 3.0, (ncol, nlay, kd.ngpt)))
+    F = np.asfortranarray
+    go_n = frontend.GasOptics(hip, kd, xn)
+    st = go_n.interpolation(ncol, nlay, F(atm.play), F(atm.tlay), F(atm.col_gas), None)
+    # (1) onto zeros, pageable host array (staged through the device arena)
+    zero = F(np.zeros((ncol, nlay, kd.ngpt)))
+    go_n.compute_tau_absorption(ncol, nlay, st, F(atm.play), F(atm.tlay), F(atm.col_gas), zero)
+    assert zero.max() > 0
+    expect = incoming + zero
+    # (2) onto the incoming values in pinned host memory (addressed in place)
+    t = torch.empty((kd.ngpt, nlay, ncol), dtype=torch.float64).pin_memory()
+    pinned = t.numpy().T
+    pinned[...] = incoming
+    go_n.compute_tau_absorption(ncol, nlay, st, F(atm.play), F(atm.tlay), F(atm.col_gas), pinned)
+    assert np.array_equal(pinned, expect)
+    # (3) onto the incoming values in device memory
+    go_d = frontend.GasOptics(hip, kd, xp)
+    A = xp.asarray
+    st_d = go_d.interpolation(ncol, nlay, A(atm.play), A(atm.tlay), A(atm.col_gas), None)
+    dev = A(incoming)
+    go_d.compute_tau_absorption(ncol, nlay, st_d, A(atm.play), A(atm.tlay), A(atm.col_gas), dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(xp.to_numpy(dev), expect)
+
+
 def test_fused_rayleigh_combine_matches_unfused(hip, oracle_c):
     """rte_hip_tau_rayleigh_combine_2str (compute_tau_rayleigh + the 2-stream branch of combine_abs_and_rayleigh in one
     pass, in place on the absorption optical depth) against the unfused ABI calls -- bit-identical -- and the oracle;
