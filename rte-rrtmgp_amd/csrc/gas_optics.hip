@@ -1624,7 +1624,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     }
     // next stage's major weights: their registers are free now, and the request is a minor pass ahead of its use
     // (requested with the minor weights at the end of the stage, their latency is exposed: 5.5 -> 5.9 ms)
-#ifdef X9_NOLOAD
+#if defined(X9_NOLOAD) || defined(X9_NOLOAD_MAJ)
     if (a.ncol < 0)
 #endif
     load_major(nq.flav_major, mj);
