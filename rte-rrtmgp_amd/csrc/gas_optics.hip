@@ -541,6 +541,7 @@ __device__ __forceinline__ void minor_chunk_g(const MinorTables& mt, const Float
 }
 
 __device__ __forceinline__ void tau_direct_column_g(const TauArgs& a, const GfastTabs& t, int icol, int ilay, int ibnd) {
+  constexpr int GH = 8;  // g-points per register chunk here (bands are whole chunks of 8 or 16 on this path)
   const int ncol = a.ncol, nlay = a.nlay, neta = a.neta, ntemp = a.ntemp, ngpt = a.ngpt;
   const size_t ncl = (size_t)ncol * nlay;
   const size_t cl = icol + (size_t)ncol * ilay;
@@ -555,58 +556,53 @@ __device__ __forceinline__ void tau_direct_column_g(const TauArgs& a, const Gfas
   Float fm[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) fm[i] = a.fmajor[8 * clf + i];
-  const size_t TE = (size_t)ntemp * neta;
-  // rows [pressure level][eta][temperature] x ngpt of the g-fastest copy
-  const Float* A00 = t.kmaj + ((size_t)(jp - 2) * TE + (size_t)(jT - 1) + (size_t)ntemp * (je1 - 1)) * ngpt;
-  const Float* A01 = A00 + (size_t)ntemp * ngpt;
-  const Float* A10 = A00 + TE * ngpt;
-  const Float* A11 = A10 + (size_t)ntemp * ngpt;
-  const Float* B00 = t.kmaj + ((size_t)(jp - 2) * TE + (size_t)jT + (size_t)ntemp * (je2 - 1)) * ngpt;
-  const Float* B01 = B00 + (size_t)ntemp * ngpt;
-  const Float* B10 = B00 + TE * ngpt;
-  const Float* B11 = B10 + (size_t)ntemp * ngpt;
+  const unsigned TE = (unsigned)ntemp * neta;
+  // rows [pressure level][eta][temperature] x ngpt of the g-fastest copy, as 32-bit element offsets (the table has
+  // (npres + 1) * TE * ngpt < 2^31 elements: checked where the copy is made)
+  const unsigned oA = ((unsigned)(jp - 2) * TE + (unsigned)(jT - 1) + (unsigned)ntemp * (je1 - 1)) * (unsigned)ngpt;
+  const unsigned oB = ((unsigned)(jp - 2) * TE + (unsigned)jT + (unsigned)ntemp * (je2 - 1)) * (unsigned)ngpt;
+  const unsigned dE = (unsigned)ntemp * ngpt, dP = TE * (unsigned)ngpt;  // next eta row, next pressure level
   const Float P = a.play[cl], T = a.tlay[cl];
   const int lay1 = ilay + 1;
   const int lo1 = a.lim[icol], lo2 = a.lim[icol + ncol];
   const int up1 = a.lim[icol + 2 * (size_t)ncol], up2 = a.lim[icol + 3 * (size_t)ncol];
   const bool in_lower = lo1 > 0 && lay1 >= lo1 && lay1 <= lo2;
   const bool in_upper = up1 > 0 && lay1 >= up1 && lay1 <= up2;
+  auto row2 = [&](unsigned off) { return *reinterpret_cast<const Float2*>(t.kmaj + off); };
 
-  for (int g0 = gptS; g0 <= gptE; g0 += GC) {
-    Float acc[GC];
+  for (int g0 = gptS; g0 <= gptE; g0 += GH) {
+    Float acc[GC];  // (minor_chunk_g works on GC-wide chunks: the upper half stays unused here)
 #pragma unroll
-    for (int j = 0; j < GC; ++j) acc[j] = (g0 + j <= gptE && !a.overwrite) ? a.tau[cl + ncl * (size_t)(g0 + j)] : (Float)0;
+    for (int j = 0; j < GC; ++j) acc[j] = (Float)0;
 #pragma unroll
-    for (int j = 0; j < GC; j += 2) {
-      if (g0 + j <= gptE) {
-        const int g = g0 + j;
-        const Float2 a00 = *reinterpret_cast<const Float2*>(A00 + g), a01 = *reinterpret_cast<const Float2*>(A01 + g);
-        const Float2 a10 = *reinterpret_cast<const Float2*>(A10 + g), a11 = *reinterpret_cast<const Float2*>(A11 + g);
-        const Float2 b00 = *reinterpret_cast<const Float2*>(B00 + g), b01 = *reinterpret_cast<const Float2*>(B01 + g);
-        const Float2 b10 = *reinterpret_cast<const Float2*>(B10 + g), b11 = *reinterpret_cast<const Float2*>(B11 + g);
-        // :791-801
-        const Float ta = cm1 * (fm[0] * a00.x + fm[1] * a01.x + fm[2] * a10.x + fm[3] * a11.x) +
-                         cm2 * (fm[4] * b00.x + fm[5] * b01.x + fm[6] * b10.x + fm[7] * b11.x);
-        const Float tb = cm1 * (fm[0] * a00.y + fm[1] * a01.y + fm[2] * a10.y + fm[3] * a11.y) +
-                         cm2 * (fm[4] * b00.y + fm[5] * b01.y + fm[6] * b10.y + fm[7] * b11.y);
-        acc[j] = acc[j] + ta;
-        acc[j + 1] = acc[j + 1] + tb;
-      }
+    for (int j = 0; j < GH; ++j) acc[j] = a.overwrite ? (Float)0 : a.tau[cl + ncl * (size_t)(g0 + j)];
+#pragma unroll
+    for (int j = 0; j < GH; j += 2) {
+      const unsigned g = (unsigned)(g0 + j);
+      const Float2 a00 = row2(oA + g), a01 = row2(oA + dE + g), a10 = row2(oA + dP + g), a11 = row2(oA + dP + dE + g);
+      const Float2 b00 = row2(oB + g), b01 = row2(oB + dE + g), b10 = row2(oB + dP + g), b11 = row2(oB + dP + dE + g);
+      // :791-801
+      const Float ta = cm1 * (fm[0] * a00.x + fm[1] * a01.x + fm[2] * a10.x + fm[3] * a11.x) +
+                       cm2 * (fm[4] * b00.x + fm[5] * b01.x + fm[6] * b10.x + fm[7] * b11.x);
+      const Float tb = cm1 * (fm[0] * a00.y + fm[1] * a01.y + fm[2] * a10.y + fm[3] * a11.y) +
+                       cm2 * (fm[4] * b00.y + fm[5] * b01.y + fm[6] * b10.y + fm[7] * b11.y);
+      acc[j] = acc[j] + ta;
+      acc[j + 1] = acc[j + 1] + tb;
     }
+    const int gEnd = g0 + GH - 1;  // this chunk only (the upper half of acc is not a g-point here)
     if (in_lower)
-      minor_chunk_g(a.lower, t.klo, t.nkl, 0, ibnd, g0, gptE, ncl, cl, ntemp, a.idx_h2o, P, T, jT, a.col_gas, a.fminor, a.jeta,
+      minor_chunk_g(a.lower, t.klo, t.nkl, 0, ibnd, g0, gEnd, ncl, cl, ntemp, a.idx_h2o, P, T, jT, a.col_gas, a.fminor, a.jeta,
                     a.gpoint_flavor, acc);
     if (in_upper)
-      minor_chunk_g(a.upper, t.kup, t.nku, 1, ibnd, g0, gptE, ncl, cl, ntemp, a.idx_h2o, P, T, jT, a.col_gas, a.fminor, a.jeta,
+      minor_chunk_g(a.upper, t.kup, t.nku, 1, ibnd, g0, gEnd, ncl, cl, ntemp, a.idx_h2o, P, T, jT, a.col_gas, a.fminor, a.jeta,
                     a.gpoint_flavor, acc);
     if (a.add_bybnd) {  // increment_1scalar_by_1scalar_bybnd fused in: tau = tau_gas + tau_2(band)
       const Float addv = a.add_bybnd[cl + ncl * (size_t)ibnd];
 #pragma unroll
-      for (int j = 0; j < GC; ++j) acc[j] = acc[j] + addv;
+      for (int j = 0; j < GH; ++j) acc[j] = acc[j] + addv;
     }
 #pragma unroll
-    for (int j = 0; j < GC; ++j)
-      if (g0 + j <= gptE) a.tau[cl + ncl * (size_t)(g0 + j)] = acc[j];
+    for (int j = 0; j < GH; ++j) a.tau[cl + ncl * (size_t)(g0 + j)] = acc[j];
   }
 }
 
@@ -1779,7 +1775,9 @@ __global__ void __launch_bounds__(256) zero_words_kernel(int* a, unsigned na, in
 // (tile, layer, band) triples the slab kernel could not hold, done by the direct-gather code
 // (work item = one entry x one 64-column chunk, taken by waves in grid stride: the few hundred entries of a call
 // spread over all CUs instead of one block walking an entry's 512 columns)
-__global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a, GfastTabs gt, const int* __restrict__ worklist,
+// (<= 168 registers: three waves per SIMD, so that a wave of it fits beside two waves of the slab kernel's blocks)
+template <bool GFAST>
+__global__ void __launch_bounds__(256, 3) tau_absorption_worklist_kernel(TauArgs a, GfastTabs gt, const int* __restrict__ worklist,
                                                                       int tile, int* __restrict__ stat) {
   const int n = worklist[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) *stat = n;  // rte_hip_stat(0)
@@ -1790,7 +1788,7 @@ __global__ void __launch_bounds__(256) tau_absorption_worklist_kernel(TauArgs a,
     const int w = it / chunks, ch = it - w * chunks;
     const int icol = worklist[1 + 3 * w] * tile + ch * 64 + (threadIdx.x & 63);
     if (icol >= a.ncol) continue;
-    if (gt.kmaj) tau_direct_column_g(a, gt, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
+    if constexpr (GFAST) tau_direct_column_g(a, gt, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
     else tau_direct_column(a, icol, worklist[2 + 3 * w], worklist[3 + 3 * w]);
   }
 }
@@ -3205,8 +3203,12 @@ static void tau_absorption_impl(
     if (aux) st = aux;
     GfastTabs gft{};
     if (!g_worklist_native) { gft.kmaj = kmaj_g; gft.klo = klo_g; gft.kup = kup_g; gft.nkl = nkl; gft.nku = nku; }
-    hipLaunchKernelGGL(tau_absorption_worklist_kernel, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw, gft,
-                       (const int*)v.worklist, use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
+    if (gft.kmaj)
+      hipLaunchKernelGGL(tau_absorption_worklist_kernel<true>, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw, gft,
+                         (const int*)v.worklist, use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
+    else
+      hipLaunchKernelGGL(tau_absorption_worklist_kernel<false>, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw, gft,
+                         (const int*)v.worklist, use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
     if (rh) rayleigh_direct(nullptr, (const int*)v.worklist, V9_NCW * 64);  // (lambda launches on st)
     st = main_st;
     if (aux) rte::aux_join();
