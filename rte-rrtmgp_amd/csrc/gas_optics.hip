@@ -338,6 +338,26 @@ struct MinorTables {
   int nminor;
 };
 
+// column amount of a minor absorber with its optional scalings: reference :461-480
+__device__ __forceinline__ Float minor_scaling(const MinorTables& mt, int imnr, size_t ncl, size_t cl, int idx_h2o, Float P, Float T,
+                                               const Float* __restrict__ col_gas) {
+  Float scaling = col_gas[cl + ncl * mt.idx_minor[imnr]];
+  if (mt.scales_with_density[imnr]) {
+    scaling = scaling * ((Float)0.01 * P / T);
+    const int isc = mt.idx_minor_scaling[imnr];
+    if (isc > 0) {
+      const Float vmr_fact = (Float)1 / col_gas[cl];
+      const Float dry_fact = (Float)1 / ((Float)1 + col_gas[cl + ncl * idx_h2o] * vmr_fact);
+      const Float cgs = col_gas[cl + ncl * isc];
+      if (mt.scale_by_complement[imnr])
+        scaling = scaling * ((Float)1 - cgs * vmr_fact * dry_fact);
+      else
+        scaling = scaling * (cgs * vmr_fact * dry_fact);
+    }
+  }
+  return scaling;
+}
+
 // contribution of one regime's minor absorbers to the register chunk acc[0..GC)
 __device__ __forceinline__ void minor_chunk(const MinorTables& mt, int flav_row, int ibnd, int g0, int gEnd,
                                             int ncol, size_t ncl, size_t cl, int ntemp, int neta, int idx_h2o,
@@ -349,21 +369,7 @@ __device__ __forceinline__ void minor_chunk(const MinorTables& mt, int flav_row,
     const int imnr = mt.list[(size_t)ibnd * mt.nminor + k];
     const int mS = mt.limits[2 * imnr] - 1, mE = mt.limits[2 * imnr + 1] - 1;  // 0-based
     if (mE < g0 || mS >= g0 + GC) continue;
-    // :461-480
-    Float scaling = col_gas[cl + ncl * mt.idx_minor[imnr]];
-    if (mt.scales_with_density[imnr]) {
-      scaling = scaling * ((Float)0.01 * P / T);
-      const int isc = mt.idx_minor_scaling[imnr];
-      if (isc > 0) {
-        const Float vmr_fact = (Float)1 / col_gas[cl];
-        const Float dry_fact = (Float)1 / ((Float)1 + col_gas[cl + ncl * idx_h2o] * vmr_fact);
-        const Float cgs = col_gas[cl + ncl * isc];
-        if (mt.scale_by_complement[imnr])
-          scaling = scaling * ((Float)1 - cgs * vmr_fact * dry_fact);
-        else
-          scaling = scaling * (cgs * vmr_fact * dry_fact);
-      }
-    }
+    const Float scaling = minor_scaling(mt, imnr, ncl, cl, idx_h2o, P, T, col_gas);
     // :485-494
     const int iflav = gpoint_flavor[flav_row + 2 * mS] - 1;
     const size_t clf = cl + ncl * iflav;
@@ -498,21 +504,7 @@ __device__ __forceinline__ void minor_chunk_g(const MinorTables& mt, const Float
     const int imnr = mt.list[(size_t)ibnd * mt.nminor + k];
     const int mS = mt.limits[2 * imnr] - 1, mE = mt.limits[2 * imnr + 1] - 1;  // 0-based
     if (mE < g0 || mS >= g0 + GC) continue;
-    // :461-480
-    Float scaling = col_gas[cl + ncl * mt.idx_minor[imnr]];
-    if (mt.scales_with_density[imnr]) {
-      scaling = scaling * ((Float)0.01 * P / T);
-      const int isc = mt.idx_minor_scaling[imnr];
-      if (isc > 0) {
-        const Float vmr_fact = (Float)1 / col_gas[cl];
-        const Float dry_fact = (Float)1 / ((Float)1 + col_gas[cl + ncl * idx_h2o] * vmr_fact);
-        const Float cgs = col_gas[cl + ncl * isc];
-        if (mt.scale_by_complement[imnr])
-          scaling = scaling * ((Float)1 - cgs * vmr_fact * dry_fact);
-        else
-          scaling = scaling * (cgs * vmr_fact * dry_fact);
-      }
-    }
+    const Float scaling = minor_scaling(mt, imnr, ncl, cl, idx_h2o, P, T, col_gas);
     // :485-494
     const int iflav = gpoint_flavor[flav_row + 2 * mS] - 1;
     const size_t clf = cl + ncl * iflav;
