@@ -1346,6 +1346,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 
   if (tid >= TILE) {
     // ================================ loader waves ================================
+    // the loaders issue little and mostly wait for memory: a raised issue priority lets their requests and LDS writes go
+    // out ahead of the eight compute waves' FMAs, so that the next slab is complete a little earlier (tau 5.34 -> 5.28 ms
+    // in one process, no change for Planck)
+    __builtin_amdgcn_s_setprio(1);
     const int lt = tid - TILE;
     const float inv_nT = 1.0f / (float)nT;
     constexpr int SB = V9_SB;  // 16-byte pieces per lane requested back to back
@@ -2273,6 +2277,10 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
 
   if (tid >= TILE) {
     // ================================ loader waves ================================
+    // the loaders issue little and mostly wait for memory: a raised issue priority lets their requests and LDS writes go
+    // out ahead of the eight compute waves' FMAs, so that the next slab is complete a little earlier (tau 5.34 -> 5.28 ms
+    // in one process, no change for Planck)
+    __builtin_amdgcn_s_setprio(1);
     const int lt = tid - TILE;
     constexpr int SB = 8;  // 16-byte pieces per lane requested back to back
 #pragma unroll 1
