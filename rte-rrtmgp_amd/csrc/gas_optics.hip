@@ -2846,9 +2846,12 @@ static void tau_absorption_impl(
   int* irregular = overlap + 1;  // some column's layer ranges are not those of its tropo flags (see tropo_limits_kernel)
   const size_t wl_cap = (size_t)cdiv(ncol, 256) * nlay * nbnd;  // tiles are at least 256 columns wide
   int* const worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
+  int* const valid_word = share_boxes() ? g_shared.valid : nullptr;  // (null until the first sharing call has allocated it)
   {
     rte::ProfScope p("tau_absorption_setup");
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, overlap, 2u, worklist, 1u, (int*)nullptr, 0u);
+    // (the validity word of a geometry shared with compute_Planck_source is cleared here too: it is set again only if this
+    //  call's geometry kernel runs)
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, overlap, 2u, worklist, 1u, valid_word, valid_word ? 1u : 0u);
   }  // (layer limits: tropo_limits_kernel below, or a role of tau_setup_kernel on the production path)
   int* d_stale = stale_flag();
   stale_poll();
@@ -3118,7 +3121,8 @@ static void tau_absorption_impl(
         g_shared.cap = need;
       }
       d_geom = g_shared.geom;
-      hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, g_shared.valid, 1u, (int*)nullptr, 0u, (int*)nullptr, 0u);
+      if (valid_word == nullptr)  // just allocated (otherwise it was cleared with this call's other flag words)
+        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, g_shared.valid, 1u, (int*)nullptr, 0u, (int*)nullptr, 0u);
       g_shared.jeta = jeta; g_shared.jtemp = jtemp; g_shared.jpress = jpress; g_shared.tropo = tropo;
       g_shared.ncol = ncol; g_shared.nlay = nlay; g_shared.nflav = nflav; g_shared.nbnd = nbnd; g_shared.gw = cache.gw;
       g_shared.seq = rte::call_seq();
