@@ -55,7 +55,12 @@ def build(precision: str = "dp", force: bool = False, verbose: bool = False, ext
     # and then find the library up to date; the link goes to a temporary name and is renamed into place
     import fcntl
 
-    with open(out + ".lock", "w") as lock:
+    import hashlib
+    import tempfile
+
+    # the lock lives outside the package directory (nothing but sources and the product is left beside them)
+    lock_path = os.path.join(tempfile.gettempdir(), "rte_hip_build_" + hashlib.sha1(out.encode()).hexdigest()[:16] + ".lock")
+    with open(lock_path, "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and not _stale(out):
