@@ -11,7 +11,9 @@
 #   2. tests/rte_lw_solver_unit_tests.F90, rte_sw_solver_unit_tests.F90, rte_optic_prop_unit_tests.F90 (they need only
 #      mo_testing_utils and mo_comparisons -- no netCDF, no data files) are linked against the HIP library and the shim
 #      into oracle/_ref/bin/.  Running them (on a GPU box: tests/test_extern_frontend.py) drives the real rte_lw /
-#      rte_sw / optical-props classes, with HOST arrays, through the library's staging path.
+#      rte_sw / optical-props classes, with HOST arrays, through the library's staging path;
+#   3. oracle/ref_frontend_driver.F90 (our driver of the reference's load -> gas_optics -> rte_lw / rte_sw) is linked
+#      once against the HIP library and once against the reference's CPU kernels.
 # Outputs are binaries only, under oracle/_ref/ (git-ignored, travels to the GPU box).  Nothing is copied.
 set -e
 R=${REFERENCE_ROOT:-/root/reference}
@@ -63,5 +65,15 @@ for t in rte_lw_solver_unit_tests rte_sw_solver_unit_tests rte_optic_prop_unit_t
         -L"$OUT" -lrefkernels -L"$HERE" -loracle -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../..'
   fi
 done
+# ---- 3. the gas-optics frontend end to end (row f4): oracle/ref_frontend_driver.F90 (ours) = raw table -> k%load ->
+#         k%gas_optics -> rte_lw / rte_sw per block of columns, ONE object linked twice (HIP library / reference CPU kernels)
+$FC $FFLAGS -c "$HERE/mo_raw_stream.F90" 2> err.log || { cat err.log >&2; exit 1; }
+$FC $FFLAGS -c "$HERE/ref_frontend_driver.F90" 2> err.log || { cat err.log >&2; exit 1; }
+$FC -o "$OUT/bin/ref_frontend_driver" ref_frontend_driver.o mo_raw_stream.o $FRONT_OBJS shim.o \
+    -L"$LIBDIR" -lrte_rrtmgp_hip -Wl,-rpath,'$ORIGIN/../../../rte-rrtmgp_amd' -Wl,-rpath,/opt/rocm/lib
+if [ -f "$OUT/librefkernels.so" ]; then
+  $FC -o "$OUT/bin/ref_frontend_driver_cpuref" ref_frontend_driver.o mo_raw_stream.o $FRONT_OBJS shim.o \
+      -L"$OUT" -lrefkernels -L"$HERE" -loracle -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../..'
+fi
 cd "$OUT"; rm -rf "$B"
 ls -l "$OUT/bin"

@@ -27,9 +27,10 @@ for f in $SRCS; do
   OBJS="$OBJS $(basename "$f" .F90).o"
 done
 $FC $FFLAGS -c "$ROOT/shim/rte_hip_fortran_shim.F90" -o shim.o 2> err.log || { cat err.log >&2; exit 1; }
+$FC $FFLAGS -c "$HERE/mo_raw_stream.F90" 2> err.log || { cat err.log >&2; exit 1; }
 $FC $FFLAGS -c "$HERE/ref_load_driver.F90" 2> err.log || { cat err.log >&2; exit 1; }
 gcc -O1 -fPIC -c "$HERE/abi_recorder.c" -o abi_recorder.o
-$FC -o "$OUT/bin/ref_load_driver" ref_load_driver.o $OBJS shim.o abi_recorder.o -L"$OUT" -lrefkernels -L"$HERE" -loracle \
+$FC -o "$OUT/bin/ref_load_driver" ref_load_driver.o mo_raw_stream.o $OBJS shim.o abi_recorder.o -L"$OUT" -lrefkernels -L"$HERE" -loracle \
     -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../..'
 cd "$OUT"; rm -rf "$B"
 ls -l "$OUT/bin/ref_load_driver"

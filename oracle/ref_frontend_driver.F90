@@ -1,0 +1,161 @@
+! ref_frontend_driver.F90 -- test infrastructure (our own file; SURVEY.md section 8 row f4): drives the REFERENCE's
+! UNCHANGED Fortran frontend end to end on host arrays, the way the RFMIP example drivers do
+! (examples/rfmip-clear-sky/rrtmgp_rfmip_lw.F90:247-281, rrtmgp_rfmip_sw.F90:262-336) but without netCDF:
+!
+!   raw k-distribution stream -> ty_gas_optics_rrtmgp%load          (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:938-1145)
+!   per block of columns:        k%gas_optics (LW :220-331, SW :337-414) -> rte_lw / rte_sw with ty_fluxes_broadband
+!                                (rte/frontend/mo_rte_lw.F90:79-473, rte/frontend/mo_rte_sw.F90:56-394)
+!
+! oracle/build_extern.sh links this one object file twice: against librte_rrtmgp_hip.so + the Fortran shim (the HIP
+! path behind the reference's bind(C) kernel interface) and against the reference's own CPU kernels
+! (oracle/_ref/librefkernels.so).  tests/test_extern_frontend.py runs both on the same seeded atmosphere and compares
+! the flux files.  The program is the same in both links: library options (host-mirror mode) are switched through
+! environment variables of the HIP library, never through symbols the reference kernels lack.
+!
+! Usage: ref_frontend_driver <k-distribution stream> <atmosphere stream> <output file> <comma-separated gases>
+! Atmosphere stream (records as in oracle/mo_raw_stream.F90):
+!   opts  int(8): ncol, nlay, block size, use_col_dry, use_tlev, checks on/off, repetitions of the block loop, n_gauss_angles
+!   p_lay, p_lev, t_lay, t_lev (ncol, nlay[+1]); vmr(ncol, nlay, ngases) in the order of <gases>; col_dry(ncol, nlay);
+!   LW: t_sfc(ncol), sfc_emis(ncol);  SW: mu0(ncol), sfc_alb(ncol)
+! Output (stream): flux_up, flux_dn (ncol, nlay+1) [, flux_dn_dir for SW], float64, column fastest.
+program ref_frontend_driver
+  use mo_rte_kind,           only: wp, wl
+  use mo_rte_config,         only: rte_config_checks
+  use mo_gas_concentrations, only: ty_gas_concs
+  use mo_gas_optics_rrtmgp,  only: ty_gas_optics_rrtmgp
+  use mo_optical_props,      only: ty_optical_props_1scl, ty_optical_props_2str
+  use mo_source_functions,   only: ty_source_func_lw
+  use mo_fluxes,             only: ty_fluxes_broadband
+  use mo_rte_lw,             only: rte_lw
+  use mo_rte_sw,             only: rte_sw
+  use mo_raw_stream,         only: split_names, load_kdist_stream, rd_i1, rd_r1, rd_r2, rd_r3
+  implicit none
+  character(len=512) :: fk, fatm, fout, gases_arg
+  character(len=32), allocatable :: gases(:)
+  type(ty_gas_optics_rrtmgp) :: k
+  logical :: is_lw
+  integer, allocatable :: opts(:)
+  integer :: ncol, nlay, bs, nblocks, nrep, n_ang, ngpt, nbnd, ngas
+  logical :: use_col_dry, use_tlev, checks
+  real(wp), allocatable :: p_lay(:,:), p_lev(:,:), t_lay(:,:), t_lev(:,:), vmr(:,:,:), col_dry(:,:), t_sfc(:), sfc_emis(:), &
+                           mu0(:), sfc_alb(:)
+  real(wp), allocatable, target :: flux_up(:,:), flux_dn(:,:), flux_dir(:,:)
+  real(wp), allocatable, target :: bup(:,:), bdn(:,:), bdir(:,:)   ! one block's fluxes (contiguous, as in the RFMIP drivers)
+  real(wp), allocatable :: bp_lay(:,:), bp_lev(:,:), bt_lay(:,:), bt_lev(:,:), bcol_dry(:,:), bsfc(:,:), toa(:,:)
+  type(ty_gas_concs), allocatable :: concs(:)
+  type(ty_optical_props_1scl) :: op1
+  type(ty_optical_props_2str) :: op2
+  type(ty_source_func_lw) :: src
+  type(ty_fluxes_broadband) :: fluxes
+  integer :: u, b, c0, c1, ig, irep, ibnd
+  integer(8) :: t0, t1, rate
+  real(8) :: secs, best
+  character(len=128) :: e
+
+  call get_command_argument(1, fk); call get_command_argument(2, fatm)
+  call get_command_argument(3, fout); call get_command_argument(4, gases_arg)
+  call split_names(gases_arg, gases)
+  ngas = size(gases)
+  call load_kdist_stream(fk, gases, k, is_lw)
+  ngpt = k%get_ngpt(); nbnd = k%get_nband()
+
+  open(newunit=u, file=trim(fatm), access='stream', form='unformatted', status='old')
+  call rd_i1(u, opts)
+  ncol = opts(1); nlay = opts(2); bs = opts(3); use_col_dry = opts(4) /= 0; use_tlev = opts(5) /= 0
+  checks = opts(6) /= 0; nrep = max(1, opts(7)); n_ang = max(1, opts(8))
+  call rd_r2(u, p_lay); call rd_r2(u, p_lev); call rd_r2(u, t_lay); call rd_r2(u, t_lev)
+  call rd_r3(u, vmr); call rd_r2(u, col_dry)
+  if (is_lw) then
+    call rd_r1(u, t_sfc); call rd_r1(u, sfc_emis)
+  else
+    call rd_r1(u, mu0); call rd_r1(u, sfc_alb)
+  end if
+  close(u)
+  if (mod(ncol, bs) /= 0) error stop 'ref_frontend_driver: ncol is not a multiple of the block size'
+  nblocks = ncol / bs
+  ! rte/frontend/mo_rte_config.F90:25-49 (the all-sky example switches the checks off after its first pass,
+  ! examples/all-sky/rrtmgp_allsky.F90:334)
+  call rte_config_checks(logical(checks, wl))
+
+  ! gas concentrations per block (examples/rfmip-clear-sky: read_and_block_gases_ty)
+  allocate(concs(nblocks))
+  do b = 1, nblocks
+    c0 = (b - 1) * bs + 1; c1 = b * bs
+    call stop_on_err(concs(b)%init(gases))
+    do ig = 1, ngas
+      call stop_on_err(concs(b)%set_vmr(trim(gases(ig)), vmr(c0:c1, :, ig)))
+    end do
+  end do
+
+  allocate(flux_up(ncol, nlay+1), flux_dn(ncol, nlay+1), bup(bs, nlay+1), bdn(bs, nlay+1))
+  allocate(bp_lay(bs, nlay), bp_lev(bs, nlay+1), bt_lay(bs, nlay), bt_lev(bs, nlay+1), bcol_dry(bs, nlay), bsfc(nbnd, bs))
+  fluxes%flux_up => bup; fluxes%flux_dn => bdn
+  if (is_lw) then
+    call stop_on_err(op1%alloc_1scl(bs, nlay, k))
+    call stop_on_err(src%alloc(bs, nlay, k))
+  else
+    allocate(flux_dir(ncol, nlay+1), bdir(bs, nlay+1), toa(bs, ngpt))
+    fluxes%flux_dn_dir => bdir
+    call stop_on_err(op2%alloc_2str(bs, nlay, k))
+  end if
+
+  best = huge(best)
+  call system_clock(count_rate=rate)
+  do irep = 1, nrep
+    call system_clock(t0)
+    do b = 1, nblocks
+      c0 = (b - 1) * bs + 1; c1 = b * bs
+      bp_lay = p_lay(c0:c1, :); bp_lev = p_lev(c0:c1, :); bt_lay = t_lay(c0:c1, :)
+      if (use_tlev) bt_lev = t_lev(c0:c1, :)
+      if (use_col_dry) bcol_dry = col_dry(c0:c1, :)
+      if (is_lw) then
+        do ibnd = 1, nbnd
+          bsfc(ibnd, :) = sfc_emis(c0:c1)
+        end do
+        if (use_col_dry .and. use_tlev) then
+          e = k%gas_optics(bp_lay, bp_lev, bt_lay, t_sfc(c0:c1), concs(b), op1, src, col_dry=bcol_dry, tlev=bt_lev)
+        else if (use_col_dry) then
+          e = k%gas_optics(bp_lay, bp_lev, bt_lay, t_sfc(c0:c1), concs(b), op1, src, col_dry=bcol_dry)
+        else if (use_tlev) then
+          e = k%gas_optics(bp_lay, bp_lev, bt_lay, t_sfc(c0:c1), concs(b), op1, src, tlev=bt_lev)
+        else
+          e = k%gas_optics(bp_lay, bp_lev, bt_lay, t_sfc(c0:c1), concs(b), op1, src)
+        end if
+        call stop_on_err(e)
+        call stop_on_err(rte_lw(op1, src, bsfc, fluxes, n_gauss_angles=n_ang))
+      else
+        do ibnd = 1, nbnd
+          bsfc(ibnd, :) = sfc_alb(c0:c1)
+        end do
+        if (use_col_dry) then
+          e = k%gas_optics(bp_lay, bp_lev, bt_lay, concs(b), op2, toa, col_dry=bcol_dry)
+        else
+          e = k%gas_optics(bp_lay, bp_lev, bt_lay, concs(b), op2, toa)
+        end if
+        call stop_on_err(e)
+        call stop_on_err(rte_sw(op2, mu0(c0:c1), toa, bsfc, bsfc, fluxes))
+        flux_dir(c0:c1, :) = bdir
+      end if
+      flux_up(c0:c1, :) = bup; flux_dn(c0:c1, :) = bdn
+    end do
+    call system_clock(t1)
+    secs = real(t1 - t0, 8) / real(rate, 8)
+    best = min(best, secs)
+    print '(a,i0,a,f10.4,a,f12.1,a)', 'pass ', irep, ': ', secs, ' s, ', real(ncol, 8) / secs, ' columns/s'
+  end do
+  print '(a,f12.1)', 'best columns/s: ', real(ncol, 8) / best
+
+  open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
+  write(u) flux_up; write(u) flux_dn
+  if (.not. is_lw) write(u) flux_dir
+  close(u)
+  print *, 'ref_frontend_driver ok'
+contains
+  subroutine stop_on_err(msg)
+    character(len=*), intent(in) :: msg
+    if (len_trim(msg) > 0) then
+      print *, 'ref_frontend_driver: ', trim(msg)
+      error stop 3
+    end if
+  end subroutine
+end program ref_frontend_driver

@@ -4,77 +4,22 @@
 ! numpy restatement of the load-time reductions (rte-rrtmgp_amd/kdist_load.py) is pinned against the reference itself.
 ! Built by oracle/build_load_check.sh into oracle/_ref/bin/ref_load_driver (needs /root/reference + flang).
 !
-! Input stream (unformatted stream, little endian): for every item a tag (character(32)), rank (int32), dims
-! (rank x int32) then the payload: float64 / int32 / logical-as-int32, or for string tables n x character(32).
+! Input stream: see oracle/mo_raw_stream.F90.
 ! Usage: ref_load_driver <input file> <output file> <comma-separated available gases>
 program ref_load_driver
   use mo_rte_kind,           only: wp, wl
   use mo_gas_concentrations, only: ty_gas_concs
   use mo_gas_optics_rrtmgp,  only: ty_gas_optics_rrtmgp
+  use mo_raw_stream,         only: split_names, load_kdist_stream
   implicit none
   character(len=512) :: fin, fout, gases_arg
   character(len=32), allocatable :: avail(:)
-  type(ty_gas_concs) :: available
   type(ty_gas_optics_rrtmgp) :: k
-  character(len=128) :: err
-  integer :: uin, i, n, p0, p1
-  ! raw fields
-  character(len=32), allocatable :: gas_names(:), gas_minor(:), identifier_minor(:), minor_gases_lower(:), &
-                                    minor_gases_upper(:), scaling_gas_lower(:), scaling_gas_upper(:)
-  integer,  allocatable :: key_species(:,:,:), band2gpt(:,:), minor_limits_gpt_lower(:,:), minor_limits_gpt_upper(:,:), &
-                           kminor_start_lower(:), kminor_start_upper(:)
-  logical(wl), allocatable :: sd_lower(:), sd_upper(:), sc_lower(:), sc_upper(:)
-  real(wp), allocatable :: band_lims(:,:), press_ref(:), temp_ref(:), vmr_ref(:,:,:), kmajor(:,:,:,:), kminor_lower(:,:,:), &
-                           kminor_upper(:,:,:), totplnk(:,:), planck_frac(:,:,:,:), optimal_angle_fit(:,:), &
-                           rayl_lower(:,:,:), rayl_upper(:,:,:), solar_quiet(:), solar_facular(:), solar_sunspot(:)
-  real(wp) :: press_ref_trop, temp_ref_p, temp_ref_t, tsi_default, mg_default, sb_default
   logical :: is_lw
 
   call get_command_argument(1, fin); call get_command_argument(2, fout); call get_command_argument(3, gases_arg)
-  n = 1
-  do i = 1, len_trim(gases_arg)
-    if (gases_arg(i:i) == ',') n = n + 1
-  end do
-  allocate(avail(n))
-  p0 = 1; n = 0
-  do i = 1, len_trim(gases_arg) + 1
-    if (i > len_trim(gases_arg) .or. gases_arg(min(i,len(gases_arg)):min(i,len(gases_arg))) == ',') then
-      p1 = i - 1; n = n + 1; avail(n) = gases_arg(p0:p1); p0 = i + 1
-    end if
-  end do
-  err = available%init(avail)
-  if (err /= '') error stop trim(err)
-
-  open(newunit=uin, file=trim(fin), access='stream', form='unformatted', status='old')
-  call rd_str(gas_names);  call rd_i3(key_species); call rd_i2(band2gpt); call rd_r2(band_lims)
-  call rd_r1(press_ref); call rd_r1(temp_ref); call rd_r0(press_ref_trop); call rd_r0(temp_ref_p); call rd_r0(temp_ref_t)
-  call rd_r3(vmr_ref); call rd_r4(kmajor); call rd_r3(kminor_lower); call rd_r3(kminor_upper)
-  call rd_str(gas_minor); call rd_str(identifier_minor); call rd_str(minor_gases_lower); call rd_str(minor_gases_upper)
-  call rd_i2(minor_limits_gpt_lower); call rd_i2(minor_limits_gpt_upper)
-  call rd_l1(sd_lower); call rd_l1(sd_upper); call rd_str(scaling_gas_lower); call rd_str(scaling_gas_upper)
-  call rd_l1(sc_lower); call rd_l1(sc_upper); call rd_i1(kminor_start_lower); call rd_i1(kminor_start_upper)
-  call rd_i0(i); is_lw = i /= 0
-  if (is_lw) then
-    call rd_r2(totplnk); call rd_r4(planck_frac); call rd_r2(optimal_angle_fit)
-    err = k%load(available, gas_names, key_species, band2gpt, band_lims, press_ref, press_ref_trop, temp_ref, temp_ref_p, &
-                 temp_ref_t, vmr_ref, kmajor, kminor_lower, kminor_upper, gas_minor, identifier_minor, minor_gases_lower, &
-                 minor_gases_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, sd_lower, sd_upper, scaling_gas_lower, &
-                 scaling_gas_upper, sc_lower, sc_upper, kminor_start_lower, kminor_start_upper, totplnk, planck_frac, &
-                 rayl_lower, rayl_upper, optimal_angle_fit)
-  else
-    call rd_r3(rayl_lower); call rd_r3(rayl_upper); call rd_r1(solar_quiet); call rd_r1(solar_facular); call rd_r1(solar_sunspot)
-    call rd_r0(tsi_default); call rd_r0(mg_default); call rd_r0(sb_default)
-    err = k%load(available, gas_names, key_species, band2gpt, band_lims, press_ref, press_ref_trop, temp_ref, temp_ref_p, &
-                 temp_ref_t, vmr_ref, kmajor, kminor_lower, kminor_upper, gas_minor, identifier_minor, minor_gases_lower, &
-                 minor_gases_upper, minor_limits_gpt_lower, minor_limits_gpt_upper, sd_lower, sd_upper, scaling_gas_lower, &
-                 scaling_gas_upper, sc_lower, sc_upper, kminor_start_lower, kminor_start_upper, solar_quiet, solar_facular, &
-                 solar_sunspot, tsi_default, mg_default, sb_default, rayl_lower, rayl_upper)
-  end if
-  close(uin)
-  if (err /= '') then
-    print *, 'load failed: ', trim(err)
-    error stop 1
-  end if
+  call split_names(gases_arg, avail)
+  call load_kdist_stream(fin, avail, k, is_lw)   ! oracle/mo_raw_stream.F90: the reference's own k%load on the raw table
 
   ! The loaded object's arrays are PRIVATE components; what matters is what reaches the kernels.  One call of
   ! gas_optics on a 3-column, 4-layer dummy atmosphere: the recorder library (oracle/abi_recorder.c, linked in front of
@@ -124,67 +69,5 @@ contains
       print *, 'gas_optics failed: ', trim(e)
       error stop 2
     end if
-  end subroutine
-  subroutine hdr(rank, dims)
-    integer, intent(out) :: rank, dims(4)
-    character(len=32) :: tag
-    dims = 1
-    read(uin) tag, rank
-    if (rank > 0) read(uin) dims(1:rank)
-  end subroutine
-  subroutine rd_str(a)
-    character(len=32), allocatable, intent(out) :: a(:)
-    integer :: r, d(4)
-    call hdr(r, d); allocate(a(d(1))); if (d(1) > 0) read(uin) a
-  end subroutine
-  subroutine rd_i0(a)
-    integer, intent(out) :: a
-    integer :: r, d(4)
-    call hdr(r, d); read(uin) a
-  end subroutine
-  subroutine rd_r0(a)
-    real(wp), intent(out) :: a
-    integer :: r, d(4)
-    call hdr(r, d); read(uin) a
-  end subroutine
-  subroutine rd_i1(a)
-    integer, allocatable, intent(out) :: a(:)
-    integer :: r, d(4)
-    call hdr(r, d); allocate(a(d(1))); if (size(a) > 0) read(uin) a
-  end subroutine
-  subroutine rd_l1(a)
-    logical(wl), allocatable, intent(out) :: a(:)
-    integer, allocatable :: t(:)
-    call rd_i1(t); allocate(a(size(t))); a = t /= 0
-  end subroutine
-  subroutine rd_i2(a)
-    integer, allocatable, intent(out) :: a(:,:)
-    integer :: r, d(4)
-    call hdr(r, d); allocate(a(d(1), d(2))); if (size(a) > 0) read(uin) a
-  end subroutine
-  subroutine rd_i3(a)
-    integer, allocatable, intent(out) :: a(:,:,:)
-    integer :: r, d(4)
-    call hdr(r, d); allocate(a(d(1), d(2), d(3))); if (size(a) > 0) read(uin) a
-  end subroutine
-  subroutine rd_r1(a)
-    real(wp), allocatable, intent(out) :: a(:)
-    integer :: r, d(4)
-    call hdr(r, d); allocate(a(d(1))); if (size(a) > 0) read(uin) a
-  end subroutine
-  subroutine rd_r2(a)
-    real(wp), allocatable, intent(out) :: a(:,:)
-    integer :: r, d(4)
-    call hdr(r, d); allocate(a(d(1), d(2))); if (size(a) > 0) read(uin) a
-  end subroutine
-  subroutine rd_r3(a)
-    real(wp), allocatable, intent(out) :: a(:,:,:)
-    integer :: r, d(4)
-    call hdr(r, d); allocate(a(d(1), d(2), d(3))); if (size(a) > 0) read(uin) a
-  end subroutine
-  subroutine rd_r4(a)
-    real(wp), allocatable, intent(out) :: a(:,:,:,:)
-    integer :: r, d(4)
-    call hdr(r, d); allocate(a(d(1), d(2), d(3), d(4))); if (size(a) > 0) read(uin) a
   end subroutine
 end program ref_load_driver

@@ -197,7 +197,13 @@ Call::Call(const char* n) : name(n) {
   ++g_seq;
   fork_candidate_ = g_fork_valid;  // the previous call left a fork point (it is consumed or dropped by this call)
   g_fork_valid = false;
-  if (!g_pending.empty()) flush_pending_zeros();
+  if (!g_pending.empty()) {
+    // recorded fills are materialised on the library stream, i.e. BEHIND the previous call's kernels; a call forked to the
+    // side stream waits only for what was queued before that previous call, so a fill of one of its outputs could land
+    // after its own stores: a call that had to materialise fills is never forked
+    fork_candidate_ = false;
+    flush_pending_zeros();
+  }
   scratch_reset();
 }
 

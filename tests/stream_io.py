@@ -1,0 +1,104 @@
+"""Flat record streams exchanged with the Fortran test drivers (oracle/mo_raw_stream.F90): a raw k-distribution table
+for the reference's own ``ty_gas_optics_rrtmgp%load`` and an atmosphere for oracle/ref_frontend_driver.F90.
+Every record: tag (32 chars), rank (int32), dims (rank x int32), payload (float64 / int32, Fortran order), or for
+string tables n x 32 chars.  Test infrastructure."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "bin")
+
+
+def _rec(f, tag, arr=None, strings=None, scalar=None, kind=None):
+    f.write(tag.ljust(32).encode()[:32])
+    if strings is not None:
+        f.write(struct.pack("<ii", 1, len(strings)))
+        for s in strings:
+            f.write(s.ljust(32).encode()[:32])
+    elif scalar is not None:
+        f.write(struct.pack("<i", 0))
+        f.write(struct.pack("<d", scalar) if kind == "r" else struct.pack("<i", scalar))
+    else:
+        a = np.asfortranarray(arr)
+        f.write(struct.pack("<i", a.ndim))
+        f.write(struct.pack("<" + "i" * a.ndim, *a.shape))
+        if kind == "r":
+            f.write(np.asfortranarray(a, dtype="<f8").tobytes(order="F"))
+        else:
+            f.write(np.asfortranarray(a, dtype="<i4").tobytes(order="F"))
+
+
+def write_kdist_stream(path, raw, is_lw):
+    """Raw table (rte-rrtmgp_amd/kdist_load.py naming) in the order oracle/mo_raw_stream.F90::load_kdist_stream reads it."""
+    rec = _rec
+    with open(path, "wb") as f:
+        rec(f, "gas_names", strings=raw["gas_names"])
+        rec(f, "key_species", raw["key_species"], kind="i")
+        rec(f, "bnd_limits_gpt", raw["bnd_limits_gpt"], kind="i")
+        rec(f, "bnd_limits_wavenumber", raw["bnd_limits_wavenumber"], kind="r")
+        rec(f, "press_ref", raw["press_ref"], kind="r")
+        rec(f, "temp_ref", raw["temp_ref"], kind="r")
+        for k in ("press_ref_trop", "absorption_coefficient_ref_P", "absorption_coefficient_ref_T"):
+            rec(f, k, scalar=float(raw[k]), kind="r")
+        rec(f, "vmr_ref", raw["vmr_ref"], kind="r")
+        rec(f, "kmajor", raw["kmajor"], kind="r")
+        rec(f, "kminor_lower", raw["kminor_lower"], kind="r")
+        rec(f, "kminor_upper", raw["kminor_upper"], kind="r")
+        for k in ("gas_minor", "identifier_minor", "minor_gases_lower", "minor_gases_upper"):
+            rec(f, k, strings=raw[k])
+        rec(f, "minor_limits_gpt_lower", raw["minor_limits_gpt_lower"], kind="i")
+        rec(f, "minor_limits_gpt_upper", raw["minor_limits_gpt_upper"], kind="i")
+        rec(f, "sd_lower", np.asarray(raw["minor_scales_with_density_lower"]).astype(np.int32), kind="i")
+        rec(f, "sd_upper", np.asarray(raw["minor_scales_with_density_upper"]).astype(np.int32), kind="i")
+        rec(f, "scaling_gas_lower", strings=raw["scaling_gas_lower"])
+        rec(f, "scaling_gas_upper", strings=raw["scaling_gas_upper"])
+        rec(f, "sc_lower", np.asarray(raw["scale_by_complement_lower"]).astype(np.int32), kind="i")
+        rec(f, "sc_upper", np.asarray(raw["scale_by_complement_upper"]).astype(np.int32), kind="i")
+        rec(f, "kminor_start_lower", raw["kminor_start_lower"], kind="i")
+        rec(f, "kminor_start_upper", raw["kminor_start_upper"], kind="i")
+        rec(f, "is_lw", scalar=1 if is_lw else 0, kind="i")
+        if is_lw:
+            rec(f, "totplnk", raw["totplnk"], kind="r")
+            rec(f, "plank_fraction", raw["plank_fraction"], kind="r")
+            rec(f, "optimal_angle_fit", raw["optimal_angle_fit"], kind="r")
+        else:
+            rec(f, "rayl_lower", raw["rayl_lower"], kind="r")
+            rec(f, "rayl_upper", raw["rayl_upper"], kind="r")
+            for k in ("solar_source_quiet", "solar_source_facular", "solar_source_sunspot"):
+                rec(f, k, raw[k], kind="r")
+            for k in ("tsi_default", "mg_default", "sb_default"):
+                rec(f, k, scalar=float(raw[k]), kind="r")
+
+
+def write_atmosphere_stream(path, atm, is_lw, block, use_col_dry=True, use_tlev=True, checks=False, nrep=1, n_gauss=1,
+                            sfc_emis=None, mu0=None, sfc_alb=None):
+    """Atmosphere (rte-rrtmgp_amd/synth.py::Atmosphere) + options for oracle/ref_frontend_driver.F90."""
+    ncol, nlay = atm.play.shape
+    with open(path, "wb") as f:
+        _rec(f, "opts", np.array([ncol, nlay, block, int(use_col_dry), int(use_tlev), int(checks), nrep, n_gauss], np.int32), kind="i")
+        for tag, a in (("p_lay", atm.play), ("p_lev", atm.plev), ("t_lay", atm.tlay), ("t_lev", atm.tlev), ("vmr", atm.vmr),
+                       ("col_dry", atm.col_dry)):
+            _rec(f, tag, a, kind="r")
+        if is_lw:
+            _rec(f, "t_sfc", atm.tsfc, kind="r")
+            _rec(f, "sfc_emis", sfc_emis if sfc_emis is not None else np.full(ncol, 0.98), kind="r")
+        else:
+            _rec(f, "mu0", mu0 if mu0 is not None else np.full(ncol, 0.86), kind="r")
+            _rec(f, "sfc_alb", sfc_alb if sfc_alb is not None else np.full(ncol, 0.06), kind="r")
+
+
+def run_frontend_driver(binary, kfile, afile, ofile, gases, ncol, nlay, is_lw, env=None, timeout=1800):
+    """Run oracle/_ref/bin/<binary>; returns (fluxes dict of (ncol, nlay+1) arrays, stdout)."""
+    path = os.path.join(BIN, binary)
+    # flang keeps automatic arrays on the stack
+    r = subprocess.run(f"ulimit -s unlimited 2>/dev/null; exec '{path}' '{kfile}' '{afile}' '{ofile}' '{','.join(gases)}'",
+                       shell=True, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0 and "ref_frontend_driver ok" in r.stdout, (binary, r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+    raw = np.fromfile(ofile, dtype="<f8")
+    names = ["flux_up", "flux_dn"] + ([] if is_lw else ["flux_dn_dir"])
+    n = ncol * (nlay + 1)
+    assert raw.size == n * len(names), (raw.size, n, names)
+    return {k: raw[i * n:(i + 1) * n].reshape((ncol, nlay + 1), order="F") for i, k in enumerate(names)}, r.stdout

@@ -72,3 +72,98 @@ def test_reference_unit_test_programs_on_the_hip_library(prog):
             return [ln.strip() for ln in s.splitlines() if ln.strip() and "accurate to within" not in ln]
 
         assert strip(r.stdout) == strip(rr.stdout)
+
+
+# ---- the gas-optics frontend end to end ---------------------------------------------------
+# oracle/ref_frontend_driver.F90 (ours): raw table -> the reference's k%load -> k%gas_optics -> rte_lw / rte_sw per block of
+# columns with ty_fluxes_broadband, on host arrays.  ONE object file, linked once against librte_rrtmgp_hip.so (+ shim)
+# and once against the reference's CPU kernels (oracle/build_extern.sh).
+import sys  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+sys.path.insert(0, ROOT)
+import stream_io  # noqa: E402
+from rte_rrtmgp_amd import frontend, kdist_load, synth  # noqa: E402
+
+GASES = list(synth.GAS_NAMES)
+
+
+def _frontend_case(tmp_path, kind, ncol, nlay, block, top_at_1, col_dry, tlev, ngpt=64, nbnd=4, seed=3, checks=True, nrep=1,
+                   n_gauss=1, **raw_kw):
+    raw = kdist_load.synth_raw(kind, ngpt=ngpt, nbnd=nbnd, **raw_kw)
+    kd = kdist_load.init_from_raw(raw, GASES)
+    kd.scalars.pop("gas_names")
+    atm = synth.make_atmosphere(ncol, nlay, seed=seed, kdist=kd, ngas=kd.ngas, top_at_1=top_at_1)
+    kf, af = str(tmp_path / "k.bin"), str(tmp_path / "a.bin")
+    stream_io.write_kdist_stream(kf, raw, kind == "lw")
+    stream_io.write_atmosphere_stream(af, atm, kind == "lw", block=block, use_col_dry=col_dry, use_tlev=tlev, checks=checks,
+                                      nrep=nrep, n_gauss=n_gauss)
+    return raw, kd, atm, kf, af
+
+
+def _have(binary):
+    return os.path.exists(os.path.join(BIN, binary))
+
+
+@pytest.mark.parametrize("kind,top_at_1", [("lw", False), ("lw", True), ("sw", False), ("sw", True)])
+def test_python_mirror_of_the_frontend_matches_the_reference_frontend(kind, top_at_1, tmp_path):
+    """rte-rrtmgp_amd/frontend.py (the call sequence bench.py and the GPU tests drive) on the C oracle against the
+    reference's own Fortran frontend on the reference's CPU kernels: same fluxes, bit for bit."""
+    if not _have("ref_frontend_driver_cpuref"):
+        pytest.skip("oracle/_ref/bin/ref_frontend_driver_cpuref absent (needs /root/reference + flang)")
+    from oracle import oracle as O
+
+    ncol, nlay = 48, 20
+    raw, kd, atm, kf, af = _frontend_case(tmp_path, kind, ncol, nlay, 16, top_at_1, True, True)
+    ref, _ = stream_io.run_frontend_driver("ref_frontend_driver_cpuref", kf, af, str(tmp_path / "o.bin"), GASES, ncol, nlay, kind == "lw")
+    c, xp = O.load_c(), frontend.NumpyArrays()
+    A = xp.asarray
+    go = frontend.GasOptics(c, kd, xp)
+    if kind == "lw":
+        b = go.gas_optics_lw(ncol, nlay, A(atm.play), A(atm.plev), A(atm.tlay), A(atm.tsfc), A(atm.col_gas), A(atm.tlev), atm.top_at_1)
+        r = frontend.rte_lw(c, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"],
+                            xp.full((ncol, kd.ngpt), 0.98), b["sfc_src"])
+        pairs = {"flux_up": "flux_up", "flux_dn": "flux_dn"}
+    else:
+        b = go.gas_optics_sw(ncol, nlay, A(atm.play), A(atm.plev), A(atm.tlay), A(atm.col_gas), A(atm.col_dry))
+        r = frontend.rte_sw(c, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["ssa"], b["g"], xp.full((ncol, nlay), 0.86),
+                            b["toa_src"], xp.full((ncol, kd.ngpt), 0.06), xp.full((ncol, kd.ngpt), 0.06))
+        pairs = {"flux_up": "flux_up", "flux_dn": "flux_dn", "flux_dn_dir": "flux_dir"}
+    for k, kk in pairs.items():
+        assert np.max(np.abs(ref[k] - r[kk])) <= 1e-13 * np.max(np.abs(ref[k])), k
+
+
+F4_CASES = [
+    # kind, top_at_1, col_dry given, tlev given, block size
+    ("lw", False, True, True, 8), ("lw", True, False, False, 8), ("lw", False, False, True, 512), ("lw", True, True, False, 512),
+    ("sw", False, True, True, 8), ("sw", True, False, True, 8), ("sw", False, False, True, 512), ("sw", True, True, True, 512),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,top_at_1,col_dry,tlev,block", F4_CASES)
+@pytest.mark.parametrize("mirror", [False, True], ids=["staged", "host-mirror"])
+def test_reference_gas_optics_frontend_on_the_hip_library(kind, top_at_1, col_dry, tlev, block, mirror, tmp_path):
+    """Row f4: load -> gas_optics (interpolation, zero_array, compute_tau_absorption [, tau_rayleigh], Planck source,
+    col_dry through the Fortran shim) -> rte_lw / rte_sw of the UNCHANGED frontend on librte_rrtmgp_hip.so, against the same
+    program on the reference's CPU kernels: 512 columns x 60 layers, g256 / g224-shaped tables, 8-column blocks (the
+    reference's usage; small-problem kernels) and one 512-column block (production kernels), both vertical orientations,
+    with and without col_dry / tlev.  Tolerance 1e-10 relative to the largest flux (contract: 1e-6)."""
+    assert _have("ref_frontend_driver"), "oracle/_ref/bin/ref_frontend_driver missing: run oracle/build_extern.sh"
+    if not _have("ref_frontend_driver_cpuref"):
+        pytest.skip("reference CPU build of the driver absent")
+    ncol, nlay = 512, 60
+    ngpt, nbnd = (256, 16) if kind == "lw" else (224, 14)
+    raw, kd, atm, kf, af = _frontend_case(tmp_path, kind, ncol, nlay, block, top_at_1, col_dry, tlev, ngpt=ngpt, nbnd=nbnd,
+                                          nminor_lower=4 * nbnd, nminor_upper=2 * nbnd + 3, seed=11)
+    ref, _ = stream_io.run_frontend_driver("ref_frontend_driver_cpuref", kf, af, str(tmp_path / "ref.bin"), GASES, ncol, nlay, kind == "lw")
+    env = {"RTE_HIP_HOST_MIRROR": "1"} if mirror else {"RTE_HIP_HOST_MIRROR": "0"}
+    out, log = stream_io.run_frontend_driver("ref_frontend_driver", kf, af, str(tmp_path / "hip.bin"), GASES, ncol, nlay, kind == "lw", env=env)
+    worst = 0.0
+    for k in ref:
+        assert np.all(np.isfinite(out[k])), k
+        err = float(np.max(np.abs(out[k] - ref[k])) / np.max(np.abs(ref[k])))
+        worst = max(worst, err)
+        assert err <= 1e-10, (k, err)
+    print(f"f4 {kind} top_at_1={top_at_1} col_dry={col_dry} tlev={tlev} block={block} mirror={mirror}: worst {worst:.2e}")

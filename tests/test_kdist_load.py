@@ -16,68 +16,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rte_rrtmgp_amd import frontend, kdist_io, kdist_load, synth  # noqa: E402
+from stream_io import write_kdist_stream as _write_stream  # noqa: E402
 
 DRIVER = os.path.join(ROOT, "oracle", "_ref", "bin", "ref_load_driver")
 ALL = list(kdist_load.FILE_GASES)
 SUBSET = ["h2o", "co2", "o3", "n2o", "co", "ch4", "o2"]  # no n2, ccl4, cfc11: their minor intervals must go
-
-
-def _write_stream(path, raw, is_lw):
-    def rec(f, tag, arr=None, strings=None, scalar=None, kind=None):
-        f.write(tag.ljust(32).encode()[:32])
-        if strings is not None:
-            f.write(struct.pack("<ii", 1, len(strings)))
-            for s in strings:
-                f.write(s.ljust(32).encode()[:32])
-        elif scalar is not None:
-            f.write(struct.pack("<i", 0))
-            f.write(struct.pack("<d", scalar) if kind == "r" else struct.pack("<i", scalar))
-        else:
-            a = np.asfortranarray(arr)
-            f.write(struct.pack("<i", a.ndim))
-            f.write(struct.pack("<" + "i" * a.ndim, *a.shape))
-            if kind == "r":
-                f.write(np.asfortranarray(a, dtype="<f8").tobytes(order="F"))
-            else:
-                f.write(np.asfortranarray(a, dtype="<i4").tobytes(order="F"))
-
-    with open(path, "wb") as f:
-        rec(f, "gas_names", strings=raw["gas_names"])
-        rec(f, "key_species", raw["key_species"], kind="i")
-        rec(f, "bnd_limits_gpt", raw["bnd_limits_gpt"], kind="i")
-        rec(f, "bnd_limits_wavenumber", raw["bnd_limits_wavenumber"], kind="r")
-        rec(f, "press_ref", raw["press_ref"], kind="r")
-        rec(f, "temp_ref", raw["temp_ref"], kind="r")
-        for k in ("press_ref_trop", "absorption_coefficient_ref_P", "absorption_coefficient_ref_T"):
-            rec(f, k, scalar=float(raw[k]), kind="r")
-        rec(f, "vmr_ref", raw["vmr_ref"], kind="r")
-        rec(f, "kmajor", raw["kmajor"], kind="r")
-        rec(f, "kminor_lower", raw["kminor_lower"], kind="r")
-        rec(f, "kminor_upper", raw["kminor_upper"], kind="r")
-        for k in ("gas_minor", "identifier_minor", "minor_gases_lower", "minor_gases_upper"):
-            rec(f, k, strings=raw[k])
-        rec(f, "minor_limits_gpt_lower", raw["minor_limits_gpt_lower"], kind="i")
-        rec(f, "minor_limits_gpt_upper", raw["minor_limits_gpt_upper"], kind="i")
-        rec(f, "sd_lower", np.asarray(raw["minor_scales_with_density_lower"]).astype(np.int32), kind="i")
-        rec(f, "sd_upper", np.asarray(raw["minor_scales_with_density_upper"]).astype(np.int32), kind="i")
-        rec(f, "scaling_gas_lower", strings=raw["scaling_gas_lower"])
-        rec(f, "scaling_gas_upper", strings=raw["scaling_gas_upper"])
-        rec(f, "sc_lower", np.asarray(raw["scale_by_complement_lower"]).astype(np.int32), kind="i")
-        rec(f, "sc_upper", np.asarray(raw["scale_by_complement_upper"]).astype(np.int32), kind="i")
-        rec(f, "kminor_start_lower", raw["kminor_start_lower"], kind="i")
-        rec(f, "kminor_start_upper", raw["kminor_start_upper"], kind="i")
-        rec(f, "is_lw", scalar=1 if is_lw else 0, kind="i")
-        if is_lw:
-            rec(f, "totplnk", raw["totplnk"], kind="r")
-            rec(f, "plank_fraction", raw["plank_fraction"], kind="r")
-            rec(f, "optimal_angle_fit", raw["optimal_angle_fit"], kind="r")
-        else:
-            rec(f, "rayl_lower", raw["rayl_lower"], kind="r")
-            rec(f, "rayl_upper", raw["rayl_upper"], kind="r")
-            for k in ("solar_source_quiet", "solar_source_facular", "solar_source_sunspot"):
-                rec(f, k, raw[k], kind="r")
-            for k in ("tsi_default", "mg_default", "sb_default"):
-                rec(f, k, scalar=float(raw[k]), kind="r")
 
 
 def _read_record(path):
