@@ -46,6 +46,20 @@ class Call {
   template <class T> const T* in(const T* p, size_t n) { return (const T*)stage((void*)p, n * sizeof(T), true, false); }
   template <class T> T* out(T* p, size_t n) { return (T*)stage((void*)p, n * sizeof(T), false, true); }
   template <class T> T* inout(T* p, size_t n) { return (T*)stage((void*)p, n * sizeof(T), true, true); }
+  // host-mirror mode (runtime.hip, rte_hip_host_mirror): an output the caller's HOST code does not read before it hands
+  // it to the next library call (interpolation state, tau, Planck sources, ...) stays on the device -- no copy back --
+  // and is served from there when that host address comes in again.  Without the mode these are out() / inout().
+  // `zero_fill`: if non-null, receives "the array is entirely zero by a recorded zero_array call and has not been
+  // materialised" -- the caller then overwrites instead of accumulating (compute_tau_absorption).
+  template <class T> T* out_lazy(T* p, size_t n) { return (T*)stage((void*)p, n * sizeof(T), false, true, true); }
+  template <class T> T* inout_lazy(T* p, size_t n, bool* zero_fill = nullptr) {
+    return (T*)stage((void*)p, n * sizeof(T), true, true, true, zero_fill);
+  }
+  // zero_array on a host array in host-mirror mode: recorded on the device copy (true) or not handled (false)
+  bool lazy_zero(void* p, size_t bytes);
+  // copy the device-resident arrays last written by the library entry `producer` back to their host addresses at the
+  // end of this call (the reference frontend reads them on the host next)
+  void writeback_produced_by(const char* producer);
   // small host-side copy of an input array that may live on the device (index tables etc.)
   template <class T> const T* host(const T* p, size_t n) { return (const T*)to_host((const void*)p, n * sizeof(T)); }
   bool any_host() const { return n_back_ > 0 || staged_in_; }
@@ -55,7 +69,7 @@ class Call {
   const char* name;
 
  private:
-  void* stage(void* p, size_t bytes, bool copy_in, bool copy_out);
+  void* stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy = false, bool* zero_fill = nullptr);
   const void* to_host(const void* p, size_t bytes);
   struct Back { void* host; void* dev; size_t bytes; };
   Back back_[16];
@@ -65,6 +79,13 @@ class Call {
   void* host_tmp_[24];
   int n_host_tmp_ = 0;
   bool fork_candidate_ = false, forked_ = false;
+  // host-mirror mode: host arrays that get their canaries at the end of the call, device buffers to recycle then
+  struct Lazy { void* host; size_t bytes; unsigned long long magic; };
+  Lazy lazy_[16];
+  int n_lazy_ = 0;
+  struct Recycle { void* dev; size_t cap; };
+  Recycle recycle_[16];
+  int n_recycle_ = 0;
 };
 long call_seq();  // sequence number of the API call in progress (every entry point counts)
 hipStream_t aux_fork();  // second stream inside one call, ordered after everything the call has queued so far (nullptr: off)

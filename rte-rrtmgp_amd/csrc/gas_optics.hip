@@ -2745,13 +2745,13 @@ void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, 
   const Float* d_play = c.in(play, ncl);
   const Float* d_tlay = c.in(tlay, ncl);
   const Float* d_col_gas = c.in(col_gas, ncl * (ngas + 1));
-  int* d_jtemp = c.out(jtemp, ncl);
-  Float* d_fmajor = c.out(fmajor, 8 * ncl * nflav);
-  Float* d_fminor = c.out(fminor, 4 * ncl * nflav);
-  Float* d_col_mix = c.out(col_mix, 2 * ncl * nflav);
-  Bool* d_tropo = c.out(tropo, ncl);
-  int* d_jeta = c.out(jeta, 2 * ncl * nflav);
-  int* d_jpress = c.out(jpress, ncl);
+  int* d_jtemp = c.out_lazy(jtemp, ncl);  // (lazy: host-mirror mode keeps the interpolation state on the device)
+  Float* d_fmajor = c.out_lazy(fmajor, 8 * ncl * nflav);
+  Float* d_fminor = c.out_lazy(fminor, 4 * ncl * nflav);
+  Float* d_col_mix = c.out_lazy(col_mix, 2 * ncl * nflav);
+  Bool* d_tropo = c.out_lazy(tropo, ncl);
+  int* d_jeta = c.out_lazy(jeta, 2 * ncl * nflav);
+  int* d_jpress = c.out_lazy(jpress, ncl);
   dim3 grid(cdiv(ncol, 256), nlay), block(256);
   // masks for the compute_tau_absorption call that follows (InterpMasks): row numbers must fit the mask words
   unsigned* d_masks = nullptr;
@@ -2802,7 +2802,7 @@ static void tau_absorption_impl(
   const int* idx_h2o_ = &idx_h2o;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
   // a deferred zero_array on exactly this buffer turns the accumulate into an overwrite
-  const bool overwrite = rh ? true : rte::take_pending_zero(tau, sizeof(Float) * (size_t)ncol * nlay * ngpt);
+  bool overwrite = rh ? true : rte::take_pending_zero(tau, sizeof(Float) * (size_t)ncol * nlay * ngpt);
   rte::Call c(api_name);
   const size_t ncl = (size_t)ncol * nlay;
   const size_t tn = (size_t)ntemp * neta;
@@ -2828,7 +2828,10 @@ static void tau_absorption_impl(
   const int* d_jeta = c.in(jeta, 2 * ncl * nflav);
   const int* d_jtemp = c.in(jtemp, ncl);
   const int* d_jpress = c.in(jpress, ncl);
-  Float* d_tau = rh ? c.out(tau, ncl * ngpt) : c.inout(tau, ncl * ngpt);
+  // (host-mirror mode: tau stays on the device; a zero_array recorded on its device copy makes this an overwrite too)
+  bool zero_recorded = false;
+  Float* d_tau = rh ? c.out_lazy(tau, ncl * ngpt) : c.inout_lazy(tau, ncl * ngpt, &zero_recorded);
+  overwrite = overwrite || zero_recorded;
   RaylCombine cb{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const Float *d_krayl = nullptr, *d_col_dry = nullptr;
   if (rh) {
@@ -2836,8 +2839,8 @@ static void tau_absorption_impl(
     d_col_dry = c.in(rh->col_dry, ncl);
     if (rh->cld_tau) { cb.cld_tau = c.in(rh->cld_tau, ncl * nbnd); cb.cld_ssa = c.in(rh->cld_ssa, ncl * nbnd); cb.cld_g = c.in(rh->cld_g, ncl * nbnd); }
     cb.tau_abs = d_tau; cb.tau = d_tau;  // the direct kernels combine in place
-    cb.ssa = c.out(rh->ssa, ncl * ngpt);
-    cb.g = c.out(rh->g, ncl * ngpt);
+    cb.ssa = c.out_lazy(rh->ssa, ncl * ngpt);
+    cb.g = c.out_lazy(rh->g, ncl * ngpt);
   }
   hipStream_t st = rte::stream();
   if (!rh && !c.any_host() && rte::is_device_memory(d_tau)) rte::fork_point(d_tau, sizeof(Float) * ncl * ngpt);
@@ -3317,6 +3320,10 @@ static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd
   const Bool* d_tropo = c.in(tropo, ncl);
   const int* d_jtemp = c.in(jtemp, ncl);
   Float* d_tau = combine ? nullptr : c.out(tau_rayleigh, ncl * ngpt);
+  // the reference ABI call: the frontend combines tau and tau_rayleigh on the HOST next (combine_abs_and_rayleigh,
+  // mo_gas_optics_rrtmgp.F90:666-678, :1954-2036), so in host-mirror mode the absorption optical depth the preceding
+  // compute_tau_absorption call left on the device goes back to its host array with this call's output
+  if (!combine) c.writeback_produced_by("rrtmgp_compute_tau_absorption");
   RaylCombine cb{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (combine && cld_tau) {
     cb.cld_tau = c.in(cld_tau, ncl * nbnd); cb.cld_ssa = c.in(cld_ssa, ncl * nbnd); cb.cld_g = c.in(cld_g, ncl * nbnd);
@@ -3445,10 +3452,10 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   const Float* d_pfracin = c.in(pfracin, (size_t)ntemp * neta * (npres + 1) * ngpt);
   const Float* d_totplnk = c.in(totplnk, (size_t)nPlanckTemp * nbnd);
   const int* d_gpoint_flavor = c.in(gpoint_flavor, (size_t)2 * ngpt);
-  Float* d_sfc_src = c.out(sfc_src, (size_t)ncol * ngpt);
-  Float* d_lay_src = c.out(lay_src, ncl * ngpt);
-  Float* d_lev_src = c.out(lev_src, (size_t)ncol * (nlay + 1) * ngpt);
-  Float* d_sfc_jac = c.out(sfc_source_Jac, (size_t)ncol * ngpt);
+  Float* d_sfc_src = c.out_lazy(sfc_src, (size_t)ncol * ngpt);  // (lazy: host-mirror mode keeps the sources on the device)
+  Float* d_lay_src = c.out_lazy(lay_src, ncl * ngpt);
+  Float* d_lev_src = c.out_lazy(lev_src, (size_t)ncol * (nlay + 1) * ngpt);
+  Float* d_sfc_jac = c.out_lazy(sfc_source_Jac, (size_t)ncol * ngpt);
   const Float totplnk_delta_r = (Float)1 / *totplnk_delta;  // :636
   {
     const void* outs[4] = {d_sfc_src, d_lay_src, d_lev_src, d_sfc_jac};

@@ -100,9 +100,10 @@ void increment(const char* name, int ncol, int nlay, int ngpt, Float* tau1, Floa
   IncArgs a;
   a.ncl = ncol * nlay; a.ngpt = ngpt; a.nbnd = nbnd; a.nmom1 = nmom1 > 0 ? nmom1 : 1; a.nmom2 = nmom2 > 0 ? nmom2 : 1;
   a.lims = lims ? c.in(lims, (size_t)2 * nbnd) : nullptr;
-  a.tau1 = c.inout(tau1, n1);
-  a.ssa1 = ssa1 ? c.inout(ssa1, n1) : nullptr;
-  a.g1 = g1 ? c.inout(g1, n1 * a.nmom1) : nullptr;
+  // (lazy: in host-mirror mode the incremented optical properties stay on the device for the solver)
+  a.tau1 = c.inout_lazy(tau1, n1);
+  a.ssa1 = ssa1 ? c.inout_lazy(ssa1, n1) : nullptr;
+  a.g1 = g1 ? c.inout_lazy(g1, n1 * a.nmom1) : nullptr;
   a.tau2 = c.in(tau2, n2);
   a.ssa2 = ssa2 ? c.in(ssa2, n2) : nullptr;
   a.g2 = g2 ? c.in(g2, n2 * a.nmom2) : nullptr;
@@ -129,7 +130,7 @@ void delta_scale(const char* name, int ncol, int nlay, int ngpt, Float* tau, Flo
   const size_t n = (size_t)ncol * nlay * ngpt;
   if (n == 0) return;
   rte::Call c(name);
-  Float *dt = c.inout(tau, n), *ds = c.inout(ssa, n), *dg = c.inout(g, n);
+  Float *dt = c.inout_lazy(tau, n), *ds = c.inout_lazy(ssa, n), *dg = c.inout_lazy(g, n);
   const Float* df = f ? c.in(f, n) : nullptr;
   rte::ProfScope p("delta_scale_kernel");
   hipLaunchKernelGGL(delta_scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, dt, ds, dg, df);

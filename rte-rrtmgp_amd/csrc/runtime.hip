@@ -6,6 +6,10 @@
 //   device pointer -> the kernel is launched in place, asynchronously, on the library stream;
 //   host pointer   -> the array is staged through the scratch arena (H2D before, D2H after) and
 //                     the call returns only after the stream has drained (functional mode).
+#include <fcntl.h>
+#include <string.h>
+#include <unistd.h>
+
 #include <mutex>
 #include <string>
 #include <vector>
@@ -188,8 +192,154 @@ void flush_pending_zeros() {
   g_pending.clear();
 }
 
-// ---- Call ---------------------------------------------------------------------------------------
 static long g_seq = 0;
+// ---- host-mirror mode (opt-in: rte_hip_host_mirror(1) or RTE_HIP_HOST_MIRROR=1) ---------------------------------
+// The unchanged Fortran frontend passes pageable HOST arrays.  Staged naively, every call copies its inputs up and its
+// outputs back, so the interpolation state, tau and the Planck sources (0.95 MB per column) cross PCIe twice although
+// no host code ever looks at them between gas_optics and rte_lw.  In this mode the outputs that entry points mark as
+// lazy (Call::out_lazy / inout_lazy: arrays the reference frontend only hands on to the next kernel) stay on the device:
+//   * the device copy ("mirror") is keyed by the host address range; the host array is NOT written;
+//   * a later call that receives that range (or a part of it) as an argument is served from the device copy;
+//   * to notice that the host reused or overwrote the memory in between (Fortran automatic / allocatable arrays come
+//     back at the same addresses), a few 16-byte CANARIES are written into the host array when the mirror is made --
+//     its contents are unspecified until a write-back anyway -- and verified, through /proc/self/mem so that a freed
+//     and unmapped range cannot fault, before the mirror is trusted.  A host program that filled the array in between
+//     has destroyed them: the mirror is dropped and the host contents are staged as usual;
+//   * small outputs (fluxes, col_dry, by-band and broadband reductions: everything an entry point does not mark lazy)
+//     are copied back before the call returns, exactly as without the mode;
+//   * rte_hip_writeback(ptr) copies a mirrored array back to the host on request; mirrors that are neither used nor
+//     written back within g_mirror_max_age library calls are dropped (their host arrays are usually gone by then).
+// Contract of the mode: host code does not READ a lazily held array before writing it back, and does not write PART of
+// one.  The reference's clear-sky / all-sky LW frontend satisfies it; its SW gas optics combines tau and tau_rayleigh on
+// the host (mo_gas_optics_rrtmgp.F90:1954-2036), so compute_tau_rayleigh writes both back (writeback_produced_by).
+struct Mirror {
+  char* host; size_t bytes;
+  char* dev; size_t cap;
+  long last_use;
+  unsigned long long magic;
+  const char* producer;
+  bool zero_pending;  // entirely zero by a recorded zero_array; the device copy has not been filled yet
+};
+static std::vector<Mirror> g_mirrors;
+struct FreeBuf { char* dev; size_t cap; };
+static std::vector<FreeBuf> g_mirror_free;
+static int g_mirror_mode = -1;          // -1: take RTE_HIP_HOST_MIRROR at the first call
+static size_t g_mirror_total = 0;       // device bytes held by mirrors and the free list
+static size_t g_mirror_limit = 0;
+static long g_mirror_max_age = 64;
+static int g_procmem_fd = -2;
+static unsigned long long g_magic_state = 0x9E3779B97F4A7C15ull;
+static hipEvent_t g_ev_h2d = nullptr;
+static long long g_mstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hits, mirrors made, H2D bytes, D2H bytes, dropped (host changed), dropped (overlap), aged out, zero fills elided
+constexpr int kCanaries = 34;
+constexpr size_t kLazyMinBytes = 4096;
+
+static bool mirror_on() {
+  if (g_mirror_mode < 0) {
+    const char* e = getenv("RTE_HIP_HOST_MIRROR");
+    g_mirror_mode = (e && atoi(e) > 0) ? 1 : 0;
+    if (const char* a = getenv("RTE_HIP_MIRROR_MAX_AGE")) g_mirror_max_age = atol(a) > 0 ? atol(a) : g_mirror_max_age;
+  }
+  return g_mirror_mode == 1;
+}
+static size_t canary_offset(size_t bytes, int k) {
+  if (k == kCanaries - 1) return bytes - 16;
+  return ((bytes - 16) / (kCanaries - 1) * (size_t)k) & ~size_t(7);
+}
+static void canary_value(unsigned long long magic, int k, unsigned long long v[2]) {
+  v[0] = magic ^ (0xD1B54A32D192ED03ull * (unsigned long long)(k + 1));
+  v[1] = ~v[0];
+}
+static void write_canaries(void* host, size_t bytes, unsigned long long magic) {
+  for (int k = 0; k < kCanaries; ++k) {
+    unsigned long long v[2];
+    canary_value(magic, k, v);
+    memcpy((char*)host + canary_offset(bytes, k), v, 16);
+  }
+}
+// are the canaries of `m` still in host memory?  Reads go through /proc/self/mem: a range that has been freed and unmapped
+// gives an error instead of a fault.
+static bool canaries_intact(const Mirror& m) {
+  if (g_procmem_fd == -2) g_procmem_fd = open("/proc/self/mem", O_RDONLY | O_CLOEXEC);
+  if (g_procmem_fd < 0) return false;  // cannot verify: never trust
+  for (int k = 0; k < kCanaries; ++k) {
+    unsigned long long v[2], w[2];
+    canary_value(m.magic, k, v);
+    if (pread(g_procmem_fd, w, 16, (off_t)(uintptr_t)(m.host + canary_offset(m.bytes, k))) != 16) return false;
+    if (w[0] != v[0] || w[1] != v[1]) return false;
+  }
+  return true;
+}
+// marks "the host-to-device copies queued so far": in host-mirror mode a call with staged inputs only waits for THIS, not
+// for its kernels (every in()/out() conversion precedes the call's first launch)
+static void mark_h2d() {
+  if (!g_ev_h2d) HIP_CHECK(hipEventCreateWithFlags(&g_ev_h2d, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(g_ev_h2d, g_stream));
+}
+static void mirror_release_buffer(char* dev, size_t cap) { g_mirror_free.push_back(FreeBuf{dev, cap}); }
+static void mirror_trim_free_list() {
+  if (g_mirror_free.empty()) return;
+  HIP_CHECK(hipStreamSynchronize(g_stream));  // kernels of earlier calls may still use them
+  for (auto& f : g_mirror_free) { HIP_CHECK(hipFree(f.dev)); g_mirror_total -= f.cap; }
+  g_mirror_free.clear();
+}
+static char* mirror_alloc(size_t bytes, size_t* cap_out) {
+  size_t best = (size_t)-1;
+  for (size_t i = 0; i < g_mirror_free.size(); ++i) {
+    const size_t cap = g_mirror_free[i].cap;
+    if (cap >= bytes && cap <= bytes + bytes / 4 + (size_t(1) << 20) && (best == (size_t)-1 || cap < g_mirror_free[best].cap)) best = i;
+  }
+  if (best != (size_t)-1) {
+    FreeBuf f = g_mirror_free[best];
+    g_mirror_free.erase(g_mirror_free.begin() + best);
+    *cap_out = f.cap;
+    return f.dev;
+  }
+  if (g_mirror_limit == 0) {
+    if (const char* e = getenv("RTE_HIP_MIRROR_MAX_GB")) g_mirror_limit = (size_t)(atof(e) * 1073741824.0);
+    if (g_mirror_limit == 0) {
+      size_t fr = 0, tot = 0;
+      HIP_CHECK(hipMemGetInfo(&fr, &tot));
+      g_mirror_limit = fr / 10 * 6;
+    }
+  }
+  const size_t cap = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+  if (g_mirror_total + cap > g_mirror_limit) mirror_trim_free_list();
+  char* d = nullptr;
+  HIP_CHECK(hipMalloc((void**)&d, cap));
+  g_mirror_total += cap;
+  *cap_out = cap;
+  return d;
+}
+static void mirror_drop(size_t i) {
+  mirror_release_buffer(g_mirrors[i].dev, g_mirrors[i].cap);
+  g_mirrors.erase(g_mirrors.begin() + i);
+}
+static void mirror_age_out() {
+  for (size_t i = g_mirrors.size(); i-- > 0;)
+    if (g_seq - g_mirrors[i].last_use > g_mirror_max_age) { mirror_drop(i); ++g_mstat[6]; }
+}
+static void mirror_drop_all() {
+  while (!g_mirrors.empty()) mirror_drop(g_mirrors.size() - 1);
+  mirror_trim_free_list();
+}
+// the mirror that CONTAINS [p, p+bytes) with its canaries intact (index), or -1; mirrors that merely overlap the range, or
+// whose host memory was changed, are dropped on the way (the host reused the memory)
+static long mirror_find(const char* p, size_t bytes) {
+  long hit = -1;
+  for (size_t i = g_mirrors.size(); i-- > 0;) {
+    Mirror& m = g_mirrors[i];
+    if (p + bytes <= m.host || m.host + m.bytes <= p) continue;
+    const bool contained = m.host <= p && p + bytes <= m.host + m.bytes;
+    if (contained && hit < 0 && canaries_intact(m)) { hit = (long)i; continue; }
+    ++g_mstat[contained ? 4 : 5];
+    mirror_drop(i);
+    if (hit > (long)i) --hit;
+  }
+  return hit;
+}
+
+// ---- Call ---------------------------------------------------------------------------------------
 long call_seq() { return g_seq; }  // number of the current (innermost) API call
 
 Call::Call(const char* n) : name(n) {
@@ -205,6 +355,7 @@ Call::Call(const char* n) : name(n) {
     flush_pending_zeros();
   }
   scratch_reset();
+  if (mirror_on() && !g_mirrors.empty()) mirror_age_out();
 }
 
 // Move the rest of this call (launches, scratch, timing events) to the side stream if that is safe: nothing of this
@@ -224,22 +375,100 @@ bool Call::try_fork(const void* const* outs, const size_t* bytes, int n) {
   return true;
 }
 
-void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out) {
+void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy, bool* zero_fill) {
+  if (zero_fill) *zero_fill = false;
   if (!p || bytes == 0) return p;
   void* dv;
   const int kind = classify(p, &dv);
   if (kind == 1) return p;
   if (kind == 2) { host_visible_ = true; return dv; }  // in place, but synchronous for the caller (see ~Call)
+  if (mirror_on()) {
+    const long hit = mirror_find((const char*)p, bytes);
+    if (hit >= 0) {
+      Mirror& m = g_mirrors[(size_t)hit];
+      m.last_use = g_seq;
+      ++g_mstat[0];
+      char* d = m.dev + ((const char*)p - m.host);
+      if (m.zero_pending) {
+        if (zero_fill && copy_out && lazy && bytes == m.bytes) { *zero_fill = true; ++g_mstat[7]; }  // the caller overwrites all of it
+        else HIP_CHECK(hipMemsetAsync(m.dev, 0, m.bytes, g_stream));
+        m.zero_pending = false;
+      }
+      if (!copy_out) return d;                        // input: served from the device copy
+      if (lazy) { m.producer = name; return d; }      // written again on the device; the host copy stays unspecified
+      // an output the caller reads on the host lies inside a mirrored range: the whole array goes back and the mirror ends
+      if (n_back_ >= 16 || n_recycle_ >= 16) { fprintf(stderr, "rte_rrtmgp_hip: too many staged outputs\n"); abort(); }
+      back_[n_back_++] = Back{m.host, m.dev, m.bytes};
+      recycle_[n_recycle_++] = Recycle{m.dev, m.cap};
+      g_mirrors.erase(g_mirrors.begin() + hit);
+      return d;
+    }
+    if (copy_out && lazy && bytes >= kLazyMinBytes && n_lazy_ < 16) {
+      size_t cap = 0;
+      char* d = mirror_alloc(bytes, &cap);
+      if (copy_in) {
+        HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, g_stream));
+        staged_in_ = true;
+        g_mstat[2] += (long long)bytes;
+        mark_h2d();
+      }
+      g_magic_state = g_magic_state * 6364136223846793005ull + 1442695040888963407ull;
+      Mirror m{(char*)p, bytes, d, cap, g_seq, g_magic_state ^ (unsigned long long)(uintptr_t)p, name, false};
+      g_mirrors.push_back(m);
+      lazy_[n_lazy_++] = Lazy{p, bytes, m.magic};
+      ++g_mstat[1];
+      return d;
+    }
+  }
   void* d = scratch(bytes);
   if (copy_in) {
     HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, g_stream));
     staged_in_ = true;
+    g_mstat[2] += (long long)bytes;
+    if (g_mirror_mode == 1) mark_h2d();
   }
   if (copy_out) {
     if (n_back_ >= 16) { fprintf(stderr, "rte_rrtmgp_hip: too many staged outputs\n"); abort(); }
     back_[n_back_++] = Back{p, d, bytes};
   }
   return d;
+}
+
+bool Call::lazy_zero(void* p, size_t bytes) {
+  void* dv;
+  if (!mirror_on() || !p || bytes < kLazyMinBytes || classify(p, &dv) != 0) return false;
+  const long hit = mirror_find((const char*)p, bytes);
+  if (hit >= 0) {
+    Mirror& m = g_mirrors[(size_t)hit];
+    m.last_use = g_seq;
+    m.producer = name;
+    ++g_mstat[0];
+    if (bytes == m.bytes) m.zero_pending = true;  // whole array: recorded, filled only if somebody reads it
+    else HIP_CHECK(hipMemsetAsync(m.dev + ((const char*)p - m.host), 0, bytes, g_stream));
+    return true;
+  }
+  if (n_lazy_ >= 16) return false;
+  size_t cap = 0;
+  char* d = mirror_alloc(bytes, &cap);
+  g_magic_state = g_magic_state * 6364136223846793005ull + 1442695040888963407ull;
+  Mirror m{(char*)p, bytes, d, cap, g_seq, g_magic_state ^ (unsigned long long)(uintptr_t)p, name, true};
+  g_mirrors.push_back(m);
+  lazy_[n_lazy_++] = Lazy{p, bytes, m.magic};
+  ++g_mstat[1];
+  return true;
+}
+
+void Call::writeback_produced_by(const char* producer) {
+  if (!mirror_on()) return;
+  for (size_t i = g_mirrors.size(); i-- > 0;) {
+    Mirror& m = g_mirrors[i];
+    if (strcmp(m.producer, producer) != 0 || g_seq - m.last_use > 8) continue;
+    if (n_back_ >= 16 || n_recycle_ >= 16) break;
+    if (m.zero_pending) { HIP_CHECK(hipMemsetAsync(m.dev, 0, m.bytes, g_stream)); m.zero_pending = false; }
+    back_[n_back_++] = Back{m.host, m.dev, m.bytes};
+    recycle_[n_recycle_++] = Recycle{m.dev, m.cap};
+    g_mirrors.erase(g_mirrors.begin() + i);
+  }
 }
 
 const void* Call::to_host(const void* p, size_t bytes) {
@@ -256,10 +485,18 @@ const void* Call::to_host(const void* p, size_t bytes) {
 }
 
 Call::~Call() {
-  for (int i = 0; i < n_back_; ++i)
+  const bool mirror = g_mirror_mode == 1;
+  for (int i = 0; i < n_back_; ++i) {
     HIP_CHECK(hipMemcpyAsync(back_[i].host, back_[i].dev, back_[i].bytes, hipMemcpyDeviceToHost, g_stream));
-  // host arrays (staged, or host-visible memory used in place): the caller owns them again when the call returns
-  if (n_back_ > 0 || staged_in_ || host_visible_) HIP_CHECK(hipStreamSynchronize(g_stream));
+    g_mstat[3] += (long long)back_[i].bytes;
+  }
+  // host arrays (staged, or host-visible memory used in place): the caller owns them again when the call returns.
+  // In host-mirror mode a call that staged inputs only waits for those copies (mark_h2d), not for its kernels: they run
+  // while the host program prepares the next call.
+  if (n_back_ > 0 || host_visible_ || (staged_in_ && !mirror)) HIP_CHECK(hipStreamSynchronize(g_stream));
+  else if (staged_in_) HIP_CHECK(hipEventSynchronize(g_ev_h2d));
+  for (int i = 0; i < n_lazy_; ++i) write_canaries(lazy_[i].host, lazy_[i].bytes, lazy_[i].magic);
+  for (int i = 0; i < n_recycle_; ++i) mirror_release_buffer((char*)recycle_[i].dev, recycle_[i].cap);
   for (int i = 0; i < n_host_tmp_; ++i) free(host_tmp_[i]);
   if (forked_) {  // join: the library stream (and whatever is queued on it from now on) waits for this call
     HIP_CHECK(hipEventRecord(g_ev_join, g_side));
@@ -360,6 +597,45 @@ int rte_hip_aux_stream(int on) {
   rte::g_aux_on = on != 0;
   return 0;
 }
+// host-mirror mode (see runtime.hip): 1 = outputs marked lazy stay on the device, 0 = off (mirrors are dropped, NOT
+// written back: call rte_hip_writeback first for arrays the host still needs)
+int rte_hip_host_mirror(int on) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::flush_pending_zeros();
+  if (!on) rte::mirror_drop_all();
+  rte::g_mirror_mode = on ? 1 : 0;
+  return 0;
+}
+// copy the device-resident array that contains host address `p` back to the host (whole array) and end its mirror;
+// returns 1 if one was written, 0 if the address is not mirrored (the host copy is current)
+int rte_hip_writeback(const void* p) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  const long hit = rte::mirror_find((const char*)p, 1);
+  if (hit < 0) return 0;
+  rte::Mirror m = rte::g_mirrors[(size_t)hit];
+  if (m.zero_pending) HIP_CHECK(hipMemsetAsync(m.dev, 0, m.bytes, rte::g_stream));
+  HIP_CHECK(hipMemcpyAsync(m.host, m.dev, m.bytes, hipMemcpyDeviceToHost, rte::g_stream));
+  HIP_CHECK(hipStreamSynchronize(rte::g_stream));
+  rte::g_mstat[3] += (long long)m.bytes;
+  rte::mirror_drop((size_t)hit);
+  return 1;
+}
+int rte_hip_mirror_drop_all(void) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  rte::mirror_drop_all();
+  return 0;
+}
+// counters of the host-staging path: 0 mirror hits, 1 mirrors made, 2 host-to-device bytes, 3 device-to-host bytes,
+// 4 mirrors dropped because the host memory had changed, 5 dropped for overlap, 6 aged out, 7 zero fills elided,
+// 8 live mirrors, 9 device bytes held; which < 0 resets
+long long rte_hip_mirror_stat(int which) {
+  std::lock_guard<std::recursive_mutex> l(rte::g_mutex);
+  if (which < 0) { for (auto& v : rte::g_mstat) v = 0; return 0; }
+  if (which < 8) return rte::g_mstat[which];
+  if (which == 8) return (long long)rte::g_mirrors.size();
+  if (which == 9) return (long long)rte::g_mirror_total;
+  return -1;
+}
 int rte_hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -403,6 +679,7 @@ int rte_hip_release(void) {
   HIP_CHECK(hipStreamSynchronize(rte::g_stream));
   if (rte::g_side) HIP_CHECK(hipStreamSynchronize(rte::g_side));
   if (rte::g_aux) HIP_CHECK(hipStreamSynchronize(rte::g_aux));
+  rte::mirror_drop_all();
   rte::release_gas_optics_buffers();
   for (auto* v : {&rte::g_blocks_main, &rte::g_blocks_side}) {
     for (auto& b : *v) HIP_CHECK(hipFree(b.base));

@@ -24,7 +24,8 @@ void fill(const char* name, Float* a, size_t n, Float v) {
     return;
   }
   rte::Call c(name);
-  Float* d = c.out(a, n);
+  if (v == (Float)0 && c.lazy_zero(a, n * sizeof(Float))) return;  // host-mirror mode: recorded on the device copy
+  Float* d = v == (Float)0 ? c.out_lazy(a, n) : c.out(a, n);
   rte::ProfScope p("fill_kernel");
   if (v == (Float)0) {
     HIP_CHECK(hipMemsetAsync(d, 0, n * sizeof(Float), rte::stream()));
