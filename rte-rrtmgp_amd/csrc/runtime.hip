@@ -10,6 +10,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -231,6 +232,19 @@ static int g_procmem_fd = -2;
 static unsigned long long g_magic_state = 0x9E3779B97F4A7C15ull;
 static hipEvent_t g_ev_h2d = nullptr;
 static long long g_mstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hits, mirrors made, H2D bytes, D2H bytes, dropped (host changed), dropped (overlap), aged out, zero fills elided
+// host wall-clock spent inside the library's host-array path (RTE_HIP_STAGING_REPORT=1 prints it when the process ends)
+static double g_t_call = 0, g_t_h2d = 0, g_t_wait = 0, g_t_find = 0;
+static long g_n_calls = 0;
+static std::chrono::steady_clock::time_point g_call_t0;
+static inline double secs_since(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+static void staging_report() {
+  fprintf(stderr, "rte_rrtmgp_hip staging report: %ld calls, %.3f s inside the library (host-to-device copies %.3f s for %.3f GB, "
+          "waits + device-to-host %.3f s for %.3f GB, mirror look-ups %.3f s); mirrors made %lld, hits %lld, dropped %lld + %lld, aged %lld, "
+          "zero fills elided %lld, device bytes held %.2f GB\n", g_n_calls, g_t_call, g_t_h2d, g_mstat[2] * 1e-9, g_t_wait, g_mstat[3] * 1e-9,
+          g_t_find, g_mstat[1], g_mstat[0], g_mstat[4], g_mstat[5], g_mstat[6], g_mstat[7], g_mirror_total * 1e-9);
+}
 constexpr int kCanaries = 34;
 constexpr size_t kLazyMinBytes = 4096;
 
@@ -238,6 +252,7 @@ static bool mirror_on() {
   if (g_mirror_mode < 0) {
     const char* e = getenv("RTE_HIP_HOST_MIRROR");
     g_mirror_mode = (e && atoi(e) > 0) ? 1 : 0;
+    if (const char* r = getenv("RTE_HIP_STAGING_REPORT")) if (atoi(r) > 0) atexit(staging_report);
     if (const char* a = getenv("RTE_HIP_MIRROR_MAX_AGE")) g_mirror_max_age = atol(a) > 0 ? atol(a) : g_mirror_max_age;
   }
   return g_mirror_mode == 1;
@@ -345,6 +360,8 @@ long call_seq() { return g_seq; }  // number of the current (innermost) API call
 Call::Call(const char* n) : name(n) {
   g_mutex.lock();
   ++g_seq;
+  ++g_n_calls;
+  g_call_t0 = std::chrono::steady_clock::now();
   fork_candidate_ = g_fork_valid;  // the previous call left a fork point (it is consumed or dropped by this call)
   g_fork_valid = false;
   if (!g_pending.empty()) {
@@ -383,7 +400,9 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
   if (kind == 1) return p;
   if (kind == 2) { host_visible_ = true; return dv; }  // in place, but synchronous for the caller (see ~Call)
   if (mirror_on()) {
+    const auto tf = std::chrono::steady_clock::now();
     const long hit = mirror_find((const char*)p, bytes);
+    g_t_find += secs_since(tf);
     if (hit >= 0) {
       Mirror& m = g_mirrors[(size_t)hit];
       m.last_use = g_seq;
@@ -407,7 +426,9 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
       size_t cap = 0;
       char* d = mirror_alloc(bytes, &cap);
       if (copy_in) {
+        const auto t0 = std::chrono::steady_clock::now();
         HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, g_stream));
+        g_t_h2d += secs_since(t0);
         staged_in_ = true;
         g_mstat[2] += (long long)bytes;
         mark_h2d();
@@ -422,7 +443,9 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
   }
   void* d = scratch(bytes);
   if (copy_in) {
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, g_stream));
+    g_t_h2d += secs_since(t0);
     staged_in_ = true;
     g_mstat[2] += (long long)bytes;
     if (g_mirror_mode == 1) mark_h2d();
@@ -486,6 +509,7 @@ const void* Call::to_host(const void* p, size_t bytes) {
 
 Call::~Call() {
   const bool mirror = g_mirror_mode == 1;
+  const auto tw = std::chrono::steady_clock::now();
   for (int i = 0; i < n_back_; ++i) {
     HIP_CHECK(hipMemcpyAsync(back_[i].host, back_[i].dev, back_[i].bytes, hipMemcpyDeviceToHost, g_stream));
     g_mstat[3] += (long long)back_[i].bytes;
@@ -495,6 +519,7 @@ Call::~Call() {
   // while the host program prepares the next call.
   if (n_back_ > 0 || host_visible_ || (staged_in_ && !mirror)) HIP_CHECK(hipStreamSynchronize(g_stream));
   else if (staged_in_) HIP_CHECK(hipEventSynchronize(g_ev_h2d));
+  g_t_wait += secs_since(tw);
   for (int i = 0; i < n_lazy_; ++i) write_canaries(lazy_[i].host, lazy_[i].bytes, lazy_[i].magic);
   for (int i = 0; i < n_recycle_; ++i) mirror_release_buffer((char*)recycle_[i].dev, recycle_[i].cap);
   for (int i = 0; i < n_host_tmp_; ++i) free(host_tmp_[i]);
@@ -508,6 +533,7 @@ Call::~Call() {
     fprintf(stderr, "rte_rrtmgp_hip: %s: launch error: %s\n", name, hipGetErrorString(e));
     abort();
   }
+  g_t_call += secs_since(g_call_t0);
   g_mutex.unlock();
 }
 

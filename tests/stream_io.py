@@ -10,6 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "oracle", "_ref", "bin")
+last_stderr = ""
 
 
 def _rec(f, tag, arr=None, strings=None, scalar=None, kind=None):
@@ -96,6 +97,8 @@ def run_frontend_driver(binary, kfile, afile, ofile, gases, ncol, nlay, is_lw, e
     # flang keeps automatic arrays on the stack
     r = subprocess.run(f"ulimit -s unlimited 2>/dev/null; exec '{path}' '{kfile}' '{afile}' '{ofile}' '{','.join(gases)}'",
                        shell=True, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
+    global last_stderr
+    last_stderr = r.stderr
     assert r.returncode == 0 and "ref_frontend_driver ok" in r.stdout, (binary, r.returncode, r.stdout[-3000:], r.stderr[-3000:])
     raw = np.fromfile(ofile, dtype="<f8")
     names = ["flux_up", "flux_dn"] + ([] if is_lw else ["flux_dn_dir"])

@@ -155,8 +155,10 @@ def test_reference_gas_optics_frontend_on_the_hip_library(kind, top_at_1, col_dr
         pytest.skip("reference CPU build of the driver absent")
     ncol, nlay = 512, 60
     ngpt, nbnd = (256, 16) if kind == "lw" else (224, 14)
+    # host-mirror mode needs the frontend's value checks off (rte_config_checks, rte/frontend/mo_rte_config.F90:25-49): they
+    # scan tau on the HOST (optical_props%validate, mo_rte_lw.F90:330), which the mode leaves on the device
     raw, kd, atm, kf, af = _frontend_case(tmp_path, kind, ncol, nlay, block, top_at_1, col_dry, tlev, ngpt=ngpt, nbnd=nbnd,
-                                          nminor_lower=4 * nbnd, nminor_upper=2 * nbnd + 3, seed=11)
+                                          nminor_lower=4 * nbnd, nminor_upper=2 * nbnd + 3, seed=11, checks=not mirror)
     ref, _ = stream_io.run_frontend_driver("ref_frontend_driver_cpuref", kf, af, str(tmp_path / "ref.bin"), GASES, ncol, nlay, kind == "lw")
     env = {"RTE_HIP_HOST_MIRROR": "1"} if mirror else {"RTE_HIP_HOST_MIRROR": "0"}
     out, log = stream_io.run_frontend_driver("ref_frontend_driver", kf, af, str(tmp_path / "hip.bin"), GASES, ncol, nlay, kind == "lw", env=env)

@@ -33,14 +33,17 @@ for mode in modes:
             fl, out = stream_io.run_frontend_driver("ref_frontend_driver_cpuref", kf, af, of, gases, n, nlay, kind == "lw")
         else:
             stream_io.write_atmosphere_stream(af, atm, kind == "lw", block=bs, checks=False, nrep=3)
-            env = {"RTE_HIP_HOST_MIRROR": "1" if mode == "mirror" else "0"}
+            env = {"RTE_HIP_HOST_MIRROR": "1" if mode == "mirror" else "0", "RTE_HIP_STAGING_REPORT": "1"}
             t0 = time.time()
             fl, out = stream_io.run_frontend_driver("ref_frontend_driver", kf, af, of, gases, ncol, nlay, kind == "lw", env=env)
-            if ref is None:
-                ref = fl
-            else:
-                for k in fl:
-                    assert np.array_equal(fl[k], ref[k]), (mode, bs, k, float(np.max(np.abs(fl[k] - ref[k]))))
+            ref = ref or {}
+            if bs not in ref:
+                ref[bs] = fl
+            for k in fl:  # same block size -> same kernels and reduction order: the modes must agree bit for bit
+                assert np.array_equal(fl[k], ref[bs][k]), (mode, bs, k, float(np.max(np.abs(fl[k] - ref[bs][k]))))
         best = [ln for ln in out.splitlines() if "best columns/s" in ln][0].split(":")[1].strip()
         passes = " | ".join(ln.split(":")[1].strip() for ln in out.splitlines() if ln.startswith("pass"))
+        rep = [ln for ln in getattr(stream_io, "last_stderr", "").splitlines() if "staging report" in ln]
+        if rep:
+            print("   ", rep[0])
         print(f"{kind} {mode:7s} block {bs:6d}: best {float(best):12.0f} columns/s   ({passes}; wall {time.time()-t0:.1f} s)", flush=True)
