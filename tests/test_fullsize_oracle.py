@@ -1,0 +1,127 @@
+"""BASELINE.json's configurations at their OWN sizes against the checker, elementwise:
+
+  configs[0]  100 x 60 x 256 LW           vs a committed fixture made by the REFERENCE kernels (tests/golden/config0_lw.npz)
+  configs[1]  1e5 x 60 x 256 LW           vs the reference kernels (oracle/_ref, else the C oracle) run over the SAME 1e5
+  configs[2]  1e5 x 60 x 224 SW 2-stream     columns on all usable cores in 32-column blocks (tests/ref_pool.py), broadband
+  configs[3]  1e5 x 72 all-sky LW + SW       fluxes compared value by value
+  (configs[4] is configs[1] sharded: tests/test_scale.py, tests/test_sharding_gloo.py)
+
+The HIP side runs exactly what bench.py times: device-resident arrays, the production kernels, the bench's opt-in
+modes (deferred zero fill, shared geometry, one-pass SW gas optics).  Tolerance: 1e-8 elementwise relative (floor 1e-6 of
+the largest flux); the contract of BASELINE.json is 1e-6.  CPU part: the C oracle against the config[0] fixture."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_config0_golden as c0  # noqa: E402
+import ref_pool  # noqa: E402
+from rte_rrtmgp_amd import frontend, synth  # noqa: E402
+
+NCOL = 100000
+TOL = 1e-8
+
+
+def _elem(a, b):
+    floor = 1e-6 * float(np.max(np.abs(b)))
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def _check_config0(lib, xp, block, tol):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "config0_lw.npz"))
+    kd, atm = c0.inputs()
+    assert str(z["__digest__"]) == c0.digest(kd, atm), "fixture was made from different inputs"
+    up, dn = c0.run(lib, xp, kd, atm, block)
+    e = max(_elem(up, z["flux_up"]), _elem(dn, z["flux_dn"]))
+    assert e <= tol, e
+    return e
+
+
+def test_c_oracle_matches_the_config0_fixture():
+    from oracle import oracle as O
+
+    e = _check_config0(O.load_c(), frontend.NumpyArrays(), 8, 1e-13)
+    print(f"configs[0] C oracle vs reference fixture: {e:.2e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block", [8, 100], ids=["blocks-of-8", "one-call"])
+def test_config0_rfmip_like_100_columns_against_the_reference_fixture(block):
+    from rte_rrtmgp_amd import hiplib
+
+    e = _check_config0(hiplib.load(), frontend.TorchArrays("cuda:0"), block, TOL)
+    print(f"configs[0] HIP (block {block}) vs reference fixture: worst elementwise relative error {e:.2e}")
+
+
+def _opt_ins(hip, on):
+    from rte_rrtmgp_amd import hiplib
+
+    hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 1 if on else 0)
+    hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 1 if on else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["lw", "sw", "allsky"])
+def test_full_size_config_against_the_reference_kernels(workload):
+    import torch
+    from rte_rrtmgp_amd import hiplib
+
+    hip = hiplib.load()
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    nlay = 72 if workload == "allsky" else 60
+    kd = synth.make_kdist("sw" if workload == "sw" else "lw")
+    atm = synth.make_atmosphere(NCOL, nlay, seed=42, kdist=kd)  # bench.py's atmosphere
+    clouds = synth.make_cloud_field(atm, synth.make_cloud_optics(kd.nbnd)) if workload == "allsky" else None
+    t0 = time.time()
+    ref = ref_pool.run(workload, atm, nlay, clouds=clouds)
+    t_ref = time.time() - t0
+    a = {k: A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry")}
+    a["top_at_1"] = atm.top_at_1
+    out = {}
+    _opt_ins(hip, True)
+    try:
+        if workload == "lw":
+            go = frontend.GasOptics(hip, kd, xp)
+            b = go.gas_optics_lw(NCOL, nlay, a["play"], a["plev"], a["tlay"], a["tsfc"], a["col_gas"], a["tlev"], atm.top_at_1)
+            r = frontend.rte_lw(hip, xp, NCOL, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"],
+                                xp.full((NCOL, kd.ngpt), 0.98), b["sfc_src"])
+            out = {"up": r["flux_up"], "dn": r["flux_dn"]}
+        elif workload == "sw":
+            go = frontend.GasOptics(hip, kd, xp)
+            b = go.gas_optics_sw(NCOL, nlay, a["play"], a["plev"], a["tlay"], a["col_gas"], a["col_dry"], fuse_rayleigh="all")
+            r = frontend.rte_sw(hip, xp, NCOL, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["ssa"], b["g"], xp.full((NCOL, nlay), 0.86),
+                                b["toa_src"], xp.full((NCOL, kd.ngpt), 0.06), xp.full((NCOL, kd.ngpt), 0.06))
+            out = {"up": r["flux_up"], "dn": r["flux_dn"], "dir": r["flux_dir"]}
+        else:
+            kds = synth.make_kdist("sw")
+            gol, gos = frontend.GasOptics(hip, kd, xp), frontend.GasOptics(hip, kds, xp)
+            col = frontend.CloudOptics(hip, synth.make_cloud_optics(kd.nbnd), xp)
+            cos_ = frontend.CloudOptics(hip, synth.make_cloud_optics(kds.nbnd), xp)
+            cl = {k: A(v) for k, v in clouds.items()}
+            _, _, rl = frontend.allsky_lw(hip, xp, gol, col, NCOL, nlay, a, cl, xp.full((NCOL, kd.ngpt), 0.98))
+            out = {"lw_up": rl["flux_up"], "lw_dn": rl["flux_dn"]}
+            out = {k: np.array(xp.to_numpy(v)) for k, v in out.items()}
+            del rl
+            torch.cuda.empty_cache()
+            _, _, rs = frontend.allsky_sw(hip, xp, gos, cos_, NCOL, nlay, a, cl, xp.full((NCOL, nlay), 0.86), xp.full((NCOL, kds.ngpt), 0.06),
+                                          fuse="all")
+            out.update({"sw_up": rs["flux_up"], "sw_dn": rs["flux_dn"], "sw_dir": rs["flux_dir"]})
+        torch.cuda.synchronize()
+        out = {k: (v if isinstance(v, np.ndarray) else np.array(xp.to_numpy(v))) for k, v in out.items()}
+    finally:
+        _opt_ins(hip, False)
+    worst = 0.0
+    for k in ref:
+        assert out[k].shape == ref[k].shape == (NCOL, nlay + 1), k
+        assert np.all(np.isfinite(out[k])), k
+        e = _elem(out[k], ref[k])
+        worst = max(worst, e)
+        assert e <= TOL, (workload, k, e)
+    print(f"full size {workload}: {NCOL} columns x {nlay} layers, {len(ref)} flux fields, worst elementwise relative error {worst:.2e} "
+          f"(CPU kernels on {ref_pool.usable_cores()} cores: {t_ref:.1f} s)")

@@ -583,9 +583,9 @@ def test_gray_radiative_equilibrium_on_device(hip):
         assert np.allclose(net, net[:, :1], rtol=2e-4)
 
 
-def test_full_size_properties(hip):
-    """BASELINE configs[1]-sized columns are too slow for the oracle; check size-independent
-    properties instead: (1) column-subset invariance -- a big batch made of a tile repeated must
+def test_size_independent_properties(hip):
+    """Size-independent properties (the full-size configurations are compared with the reference kernels value by
+    value in tests/test_fullsize_oracle.py): (1) column-subset invariance -- a big batch made of a tile repeated must
     reproduce the tile's fluxes exactly in every copy (reference tests/rte_lw_solver_unit_tests.F90
     :139-144); (2) vertical-flip invariance (:150-165)."""
     import torch

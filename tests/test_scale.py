@@ -1,4 +1,5 @@
-"""Full-size and sharding checks on the GPU (size-independent properties; the oracle cannot run these sizes):
+"""Full-size and sharding checks on the GPU (size-independent properties; the elementwise comparison of the full-size
+configurations with the reference kernels is tests/test_fullsize_oracle.py):
 BASELINE configs[1] (1e5 columns), the per-GPU shard of configs[4] (1e6 / 8 = 125 000 columns), shard invariance of
 the column decomposition, the RCCL reduction under a real (1-rank) nccl group, and the 32-bit-offset guard."""
 import os
