@@ -58,6 +58,9 @@ def algorithmic_bytes_per_collay(nflav=10, ngas=8, ngpt=NGPT, nlay=NLAY, defer_z
         "combine_2str_kernel": 16 * N + 24 * N,
         # compute_tau_rayleigh fused with combine_abs_and_rayleigh (library extension): tau_abs in, tau / ssa / g out
         "tau_rayleigh_combine_kernel": (40 * F + 21) + 8 * N + 24 * N,
+        # one-pass SW gas optics (library extension rte_hip_gas_optics_sw_2str): the inputs of compute_tau_absorption plus
+        # col_dry in, tau / ssa / g out -- the bytes THIS kernel must move (tau_abs and tau_rayleigh never exist in memory)
+        "gas_optics_sw_onepass_kernel": (25 + 120 * F + 8 * (G + 1)) + 8 + 24 * N,
         "sw_2stream_seg_kernel": (24 * N + 8 + 32 * N / nlay) + 24 * r,
     }
     return k
@@ -78,6 +81,7 @@ def allsky_bytes_per_collay(kd_lw, kd_sw, nlay):
         "lw_noscat_seg_kernel": lw["lw_noscat_seg_kernel"],
         # SW: Rayleigh + combine + the two-stream clouds' band-wise increment in one pass (library extension)
         "tau_rayleigh_combine_kernel": sw["tau_rayleigh_combine_kernel"] + 24 * b2,
+        "gas_optics_sw_onepass_kernel": sw["gas_optics_sw_onepass_kernel"] + 24 * b2,
         "sw_2stream_seg_kernel": sw["sw_2stream_seg_kernel"],
         # cloud optics in one pass each (look-ups, liquid + ice, delta scaling): 4 inputs, 1 (LW) or 3 (SW) band arrays out
         "cloud_optics_fused_kernel": (32 + 8 * b1) + (32 + 24 * b2),
@@ -280,12 +284,44 @@ def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw")
     except OSError:
         pass
     gpt = gpt.replace("+", " + ")
-    return {"value": rate, "unit": "columns/s", "cores": cores, "kind": kind,
+    # beside it: the reference's UNCHANGED Fortran frontend on pageable host arrays (oracle/_ref/bin/ref_frontend_driver, the
+    # program of tests/test_extern_frontend.py) -- on the HIP library in host-mirror mode and staged, and on the reference's CPU
+    # kernels -- i.e. what a host model that keeps its arrays on the host gets from the drop-in.  Never `value`.
+    host_arrays = None
+    if workload == "lw" and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "bin", "ref_frontend_driver")):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import stream_io
+
+            m = stream_io.measure_frontend_driver("lw", 98304, 16384, ("mirror", "staged", "cpuref"), nrep=2)
+            host_arrays = {"hip_host_mirror_columns_per_s": round(m["mirror"]["columns_per_s"], 1),
+                           "hip_staged_columns_per_s": round(m["staged"]["columns_per_s"], 1),
+                           "reference_cpu_kernels_1core_columns_per_s": round(m["cpuref"]["columns_per_s"], 1),
+                           "what": "reference Fortran frontend (load -> gas_optics -> rte_lw, ty_fluxes_broadband), one host thread, "
+                                   "98304 columns in blocks of 16384, pageable host arrays, value checks off",
+                           "staging_report": m["mirror"]["report"]}
+        except Exception as e:  # noqa: BLE001
+            host_arrays = {"failed": str(e)[-300:]}
+    return {"value": rate, "reference_frontend_host_arrays": host_arrays, "unit": "columns/s", "cores": cores, "kind": kind,
             "value_1core": rate1, "per_core_at_full_load": rate / cores, "cpu_model": model, "cores_note": cores_note,
             "sample": f"{blocks * ncol_block} columns in {dt:.1f} s ({cores} single-threaded processes, one per core, "
                       f"{blocks} blocks of {ncol_block} columns x {nlay_b} lay x {gpt} gpt, k-distribution tables shared read-only), "
                       f"same kernel chain; "
                       f"1-core figure: {blocks1 * ncol_block} columns in {dt1:.1f} s by one process alone"}
+
+
+def _device_uuid(torch, idx):
+    try:
+        return str(torch.cuda.get_device_properties(idx).uuid)
+    except Exception:  # noqa: BLE001
+        try:
+            import subprocess
+
+            out = subprocess.run(["rocm-smi", "--showuniqueid"], capture_output=True, text=True, timeout=20).stdout
+            ids = [ln.split(":")[-1].strip() for ln in out.splitlines() if "Unique ID" in ln]
+            return ids[idx] if idx < len(ids) else None
+        except Exception:  # noqa: BLE001
+            return None
 
 
 def main():
@@ -502,6 +538,35 @@ def main():
             hiplib.ext_call(lib, "rte_hip_secants_fill", "iiiaa", ncol, kd.ngpt, 1, ds_d, sec_d)
 
         glue_ms = timed_ms(glue)
+    # the same step WITHOUT the library's opt-in modes (what an unchanged caller of the reference ABI gets): zero_array as
+    # its own fill, compute_tau_absorption accumulating, every call deriving its own geometry, SW / all-sky through the
+    # unfused chain of reference-ABI kernels; 3 steps outside the timed region
+    hiplib.ext_call(lib, "rte_hip_defer_zero", ["i"], 0)
+    hiplib.ext_call(lib, "rte_hip_share_geometry", ["i"], 0)
+    hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 0)
+    bufs_p, rb_p, st_p = {}, {}, {}
+
+    def step_plain():
+        if args.workload == "lw":
+            go.gas_optics_lw(ncol, NLAY, play, plev, tlay, tsfc, col_gas, tlev, atm.top_at_1, buffers=bufs)
+            frontend.rte_lw(lib, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["lay_src"], bufs["lev_src"], emis, bufs["sfc_src"], buffers=rb)
+        elif args.workload == "sw":
+            go.gas_optics_sw(ncol, NLAY, play, plev, tlay, col_gas, col_dry, buffers=bufs_p)
+            frontend.rte_sw(lib, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, bufs_p["tau"], bufs_p["ssa"], bufs_p["g"], mu0, bufs_p["toa_src"], alb, alb, buffers=rb_p)
+        else:
+            st_p["l"] = frontend.allsky_lw(lib, xp, go, col, ncol, nlay_w, a_dev, clouds, emis, *st_p.get("l", (None, None, None)), fuse=False)
+            st_p["s"] = frontend.allsky_sw(lib, xp, gos, cos_, ncol, nlay_w, a_dev, clouds, mu0, alb, *st_p.get("s", (None, None, None)), fuse=False)
+
+    plain_abi_ms = None
+    try:
+        plain_abi_ms = timed_ms(step_plain, reps=3)
+    except Exception as e:  # noqa: BLE001  (e.g. not enough memory for the unfused all-sky chain beside the fused one)
+        plain_abi_ms = f"failed: {e}"
+    bufs_p.clear(); rb_p.clear(); st_p.clear()
+    torch.cuda.empty_cache()
+    hiplib.ext_call(lib, "rte_hip_defer_zero", ["i"], 0 if args.no_defer_zero else 1)
+    hiplib.ext_call(lib, "rte_hip_share_geometry", ["i"], (args.share_geometry_mode if share_geom else 0))
+    hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1 if overlap else 0)
     # assembling the global broadband field on every rank (all-gather of the per-rank slabs), outside the timed region
     allgather_ms = None
     if dist is not None:
@@ -526,11 +591,24 @@ def main():
         hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1)
 
     if rank == 0:
-        # the one-pass SW gas optics runs under the name of compute_tau_absorption: it stands for the bytes of the two
-        # ABI calls it replaces (the chain's algorithmic bytes stay those of the reference-ABI chain)
-        if (args.workload in ("sw", "allsky") and "tau_rayleigh_combine_kernel" in ab and "tau_rayleigh_combine_kernel" not in kern
-                and "tau_absorption_kernel" in kern):
-            ab["tau_absorption_kernel"] += ab.pop("tau_rayleigh_combine_kernel")
+        # Fused extension kernels get their OWN byte model (the bytes that kernel must move): the one-pass SW gas optics runs
+        # under the scope name of compute_tau_absorption; `abi_equivalent_GB` is what the chain of reference-ABI calls it
+        # replaces would have moved (reported beside it, never used for a per-kernel fraction).
+        abi_equiv = {}
+        ab_abi_chain = dict(ab)  # per (column, layer) bytes of the unfused reference-ABI chain
+        onepass = (args.workload in ("sw", "allsky") and "tau_rayleigh_combine_kernel" in ab and "tau_rayleigh_combine_kernel" not in kern
+                   and "tau_absorption_kernel" in kern)
+        if onepass:
+            if args.workload == "sw":
+                abi_equiv["tau_absorption_kernel"] = ab["tau_absorption_kernel"] + ab["tau_rayleigh_combine_kernel"]
+                ab["tau_absorption_kernel"] = ab["gas_optics_sw_onepass_kernel"]
+            else:  # all-sky: the scope holds the LW call (own model, with the by-band increment) AND the one-pass SW call
+                lw_part = ab["tau_absorption_kernel"] - algorithmic_bytes_per_collay(kds.nflav, kds.ngas, kds.ngpt, nlay_w, defer_zero=True)["tau_absorption_kernel"]
+                abi_equiv["tau_absorption_kernel"] = ab["tau_absorption_kernel"] + ab["tau_rayleigh_combine_kernel"]
+                ab["tau_absorption_kernel"] = lw_part + ab["gas_optics_sw_onepass_kernel"]
+            ab.pop("tau_rayleigh_combine_kernel")
+        ab.pop("gas_optics_sw_onepass_kernel", None)
+        ab_abi_chain.pop("gas_optics_sw_onepass_kernel", None)
         per_kernel = {}
         for name, bytes_cl in ab.items():
             if name in kern:
@@ -540,6 +618,10 @@ def main():
                                     "GBps": round(gb / (ms * 1e-3), 1), "frac": round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4),
                                     "events": ("timed region" if kern[name].get("timed_region") else
                                                f"{PRE} instrumented steps before the timed region")}
+                assert per_kernel[name]["frac"] <= 1.0, (name, per_kernel[name])  # a fraction of the HBM peak, on the kernel's own bytes
+                if name in abi_equiv:
+                    per_kernel[name]["abi_equivalent_GB"] = round(abi_equiv[name] * ncol * nlay_w / 1e9, 3)
+                    per_kernel[name]["fused"] = "one-pass SW gas optics (rte_hip_gas_optics_sw_2str): alg_GB is this kernel's own byte model"
                 if kern_serial and name.startswith(concurrent) and name in kern_serial:
                     # timed-region duration = while the other kernel shares the chip; the kernel's own duration:
                     sm = kern_serial[name]["avg_ms"]
@@ -550,7 +632,8 @@ def main():
         # the dominant kernel is chosen among those whose timed-region duration is their own (not the concurrent pair)
         cand = [k for k in per_kernel if not k.startswith(concurrent)] or list(per_kernel)
         dom = dom_scope if dom_scope in per_kernel else (max(cand, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None)
-        chain_gb = sum(v["alg_GB"] for v in per_kernel.values())
+        chain_gb = sum(v["alg_GB"] for v in per_kernel.values())                                     # bytes the launched kernels must move
+        chain_abi_gb = sum(v.get("abi_equivalent_GB", v["alg_GB"]) for v in per_kernel.values())   # bytes of the reference-ABI chain
         if overlap:  # event durations of concurrent kernels double-count: the chain is the wall clock of a step
             chain_ms = dt / args.steps * 1e3
         else:
@@ -581,7 +664,12 @@ def main():
                                                if overlap else "sum of the kernels' event durations (the dominant kernel's from the timed region, "
                                                "the others' from the instrumented steps before it)"),
                               "GBps": round(chain_gb / (chain_ms * 1e-3), 1),
-                              "frac": round(chain_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4)},
+                              "frac": round(chain_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4),
+                              "frac_is": "actual: bytes the launched kernels must move (own model per kernel) / kernel time / 8 TB/s",
+                              "abi_equivalent": {"alg_GB_per_step": round(chain_abi_gb, 3),
+                                                 "frac": round(chain_abi_gb / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4),
+                                                 "note": "bytes of the unfused reference-ABI chain over the same time (equals `actual` "
+                                                         "when no fused extension kernel runs, i.e. for the LW headline)"}},
                     "per_kernel": per_kernel, "other_kernels_avg_ms": others}
         res = {
             "metric": {"lw": "columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)",
@@ -605,7 +693,11 @@ def main():
                        "direct_gather_worklist": {"tau_tile_layer_bands": wl_tau, "of": tiles * nlay_w * kd.nbnd,
                                                   "planck_tile_bands": wl_planck, "of_planck": tiles * kd.nbnd},
                        "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
-                       "device": torch.cuda.get_device_name(local_rank),
+                       "device": torch.cuda.get_device_name(local_rank), "device_uuid": _device_uuid(torch, local_rank),
+                       "opt_in_modes": "rte_hip_defer_zero + rte_hip_share_geometry" + (" + one-pass SW gas optics / fused cloud kernels" if args.workload != "lw" else ""),
+                       "plain_abi_ms_per_step": (round(plain_abi_ms, 4) if isinstance(plain_abi_ms, float) else plain_abi_ms),
+                       "plain_abi_columns_per_s": (round(ncol * world / (plain_abi_ms * 1e-3), 1) if isinstance(plain_abi_ms, float) else None),
+                       "plain_abi_note": "the same step through the reference ABI only, no rte_hip_* opt-ins (3 steps outside the timed region)",
                        "glue_ms_per_step_outside_timed_region": (round(glue_ms, 4) if glue_ms is not None else None),
                        "allgather_global_fluxes_ms_outside_timed_region": (round(allgather_ms, 4) if allgather_ms is not None else None),
                        "scaling_note": "weak scaling: columns_per_gpu per rank; no multi-GPU curve has been measured by the builder"},
@@ -614,6 +706,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(workload=args.workload)
+                ha = res["cpu_baseline"].get("reference_frontend_host_arrays") or {}
+                # the unchanged Fortran frontend with HOST arrays on the HIP library (host-mirror mode); PCIe-inclusive, never `value`
+                res["config"]["host_array_mode_columns_per_s"] = ha.get("hip_host_mirror_columns_per_s")
             except Exception as e:  # noqa: BLE001
                 res["cpu_baseline"] = {"value": None, "unit": "columns/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}

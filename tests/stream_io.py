@@ -105,3 +105,51 @@ def run_frontend_driver(binary, kfile, afile, ofile, gases, ncol, nlay, is_lw, e
     n = ncol * (nlay + 1)
     assert raw.size == n * len(names), (raw.size, n, names)
     return {k: raw[i * n:(i + 1) * n].reshape((ncol, nlay + 1), order="F") for i, k in enumerate(names)}, r.stdout
+
+
+def measure_frontend_driver(kind="lw", ncol=98304, block=8192, modes=("mirror",), nlay=60, nrep=3, seed=42, env_extra=None):
+    """Columns/s of the reference's UNCHANGED Fortran frontend (oracle/_ref/bin/ref_frontend_driver: k%load -> k%gas_optics
+    -> rte_lw / rte_sw per block, pageable host arrays) on the HIP library in the given modes ("mirror": host-mirror mode,
+    "staged": every array staged both ways), and with "cpuref" the same program on the reference's CPU kernels (one core,
+    bounded sample).  Fluxes of the HIP modes must agree bit for bit.  Returns {mode: {"columns_per_s", "report"}}."""
+    import shutil
+    import sys
+    import tempfile
+
+    sys.path.insert(0, ROOT)
+    from rte_rrtmgp_amd import kdist_load, synth
+
+    ngpt, nbnd = (256, 16) if kind == "lw" else (224, 14)
+    gases = list(synth.GAS_NAMES)
+    raw = kdist_load.synth_raw(kind, ngpt=ngpt, nbnd=nbnd, nminor_lower=4 * nbnd, nminor_upper=2 * nbnd + 3)
+    kd = kdist_load.init_from_raw(raw, gases)
+    kd.scalars.pop("gas_names")
+    d = tempfile.mkdtemp(prefix="rte_f4_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out = {}
+    try:
+        kf, af, of = (os.path.join(d, n) for n in ("k.bin", "a.bin", "o.bin"))
+        write_kdist_stream(kf, raw, kind == "lw")
+        ref = None
+        for mode in modes:
+            if mode == "cpuref":
+                n = min(ncol, 2048)
+                atm = synth.make_atmosphere(n, nlay, seed=seed, kdist=kd, ngas=kd.ngas)
+                write_atmosphere_stream(af, atm, kind == "lw", block=32, checks=False, nrep=1)
+                fl, log = run_frontend_driver("ref_frontend_driver_cpuref", kf, af, of, gases, n, nlay, kind == "lw")
+            else:
+                atm = synth.make_atmosphere(ncol, nlay, seed=seed, kdist=kd, ngas=kd.ngas)
+                write_atmosphere_stream(af, atm, kind == "lw", block=block, checks=False, nrep=nrep)
+                env = {"RTE_HIP_HOST_MIRROR": "1" if mode == "mirror" else "0", "RTE_HIP_STAGING_REPORT": "1"}
+                env.update(env_extra or {})
+                fl, log = run_frontend_driver("ref_frontend_driver", kf, af, of, gases, ncol, nlay, kind == "lw", env=env)
+                if ref is None:
+                    ref = fl
+                for k in fl:  # same block size -> same kernels and reduction order: the modes must agree bit for bit
+                    assert np.array_equal(fl[k], ref[k]), (mode, k, float(np.max(np.abs(fl[k] - ref[k]))))
+            best = float([ln for ln in log.splitlines() if "best columns/s" in ln][0].split(":")[1])
+            rep = [ln.strip() for ln in last_stderr.splitlines() if "staging report" in ln]
+            out[mode] = {"columns_per_s": best, "report": rep[0] if rep else None,
+                         "passes": [ln.split(":", 1)[1].strip() for ln in log.splitlines() if ln.startswith("pass")]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
