@@ -18,6 +18,8 @@
 !   p_lay, p_lev, t_lay, t_lev (ncol, nlay[+1]); vmr(ncol, nlay, ngases) in the order of <gases>; col_dry(ncol, nlay);
 !   LW: t_sfc(ncol), sfc_emis(ncol);  SW: mu0(ncol), sfc_alb(ncol)
 ! Output (stream): flux_up, flux_dn (ncol, nlay+1) [, flux_dn_dir for SW], float64, column fastest.
+! Built a second time with -fopenmp (ref_frontend_driver_omp[_cpuref]): the blocks are then spread over OMP_NUM_THREADS host
+! threads; with RTE_HIP_THREAD_CONTEXTS=1 the HIP library gives every thread a context (stream, arena) of its own.
 program ref_frontend_driver
   use mo_rte_kind,           only: wp, wl
   use mo_rte_config,         only: rte_config_checks
@@ -29,6 +31,7 @@ program ref_frontend_driver
   use mo_rte_lw,             only: rte_lw
   use mo_rte_sw,             only: rte_sw
   use mo_raw_stream,         only: split_names, load_kdist_stream, rd_i1, rd_r1, rd_r2, rd_r3
+  !$ use omp_lib
   implicit none
   character(len=512) :: fk, fatm, fout, gases_arg
   character(len=32), allocatable :: gases(:)
@@ -40,17 +43,10 @@ program ref_frontend_driver
   real(wp), allocatable :: p_lay(:,:), p_lev(:,:), t_lay(:,:), t_lev(:,:), vmr(:,:,:), col_dry(:,:), t_sfc(:), sfc_emis(:), &
                            mu0(:), sfc_alb(:)
   real(wp), allocatable, target :: flux_up(:,:), flux_dn(:,:), flux_dir(:,:)
-  real(wp), allocatable, target :: bup(:,:), bdn(:,:), bdir(:,:)   ! one block's fluxes (contiguous, as in the RFMIP drivers)
-  real(wp), allocatable :: bp_lay(:,:), bp_lev(:,:), bt_lay(:,:), bt_lev(:,:), bcol_dry(:,:), bsfc(:,:), toa(:,:)
   type(ty_gas_concs), allocatable :: concs(:)
-  type(ty_optical_props_1scl) :: op1
-  type(ty_optical_props_2str) :: op2
-  type(ty_source_func_lw) :: src
-  type(ty_fluxes_broadband) :: fluxes
-  integer :: u, b, c0, c1, ig, irep, ibnd
+  integer :: u, b, c0, c1, ig, irep, nth
   integer(8) :: t0, t1, rate
   real(8) :: secs, best
-  character(len=128) :: e
 
   call get_command_argument(1, fk); call get_command_argument(2, fatm)
   call get_command_argument(3, fout); call get_command_argument(4, gases_arg)
@@ -87,23 +83,59 @@ program ref_frontend_driver
     end do
   end do
 
-  allocate(flux_up(ncol, nlay+1), flux_dn(ncol, nlay+1), bup(bs, nlay+1), bdn(bs, nlay+1))
-  allocate(bp_lay(bs, nlay), bp_lev(bs, nlay+1), bt_lay(bs, nlay), bt_lev(bs, nlay+1), bcol_dry(bs, nlay), bsfc(nbnd, bs))
-  fluxes%flux_up => bup; fluxes%flux_dn => bdn
-  if (is_lw) then
-    call stop_on_err(op1%alloc_1scl(bs, nlay, k))
-    call stop_on_err(src%alloc(bs, nlay, k))
-  else
-    allocate(flux_dir(ncol, nlay+1), bdir(bs, nlay+1), toa(bs, ngpt))
-    fluxes%flux_dn_dir => bdir
-    call stop_on_err(op2%alloc_2str(bs, nlay, k))
-  end if
+  allocate(flux_up(ncol, nlay+1), flux_dn(ncol, nlay+1))
+  if (.not. is_lw) allocate(flux_dir(ncol, nlay+1))
 
+  ! The block loop of the RFMIP drivers; with OpenMP (the same source built with -fopenmp: ref_frontend_driver_omp) the
+  ! blocks are dealt round-robin to the threads, each with its own optical-property / source / flux objects -- concurrent
+  ! calls on distinct buffers, the use the reference intends (examples/all-sky/rrtmgp_allsky.F90:331).
+  nth = 1
+  !$ nth = omp_get_max_threads()
   best = huge(best)
   call system_clock(count_rate=rate)
   do irep = 1, nrep
     call system_clock(t0)
-    do b = 1, nblocks
+    !$omp parallel default(shared)
+    call worker()
+    !$omp end parallel
+    call system_clock(t1)
+    secs = real(t1 - t0, 8) / real(rate, 8)
+    best = min(best, secs)
+    print '(a,i0,a,f10.4,a,f12.1,a,i0,a)', 'pass ', irep, ': ', secs, ' s, ', real(ncol, 8) / secs, ' columns/s (', nth, ' host threads)'
+  end do
+  print '(a,f12.1)', 'best columns/s: ', real(ncol, 8) / best
+
+  open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
+  write(u) flux_up; write(u) flux_dn
+  if (.not. is_lw) write(u) flux_dir
+  close(u)
+  print *, 'ref_frontend_driver ok'
+contains
+  ! one thread's share of the blocks: its own work arrays and frontend objects (all local, i.e. private)
+  subroutine worker()
+    real(wp), allocatable, target :: bup(:,:), bdn(:,:), bdir(:,:)   ! one block's fluxes (contiguous, as in the RFMIP drivers)
+    real(wp), allocatable :: bp_lay(:,:), bp_lev(:,:), bt_lay(:,:), bt_lev(:,:), bcol_dry(:,:), bsfc(:,:), toa(:,:)
+    type(ty_optical_props_1scl) :: op1
+    type(ty_optical_props_2str) :: op2
+    type(ty_source_func_lw) :: src
+    type(ty_fluxes_broadband) :: fluxes
+    integer :: b, c0, c1, ibnd, tid, nthr
+    character(len=128) :: e
+    tid = 0; nthr = 1
+    !$ tid = omp_get_thread_num()
+    !$ nthr = omp_get_num_threads()
+    allocate(bup(bs, nlay+1), bdn(bs, nlay+1))
+    allocate(bp_lay(bs, nlay), bp_lev(bs, nlay+1), bt_lay(bs, nlay), bt_lev(bs, nlay+1), bcol_dry(bs, nlay), bsfc(nbnd, bs))
+    fluxes%flux_up => bup; fluxes%flux_dn => bdn
+    if (is_lw) then
+      call stop_on_err(op1%alloc_1scl(bs, nlay, k))
+      call stop_on_err(src%alloc(bs, nlay, k))
+    else
+      allocate(bdir(bs, nlay+1), toa(bs, ngpt))
+      fluxes%flux_dn_dir => bdir
+      call stop_on_err(op2%alloc_2str(bs, nlay, k))
+    end if
+    do b = 1 + tid, nblocks, nthr
       c0 = (b - 1) * bs + 1; c1 = b * bs
       bp_lay = p_lay(c0:c1, :); bp_lev = p_lev(c0:c1, :); bt_lay = t_lay(c0:c1, :)
       if (use_tlev) bt_lev = t_lev(c0:c1, :)
@@ -138,19 +170,7 @@ program ref_frontend_driver
       end if
       flux_up(c0:c1, :) = bup; flux_dn(c0:c1, :) = bdn
     end do
-    call system_clock(t1)
-    secs = real(t1 - t0, 8) / real(rate, 8)
-    best = min(best, secs)
-    print '(a,i0,a,f10.4,a,f12.1,a)', 'pass ', irep, ': ', secs, ' s, ', real(ncol, 8) / secs, ' columns/s'
-  end do
-  print '(a,f12.1)', 'best columns/s: ', real(ncol, 8) / best
-
-  open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
-  write(u) flux_up; write(u) flux_dn
-  if (.not. is_lw) write(u) flux_dir
-  close(u)
-  print *, 'ref_frontend_driver ok'
-contains
+  end subroutine
   subroutine stop_on_err(msg)
     character(len=*), intent(in) :: msg
     if (len_trim(msg) > 0) then

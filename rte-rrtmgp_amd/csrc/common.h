@@ -16,20 +16,34 @@
 
 #define RTE_WAVE 64
 
-#define HIP_CHECK(expr)                                                                       \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess) {                                                                   \
-      fprintf(stderr, "rte_rrtmgp_hip: %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__,  \
-              hipGetErrorString(e_));                                                         \
-      abort(); /* the reference kernel interface has no error channel */                     \
-    }                                                                                         \
+#include <string>
+
+namespace rte {
+// A failing HIP call throws rte::Error out of the entry point's body; the entry point's RTE_CATCH hands it to
+// rte::on_error, which prints and abort()s (the reference kernel interface has no error channel) unless the context is in
+// sticky-error mode (rte_hip_error_mode(1): recorded, readable with rte_hip_last_error; runtime.hip).  An entry point
+// without the macros lets the exception reach the extern "C" boundary, i.e. std::terminate -> abort().
+struct Error { int code; std::string what; };
+[[noreturn]] void fail(hipError_t e, const char* expr, const char* file, int line);
+void on_error(const char* entry, const Error& e);
+}  // namespace rte
+
+#define HIP_CHECK(expr)                                                  \
+  do {                                                                   \
+    hipError_t e_ = (expr);                                              \
+    if (e_ != hipSuccess) rte::fail(e_, #expr, __FILE__, __LINE__);      \
   } while (0)
+#define RTE_TRY try {
+#define RTE_CATCH(entry_name) } catch (const rte::Error& err_) { rte::on_error(entry_name, err_); }
 
 namespace rte {
 
 // ---- runtime (runtime.hip) ---------------------------------------------------------------
+// All mutable state belongs to the calling thread's current CONTEXT (rte_hip_ctx_*; default: one per process).
 hipStream_t stream();
+// per-context state owned by another translation unit (the gas-optics plan caches): created on first use with `make`,
+// released with `destroy` when the context releases its buffers
+void* gas_state(void* (*make)(), void (*destroy)(void*));
 // device scratch that lives until the end of the current API call (bump allocator; grows)
 void* scratch(size_t bytes);
 // persistent named device buffers (LUT re-layouts etc.), keyed by a caller-chosen id
@@ -42,7 +56,7 @@ void* persistent(int slot, size_t bytes, bool* fresh);
 class Call {
  public:
   explicit Call(const char* name);
-  ~Call();
+  ~Call() noexcept(false);  // reports launch errors of the call (throws rte::Error unless already unwinding)
   template <class T> const T* in(const T* p, size_t n) { return (const T*)stage((void*)p, n * sizeof(T), true, false); }
   template <class T> T* out(T* p, size_t n) { return (T*)stage((void*)p, n * sizeof(T), false, true); }
   template <class T> T* inout(T* p, size_t n) { return (T*)stage((void*)p, n * sizeof(T), true, true); }
@@ -79,6 +93,7 @@ class Call {
   void* host_tmp_[24];
   int n_host_tmp_ = 0;
   bool fork_candidate_ = false, forked_ = false;
+  void* locked_ = nullptr;  // the context this call holds
   // host-mirror mode: host arrays that get their canaries at the end of the call, device buffers to recycle then
   struct Lazy { void* host; size_t bytes; unsigned long long magic; };
   Lazy lazy_[16];
@@ -106,7 +121,7 @@ void prof_begin(const char* kernel);
 void prof_end();
 struct ProfScope {
   explicit ProfScope(const char* k) { prof_begin(k); }
-  ~ProfScope() { prof_end(); }
+  ~ProfScope() noexcept(false) { prof_end(); }
 };
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

@@ -2602,37 +2602,9 @@ static int g_tau_variant = 9;
 static const bool g_worklist_native = getenv("RTE_WORKLIST_NATIVE") != nullptr;  // A/B: worklist entries from the native-layout tables
 static int g_planck_variant = 9;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
 static int g_geom_variant = 2;  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
-static int g_plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget cached host-side plans
-// Raised ON THE DEVICE by the plan guards when a cached plan no longer matches the caller's tables: one int in pinned,
-// device-mapped host memory that the guard kernels write directly.  The host looks at it at every plan look-up and then
-// drops the cached plans, so that they are rebuilt instead of the direct kernels doing every later call.
-static volatile int* g_stale_host = nullptr;
-static int* g_stale_dev = nullptr;
-// diagnostics: entries handed to the direct-gather worklists by the last tau / Planck call (rte_hip_stat)
-static int* g_stats_dev = nullptr;
-static int* stats_dev() {
-  if (!g_stats_dev) {
-    HIP_CHECK(hipMalloc((void**)&g_stats_dev, 4 * sizeof(int)));
-    HIP_CHECK(hipMemset(g_stats_dev, 0, 4 * sizeof(int)));
-  }
-  return g_stats_dev;
-}
-static int* stale_flag() {
-  if (!g_stale_dev) {
-    HIP_CHECK(hipHostMalloc((void**)&g_stale_host, sizeof(int), hipHostMallocMapped));
-    *g_stale_host = 0;
-    HIP_CHECK(hipHostGetDevicePointer((void**)&g_stale_dev, (void*)g_stale_host, 0));
-  }
-  return g_stale_dev;
-}
-static void stale_poll() {
-  (void)stale_flag();
-  if (*g_stale_host) {  // a guard fired in an earlier call: forget every plan
-    ++g_plan_epoch;
-    *g_stale_host = 0;
-  }
-}
-
+// Every piece of mutable host-side state of this file lives in the calling thread's current CONTEXT (runtime.hip):
+// plan caches, the geometry shared between consecutive calls, the guards' flag words.  Tuning switches (rte_hip_*_variant)
+// are process-wide.
 namespace {
 struct TauPlanCache {
   const void* key[14] = {};
@@ -2664,9 +2636,6 @@ struct TauPlanCache {
 // indices, each by reading all of jeta (0.13 ms).  Like the deferred zero fill, for callers that touch the
 // interpolation arrays only through this library between the two calls; keyed by the arrays' addresses, the
 // dimensions and the library's call sequence (the Planck call must be the very next one).
-static int g_share_geom = 0;  // 0 off, 1 on; 2 = tau -> Planck only, 3 = interpolation -> tau only (A/B)
-static bool share_boxes() { return g_share_geom == 1 || g_share_geom == 2; }
-static bool share_masks() { return g_share_geom == 1 || g_share_geom == 3; }
 struct SharedGeom {
   const void *jeta = nullptr, *jtemp = nullptr, *jpress = nullptr, *tropo = nullptr;
   int ncol = 0, nlay = 0, nflav = 0, nbnd = 0, gw = 0;
@@ -2675,8 +2644,6 @@ struct SharedGeom {
   int* valid = nullptr;      // device word: 1 once that call's geometry kernel ran (it does not when the call is rerouted)
   size_t cap = 0;
 };
-static SharedGeom g_shared;
-
 // The same option also lets rrtmgp_interpolation leave, per (256-column block, layer), the bit masks of the LUT rows
 // its columns touch (it has every index in registers), and the compute_tau_absorption call that is the very next
 // library call on the same interpolation arrays builds its tile geometry from these few megabytes instead of reading
@@ -2690,25 +2657,81 @@ struct InterpMasks {
   unsigned* buf = nullptr;   // persistent
   size_t cap = 0;
 };
-static InterpMasks g_imask;
-
-namespace rte {
-void release_gas_optics_buffers() {  // rte_hip_release()
-  if (g_shared.geom) HIP_CHECK(hipFree(g_shared.geom));
-  if (g_shared.valid) HIP_CHECK(hipFree(g_shared.valid));
-  g_shared = SharedGeom{};
-  if (g_imask.buf) HIP_CHECK(hipFree(g_imask.buf));
-  g_imask = InterpMasks{};
+// "are this table's bands whole aligned chunks of 16 or 8 g-points" -- checked once per table pointer and contents
+struct BandCheck {
+  const void* key = nullptr;
+  int n = -1, epoch = -1;
+  bool ok = false;
+  int gw = 0;
+  unsigned fp_seen = 0;
+};
+constexpr int NPLAN = 4;  // a few plans are kept (e.g. an LW and an SW k-distribution used alternately), least recently built evicted
+struct GasState {
+  int plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget cached host-side plans
+  // Raised ON THE DEVICE by the plan guards when a cached plan no longer matches the caller's tables: one int in pinned,
+  // device-mapped host memory that the guard kernels write directly.  The host looks at it at every plan look-up and then
+  // drops the cached plans, so that they are rebuilt instead of the direct kernels doing every later call.
+  volatile int* stale_host = nullptr;
+  int* stale_dev = nullptr;
+  int* stats_dev = nullptr;  // diagnostics: entries handed to the direct-gather worklists by the last tau / Planck call (rte_hip_stat)
+  int share_geom = 0;        // 0 off, 1 on; 2 = tau -> Planck only, 3 = interpolation -> tau only (A/B)
+  SharedGeom shared;
+  InterpMasks imask;
+  TauPlanCache plans[NPLAN];
+  int plan_next = 0;
+  BandCheck rayl_bands, planck_bands;
+};
+static int g_share_geom_default = 0;  // what a context starts with (the last rte_hip_share_geometry of any context)
+static void* make_gas_state() {
+  auto* g = new GasState();
+  g->share_geom = g_share_geom_default;
+  return g;
 }
-}  // namespace rte
+static void free_gas_state(void* p) {
+  auto* g = (GasState*)p;
+  if (g->shared.geom) (void)hipFree(g->shared.geom);
+  if (g->shared.valid) (void)hipFree(g->shared.valid);
+  if (g->imask.buf) (void)hipFree(g->imask.buf);
+  if (g->stats_dev) (void)hipFree(g->stats_dev);
+  if (g->stale_host) (void)hipHostFree((void*)g->stale_host);
+  delete g;
+}
+static GasState& gs() { return *(GasState*)rte::gas_state(make_gas_state, free_gas_state); }
+static int* stats_dev() {
+  GasState& g = gs();
+  if (!g.stats_dev) {
+    HIP_CHECK(hipMalloc((void**)&g.stats_dev, 4 * sizeof(int)));
+    HIP_CHECK(hipMemset(g.stats_dev, 0, 4 * sizeof(int)));
+  }
+  return g.stats_dev;
+}
+static int* stale_flag() {
+  GasState& g = gs();
+  if (!g.stale_dev) {
+    HIP_CHECK(hipHostMalloc((void**)&g.stale_host, sizeof(int), hipHostMallocMapped));
+    *g.stale_host = 0;
+    HIP_CHECK(hipHostGetDevicePointer((void**)&g.stale_dev, (void*)g.stale_host, 0));
+  }
+  return g.stale_dev;
+}
+static void stale_poll() {
+  (void)stale_flag();
+  GasState& g = gs();
+  if (*g.stale_host) {  // a guard fired in an earlier call: forget every plan
+    ++g.plan_epoch;
+    *g.stale_host = 0;
+  }
+}
+static bool share_boxes() { const int v = gs().share_geom; return v == 1 || v == 2; }
+static bool share_masks() { const int v = gs().share_geom; return v == 1 || v == 3; }
 
 extern "C" {
 
-int rte_hip_share_geometry(int on) { g_share_geom = on; g_shared.seq = -1; g_imask.seq = -1; return 0; }
+int rte_hip_share_geometry(int on) { g_share_geom_default = on; gs().share_geom = on; gs().shared.seq = -1; gs().imask.seq = -1; return 0; }
 int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
 int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
 int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
-int rte_hip_invalidate_plans(void) { ++g_plan_epoch; return 0; }
+int rte_hip_invalidate_plans(void) { ++gs().plan_epoch; return 0; }
 int rte_hip_geom_variant(int v) { g_geom_variant = v; return 0; }
 // diagnostics (synchronises): 0 = (column tile, layer, band) triples the last compute_tau_absorption call handed to the
 // direct-gather worklist, 1 = (column tile, band) pairs of the last compute_Planck_source call
@@ -2732,6 +2755,7 @@ void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, 
   const int ncol = *ncol_, nlay = *nlay_, ngas = *ngas_, nflav = *nflav_, neta = *neta_,
             npres = *npres_, ntemp = *ntemp_;
   if (ncol <= 0 || nlay <= 0 || nflav <= 0) return;
+  RTE_TRY
   rte::Call c("rrtmgp_interpolation");
   const size_t ncl = (size_t)ncol * nlay;
   // scalar preparation exactly as reference :99-102
@@ -2755,25 +2779,26 @@ void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, 
   dim3 grid(cdiv(ncol, 256), nlay), block(256);
   // masks for the compute_tau_absorption call that follows (InterpMasks): row numbers must fit the mask words
   unsigned* d_masks = nullptr;
-  g_imask.seq = -1;
+  gs().imask.seq = -1;
   if (share_masks() && !c.any_host() && rte::is_device_memory(jeta) && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63) {
     const size_t need = sizeof(unsigned) * (size_t)grid.x * nlay * (4 + 2 * nflav);
-    if (g_imask.cap < need) {
+    if (gs().imask.cap < need) {
       HIP_CHECK(hipStreamSynchronize(rte::stream()));
-      if (g_imask.buf) HIP_CHECK(hipFree(g_imask.buf));
-      HIP_CHECK(hipMalloc((void**)&g_imask.buf, need));
-      g_imask.cap = need;
+      if (gs().imask.buf) HIP_CHECK(hipFree(gs().imask.buf));
+      HIP_CHECK(hipMalloc((void**)&gs().imask.buf, need));
+      gs().imask.cap = need;
     }
-    d_masks = g_imask.buf;
-    g_imask.jeta = jeta; g_imask.jtemp = jtemp; g_imask.jpress = jpress; g_imask.tropo = tropo;
-    g_imask.ncol = ncol; g_imask.nlay = nlay; g_imask.nflav = nflav;
-    g_imask.seq = rte::call_seq();
+    d_masks = gs().imask.buf;
+    gs().imask.jeta = jeta; gs().imask.jtemp = jtemp; gs().imask.jpress = jpress; gs().imask.tropo = tropo;
+    gs().imask.ncol = ncol; gs().imask.nlay = nlay; gs().imask.nflav = nflav;
+    gs().imask.seq = rte::call_seq();
   }
   rte::ProfScope p("interpolation_kernel");
   hipLaunchKernelGGL(interpolation_kernel, grid, block, sizeof(Float) * 256 * (ngas + 1), rte::stream(), ncol, nlay, ngas, nflav, neta,
                      npres, ntemp, d_flavor, d_temp_ref, d_press_ref_log, press_ref_log_delta_inv,
                      *temp_ref_min, *temp_ref_delta, temp_ref_delta_inv, press_ref_trop, d_vmr_ref, d_play,
                      d_tlay, d_col_gas, d_jtemp, d_fmajor, d_fminor, d_col_mix, d_tropo, d_jeta, d_jpress, d_masks);
+  RTE_CATCH("rrtmgp_interpolation")
 }
 
 }  // extern "C"
@@ -2803,6 +2828,7 @@ static void tau_absorption_impl(
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
   // a deferred zero_array on exactly this buffer turns the accumulate into an overwrite
   bool overwrite = rh ? true : rte::take_pending_zero(tau, sizeof(Float) * (size_t)ncol * nlay * ngpt);
+  RTE_TRY
   rte::Call c(api_name);
   const size_t ncl = (size_t)ncol * nlay;
   const size_t tn = (size_t)ntemp * neta;
@@ -2850,7 +2876,7 @@ static void tau_absorption_impl(
   int* irregular = overlap + 1;  // some column's layer ranges are not those of its tropo flags (see tropo_limits_kernel)
   const size_t wl_cap = (size_t)cdiv(ncol, 256) * nlay * nbnd;  // tiles are at least 256 columns wide
   int* const worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
-  int* const valid_word = share_boxes() ? g_shared.valid : nullptr;  // (null until the first sharing call has allocated it)
+  int* const valid_word = share_boxes() ? gs().shared.valid : nullptr;  // (null until the first sharing call has allocated it)
   {
     rte::ProfScope p("tau_absorption_setup");
     // (the validity word of a geometry shared with compute_Planck_source is cleared here too: it is set again only if this
@@ -2862,9 +2888,8 @@ static void tau_absorption_impl(
   // ---- host-side plan from the small index tables (cached while the caller's table pointers and
   // dimensions do not change; rte_hip_release() drops the cache)
   // a few plans are kept (e.g. an LW and an SW k-distribution used alternately), least recently built evicted
-  constexpr int NPLAN = 4;
-  static TauPlanCache plans[NPLAN];
-  static int plan_next = 0;
+  TauPlanCache* const plans = gs().plans;
+  int& plan_next = gs().plan_next;
   const void* key[14] = {gpoint_flavor, band_lims_gpt, minor_limits_gpt_lower, minor_limits_gpt_upper, kminor_start_lower,
                          kminor_start_upper, idx_minor_lower, idx_minor_upper, idx_minor_scaling_lower,
                          idx_minor_scaling_upper, minor_scales_with_density_lower, minor_scales_with_density_upper,
@@ -2897,12 +2922,12 @@ static void tau_absorption_impl(
   const int dims[7] = {nbnd, ngpt, nlo, nup, *nminorklower_, *nminorkupper_, (int)fp};
   int plan_slot = -1;
   for (int i = 0; i < NPLAN; ++i)
-    if (plans[i].matches(key, dims, g_plan_epoch)) plan_slot = i;
+    if (plans[i].matches(key, dims, gs().plan_epoch)) plan_slot = i;
   const bool plan_hit = plan_slot >= 0;
   if (!plan_hit) { plan_slot = plan_next; plan_next = (plan_next + 1) % NPLAN; }
   TauPlanCache& cache = plans[plan_slot];
   if (!plan_hit) {
-    cache.set(key, dims, g_plan_epoch);
+    cache.set(key, dims, gs().plan_epoch);
     const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
     const int* ml[2] = {c.host(minor_limits_gpt_lower, (size_t)2 * nlo), c.host(minor_limits_gpt_upper, (size_t)2 * nup)};
     const int* ks[2] = {c.host(kminor_start_lower, (size_t)nlo), c.host(kminor_start_upper, (size_t)nup)};
@@ -3114,22 +3139,22 @@ static void tau_absorption_impl(
     const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
     const bool share = share_boxes() && geom2 && NCW * 64 == 512 && !c.any_host() && !rh;
     TileGeom* d_geom;
-    g_shared.seq = -1;
+    gs().shared.seq = -1;
     if (share) {  // the geometry outlives this call: a compute_Planck_source call right behind it may use it
       const size_t need = sizeof(TileGeom) * (size_t)tiles * nlay;
-      if (g_shared.cap < need) {
+      if (gs().shared.cap < need) {
         HIP_CHECK(hipStreamSynchronize(st));
-        if (g_shared.geom) HIP_CHECK(hipFree(g_shared.geom));
-        HIP_CHECK(hipMalloc((void**)&g_shared.geom, need));
-        if (!g_shared.valid) HIP_CHECK(hipMalloc((void**)&g_shared.valid, sizeof(int)));
-        g_shared.cap = need;
+        if (gs().shared.geom) HIP_CHECK(hipFree(gs().shared.geom));
+        HIP_CHECK(hipMalloc((void**)&gs().shared.geom, need));
+        if (!gs().shared.valid) HIP_CHECK(hipMalloc((void**)&gs().shared.valid, sizeof(int)));
+        gs().shared.cap = need;
       }
-      d_geom = g_shared.geom;
+      d_geom = gs().shared.geom;
       if (valid_word == nullptr)  // just allocated (otherwise it was cleared with this call's other flag words)
-        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, g_shared.valid, 1u, (int*)nullptr, 0u, (int*)nullptr, 0u);
-      g_shared.jeta = jeta; g_shared.jtemp = jtemp; g_shared.jpress = jpress; g_shared.tropo = tropo;
-      g_shared.ncol = ncol; g_shared.nlay = nlay; g_shared.nflav = nflav; g_shared.nbnd = nbnd; g_shared.gw = cache.gw;
-      g_shared.seq = rte::call_seq();
+        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, gs().shared.valid, 1u, (int*)nullptr, 0u, (int*)nullptr, 0u);
+      gs().shared.jeta = jeta; gs().shared.jtemp = jtemp; gs().shared.jpress = jpress; gs().shared.tropo = tropo;
+      gs().shared.ncol = ncol; gs().shared.nlay = nlay; gs().shared.nflav = nflav; gs().shared.nbnd = nbnd; gs().shared.gw = cache.gw;
+      gs().shared.seq = rte::call_seq();
     } else {
       d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
     }
@@ -3143,14 +3168,14 @@ static void tau_absorption_impl(
     Geom2Args ga{};
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = false;
     ga.lim = lim; ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.bmeta = d_bm;
-    ga.skip_if = overlap; ga.worklist = v.worklist; ga.valid_out = share ? g_shared.valid : nullptr;
+    ga.skip_if = overlap; ga.worklist = v.worklist; ga.valid_out = share ? gs().shared.valid : nullptr;
     ga.extra_planes = rh ? 2 : 0;
     ga.irregular = irregular;
     ga.stat = stats_dev() + 2;
-    if (share_masks() && g_imask.seq >= 0 && g_imask.seq + 1 == rte::call_seq() && g_imask.jeta == jeta && g_imask.jtemp == jtemp &&
-        g_imask.jpress == jpress && g_imask.tropo == tropo && g_imask.ncol == ncol && g_imask.nlay == nlay &&
-        g_imask.nflav == nflav && !c.any_host()) {
-      ga.imask = g_imask.buf;
+    if (share_masks() && gs().imask.seq >= 0 && gs().imask.seq + 1 == rte::call_seq() && gs().imask.jeta == jeta && gs().imask.jtemp == jtemp &&
+        gs().imask.jpress == jpress && gs().imask.tropo == tropo && gs().imask.ncol == ncol && gs().imask.nlay == nlay &&
+        gs().imask.nflav == nflav && !c.any_host()) {
+      ga.imask = gs().imask.buf;
       ga.imask_nblk = cdiv(ncol, 256);
     }
 #define RTE_LAUNCH_TAU9R_(GW, MMV, RV) \
@@ -3221,6 +3246,7 @@ static void tau_absorption_impl(
     st = main_st;
     if (aux) rte::aux_join();
   }
+  RTE_CATCH(api_name)
 }
 
 extern "C" {
@@ -3307,6 +3333,7 @@ static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd
                               const Float* tau_abs, Float* tau, Float* ssa, Float* g, const Float* cld_tau = nullptr,
                               const Float* cld_ssa = nullptr, const Float* cld_g = nullptr) {
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  RTE_TRY
   rte::Call c(api_name);
   const bool combine = tau_abs != nullptr;
   const size_t ncl = (size_t)ncol * nlay;
@@ -3336,15 +3363,16 @@ static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd
   }
   stale_poll();
   // production kernel: 16-aligned whole-chunk bands (checked once per table pointer), aligned inputs
-  static const void* bl_key = nullptr;
-  static int bl_n = -1, bl_epoch = -1;
-  static bool bl_ok = false;
-  static int bl_gw = 0;
+  BandCheck& bc_ = gs().rayl_bands;
+  const void*& bl_key = bc_.key;
+  int &bl_n = bc_.n, &bl_epoch = bc_.epoch;
+  bool& bl_ok = bc_.ok;
+  int& bl_gw = bc_.gw;
   unsigned bl_fp = 0;
   if (!rte::is_device_pointer(band_lims_gpt))  // host tables: fingerprint the contents (see compute_tau_absorption)
     for (int i = 0; i < 2 * nbnd; ++i) bl_fp = (bl_fp ^ (unsigned)band_lims_gpt[i]) * 16777619u;
-  static unsigned bl_fp_seen = 0;
-  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch || bl_fp != bl_fp_seen) {
+  unsigned& bl_fp_seen = bc_.fp_seen;
+  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != gs().plan_epoch || bl_fp != bl_fp_seen) {
     bl_fp_seen = bl_fp;
     const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
     auto aligned = [&](int w) {
@@ -3354,7 +3382,7 @@ static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd
     };
     bl_gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);  // g-points per stage of the production kernel
     bl_ok = bl_gw > 0;
-    bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = g_plan_epoch;
+    bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = gs().plan_epoch;
   }
   const size_t slab_bytes = sizeof(Float) * 2 * (size_t)ntemp * neta * (bl_gw + 2);
   hipStream_t st = rte::stream();
@@ -3392,6 +3420,7 @@ static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd
                        idx_h2o, d_gpoint_flavor, d_band_lims, d_krayl, d_col_dry, d_col_gas, d_fminor, d_jeta,
                        d_tropo, d_jtemp, d_tau, cb, (const int*)guard);
   }
+  RTE_CATCH(api_name)
 }
 extern "C" {
 void rrtmgp_compute_tau_rayleigh(const int* ncol_, const int* nlay_, const int* nbnd_,
@@ -3438,6 +3467,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
             npres = *npres_, ntemp = *ntemp_, nPlanckTemp = *nPlanckTemp_;
   (void)gpoint_bands;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  RTE_TRY
   rte::Call c("rrtmgp_compute_Planck_source");
   const size_t ncl = (size_t)ncol * nlay;
   const Float* d_tlay = c.in(tlay, ncl);
@@ -3467,15 +3497,16 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   int* d_stale = stale_flag();
   stale_poll();
   // production kernel: 16-aligned whole-chunk bands (checked once per table pointer), aligned inputs
-  static const void* bl_key = nullptr;
-  static int bl_n = -1, bl_epoch = -1;
-  static bool bl_ok = false;
-  static int bl_gw = 0;
+  BandCheck& bc_ = gs().planck_bands;
+  const void*& bl_key = bc_.key;
+  int &bl_n = bc_.n, &bl_epoch = bc_.epoch;
+  bool& bl_ok = bc_.ok;
+  int& bl_gw = bc_.gw;
   unsigned bl_fp = 0;
   if (!rte::is_device_pointer(band_lims_gpt))  // host tables: fingerprint the contents (see compute_tau_absorption)
     for (int i = 0; i < 2 * nbnd; ++i) bl_fp = (bl_fp ^ (unsigned)band_lims_gpt[i]) * 16777619u;
-  static unsigned bl_fp_seen = 0;
-  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != g_plan_epoch || bl_fp != bl_fp_seen) {
+  unsigned& bl_fp_seen = bc_.fp_seen;
+  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != gs().plan_epoch || bl_fp != bl_fp_seen) {
     bl_fp_seen = bl_fp;
     const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
     auto aligned = [&](int w) {
@@ -3485,7 +3516,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     };
     bl_gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);  // g-points per stage of the production kernel
     bl_ok = bl_gw > 0;
-    bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = g_plan_epoch;
+    bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = gs().plan_epoch;
   }
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
   const bool fast = bl_ok && ncol >= 512 && !g_tau_force_direct && (size_t)ncol * (nlay + 1) < ((size_t)1 << 31) &&
@@ -3539,13 +3570,13 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     wl_tile = NCW * 64;
     const unsigned tiles = cdiv(ncol, NCW * 64);
     // the geometry of the compute_tau_absorption call immediately before this one, if it is for the same arrays
-    const bool shared = share_boxes() && g_shared.seq >= 0 && g_shared.seq + 1 == rte::call_seq() && g_shared.jeta == jeta &&
-                        g_shared.jtemp == jtemp && g_shared.jpress == jpress && g_shared.tropo == tropo &&
-                        g_shared.ncol == ncol && g_shared.nlay == nlay && g_shared.nflav == nflav &&
-                        g_shared.nbnd == nbnd && g_shared.gw == bl_gw && !c.any_host() &&
+    const bool shared = share_boxes() && gs().shared.seq >= 0 && gs().shared.seq + 1 == rte::call_seq() && gs().shared.jeta == jeta &&
+                        gs().shared.jtemp == jtemp && gs().shared.jpress == jpress && gs().shared.tropo == tropo &&
+                        gs().shared.ncol == ncol && gs().shared.nlay == nlay && gs().shared.nflav == nflav &&
+                        gs().shared.nbnd == nbnd && gs().shared.gw == bl_gw && !c.any_host() &&
                         !c.forked();  // (on the side stream this call does not wait for that call's kernels)
-    g_shared.seq = -1;
-    TileGeom* d_geom = shared ? g_shared.geom : (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
+    gs().shared.seq = -1;
+    TileGeom* d_geom = shared ? gs().shared.geom : (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
     static_assert(NCW * 64 == 512, "d_flags is sized for 512-column tiles");
 #ifdef EXP_CLOCKS
     v.clocks = (unsigned long long*)rte::scratch(64);
@@ -3556,13 +3587,13 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = true;
     ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.band_lims = d_band_lims;
     ga.gpoint_flavor = d_gpoint_flavor; ga.worklist = v.worklist; ga.flags = d_flags; ga.skip_if = guard;
-    ga.skip_if2 = shared ? g_shared.valid : nullptr;  // (set on the device by that call's geometry kernel, if it ran)
+    ga.skip_if2 = shared ? gs().shared.valid : nullptr;  // (set on the device by that call's geometry kernel, if it ran)
 #define RTE_LAUNCH_PLANCK9(GW)                                                                                    \
   do {                                                                                                            \
     {                                                                                                             \
       rte::ProfScope p("planck_source_setup");                                                                    \
       if (shared) hipLaunchKernelGGL(planck_flags_kernel, dim3(cdiv(tiles * nbnd, 4)), dim3(256), 0, st, (const TileGeom*)d_geom, \
-                                     (int)tiles, nlay, nbnd, SLAB9, GW + 2, d_flags, v.worklist, (const int*)g_shared.valid, \
+                                     (int)tiles, nlay, nbnd, SLAB9, GW + 2, d_flags, v.worklist, (const int*)gs().shared.valid, \
                                      (const int*)guard);                                                          \
       if (geom2) hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, ga, d_geom); \
       else hipLaunchKernelGGL((planck_geom_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, \
@@ -3597,6 +3628,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     // the whole call on the direct kernel if the guard fired
     hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)guard);
   }
+  RTE_CATCH("rrtmgp_compute_Planck_source")
 }
 
 }  // extern "C"

@@ -211,53 +211,63 @@ void rte_compute_Planck_source_2D(const int* ncol, const int* nlay, const int* n
                                   const Float* T, Float* source) {
   const size_t n = (size_t)*ncol * *nlay;
   if (n == 0 || *nnu <= 0) return;
+  RTE_TRY
   rte::Call c("rte_compute_Planck_source_2D");
   const Float *dn = c.in(nus, (size_t)*nnu), *dd = c.in(dnus, (size_t)*nnu), *dT = c.in(T, n);
   Float* ds = c.out(source, n * *nnu);
   rte::ProfScope p("planck_nu_kernel");
   hipLaunchKernelGGL(planck_nu_kernel, dim3(cdiv(n, 256), *nnu), dim3(256), 0, rte::stream(), n, dn, dd, dT, ds);
+  RTE_CATCH("rte_compute_Planck_source_2D")
 }
 void rte_compute_Planck_source_1D(const int* ncol, const int* nnu, const Float* nus, const Float* dnus, const Float* T,
                                   Float* source) {
   const size_t n = (size_t)*ncol;
   if (n == 0 || *nnu <= 0) return;
+  RTE_TRY
   rte::Call c("rte_compute_Planck_source_1D");
   const Float *dn = c.in(nus, (size_t)*nnu), *dd = c.in(dnus, (size_t)*nnu), *dT = c.in(T, n);
   Float* ds = c.out(source, n * *nnu);
   rte::ProfScope p("planck_nu_kernel");
   hipLaunchKernelGGL(planck_nu_kernel, dim3(cdiv(n, 256), *nnu), dim3(256), 0, rte::stream(), n, dn, dd, dT, ds);
+  RTE_CATCH("rte_compute_Planck_source_1D")
 }
 void rte_sum_byband(const int* ncol, const int* nlev, const int* ngpt, const int* nbnd, const int* band_lims,
                     const Float* spectral_flux, Float* byband_flux) {
   const size_t n2 = (size_t)*ncol * *nlev;
   if (n2 == 0 || *nbnd <= 0) return;
+  RTE_TRY
   rte::Call c("rte_sum_byband");
   const int* bl = c.in(band_lims, (size_t)2 * *nbnd);
   const Float* s = c.in(spectral_flux, n2 * *ngpt);
   Float* o = c.out(byband_flux, n2 * *nbnd);
   rte::ProfScope p("sum_byband_kernel");
   hipLaunchKernelGGL(sum_byband_kernel, dim3(cdiv(n2, 256), *nbnd), dim3(256), 0, rte::stream(), n2, bl, s, o);
+  RTE_CATCH("rte_sum_byband")
 }
 void rte_net_byband_full(const int* ncol, const int* nlev, const int* ngpt, const int* nbnd, const int* band_lims,
                          const Float* spectral_flux_dn, const Float* spectral_flux_up, Float* byband_flux_net) {
   const size_t n2 = (size_t)*ncol * *nlev;
   if (n2 == 0 || *nbnd <= 0) return;
+  RTE_TRY
   rte::Call c("rte_net_byband_full");
   const int* bl = c.in(band_lims, (size_t)2 * *nbnd);
   const Float *d = c.in(spectral_flux_dn, n2 * *ngpt), *u = c.in(spectral_flux_up, n2 * *ngpt);
   Float* o = c.out(byband_flux_net, n2 * *nbnd);
   rte::ProfScope p("net_byband_full_kernel");
   hipLaunchKernelGGL(net_byband_full_kernel, dim3(cdiv(n2, 256), *nbnd), dim3(256), 0, rte::stream(), n2, bl, d, u, o);
+  RTE_CATCH("rte_net_byband_full")
 }
 void net_byband_precalc(const int* ncol, const int* nlev, const int* nbnd, const Float* byband_flux_dn,
                         const Float* byband_flux_up, Float* byband_flux_net) {
   const size_t n = (size_t)*ncol * *nlev * *nbnd;
   if (n == 0) return;
+  RTE_TRY
   rte::Call c("net_byband_precalc");
   const Float *d = c.in(byband_flux_dn, n), *u = c.in(byband_flux_up, n);
   Float* o = c.out(byband_flux_net, n);
   rte::ProfScope p("sub_kernel");
   hipLaunchKernelGGL(sub_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, d, u, o);
+  RTE_CATCH("net_byband_precalc")
 }
 
 // ---- extension symbols (scalars by value) -------------------------------------------------------
@@ -265,6 +275,7 @@ int rte_hip_get_layer_number(int ncol, int nlay, const Float* vmr_h2o, const Flo
                              Float* col_dry) {
   const size_t n = (size_t)ncol * nlay;
   if (n == 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_get_layer_number");
   const Float *v = c.in(vmr_h2o, n), *pl = c.in(plev, (size_t)ncol * (nlay + 1));
   Float* o = c.out(col_dry, n);
@@ -272,11 +283,14 @@ int rte_hip_get_layer_number(int ncol, int nlay, const Float* vmr_h2o, const Flo
   hipLaunchKernelGGL(layer_number_kernel, dim3(cdiv(ncol, 256), nlay), dim3(256), 0, rte::stream(), ncol, nlay, v, pl,
                      (Float)m_dry, (Float)grav, o);
   return 0;
+  RTE_CATCH("rte_hip_get_layer_number")
+  return -1;
 }
 int rte_hip_get_layer_mass(int ncol, int nlay, int ngas, const Float* vmr, const Float* plev, const Float* mol_weights,
                            double m_dry, double grav, Float* layer_mass) {
   const size_t n = (size_t)ngas * ncol * nlay;
   if (n == 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_get_layer_mass");
   const Float *v = c.in(vmr, n), *pl = c.in(plev, (size_t)ncol * (nlay + 1)), *mw = c.in(mol_weights, (size_t)ngas);
   Float* o = c.out(layer_mass, n);
@@ -284,30 +298,39 @@ int rte_hip_get_layer_mass(int ncol, int nlay, int ngas, const Float* vmr, const
   hipLaunchKernelGGL(layer_mass_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), ncol, nlay, ngas, v, pl, mw,
                      (Float)m_dry, (Float)grav, o);
   return 0;
+  RTE_CATCH("rte_hip_get_layer_mass")
+  return -1;
 }
 int rte_hip_col_gas_fill(int ncol, int nlay, int ngas, const Float* vmr, const Float* col_dry, Float* col_gas) {
   const size_t ncl = (size_t)ncol * nlay;
   if (ncl == 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_col_gas_fill");
   const Float *v = c.in(vmr, ncl * ngas), *cd = c.in(col_dry, ncl);
   Float* o = c.out(col_gas, ncl * (ngas + 1));
   rte::ProfScope p("col_gas_fill_kernel");
   hipLaunchKernelGGL(col_gas_fill_kernel, dim3(cdiv(ncl, 256), ngas + 1), dim3(256), 0, rte::stream(), ncl, v, cd, o);
   return 0;
+  RTE_CATCH("rte_hip_col_gas_fill")
+  return -1;
 }
 int rte_hip_tlev_interp(int ncol, int nlay, const Float* play, const Float* plev, const Float* tlay, Float* tlev) {
   if (ncol <= 0 || nlay < 2) return nlay < 2 ? -1 : 0;
   const size_t ncl = (size_t)ncol * nlay;
+  RTE_TRY
   rte::Call c("rte_hip_tlev_interp");
   const Float *pa = c.in(play, ncl), *pe = c.in(plev, ncl + ncol), *tl = c.in(tlay, ncl);
   Float* o = c.out(tlev, ncl + ncol);
   rte::ProfScope p("tlev_interp_kernel");
   hipLaunchKernelGGL(tlev_interp_kernel, dim3(cdiv(ncol, 256), nlay + 1), dim3(256), 0, rte::stream(), ncol, nlay, pa, pe, tl, o);
   return 0;
+  RTE_CATCH("rte_hip_tlev_interp")
+  return -1;
 }
 int rte_hip_compute_optimal_angles(int ncol, int nlay, int ngpt, int nbnd, const int* band_lims, const Float* tau,
                                    const Float* optimal_angle_fit, Float* optimal_angles) {
   if (ncol <= 0 || ngpt <= 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_compute_optimal_angles");
   const int* bl = c.in(band_lims, (size_t)2 * nbnd);
   const Float *t = c.in(tau, (size_t)ncol * nlay * ngpt), *f = c.in(optimal_angle_fit, (size_t)2 * nbnd);
@@ -315,30 +338,39 @@ int rte_hip_compute_optimal_angles(int ncol, int nlay, int ngpt, int nbnd, const
   rte::ProfScope p("optimal_angles_kernel");
   hipLaunchKernelGGL(optimal_angles_kernel, dim3(cdiv(ncol, 256), ngpt), dim3(256), 0, rte::stream(), ncol, nlay, nbnd, bl, t, f, o);
   return 0;
+  RTE_CATCH("rte_hip_compute_optimal_angles")
+  return -1;
 }
 int rte_hip_combine_abs_and_rayleigh_1scl(int ncol, int nlay, int ngpt, const Float* tau_abs, const Float* tau_ray, Float* tau) {
   const size_t n = (size_t)ncol * nlay * ngpt;
   if (n == 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_combine_abs_and_rayleigh_1scl");
   const Float *a = c.in(tau_abs, n), *r = c.in(tau_ray, n);
   Float* t = c.out(tau, n);
   rte::ProfScope p("combine_1scl_kernel");
   hipLaunchKernelGGL(combine_1scl_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, a, r, t);
   return 0;
+  RTE_CATCH("rte_hip_combine_abs_and_rayleigh_1scl")
+  return -1;
 }
 int rte_hip_combine_abs_and_rayleigh_nstr(int ncol, int nlay, int ngpt, int nmom, const Float* tau_abs, const Float* tau_ray,
                                           Float* tau, Float* ssa, Float* p) {
   const size_t n = (size_t)ncol * nlay * ngpt;
   if (n == 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_combine_abs_and_rayleigh_nstr");
   const Float *a = c.in(tau_abs, n), *r = c.in(tau_ray, n);
   Float *t = c.out(tau, n), *s = c.out(ssa, n), *pp = c.out(p, n * nmom);
   rte::ProfScope pr("combine_nstr_kernel");
   hipLaunchKernelGGL(combine_nstr_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, nmom, a, r, t, s, pp);
   return 0;
+  RTE_CATCH("rte_hip_combine_abs_and_rayleigh_nstr")
+  return -1;
 }
 int rte_hip_expand_and_transpose(int ncol, int nbnd, int ngpt, const int* band_lims, const Float* arr_in, Float* arr_out) {
   if (ncol <= 0 || nbnd <= 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_expand_and_transpose");
   const int* bl = c.in(band_lims, (size_t)2 * nbnd);
   const Float* in = c.in(arr_in, (size_t)nbnd * ncol);
@@ -346,28 +378,37 @@ int rte_hip_expand_and_transpose(int ncol, int nbnd, int ngpt, const int* band_l
   rte::ProfScope p("expand_transpose_kernel");
   hipLaunchKernelGGL(expand_transpose_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, rte::stream(), ncol, nbnd, bl, in, out);
   return 0;
+  RTE_CATCH("rte_hip_expand_and_transpose")
+  return -1;
 }
 int rte_hip_secants_fill(int ncol, int ngpt, int nmus, const Float* Ds, Float* secants) {
   const size_t ncg = (size_t)ncol * ngpt;
   if (ncg == 0 || nmus <= 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_secants_fill");
   const Float* d = c.in(Ds, (size_t)nmus);
   Float* o = c.out(secants, ncg * nmus);
   rte::ProfScope p("secants_fill_kernel");
   hipLaunchKernelGGL(secants_fill_kernel, dim3(cdiv(ncg, 256), nmus), dim3(256), 0, rte::stream(), ncg, d, o);
   return 0;
+  RTE_CATCH("rte_hip_secants_fill")
+  return -1;
 }
 int rte_hip_rfmip_sw_toa_renorm(int ncol, int ngpt, const Float* total_solar_irradiance, Float* toa_flux) {
   if (ncol <= 0 || ngpt <= 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_rfmip_sw_toa_renorm");
   const Float* tsi = c.in(total_solar_irradiance, (size_t)ncol);
   Float* toa = c.inout(toa_flux, (size_t)ncol * ngpt);
   rte::ProfScope p("toa_renorm_kernel");
   hipLaunchKernelGGL(toa_renorm_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, rte::stream(), ncol, ngpt, tsi, toa);
   return 0;
+  RTE_CATCH("rte_hip_rfmip_sw_toa_renorm")
+  return -1;
 }
 int rte_hip_rfmip_sw_mu0(int ncol, const Float* solar_zenith_angle, const Bool* usecol, Float* mu0) {
   if (ncol <= 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_rfmip_sw_mu0");
   const Float* z = c.in(solar_zenith_angle, (size_t)ncol);
   const Bool* u = c.in(usecol, (size_t)ncol);
@@ -375,24 +416,32 @@ int rte_hip_rfmip_sw_mu0(int ncol, const Float* solar_zenith_angle, const Bool* 
   rte::ProfScope p("rfmip_mu0_kernel");
   hipLaunchKernelGGL(rfmip_mu0_kernel, dim3(cdiv(ncol, 256)), dim3(256), 0, rte::stream(), ncol, z, u, m);
   return 0;
+  RTE_CATCH("rte_hip_rfmip_sw_mu0")
+  return -1;
 }
 int rte_hip_broadcast_cols(int n, int ncol, const Float* per_col, Float* out) {
   if (n <= 0 || ncol <= 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_broadcast_cols");
   const Float* in = c.in(per_col, (size_t)ncol);
   Float* o = c.out(out, (size_t)n * ncol);
   rte::ProfScope p("broadcast_cols_kernel");
   hipLaunchKernelGGL(broadcast_cols_kernel, dim3(cdiv((size_t)n * ncol, 256)), dim3(256), 0, rte::stream(), n, ncol, in, o);
   return 0;
+  RTE_CATCH("rte_hip_broadcast_cols")
+  return -1;
 }
 int rte_hip_mask_columns(int ncol, int nlev, const Bool* usecol, Float* flux_up, Float* flux_dn) {
   if (ncol <= 0 || nlev <= 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_mask_columns");
   const Bool* u = c.in(usecol, (size_t)ncol);
   Float *up = c.inout(flux_up, (size_t)ncol * nlev), *dn = c.inout(flux_dn, (size_t)ncol * nlev);
   rte::ProfScope p("mask_columns_kernel");
   hipLaunchKernelGGL(mask_columns_kernel, dim3(cdiv(ncol, 256), nlev), dim3(256), 0, rte::stream(), ncol, nlev, u, up, dn);
   return 0;
+  RTE_CATCH("rte_hip_mask_columns")
+  return -1;
 }
 
 }  // extern "C"

@@ -95,6 +95,7 @@ template <int OP>
 void increment(const char* name, int ncol, int nlay, int ngpt, Float* tau1, Float* ssa1, Float* g1, int nmom1,
                const Float* tau2, const Float* ssa2, const Float* g2, int nmom2, int nbnd, const int* lims) {
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  RTE_TRY
   rte::Call c(name);
   const size_t n1 = (size_t)ncol * nlay * ngpt, n2 = (size_t)ncol * nlay * (lims ? nbnd : ngpt);
   IncArgs a;
@@ -110,6 +111,7 @@ void increment(const char* name, int ncol, int nlay, int ngpt, Float* tau1, Floa
   rte::ProfScope p("increment_kernel");
   hipLaunchKernelGGL(increment_kernel<OP>, dim3(cdiv(a.ncl, 256), lims ? nbnd : ngpt), dim3(256), 0,
                      rte::stream(), a);
+  RTE_CATCH(name)
 }
 
 // :44-98
@@ -129,11 +131,13 @@ delta_scale_kernel(size_t n, Float* __restrict__ tau, Float* __restrict__ ssa, F
 void delta_scale(const char* name, int ncol, int nlay, int ngpt, Float* tau, Float* ssa, Float* g, const Float* f) {
   const size_t n = (size_t)ncol * nlay * ngpt;
   if (n == 0) return;
+  RTE_TRY
   rte::Call c(name);
   Float *dt = c.inout_lazy(tau, n), *ds = c.inout_lazy(ssa, n), *dg = c.inout_lazy(g, n);
   const Float* df = f ? c.in(f, n) : nullptr;
   rte::ProfScope p("delta_scale_kernel");
   hipLaunchKernelGGL(delta_scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, dt, ds, dg, df);
+  RTE_CATCH(name)
 }
 
 // :713-778; nmom = leading dimension (1 for 3-D arrays); ssa_in non-null: absorption optical depth
@@ -154,6 +158,7 @@ void extract_subset(const char* name, int nmom, int ncol, int nlay, int ngpt, co
   const int nc = colE - colS + 1;
   const size_t nk = (size_t)nlay * ngpt;
   if (nc <= 0 || nk == 0) return;
+  RTE_TRY
   rte::Call c(name);
   const Float* d_in = c.in(in, (size_t)nmom * ncol * nk);
   const Float* d_ssa = ssa_in ? c.in(ssa_in, (size_t)nmom * ncol * nk) : nullptr;
@@ -167,6 +172,7 @@ void extract_subset(const char* name, int nmom, int ncol, int nlay, int ngpt, co
                        rte::stream(), nmom, ncol, nc, colS - 1, kn, d_in + (size_t)nmom * ncol * k0,
                        d_ssa ? d_ssa + (size_t)nmom * ncol * k0 : nullptr, d_out + (size_t)nmom * nc * k0);
   }
+  RTE_CATCH(name)
 }
 
 // rrtmgp/kernels/mo_cloud_optics_rrtmgp_kernels.F90:40-64
@@ -367,6 +373,7 @@ void rrtmgp_compute_cld_from_table(const int* ncol_, const int* nlay_, const int
                                    const Float* asy_table, Float* tau, Float* taussa, Float* taussag) {
   const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_, nsteps = *nsteps_;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  RTE_TRY
   rte::Call c("rrtmgp_compute_cld_from_table");
   const size_t ncl = (size_t)ncol * nlay, n = ncl * ngpt, nt = (size_t)nsteps * ngpt;
   const Bool* d_mask = c.in(mask, ncl);
@@ -376,6 +383,7 @@ void rrtmgp_compute_cld_from_table(const int* ncol_, const int* nlay_, const int
   rte::ProfScope p("cld_from_table_kernel");
   hipLaunchKernelGGL(cld_from_table_kernel, dim3(cdiv(ncl, 256), ngpt), dim3(256), 0, rte::stream(), (int)ncl, nsteps,
                      *step_size, *offset, d_mask, d_lwp, d_re, d_tt, d_st, d_at, d_tau, d_ts, d_tsg);
+  RTE_CATCH("rrtmgp_compute_cld_from_table")
 }
 // cloud_optics (look-up tables) in one pass; twostr = 0: absorption optical depth only (tau); delta_scale != 0: the
 // two-stream result is delta-scaled with f = g^2.  Tables are (nsteps, nbnd); outputs (ncol, nlay, nbnd).
@@ -386,6 +394,7 @@ int rte_hip_cloud_optics_fused(int ncol, int nlay, int nbnd, int twostr, int del
                                const Float* asyice, Float* tau, Float* ssa, Float* g) {
   const size_t ncl = (size_t)ncol * nlay;
   if (ncl == 0 || nbnd <= 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_cloud_optics_fused");
   CldFused a;
   a.ncl = (int)ncl; a.nbnd = nbnd; a.liq_nsteps = liq_nsteps; a.ice_nsteps = ice_nsteps;
@@ -402,5 +411,7 @@ int rte_hip_cloud_optics_fused(int ncol, int nlay, int nbnd, int twostr, int del
   else if (delta_scale) hipLaunchKernelGGL((cloud_optics_fused_kernel<true, true>), grid, blk, 0, rte::stream(), a);
   else hipLaunchKernelGGL((cloud_optics_fused_kernel<true, false>), grid, blk, 0, rte::stream(), a);
   return 0;
+  RTE_CATCH("rte_hip_cloud_optics_fused")
+  return -1;
 }
 }

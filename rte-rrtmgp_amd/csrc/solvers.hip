@@ -1430,6 +1430,7 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
   const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_, nmus = *nmus_, nlev = nlay + 1;
   const bool do_broadband = *do_broadband_, do_jac = *do_Jacobians_, do_rescaling = *do_rescaling_;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0 || nmus <= 0) return;
+  RTE_TRY
   rte::Call c("rte_lw_solver_noscat");
   const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev, ncg = (size_t)ncol * ngpt;
   const Float* w_h = c.host(weights, (size_t)nmus);
@@ -1593,6 +1594,7 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
       }
     }
   }
+  RTE_CATCH("rte_lw_solver_noscat")
 }
 
 void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
@@ -1602,6 +1604,7 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
                            Float* flux_dn) {
   const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_, nlev = nlay + 1;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  RTE_TRY
   rte::Call c("rte_lw_solver_2stream");
   const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev, ncg = (size_t)ncol * ngpt;
   Lw2Args a;
@@ -1637,6 +1640,7 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     a.g_begin = g0;
     hipLaunchKernelGGL(lw_2stream_generic_kernel, dim3(cdiv(ncol, 256), gc), dim3(256), 0, rte::stream(), a);
   }
+  RTE_CATCH("rte_lw_solver_2stream")
 }
 
 void rte_sw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
@@ -1644,6 +1648,7 @@ void rte_sw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
                           Float* flux_dir) {
   const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  RTE_TRY
   rte::Call c("rte_sw_solver_noscat");
   const size_t ncl = (size_t)ncol * nlay;
   const Float* d_tau = c.in(tau, ncl * ngpt);
@@ -1653,6 +1658,7 @@ void rte_sw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
   rte::ProfScope p("sw_noscat_kernel");
   hipLaunchKernelGGL(sw_noscat_kernel, dim3(cdiv(ncol, 256), ngpt), dim3(256), 0, rte::stream(), ncol, nlay, ngpt,
                      (bool)*top_at_1, d_tau, d_mu0, d_inc, d_dir);
+  RTE_CATCH("rte_sw_solver_noscat")
 }
 
 void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
@@ -1665,6 +1671,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
   const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_, nlev = nlay + 1;
   const bool do_broadband = *do_broadband_;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  RTE_TRY
   rte::Call c("rte_sw_solver_2stream");
   const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev, ncg = (size_t)ncol * ngpt;
   Sw2Args a;
@@ -1738,6 +1745,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
       hipLaunchKernelGGL(sum_gpt_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, gc, a.dir, d_bdir, (Float)1, mode);
     }
   }
+  RTE_CATCH("rte_sw_solver_2stream")
 }
 
 }  // extern "C"

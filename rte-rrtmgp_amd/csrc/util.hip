@@ -23,6 +23,7 @@ void fill(const char* name, Float* a, size_t n, Float v) {
     rte::defer_zero(a, n * sizeof(Float));  // materialised by the next library call unless consumed
     return;
   }
+  RTE_TRY
   rte::Call c(name);
   if (v == (Float)0 && c.lazy_zero(a, n * sizeof(Float))) return;  // host-mirror mode: recorded on the device copy
   Float* d = v == (Float)0 ? c.out_lazy(a, n) : c.out(a, n);
@@ -33,6 +34,7 @@ void fill(const char* name, Float* a, size_t n, Float v) {
     const unsigned blocks = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
     hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, rte::stream(), d, n, v);
   }
+  RTE_CATCH(name)
 }
 
 // sequential sum over g-points, exactly the reference's order
@@ -144,33 +146,39 @@ void rte_sum_broadband(const int* ncol, const int* nlev, const int* ngpt, const 
                        Float* broadband_flux) {
   const size_t n2 = (size_t)*ncol * *nlev;
   if (n2 == 0) return;
+  RTE_TRY
   rte::Call c("rte_sum_broadband");
   const Float* s = c.in(spectral_flux, n2 * *ngpt);
   Float* o = c.out(broadband_flux, n2);
   rte::ProfScope p("sum_broadband_kernel");
   hipLaunchKernelGGL(sum_broadband_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, rte::stream(), n2, *ngpt, s, o);
+  RTE_CATCH("rte_sum_broadband")
 }
 void rte_net_broadband_full(const int* ncol, const int* nlev, const int* ngpt, const Float* spectral_flux_dn,
                             const Float* spectral_flux_up, Float* broadband_flux_net) {
   const size_t n2 = (size_t)*ncol * *nlev;
   if (n2 == 0) return;
+  RTE_TRY
   rte::Call c("rte_net_broadband_full");
   const Float* d = c.in(spectral_flux_dn, n2 * *ngpt);
   const Float* u = c.in(spectral_flux_up, n2 * *ngpt);
   Float* o = c.out(broadband_flux_net, n2);
   rte::ProfScope p("net_broadband_full_kernel");
   hipLaunchKernelGGL(net_broadband_full_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, rte::stream(), n2, *ngpt, d, u, o);
+  RTE_CATCH("rte_net_broadband_full")
 }
 void rte_net_broadband_precalc(const int* ncol, const int* nlev, const Float* flux_dn, const Float* flux_up,
                                Float* broadband_flux_net) {
   const size_t n2 = (size_t)*ncol * *nlev;
   if (n2 == 0) return;
+  RTE_TRY
   rte::Call c("rte_net_broadband_precalc");
   const Float* d = c.in(flux_dn, n2);
   const Float* u = c.in(flux_up, n2);
   Float* o = c.out(broadband_flux_net, n2);
   rte::ProfScope p("net_precalc_kernel");
   hipLaunchKernelGGL(net_precalc_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, rte::stream(), n2, d, u, o);
+  RTE_CATCH("rte_net_broadband_precalc")
 }
 
 // ---- extension symbols (scalars by value) ---------------------------------------------------
@@ -178,6 +186,7 @@ int rte_hip_combine_abs_and_rayleigh_2str(int ncol, int nlay, int ngpt, const Fl
                                           Float* tau, Float* ssa, Float* g) {
   const size_t n = (size_t)ncol * nlay * ngpt;
   if (n == 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_combine_abs_and_rayleigh_2str");
   const Float* a = c.in(tau_abs, n);
   const Float* r = c.in(tau_ray, n);
@@ -185,27 +194,35 @@ int rte_hip_combine_abs_and_rayleigh_2str(int ncol, int nlay, int ngpt, const Fl
   rte::ProfScope p("combine_2str_kernel");
   hipLaunchKernelGGL(combine_2str_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, a, r, t, s, gg);
   return 0;
+  RTE_CATCH("rte_hip_combine_abs_and_rayleigh_2str")
+  return -1;
 }
 int rte_hip_broadcast_gpt(int ncol, int ngpt, const Float* per_gpt, Float* out) {
   if (ncol <= 0 || ngpt <= 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_broadcast_gpt");
   const Float* pg = c.in(per_gpt, (size_t)ngpt);
   Float* o = c.out(out, (size_t)ncol * ngpt);
   rte::ProfScope p("broadcast_gpt_kernel");
   hipLaunchKernelGGL(broadcast_gpt_kernel, dim3(cdiv(ncol, 256), ngpt), dim3(256), 0, rte::stream(), ncol, ngpt, pg, o);
   return 0;
+  RTE_CATCH("rte_hip_broadcast_gpt")
+  return -1;
 }
 
 // liqmsk = clwp > 0, icemsk = ciwp > 0 (mo_cloud_optics_rrtmgp.F90:334-341)
 int rte_hip_cloud_masks(int ncol, int nlay, const Float* clwp, const Float* ciwp, Bool* liqmsk, Bool* icemsk) {
   const size_t n = (size_t)ncol * nlay;
   if (n == 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_cloud_masks");
   const Float *l = c.in(clwp, n), *i = c.in(ciwp, n);
   Bool *lm = c.out(liqmsk, n), *im = c.out(icemsk, n);
   rte::ProfScope p("cloud_masks_kernel");
   hipLaunchKernelGGL(cloud_masks_kernel, dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, l, i, lm, im);
   return 0;
+  RTE_CATCH("rte_hip_cloud_masks")
+  return -1;
 }
 // liquid + ice -> cloud optical properties (mo_cloud_optics_rrtmgp.F90:392-425); twostr = 0: tau only
 int rte_hip_cloud_combine(int ncol, int nlay, int nspec, int twostr, const Float* ltau, const Float* ltaussa,
@@ -213,6 +230,7 @@ int rte_hip_cloud_combine(int ncol, int nlay, int nspec, int twostr, const Float
                           Float* tau, Float* ssa, Float* g) {
   const size_t n = (size_t)ncol * nlay * nspec;
   if (n == 0) return 0;
+  RTE_TRY
   rte::Call c("rte_hip_cloud_combine");
   const Float *a0 = c.in(ltau, n), *a1 = c.in(ltaussa, n), *a2 = c.in(ltaussag, n);
   const Float *b0 = c.in(itau, n), *b1 = c.in(itaussa, n), *b2 = c.in(itaussag, n);
@@ -225,5 +243,7 @@ int rte_hip_cloud_combine(int ncol, int nlay, int nspec, int twostr, const Float
   else
     hipLaunchKernelGGL((cloud_combine_kernel<false>), dim3(cdiv(n, 256)), dim3(256), 0, rte::stream(), n, a0, a1, a2, b0, b1, b2, t, s_, g_);
   return 0;
+  RTE_CATCH("rte_hip_cloud_combine")
+  return -1;
 }
 }

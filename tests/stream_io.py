@@ -107,11 +107,12 @@ def run_frontend_driver(binary, kfile, afile, ofile, gases, ncol, nlay, is_lw, e
     return {k: raw[i * n:(i + 1) * n].reshape((ncol, nlay + 1), order="F") for i, k in enumerate(names)}, r.stdout
 
 
-def measure_frontend_driver(kind="lw", ncol=98304, block=8192, modes=("mirror",), nlay=60, nrep=3, seed=42, env_extra=None):
+def measure_frontend_driver(kind="lw", ncol=98304, block=8192, modes=("mirror",), nlay=60, nrep=3, seed=42, env_extra=None, threads=1):
     """Columns/s of the reference's UNCHANGED Fortran frontend (oracle/_ref/bin/ref_frontend_driver: k%load -> k%gas_optics
     -> rte_lw / rte_sw per block, pageable host arrays) on the HIP library in the given modes ("mirror": host-mirror mode,
     "staged": every array staged both ways), and with "cpuref" the same program on the reference's CPU kernels (one core,
-    bounded sample).  Fluxes of the HIP modes must agree bit for bit.  Returns {mode: {"columns_per_s", "report"}}."""
+    bounded sample).  threads > 1: the OpenMP build of the driver with that many host threads, each on its own library
+    context (RTE_HIP_THREAD_CONTEXTS=1).  Fluxes of the HIP modes must agree bit for bit.  Returns {mode: {"columns_per_s", "report"}}."""
     import shutil
     import sys
     import tempfile
@@ -140,15 +141,18 @@ def measure_frontend_driver(kind="lw", ncol=98304, block=8192, modes=("mirror",)
                 atm = synth.make_atmosphere(ncol, nlay, seed=seed, kdist=kd, ngas=kd.ngas)
                 write_atmosphere_stream(af, atm, kind == "lw", block=block, checks=False, nrep=nrep)
                 env = {"RTE_HIP_HOST_MIRROR": "1" if mode == "mirror" else "0", "RTE_HIP_STAGING_REPORT": "1"}
+                if threads > 1:
+                    env.update({"OMP_NUM_THREADS": str(threads), "RTE_HIP_THREAD_CONTEXTS": "1"})
                 env.update(env_extra or {})
-                fl, log = run_frontend_driver("ref_frontend_driver", kf, af, of, gases, ncol, nlay, kind == "lw", env=env)
+                fl, log = run_frontend_driver("ref_frontend_driver_omp" if threads > 1 else "ref_frontend_driver", kf, af, of, gases,
+                                              ncol, nlay, kind == "lw", env=env)
                 if ref is None:
                     ref = fl
                 for k in fl:  # same block size -> same kernels and reduction order: the modes must agree bit for bit
                     assert np.array_equal(fl[k], ref[k]), (mode, k, float(np.max(np.abs(fl[k] - ref[k]))))
             best = float([ln for ln in log.splitlines() if "best columns/s" in ln][0].split(":")[1])
             rep = [ln.strip() for ln in last_stderr.splitlines() if "staging report" in ln]
-            out[mode] = {"columns_per_s": best, "report": rep[0] if rep else None,
+            out[mode] = {"columns_per_s": best, "report": rep[0] if rep else None, "reports": rep,
                          "passes": [ln.split(":", 1)[1].strip() for ln in log.splitlines() if ln.startswith("pass")]}
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -41,6 +41,13 @@ def test_library_builds_and_exports_every_header_symbol():
                 "rte_hip_cloud_optics_fused", "rte_hip_lw_sfc_lds", "rte_hip_stat", "rte_hip_overlap_planck", "rte_hip_share_geometry", "rte_hip_gas_optics_sw_2str",
                 "rte_hip_aux_stream", "rte_hip_profile_only"):
         assert hasattr(dll, ext)
+    # the public extension header: contexts, error channel, host-mirror mode, opt-in modes, timing
+    ext_h = open(os.path.join(ROOT, "include", "rte_hip_ext.h")).read()
+    ext_h = re.sub(r"/\*.*?\*/", "", ext_h, flags=re.S)
+    declared = re.findall(r"\b(rte_hip_\w+)\s*\(", ext_h)
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(dll, name), f"{name} declared in include/rte_hip_ext.h but not exported"
 
 
 def test_signature_table_matches_header():

@@ -169,3 +169,38 @@ def test_reference_gas_optics_frontend_on_the_hip_library(kind, top_at_1, col_dr
         worst = max(worst, err)
         assert err <= 1e-10, (k, err)
     print(f"f4 {kind} top_at_1={top_at_1} col_dry={col_dry} tlev={tlev} block={block} mirror={mirror}: worst {worst:.2e}")
+
+
+def test_openmp_build_of_the_driver_matches_the_serial_one_on_the_reference_kernels(tmp_path):
+    """The same driver source built with -fopenmp (blocks dealt to host threads, one set of frontend objects per thread):
+    same fluxes as the serial program -- the reference frontend is re-entrant for calls on distinct buffers."""
+    if not (_have("ref_frontend_driver_cpuref") and _have("ref_frontend_driver_omp_cpuref")):
+        pytest.skip("reference CPU builds of the driver absent")
+    ncol, nlay = 96, 20
+    raw, kd, atm, kf, af = _frontend_case(tmp_path, "lw", ncol, nlay, 8, False, True, True)
+    ref, _ = stream_io.run_frontend_driver("ref_frontend_driver_cpuref", kf, af, str(tmp_path / "o1.bin"), GASES, ncol, nlay, True)
+    omp, log = stream_io.run_frontend_driver("ref_frontend_driver_omp_cpuref", kf, af, str(tmp_path / "o2.bin"), GASES, ncol, nlay, True,
+                                             env={"OMP_NUM_THREADS": "3"})
+    assert "3 host threads" in log
+    for k in ref:
+        assert np.array_equal(ref[k], omp[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+def test_openmp_frontend_threads_on_their_own_contexts(kind, tmp_path):
+    """Four host threads of the OpenMP build, each driving the unchanged frontend on its own blocks; RTE_HIP_THREAD_CONTEXTS=1
+    gives every thread a context of its own (stream, arena, mirrors), host-mirror mode on: fluxes equal the serial staged run
+    of the same block size bit for bit."""
+    assert _have("ref_frontend_driver") and _have("ref_frontend_driver_omp")
+    ncol, nlay, block = 4096, 60, 512
+    ngpt, nbnd = (256, 16) if kind == "lw" else (224, 14)
+    raw, kd, atm, kf, af = _frontend_case(tmp_path, kind, ncol, nlay, block, False, True, True, ngpt=ngpt, nbnd=nbnd,
+                                          nminor_lower=4 * nbnd, nminor_upper=2 * nbnd + 3, seed=12, checks=False, nrep=2)
+    ser, _ = stream_io.run_frontend_driver("ref_frontend_driver", kf, af, str(tmp_path / "s.bin"), GASES, ncol, nlay, kind == "lw",
+                                           env={"RTE_HIP_HOST_MIRROR": "0"})
+    omp, log = stream_io.run_frontend_driver("ref_frontend_driver_omp", kf, af, str(tmp_path / "p.bin"), GASES, ncol, nlay, kind == "lw",
+                                             env={"RTE_HIP_HOST_MIRROR": "1", "RTE_HIP_THREAD_CONTEXTS": "1", "OMP_NUM_THREADS": "4"})
+    assert "4 host threads" in log
+    for k in ser:
+        assert np.array_equal(ser[k], omp[k]), (k, float(np.max(np.abs(ser[k] - omp[k]))))
