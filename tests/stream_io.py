@@ -94,6 +94,9 @@ def write_atmosphere_stream(path, atm, is_lw, block, use_col_dry=True, use_tlev=
 def run_frontend_driver(binary, kfile, afile, ofile, gases, ncol, nlay, is_lw, env=None, timeout=1800):
     """Run oracle/_ref/bin/<binary>; returns (fluxes dict of (ncol, nlay+1) arrays, stdout)."""
     path = os.path.join(BIN, binary)
+    env = dict(env or {})
+    if "_omp" in binary:  # ... and OpenMP worker threads have stacks of their own (virtual reservation only)
+        env.setdefault("OMP_STACKSIZE", "24G")
     # flang keeps automatic arrays on the stack
     r = subprocess.run(f"ulimit -s unlimited 2>/dev/null; exec '{path}' '{kfile}' '{afile}' '{ofile}' '{','.join(gases)}'",
                        shell=True, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
