@@ -347,6 +347,9 @@ def main():
                     help="rce: one RCE-like climate, every column a random perturbation (default, the headline); "
                          "sites: 100 distinct RFMIP-like sites (polar to tropical, sea level to plateaus), each repeated in a "
                          "contiguous run; sites-shuffled: the same columns in random order")
+    ap.add_argument("--minor-distribution", choices=("even", "ragged"), default="even",
+                    help="ragged: the synthetic table's minor-absorber intervals spread unevenly over the bands (0 ... 8 per band and "
+                         "regime, same totals), as in real coefficient files; even (default): 4 per band lower, 2-3 upper")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
     ap.add_argument("--seg-groups", type=int, default=0, help="experiment: g-point groups per column tile of the segmented solvers (0 = automatic)")
@@ -398,7 +401,7 @@ def main():
     xp = frontend.TorchArrays(dev)
     ncol = args.ncol
     nlay_w = 72 if args.workload == "allsky" else NLAY
-    kd = synth.make_kdist("lw" if args.workload == "allsky" else args.workload)
+    kd = synth.make_kdist("lw" if args.workload == "allsky" else args.workload, minor_distribution=args.minor_distribution)
     if args.atmosphere == "rce":
         atm = synth.make_atmosphere(ncol, nlay_w, seed=42 + rank, kdist=kd)  # each rank owns different columns
     else:
@@ -416,7 +419,7 @@ def main():
     bufs, rb = {}, {}
     mean_profile = torch.zeros(2, nlay_w + 1, dtype=torch.float64, device=dev)
     if args.workload == "allsky":
-        kds = synth.make_kdist("sw")
+        kds = synth.make_kdist("sw", minor_distribution=args.minor_distribution)
         gos = frontend.GasOptics(lib, kds, xp)
         tbl, tbs = synth.make_cloud_optics(kd.nbnd), synth.make_cloud_optics(kds.nbnd)
         col, cos_ = frontend.CloudOptics(lib, tbl, xp), frontend.CloudOptics(lib, tbs, xp)
@@ -696,7 +699,7 @@ def main():
                                     f"synthetic k-distributions and cloud tables, cloud field of examples/all-sky"),
                        "columns_per_gpu": ncol, "nlay": nlay_w, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero,
                        "overlap_tau_planck": overlap, "share_geometry": share_geom, "worklist_beside_slab_kernel": not args.no_aux_stream,
-                       "atmosphere": args.atmosphere,
+                       "atmosphere": args.atmosphere, "minor_distribution": args.minor_distribution,
                        "direct_gather_worklist": {"tau_tile_layer_bands": wl_tau, "of": tiles * nlay_w * kd.nbnd,
                                                   "planck_tile_bands": wl_planck, "of_planck": tiles * kd.nbnd},
                        "rccl_world_size": (dist.get_world_size() if dist is not None else 1),

@@ -31,7 +31,8 @@ __device__ __forceinline__ double fma_c(double p, double r, double c) {
 
 __device__ __forceinline__ double exp_nonpos(double x) {
   // x = k ln2 + r, |r| <= ln2/2; exp(r) by its Taylor polynomial of degree 13 (truncation 4e-18 relative)
-  x = fmax(x, -1100.0);  // exp underflows to 0 long before; keeps k and r finite for any input
+  x = x < -1100.0 ? -1100.0 : x;  // exp underflows to 0 long before; keeps k and r finite for any input; a NaN stays a NaN
+                                  // (fmax would turn it into -1100, i.e. a silent 0 where the reference's exp propagates it)
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double r = __builtin_fma(k, -6.93147180369123816490e-01, x);  // ln2 high part: k * hi is exact
   r = __builtin_fma(k, -1.90821492927058770002e-10, r);         // ln2 low part
@@ -52,7 +53,9 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return __builtin_amdgcn_ldexp(p, (int)k);  // gradual underflow / 0 for large |x|
 }
 
-// 1/d: hardware estimate + two Newton steps (quadratic: 2^-26 -> 2^-52 -> rounding level)
+// 1/d: hardware estimate + two Newton steps (quadratic: 2^-26 -> 2^-52 -> rounding level).  Deviation from IEEE division:
+// d = 0 gives NaN (inf * 0 in the Newton step), not +-inf; the solvers' denominators are bounded away from 0 by the
+// reference's own guards (k floors, eps thresholds: SURVEY section 9-11) wherever these sequences are used.
 __device__ __forceinline__ double rcp_nr(double d) {
   double x = __builtin_amdgcn_rcp(d);
   double e = __builtin_fma(-d, x, 1.0);

@@ -20,6 +20,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -56,7 +58,7 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
                      const Float* __restrict__ tlay, const Float* __restrict__ col_gas,
                      int* __restrict__ jtemp, Float* __restrict__ fmajor, Float* __restrict__ fminor,
                      Float* __restrict__ col_mix, Bool* __restrict__ tropo, int* __restrict__ jeta,
-                     int* __restrict__ jpress, unsigned* __restrict__ masks) {
+                     int* __restrict__ jpress, unsigned* __restrict__ masks, int cg_lds) {
   // block = (256 columns, one layer); the flavors are walked INSIDE the block: pressure / temperature terms (one log)
   // are formed once per (column, layer), and play, tlay and the column amounts are read once instead of once per flavor
   // (as a grid dimension the flavors' blocks ran far apart: 1.9 GB of reads for 0.5 GB of inputs)
@@ -99,9 +101,12 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
     if ((threadIdx.x & 63) == 0) { atomicOr(&s_mask[0], tm); atomicOr(&s_mask[1], p0); atomicOr(&s_mask[2], p1); atomicOr(&s_mask[3], rg); }
   }
   // this column's amounts of every gas, parked in LDS (lane-private slots; the flavor's two gases are block-uniform indices)
+  // (tables with many gases -- the real files have ~20 -- would need more LDS than a block may have beside the transpose
+  //  buffers: `cg_lds` == 0 then reads the two amounts of a flavor from global memory, L2-resident after the first touch)
   extern __shared__ Float s_cg[];  // [ngas + 1][256]
   const int t = threadIdx.x;
-  for (int ig = 0; ig <= ngas; ++ig) s_cg[ig * 256 + t] = col_gas[cl + ncl * ig];
+  if (cg_lds)
+    for (int ig = 0; ig <= ngas; ++ig) s_cg[ig * 256 + t] = col_gas[cl + ncl * ig];
   // The outputs are interleaved records per column (8, 4, 2, 2 values): written straight from the
   // registers every store instruction would scatter 8-16 bytes per lane over kilobytes.  Transpose
   // through LDS instead, so each store instruction of the block writes one contiguous 2-4 KB run.
@@ -113,7 +118,8 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
   for (int iflav = 0; iflav < nflav; ++iflav) {
     // :121-168
     const int igas_1 = flavor[2 * iflav], igas_2 = flavor[2 * iflav + 1];
-    const Float cg1 = s_cg[igas_1 * 256 + t], cg2 = s_cg[igas_2 * 256 + t];
+    const Float cg1 = cg_lds ? s_cg[igas_1 * 256 + t] : col_gas[cl + ncl * igas_1];
+    const Float cg2 = cg_lds ? s_cg[igas_2 * 256 + t] : col_gas[cl + ncl * igas_2];
     Float fmn[4], fmj[8], cm[2];
     int je[2];
 #pragma unroll
@@ -692,7 +698,7 @@ __global__ void __launch_bounds__(256) tau_setup_kernel(TauSetupArgs a) {
 // fused multiply-adds and col_mix folded into the major weights; differences from the reference
 // association are a few ulp (tests: 1e-12 relative).
 // -------------------------------------------------------------------------------------------
-constexpr int MAXM = 8;    // minor intervals per (band, regime) handled here; more -> native kernel
+constexpr int MAXM = 12;   // minor intervals per (band, regime) handled by the production kernels; more -> native kernel
 constexpr int MAXB = 32;   // bands
 
 struct MinorMeta {  // one minor interval
@@ -1312,8 +1318,10 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
   }
 }
 
-// MM = minor intervals per (band, regime) kept in registers (column amounts of the current and of the next stage):
-// 4 when no band of the table has more (saves 16 VGPRs and their selects), else MAXM
+// MM = minor intervals per (band, regime) whose column amounts are kept in registers a stage ahead (4: what the register
+// budget allows without spills -- an MM = 8 instantiation spilled 4 registers, 52 in the fused SW variant).  A band with
+// more intervals (the real tables are ragged: 1 ... 9 per band and regime) runs its first MM this way and the rest in a
+// tail pass whose column amounts are requested where they are used (their latency is exposed, for those bands only).
 // ADDB: a band-wise operand is added (rte_hip_compute_tau_absorption_inc_bybnd) -- a template parameter, not a run-time
 // test: a conditional load changes the number of outstanding memory operations from path to path, and the compiler
 // then waits for (nearly) all of them, i.e. for the previous stage's stores, at the top of every stage.
@@ -1442,7 +1450,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // `s_waitcnt vmcnt(0)` -- in the middle of the minor pass that drains the previous stage's 48 stores (vector memory
   // retires in order).  These three per-column factors are used a few times per stage only: park them in the thread's
   // own LDS slots instead (a `ds_read` waits on lgkmcnt).  The unfused variants keep them in registers.
-  constexpr bool PARK = RAYL != 0 || MM > 4;  // (the variants that would otherwise spill)
+  constexpr bool PARK = RAYL != 0;  // (the variants that would otherwise spill)
   constexpr int NPARK = PARK ? 3 : 0;
   __shared__ Float s_park[NPARK ? NPARK : 1][NPARK ? TILE : 1];
   unsigned park_at = 0;  // LDS byte address of this thread's first slot (the low half of the generic address)
@@ -1650,18 +1658,12 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     __builtin_amdgcn_sched_barrier(0);
 #endif
     const Float f0 = fn0.x, f1 = fn0.y, f2 = fn1.x, f3 = fn1.y;
-#pragma unroll 1
-    for (int k = 0; k < n_my; ++k) {
-      const MinorMeta& mm = bm[ibnd].m[rsel][k];
-      if (mm.mE < g0 || mm.mS > g0) continue;  // intervals are whole 16-aligned chunks inside the band
-      Float scaling = sc[0];
-#pragma unroll
-      for (int q = 1; q < MM; ++q) scaling = (k == q) ? sc[q] : scaling;
+    // one minor interval's contribution (:757-760, :493): 4 corner rows of its plane, 2 g-points per LDS read
+    auto minor_rows = [&](int k, Float scaling) {
       const Float* r1 = M0 + ((k * nT + (jT - Tmin)) * nE + (em.x - emin)) * RS;
       const Float* r2 = M0 + ((k * nT + (jT + 1 - Tmin)) * nE + (em.y - emin)) * RS;
 #pragma unroll
       for (int j = 0; j < G; j += 2) {
-        // :757-760, :493
 #ifdef X9_NOGATHER
         const Float2 q0{f1, f2}, q1{f2, f3}, q2{f3, scaling}, q3{scaling, f0};
         (void)r1; (void)r2;
@@ -1676,6 +1678,36 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         acc[j + 1] = fma(scaling, t_, acc[j + 1]);
         asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
         if ((j & 6) == 6) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads in flight
+      }
+    };
+    const int n_reg = n_my < MM ? n_my : MM;
+#pragma unroll 1
+    for (int k = 0; k < n_reg; ++k) {
+      const MinorMeta& mm = bm[ibnd].m[rsel][k];
+      if (mm.mE < g0 || mm.mS > g0) continue;  // intervals are whole 16-aligned chunks inside the band
+      Float scaling = sc[0];
+#pragma unroll
+      for (int q = 1; q < MM; ++q) scaling = (k == q) ? sc[q] : scaling;
+      minor_rows(k, scaling);
+    }
+    if (n_my > MM) {
+      // the band's intervals beyond the MM held in registers: amounts requested here, same expressions (:461-480)
+#pragma unroll 1
+      for (int k = MM; k < n_my; ++k) {
+        const MinorMeta& mm = bm[ibnd].m[rsel][k];
+        if (mm.mE < g0 || mm.mS > g0) continue;
+        Float scaling = a.col_gas[cl + (size_t)ncl * mm.idx_minor];
+        if (mm.flags & 1) {
+          scaling = scaling * RTE_PARKED(0, dens);  // :469
+          if (mm.idx_scaling > 0) {                 // :470-478
+            const Float cg = a.col_gas[cl + (size_t)ncl * mm.idx_scaling];
+            if (mm.flags & 2)
+              scaling = scaling * ((Float)1 - cg * RTE_PARKED(1, vmr_fact) * RTE_PARKED(2, dry_fact));
+            else
+              scaling = scaling * (cg * RTE_PARKED(1, vmr_fact) * RTE_PARKED(2, dry_fact));
+          }
+        }
+        minor_rows(k, scaling);
       }
     }
 #ifndef X9_EARLY_SC
@@ -2597,11 +2629,12 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
 // ===============================================================================================
 // C ABI
 // ===============================================================================================
-static int g_tau_force_direct = 0;
-static int g_tau_variant = 9;
+// process-wide tuning switches (set from any thread: relaxed atomics)
+static std::atomic<int> g_tau_force_direct{0};
+static std::atomic<int> g_tau_variant{9};
 static const bool g_worklist_native = getenv("RTE_WORKLIST_NATIVE") != nullptr;  // A/B: worklist entries from the native-layout tables
-static int g_planck_variant = 9;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
-static int g_geom_variant = 2;  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
+static std::atomic<int> g_planck_variant{9};  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
+static std::atomic<int> g_geom_variant{2};  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
 // Every piece of mutable host-side state of this file lives in the calling thread's current CONTEXT (runtime.hip):
 // plan caches, the geometry shared between consecutive calls, the guards' flag words.  Tuning switches (rte_hip_*_variant)
 // are process-wide.
@@ -2681,7 +2714,7 @@ struct GasState {
   int plan_next = 0;
   BandCheck rayl_bands, planck_bands;
 };
-static int g_share_geom_default = 0;  // what a context starts with (the last rte_hip_share_geometry of any context)
+static std::atomic<int> g_share_geom_default{0};  // what a context starts with (the last rte_hip_share_geometry of any context)
 static void* make_gas_state() {
   auto* g = new GasState();
   g->share_geom = g_share_geom_default;
@@ -2794,10 +2827,13 @@ void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, 
     gs().imask.seq = rte::call_seq();
   }
   rte::ProfScope p("interpolation_kernel");
-  hipLaunchKernelGGL(interpolation_kernel, grid, block, sizeof(Float) * 256 * (ngas + 1), rte::stream(), ncol, nlay, ngas, nflav, neta,
+  // the gas amounts of a (column, layer) in LDS while they fit beside the 38 KB of transpose buffers in the 64 KB a block
+  // gets without asking for more (ngas <= 11); larger tables read them through L2
+  const int cg_lds = (ngas + 1) <= 12 ? 1 : 0;
+  hipLaunchKernelGGL(interpolation_kernel, grid, block, cg_lds ? sizeof(Float) * 256 * (ngas + 1) : 0, rte::stream(), ncol, nlay, ngas, nflav, neta,
                      npres, ntemp, d_flavor, d_temp_ref, d_press_ref_log, press_ref_log_delta_inv,
                      *temp_ref_min, *temp_ref_delta, temp_ref_delta_inv, press_ref_trop, d_vmr_ref, d_play,
-                     d_tlay, d_col_gas, d_jtemp, d_fmajor, d_fminor, d_col_mix, d_tropo, d_jeta, d_jpress, d_masks);
+                     d_tlay, d_col_gas, d_jtemp, d_fmajor, d_fminor, d_col_mix, d_tropo, d_jeta, d_jpress, d_masks, cg_lds);
   RTE_CATCH("rrtmgp_interpolation")
 }
 
@@ -3161,10 +3197,6 @@ static void tau_absorption_impl(
     const dim3 grid(tiles, nlay), blk((NCW + NLW) * 64);
     const size_t dyn = sizeof(BandMeta) * nbnd;
     const TileGeom* cg = d_geom;
-    bool mm4 = true;
-    for (const BandMeta& bmh : cache.bands) mm4 = mm4 && bmh.cnt[0] <= 4 && bmh.cnt[1] <= 4;
-    static const bool force_mm8 = getenv("RTE_FORCE_MM8") != nullptr;  // timing experiment: the variant for tables with more than
-    if (force_mm8) mm4 = false;                                           // 4 minor intervals per band and regime
     Geom2Args ga{};
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = false;
     ga.lim = lim; ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.bmeta = d_bm;
@@ -3182,13 +3214,8 @@ static void tau_absorption_impl(
   hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MMV, false, RV>), grid, blk, dyn, st, v, cg)
 #define RTE_LAUNCH_TAU9_(GW, AB)                                                                                  \
   do {                                                                                                            \
-    if (mm4) {                                                                                                    \
-      if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
-      else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
-    } else {                                                                                                      \
-      if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MAXM, AB>), grid, blk, dyn, st, v, cg); \
-      else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, MAXM, AB>), grid, blk, dyn, st, v, cg); \
-    }                                                                                                             \
+    if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
+    else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
   } while (0)
 #define RTE_LAUNCH_TAU9(GW)                                                                                       \
   do {                                                                                                            \
@@ -3200,8 +3227,8 @@ static void tau_absorption_impl(
     aux = rte::aux_fork(); /* the worklist is complete: its kernel may run beside the slab kernel */             \
     rte::ProfScope p("tau_absorption_kernel");                                                                    \
     if (rh) {                                                                                                     \
-      if (cb.cld_tau) { if (mm4) RTE_LAUNCH_TAU9R_(GW, 4, 2); else RTE_LAUNCH_TAU9R_(GW, MAXM, 2); }              \
-      else            { if (mm4) RTE_LAUNCH_TAU9R_(GW, 4, 1); else RTE_LAUNCH_TAU9R_(GW, MAXM, 1); }              \
+      if (cb.cld_tau) RTE_LAUNCH_TAU9R_(GW, 4, 2);                                                                \
+      else            RTE_LAUNCH_TAU9R_(GW, 4, 1);                                                                \
     } else if (d_add) RTE_LAUNCH_TAU9_(GW, true); else RTE_LAUNCH_TAU9_(GW, false);                               \
   } while (0)
     if (cache.gw == 16) RTE_LAUNCH_TAU9(16); else RTE_LAUNCH_TAU9(8);
@@ -3235,7 +3262,11 @@ static void tau_absorption_impl(
     hipStream_t main_st = st;
     if (aux) st = aux;
     GfastTabs gft{};
-    if (!g_worklist_native) { gft.kmaj = kmaj_g; gft.klo = klo_g; gft.kup = kup_g; gft.nkl = nkl; gft.nku = nku; }
+    // (tau_direct_column_g addresses the g-fastest copies with 32-bit element offsets: tables beyond 2^31 elements take the
+    //  native-layout worklist kernel)
+    const bool offsets_fit = (size_t)(npres + 1) * TE * ngpt < ((size_t)1 << 31) && (size_t)TE * nkl < ((size_t)1 << 31) &&
+                             (size_t)TE * nku < ((size_t)1 << 31);
+    if (!g_worklist_native && offsets_fit) { gft.kmaj = kmaj_g; gft.klo = klo_g; gft.kup = kup_g; gft.nkl = nkl; gft.nku = nku; }
     if (gft.kmaj)
       hipLaunchKernelGGL(tau_absorption_worklist_kernel<true>, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw, gft,
                          (const int*)v.worklist, use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);

@@ -19,6 +19,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.h"
 #include "fastmath.h"
 
@@ -1388,11 +1390,11 @@ size_t pick_gchunk(size_t bytes_per_g, int ngpt) {
 // 0 (default) = each g-point uses its own level source (what the reference accel kernel and
 // the physics intend); 1 = replicate the reference default CPU kernel, which passes the 3-D
 // lev_source to a 2-D dummy and therefore uses g-point 1's level source everywhere.
-static int g_lw2str_gpt1_levsource = 0;
-static int g_lw_force_generic = 0;
-static int g_sw_force_generic = 0;
-static int g_lw_sfc_lds = 1;  // surface arrays of the LW segmented solver through LDS chunks (rte_hip_lw_sfc_lds)
-static int g_seg_groups = 0;  // > 0: g-point groups per column tile of the segmented solvers (rte_hip_seg_groups; 0 = automatic;
+static std::atomic<int> g_lw2str_gpt1_levsource{0};
+static std::atomic<int> g_lw_force_generic{0};
+static std::atomic<int> g_sw_force_generic{0};
+static std::atomic<int> g_lw_sfc_lds{1};  // surface arrays of the LW segmented solver through LDS chunks (rte_hip_lw_sfc_lds)
+static std::atomic<int> g_seg_groups{0};  // > 0: g-point groups per column tile of the segmented solvers (rte_hip_seg_groups; 0 = automatic;
                               // < 0: g-points per block given directly)
 // g-points per block of the segmented broadband solvers (grid = column tiles x groups, each block accumulates its
 // g-points into a partial slab).  A few LONG groups and one SHORT last group -- grid.y is the slow launch index, so the
@@ -1406,8 +1408,9 @@ static int seg_g_per_block(int col_tiles, int ngpt) {
   while (nlong < 15 && (size_t)col_tiles * nlong < 3072 && (ngpt - tail_g) / (nlong + 1) >= 8) ++nlong;  // >= 12 long blocks per CU
   int gpb = ((ngpt - tail_g + nlong - 1) / nlong + 7) / 8 * 8;
   if (gpb > ngpt) gpb = ngpt;
-  if (g_seg_groups > 0) { const int n = g_seg_groups < ngpt ? g_seg_groups : ngpt; gpb = (ngpt + n - 1) / n; }
-  if (g_seg_groups < 0) gpb = -g_seg_groups < ngpt ? -g_seg_groups : ngpt;
+  const int sg = g_seg_groups;
+  if (sg > 0) { const int n = sg < ngpt ? sg : ngpt; gpb = (ngpt + n - 1) / n; }
+  if (sg < 0) gpb = -sg < ngpt ? -sg : ngpt;
   return gpb;
 }
 

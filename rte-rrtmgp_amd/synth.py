@@ -80,8 +80,12 @@ def _planck_band_integrals(temps: np.ndarray, edges_cm: np.ndarray) -> np.ndarra
 
 def make_kdist(kind: str = "lw", seed: int = 1234, ngpt: int | None = None, nbnd: int | None = None,
                ntemp: int = 14, npres: int = 59, neta: int = 9, nflav: int = 10, ngas: int = 8,
-               nminor_lower: int | None = None, nminor_upper: int | None = None) -> KDist:
-    """Seeded synthetic k-distribution with the g256 (LW) / g224 (SW) shapes by default."""
+               nminor_lower: int | None = None, nminor_upper: int | None = None, minor_distribution: str = "even") -> KDist:
+    """Seeded synthetic k-distribution with the g256 (LW) / g224 (SW) shapes by default.
+    ``minor_distribution``: "even" -- every band gets the same number of minor-absorber intervals per regime (4 lower, 2-3
+    upper); "ragged" -- the same totals spread unevenly, 1 ... 8 intervals per band in the lower atmosphere and 0 ... 6 in
+    the upper, as in real coefficient files (what ``reduce_minor_arrays`` leaves is whatever the file holds,
+    rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:1790-1907)."""
     rng = np.random.default_rng(seed + (0 if kind == "lw" else 7))
     if ngpt is None:
         ngpt = 256 if kind == "lw" else 224
@@ -139,7 +143,18 @@ def make_kdist(kind: str = "lw", seed: int = 1234, ngpt: int | None = None, nbnd
 
     # ---- minor absorbers, per regime
     for reg, nmin in (("lower", nminor_lower), ("upper", nminor_upper)):
-        bands = np.sort(np.arange(nmin) % nbnd)  # intervals are whole bands, ascending
+        if minor_distribution == "ragged":
+            lo_cnt, hi_cnt = (1, 8) if reg == "lower" else (0, 6)
+            assert lo_cnt * nbnd <= nmin <= hi_cnt * nbnd
+            rr = np.random.default_rng(seed + (91 if reg == "lower" else 92))
+            counts = np.full(nbnd, lo_cnt)
+            while counts.sum() < nmin:
+                b = int(rr.integers(0, nbnd))
+                if counts[b] < hi_cnt:
+                    counts[b] += 1
+            bands = np.repeat(np.arange(nbnd), counts)
+        else:
+            bands = np.sort(np.arange(nmin) % nbnd)  # intervals are whole bands, ascending
         lims = np.stack([band_lims[0, bands], band_lims[1, bands]]).astype(np.int32)
         A[f"minor_limits_gpt_{reg}"] = F(lims, np.int32)
         A[f"kminor_start_{reg}"] = F(1 + gpb * np.arange(nmin), np.int32)

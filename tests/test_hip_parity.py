@@ -244,6 +244,54 @@ def test_wide_bands_on_production_kernels(hip, oracle_c, nbnd, ngpt, top_at_1):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("top_at_1", [False, True])
+def test_ragged_minor_intervals_on_production_kernels(hip, oracle_c, top_at_1):
+    """Real coefficient files are ragged: 1 ... 9 minor-absorber intervals per band and regime (whatever
+    reduce_minor_arrays leaves, rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:1790-1907).  The production tau kernels keep the
+    column amounts of 4 intervals per stage in registers and run a band's further intervals in a tail pass: g256 / g224-shaped
+    tables with 0 ... 8 intervals per band, 1100 columns, LW (tau), SW chain (tau_abs), and the one-pass SW gas optics
+    (tau, ssa, g), against the oracle and the direct kernels."""
+    from rte_rrtmgp_amd import synth
+
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    ncol, nlay = 1100, 24
+    for kind in ("lw", "sw"):
+        kd = synth.make_kdist(kind, minor_distribution="ragged")
+        gpb = kd.ngpt // kd.nbnd
+        per_band = np.bincount((np.asarray(kd.arrays["minor_limits_gpt_lower"])[0] - 1) // gpb, minlength=kd.nbnd)
+        assert per_band.max() > 4 and per_band.min() < 4
+        atm = synth.make_atmosphere(ncol, nlay, seed=8, kdist=kd, top_at_1=top_at_1)
+        outs = {}
+        for mode in ("fast", "direct", "oracle", "onepass"):
+            if mode == "onepass" and kind == "lw":
+                continue
+            if mode == "oracle":
+                lib, arr, conv = oracle_c, frontend.NumpyArrays(), (lambda v: v)
+            else:
+                lib, arr, conv = hip, xp, A
+            hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 1 if mode == "direct" else 0)
+            try:
+                go = frontend.GasOptics(lib, kd, arr)
+                if kind == "lw":
+                    b = go.gas_optics_lw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.tsfc),
+                                         conv(atm.col_gas), conv(atm.tlev), atm.top_at_1)
+                    keys = ("tau", "lay_src")
+                else:
+                    b = go.gas_optics_sw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.col_gas),
+                                         conv(atm.col_dry), fuse_rayleigh=("all" if mode == "onepass" else False))
+                    keys = ("tau", "ssa", "g") if mode == "onepass" else ("tau_abs", "tau", "ssa", "g")
+                outs[mode] = {k: np.array(arr.to_numpy(b[k])) for k in keys}
+            finally:
+                hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 0)
+        for k in outs["oracle"]:
+            assert cases.rel_err(outs["fast"][k], outs["direct"][k]) <= 1e-13, (kind, k)
+            assert cases.rel_err(outs["fast"][k], outs["oracle"][k]) <= RTOL_GAS, (kind, k)
+            if "onepass" in outs and k in outs["onepass"]:
+                assert cases.rel_err(outs["onepass"][k], outs["oracle"][k]) <= RTOL_GAS, (kind, k, "one-pass")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("top_at_1", [False, True])
 def test_tile_geometry_prepasses_agree(hip, top_at_1):
     """The bit-mask tile geometry pre-pass (DPP OR-reductions, rte_hip_geom_variant(2), default) and the
     band-walking pre-passes (variant 1) give the production tau / Planck kernels the same LUT boxes: results
