@@ -124,6 +124,16 @@ struct ProfScope {
   ~ProfScope() noexcept(false) { prof_end(); }
 };
 
+// write-once output planes: non-temporal stores keep them out of the L2 the kernel's re-read inputs live in
+template <typename T>
+__device__ __forceinline__ void store_stream(T* p, T v) {
+#ifdef RTE_NO_NT_STORES
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
+
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 }  // namespace rte

@@ -407,15 +407,6 @@ struct alignas(2 * sizeof(Float)) Float2 { Float x, y; };
 // Measured (PMC FETCH_SIZE, 1e5 columns): compute_Planck_source reads 7.65 -> 5.33 GB (4.5 GB is the algorithmic
 // minimum) and runs 5.37 -> 5.06 ms; compute_tau_absorption 14.1 -> 12.1 GB, 5.3 -> 5.2 ms.  (Before the wait-count
 // fixes of round 2 the same change made no difference: the kernels were stalled on their own stores then.)
-template <typename T>
-__device__ __forceinline__ void store_stream(T* p, T v) {
-#ifdef RTE_NO_NT_STORES
-  *p = v;
-#else
-  __builtin_nontemporal_store(v, p);
-#endif
-}
-
 struct TauArgs {
   int ncol, nlay, ngpt, neta, npres, ntemp, idx_h2o;
   const int *gpoint_flavor, *band_lims_gpt;

@@ -316,14 +316,19 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, 
 // [, surface source Jacobian] -- are fetched ONCE per block in chunks of 16 g-points, each wave loading two g-points'
 // worth a chunk ahead, and handed to all waves through LDS; otherwise every wave loads all of them for every g-point
 // (8 waves x 4 arrays of the same 512 bytes: 32 of the block's 232 load instructions per g-point, 28 of them redundant).
-template <int L, bool do_jac, bool SFCLDS>
+// SPEC: spectral output (the interface's flux_up / flux_dn (ncol, nlay+1, ngpt), what rte_lw asks for with any ty_fluxes
+// other than ty_fluxes_broadband, rte/frontend/mo_rte_lw.F90:297-321): every wave stores pi * weight * radiance at the
+// levels it owns, per g-point, instead of accumulating; `spec_add` (angles after the first, :343-361) adds to what is
+// there.  The Jacobian stays a broadband quantity (partial slabs as before).
+template <int L, bool do_jac, bool SFCLDS, bool SPEC = false>
 __global__ void __launch_bounds__(64 * 8)
 lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
                      const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
                      const Float* __restrict__ lay_source_, const Float* __restrict__ lev_source_,
                      const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
                      const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
-                     Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac) {
+                     Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac,
+                     Float* __restrict__ spec_up = nullptr, Float* __restrict__ spec_dn = nullptr, bool spec_add = false) {
 #pragma clang fp contract(fast)  // this kernel is fp64-issue bound: fuse the recurrences' a*b+c
   extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][MAXS][64]
   const int lane = threadIdx.x & 63;
@@ -351,13 +356,26 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     if (q >= S) lds[i] = k == 0 ? (Float)1 : (Float)0;
   }
 
-  Float acc_dn[L + 1], acc_up[L + 1], acc_j[do_jac ? L + 1 : 1];
+  Float acc_dn[SPEC ? 1 : L + 1], acc_up[SPEC ? 1 : L + 1], acc_j[do_jac ? L + 1 : 1];
 #pragma unroll
-  for (int i = 0; i <= L; ++i) { acc_dn[i] = 0; acc_up[i] = 0; if (do_jac) acc_j[i] = 0; }
+  for (int i = 0; i <= L; ++i) { if (!SPEC) { acc_dn[i] = 0; acc_up[i] = 0; } if (do_jac) acc_j[i] = 0; }
+  SegOffsets<L> offs;
+  seg_offsets<L>(offs, c, ncol, nlay, p0, np, top_at_1);
+  // level slot i of this wave: accumulate (broadband) or store the flux of g-point `ig` (spectral; owned levels only)
+  auto put = [&](Float* acc, Float* __restrict__ spec, int i, Float v, int ig) {
+    if constexpr (SPEC) {
+      if (active && (i < np || (last && i == np))) {
+        Float* q = reinterpret_cast<Float*>(reinterpret_cast<char*>(spec + nclv * ig) + offs.lev[i]);
+        const Float f = v * piw;
+        if (spec_add) *q = *q + f; else rte::store_stream(q, f);
+      }
+    } else {
+      acc[i] += v;
+    }
+  };
 
-  // One g-point of work on tile `cur` (FULL: the segment has all L layers, no predication needed)
   // One g-point of work on tile `cur` (padded slots are neutral, see seg_load: no predication)
-  auto process = [&](const SegTile<L>& cur_, int buf, int gl, int cbuf) {
+  auto process = [&](const SegTile<L>& cur_, int buf, int gl, int cbuf, int ig) {
 #pragma clang fp contract(fast)
     struct Sfc { Float D, emis, ssrc, inc, sjac; } cur;
     if (SFCLDS) {
@@ -439,28 +457,26 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       }
     }
     // the level below the segment's last slot (used only by a FULL last segment: the surface)
-    acc_up[L] += u;
+    put(acc_up, spec_up, L, u, ig);
     if (do_jac) acc_j[L] += jv;
     // ---- pass 2: down; slot i is the level at the top of layer i.  In a partial last segment the
     // neutral slots i >= np all see the surface radiance, so slot np receives the surface value.
     r = r_in;
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-      acc_dn[i] += r;
+      put(acc_dn, spec_dn, i, r, ig);
       r = t[i] * r + sd[i];
     }
-    acc_dn[L] += r;
+    put(acc_dn, spec_dn, L, r, ig);
     // ---- pass 2: up (+ Jacobian, :729-743); neutral slots leave u at the surface value, which is
     // exactly what slot np of a partial last segment must accumulate
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) {
       u = t[i] * u + su[i];
-      acc_up[i] += u;
+      put(acc_up, spec_up, i, u, ig);
       if (do_jac) { jv = t[i] * jv; acc_j[i] += jv; }
     }
   };
-  SegOffsets<L> offs;
-  seg_offsets<L>(offs, c, ncol, nlay, p0, np, top_at_1);
   auto load = [&](SegTile<L>& tile, int igpt) {
     seg_load<L, do_jac, !SFCLDS>(tile, offs, min(igpt, g_end - 1), ncol, nlay, np, Dsec, tau_, lay_source_, lev_source_,
                                  sfc_emis, sfc_src, inc_flux, sfc_srcJac);
@@ -496,20 +512,22 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     if (SFCLDS && gl == 0) sfc_fetch(chunk + 1);           // a chunk ahead, behind this g-point's barrier ...
     load(nxt, igpt + 1);
     if (SFCLDS && gl == 1) sfc_publish((chunk + 1) & 1);   // ... written an iteration later, read 14 barriers later
-    process(cur, buf, gl, chunk & 1);
+    process(cur, buf, gl, chunk & 1, igpt);
     cur = nxt;
     if (++gl == CH) { gl = 0; ++chunk; }
   }
   // ---- partial broadband for this g-group: (ncol, nlev, ngroups)
-  if (active) {
+  if (active && (!SPEC || do_jac)) {
     const size_t base = icol + nclv * blockIdx.y;
 #pragma unroll
     for (int i = 0; i <= L; ++i) {
       if (i < np || (last && i == np)) {
         const int p = p0 + i;  // level position from the top
         const int ilev = top_at_1 ? p : nlay - p;
-        part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
-        part_up[base + (size_t)ncol * ilev] = acc_up[i];
+        if constexpr (!SPEC) {
+          part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
+          part_up[base + (size_t)ncol * ilev] = acc_up[i];
+        }
         if (do_jac) part_jac[base + (size_t)ncol * ilev] = acc_j[i];
       }
     }
@@ -773,9 +791,12 @@ struct Sw2SegArgs {
   bool top_at_1, has_dif_bc;
   const Float *tau, *ssa, *g, *mu0, *sfc_alb_dir, *sfc_alb_dif, *inc_flux_dir, *inc_flux_dif;
   Float *part_up, *part_dn, *part_dir;  // (ncol, nlev, ngroups)
+  Float *spec_up, *spec_dn, *spec_dir;  // SPEC: the interface's spectral flux arrays (ncol, nlev, ngpt)
 };
 
-template <int L>
+// SPEC: spectral output (rte_sw with a ty_fluxes other than ty_fluxes_broadband, rte/frontend/mo_rte_sw.F90): every wave
+// stores the three fluxes of the levels it owns per g-point instead of accumulating them
+template <int L, bool SPEC = false>
 __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 #pragma clang fp contract(fast)  // VALU-bound: fuse a*b+c (the segment composites already differ from the reference's rounding)
   constexpr int SMAX = 8, NC1 = 8, NC2 = 2;
@@ -802,10 +823,10 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     return a.top_at_1 ? p : nlay - 1 - p;
   };
 
-  constexpr bool DIRLDS = L <= 9;  // the direct-flux accumulators in LDS (ds_add_f64 on the thread's own slots): 2L+2 registers
+  constexpr bool DIRLDS = L <= 9 && !SPEC;  // the direct-flux accumulators in LDS (ds_add_f64 on the thread's own slots): 2L+2 registers
   // L == 9 (72 layers) is 15 registers over: the upward-flux accumulators go to LDS as well, and to make room there
   // only ONE value per layer is parked (the reciprocal is formed again per g-point, 6 instructions per layer)
-  constexpr bool UPLDS = L == 9;
+  constexpr bool UPLDS = L == 9 && !SPEC;
   constexpr int NMU = UPLDS ? 1 : 2;
   Float* const dirs = MU + (size_t)SMAX * NMU * L * 64 + (size_t)s * (L + 1) * 64 + lane;  // acc_dir slot i at dirs[i * 64]
   Float* const ups = MU + (size_t)SMAX * NMU * L * 64 + (size_t)SMAX * (L + 1) * 64 + (size_t)s * (L + 1) * 64 + lane;
@@ -828,15 +849,40 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   const Float mu0_top = a.mu0[c + (size_t)ncol * (a.top_at_1 ? 0 : nlay - 1)];
   const Float mu0_sfc = a.mu0[c + (size_t)ncol * (a.top_at_1 ? nlay - 1 : 0)];
 
-  Float acc_up[UPLDS ? 1 : L + 1], acc_dn[L + 1], acc_dir[DIRLDS ? 1 : L + 1];
+  Float acc_up[UPLDS || SPEC ? 1 : L + 1], acc_dn[SPEC ? 1 : L + 1], acc_dir[DIRLDS || SPEC ? 1 : L + 1];
+  // SPEC: byte offset of the wave's first level row inside one g-point plane and the step to the next level (two
+  // registers instead of L + 1: the stores are the only users)
+  unsigned olev0 = ((unsigned)c + (unsigned)ncol * (unsigned)(a.top_at_1 ? p0 : nlay - p0)) * (unsigned)sizeof(Float);
+  const unsigned dlev = (a.top_at_1 ? (unsigned)ncol : 0u - (unsigned)ncol) * (unsigned)sizeof(Float);
+  int gcur = g_begin;               // SPEC: the g-point being processed
+  if constexpr (SPEC) {
+    asm volatile("" : "+v"(olev0));
+  } else {
 #pragma unroll
-  for (int i = 0; i <= L; ++i) {
-    acc_dn[i] = 0;
-    if constexpr (UPLDS) ups[i * 64] = 0; else acc_up[i] = 0;
-    if constexpr (DIRLDS) dirs[i * 64] = 0; else acc_dir[i] = 0;
+    for (int i = 0; i <= L; ++i) {
+      acc_dn[i] = 0;
+      if constexpr (UPLDS) ups[i * 64] = 0; else acc_up[i] = 0;
+      if constexpr (DIRLDS) dirs[i * 64] = 0; else acc_dir[i] = 0;
+    }
   }
-  auto add_dir = [&](int i, Float v) { if constexpr (DIRLDS) atomicAdd(&dirs[i * 64], v); else acc_dir[i] += v; };
-  auto add_up = [&](int i, Float v) { if constexpr (UPLDS) atomicAdd(&ups[i * 64], v); else acc_up[i] += v; };
+  auto spec_store = [&](Float* __restrict__ arr, int i, Float v) {
+    if (active && (i < np || (last && i == np)))
+      rte::store_stream(reinterpret_cast<Float*>(reinterpret_cast<char*>(arr + nclv * gcur) + (olev0 + (unsigned)i * dlev)), v);
+  };
+  auto add_dir = [&](int i, Float v) {
+    if constexpr (SPEC) spec_store(a.spec_dir, i, v);
+    else if constexpr (DIRLDS) atomicAdd(&dirs[i * 64], v);
+    else acc_dir[i] += v;
+  };
+  auto add_up = [&](int i, Float v) {
+    if constexpr (SPEC) spec_store(a.spec_up, i, v);
+    else if constexpr (UPLDS) atomicAdd(&ups[i * 64], v);
+    else acc_up[i] += v;
+  };
+  auto add_dn = [&](int i, Float v) {
+    if constexpr (SPEC) spec_store(a.spec_dn, i, v);
+    else acc_dn[i] += v;
+  };
 
   struct In { Float tau[L], ssa[L], g[L], inc_dir, alb_dir, alb_dif, inc_dif; };
   // loads as (wave-uniform plane base, advanced per g-point) + (32-bit byte offset of the lane's row): the saddr form
@@ -996,19 +1042,20 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       add_up(i, fd * al[i] + sr[i]);
-      acc_dn[i] += fd + dirl;
+      add_dn(i, fd + dirl);
       add_dir(i, dirl);
       fd = fa[i] * fd + fb[i];
       dirl = Tn[i] * dirl;
     }
     add_up(L, fd * al[L] + sr[L]);
-    acc_dn[L] += fd + dirl;
+    add_dn(L, fd + dirl);
     add_dir(L, dirl);
   };
 
   In cur;
   load(cur, g_begin);
-  for (int igpt = g_begin; igpt < g_end; ++igpt) process(cur, igpt + 1);
+  for (int igpt = g_begin; igpt < g_end; ++igpt) { gcur = igpt; process(cur, igpt + 1); }
+  if constexpr (SPEC) return;
   if (active) {
     const size_t base = icol + nclv * blockIdx.y;
 #pragma unroll
@@ -1535,6 +1582,36 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     return;
   }
 
+  if (!do_broadband && !do_rescaling && nlay <= 80 && !g_lw_force_generic && nclv < ((size_t)1 << 29)) {
+    // ---------------------------------------------------------------- production path, spectral output
+    // the same segmented kernel; every wave stores the fluxes of the levels it owns per g-point (25 GB of stores at
+    // 1e5 x 60 x 256: the kernel is bound by them); angles after the first add to the arrays
+    const int col_tiles = cdiv(ncol, 64);
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    Float* part_jac = do_jac ? (Float*)rte::scratch(sizeof(Float) * nclv * ngroups) : nullptr;
+    const size_t lds_bytes = sizeof(Float) * (2 * 3 * 8 * 64);
+    for (int imu = 0; imu < nmus; ++imu) {
+      {
+        rte::ProfScope p("lw_noscat_seg_spectral_kernel");
+#define RTE_LAUNCH_SEGS(LL, JJ)                                                                                        \
+  hipLaunchKernelGGL((lw_noscat_seg_kernel<LL, JJ, false, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st, ncol, \
+                     nlay, ngpt, S, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev,    \
+                     d_emis, d_sfc, d_inc, d_srcJac, (Float*)nullptr, (Float*)nullptr, part_jac, d_flux_up, d_flux_dn, imu > 0)
+        if (L == 8) { if (do_jac) RTE_LAUNCH_SEGS(8, true); else RTE_LAUNCH_SEGS(8, false); }
+        else if (L == 9) { if (do_jac) RTE_LAUNCH_SEGS(9, true); else RTE_LAUNCH_SEGS(9, false); }
+        else { if (do_jac) RTE_LAUNCH_SEGS(10, true); else RTE_LAUNCH_SEGS(10, false); }
+#undef RTE_LAUNCH_SEGS
+      }
+      if (do_jac) {
+        rte::ProfScope p("lw_reduce_parts");
+        const Float piw = (Float)3.14159265358979323846264338327950288 * w_h[imu];
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_jac, d_jac, piw, imu > 0);
+      }
+    }
+    return;
+  }
+
   // ------------------------------------------------------------------ generic path
   // spectral intensities for a chunk of g-points: in the caller's arrays (single angle, spectral
   // output) or in scratch; then reduce / accumulate.
@@ -1708,6 +1785,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     q.part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * 3);
     q.part_dn = q.part_up + nclv * ngroups;
     q.part_dir = q.part_dn + nclv * ngroups;
+    q.spec_up = q.spec_dn = q.spec_dir = nullptr;
     // composites, flux maps, mu0 (clamped, reciprocal; L == 9: one value), direct-flux (L == 9: and upward-flux) accumulators
     const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + (L == 9 ? 1 : 2) * 8 * L + (L <= 9 ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
     {
@@ -1720,6 +1798,28 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_up, d_bu, (Float)1, false);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_dn, d_bd, (Float)1, false);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_dir, d_bdir, (Float)1, false);
+    return;
+  }
+  if (!do_broadband && nlay <= 80 && !g_sw_force_generic && nclv < ((size_t)1 << 29)) {
+    // ---------------------------------------------------------------- production path, spectral output: the same
+    // segmented kernel, every wave storing the three fluxes of the levels it owns per g-point
+    const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);
+    const int S = (nlay + L - 1) / L;
+    const int col_tiles = cdiv(ncol, 64);
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    Sw2SegArgs q;
+    q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = S; q.g_per_block = g_per_block;
+    q.top_at_1 = *top_at_1; q.has_dif_bc = *has_dif_bc;
+    q.tau = a.tau; q.ssa = a.ssa; q.g = a.g; q.mu0 = a.mu0; q.sfc_alb_dir = a.sfc_alb_dir; q.sfc_alb_dif = a.sfc_alb_dif;
+    q.inc_flux_dir = a.inc_flux_dir; q.inc_flux_dif = a.inc_flux_dif;
+    q.part_up = q.part_dn = q.part_dir = nullptr;
+    q.spec_up = d_up; q.spec_dn = d_dn; q.spec_dir = d_dir;
+    const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 2 * 8 * L);  // composites, flux maps, mu0 (clamped, reciprocal)
+    rte::ProfScope p("sw_2stream_seg_spectral_kernel");
+    if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+    else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+    else hipLaunchKernelGGL((sw_2stream_seg_kernel<10, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
     return;
   }
   // ------------------------------------------------------------------ generic path

@@ -110,7 +110,8 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
         b = cases.run_suite(hip, xp, case, inp)
     finally:
         hiplib.ext_call(hip, "rte_hip_force_generic_sw", ["i"], 0)
-    for k in ("sw.flux_up", "sw.flux_dn", "sw.flux_dir", "swc.flux_up", "swc.flux_dn", "swc.flux_dir"):
+    for k in ("sw.flux_up", "sw.flux_dn", "sw.flux_dir", "swc.flux_up", "swc.flux_dn", "swc.flux_dir",
+              "sws.gpt_flux_up", "sws.gpt_flux_dn", "sws.gpt_flux_dir"):  # sws: spectral output from the segmented kernel
         assert cases.rel_err(a[k], b[k]) <= 1e-12, k
     # direct call: night columns + diffuse boundary condition, broadband, against the oracle
     rng = np.random.default_rng(11)
@@ -126,6 +127,13 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
         out = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(ssa), A(g), A(mu0), A(idir), A(adir), A(adif),
                               inc_flux_dif=A(idif))
         for k in ("flux_up", "flux_dn", "flux_dir"):
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
+        # the same with spectral output: the segmented kernel stores the fluxes of the levels each wave owns
+        ref = frontend.rte_sw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, idir, adir, adif,
+                              inc_flux_dif=idif, do_broadband=False)
+        out = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(ssa), A(g), A(mu0), A(idir), A(adir), A(adif),
+                              inc_flux_dif=A(idif), do_broadband=False)
+        for k in ("gpt_flux_up", "gpt_flux_dn", "gpt_flux_dir"):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
         # the LW two-stream solver on the same optical properties (segmented kernel) against the oracle
         lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
@@ -145,6 +153,14 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
                               inc_flux=A(inc), n_gauss_angles=2, sfc_src_jac=A(sj), do_jacobians=True)
         for k in ("flux_up", "flux_dn", "flux_up_jac"):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
+        # the no-scattering solver with spectral output, three angles + Jacobian (segmented kernel, angles accumulated in
+        # the caller's arrays) vs oracle
+        ref = frontend.rte_lw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, lay, lev, emis, sfc, inc_flux=inc,
+                              n_gauss_angles=3, sfc_src_jac=sj, do_jacobians=True, do_broadband=False)
+        out = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(lay), A(lev), A(emis), A(sfc), inc_flux=A(inc),
+                              n_gauss_angles=3, sfc_src_jac=A(sj), do_jacobians=True, do_broadband=False)
+        for k in ("gpt_flux_up", "gpt_flux_dn", "flux_up_jac"):
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
 
 
 @pytest.mark.parametrize("name", ["lw_mid_ragged", "lw_mid_top1", "lw_g256"])
@@ -160,7 +176,8 @@ def test_segmented_and_generic_lw_solvers_agree(hip, name):
         b = cases.run_suite(hip, xp, case, inp)
     finally:
         hiplib.ext_call(hip, "rte_hip_force_generic_lw", ["i"], 0)
-    for k in ("lw1.flux_up", "lw1.flux_dn", "lw3j.flux_up", "lw3j.flux_dn", "lw3j.flux_up_jac"):
+    for k in ("lw1.flux_up", "lw1.flux_dn", "lw3j.flux_up", "lw3j.flux_dn", "lw3j.flux_up_jac",
+              "lw2s.gpt_flux_up", "lw2s.gpt_flux_dn", "lwDs.gpt_flux_up", "lwDs.gpt_flux_dn", "lwDs.flux_up_jac"):  # spectral output too
         assert cases.rel_err(a[k], b[k]) <= 1e-13, k
     # the two-stream solver (segmented with projective composites vs thread-per-column generic kernel)
     for k in ("lw2str.gpt_flux_up", "lw2str.gpt_flux_dn"):
