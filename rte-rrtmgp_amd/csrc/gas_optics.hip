@@ -27,6 +27,7 @@
 namespace {
 
 using rte::cdiv;
+using rte::store_stream;
 
 constexpr int GC = 16;  // g-points held in registers per chunk
 
