@@ -110,9 +110,12 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
         b = cases.run_suite(hip, xp, case, inp)
     finally:
         hiplib.ext_call(hip, "rte_hip_force_generic_sw", ["i"], 0)
-    for k in ("sw.flux_up", "sw.flux_dn", "sw.flux_dir", "swc.flux_up", "swc.flux_dn", "swc.flux_dir",
-              "sws.gpt_flux_up", "sws.gpt_flux_dn", "sws.gpt_flux_dir"):  # sws: spectral output from the segmented kernel
+    for k in ("sw.flux_up", "sw.flux_dn", "sw.flux_dir", "swc.flux_up", "swc.flux_dn", "swc.flux_dir"):
         assert cases.rel_err(a[k], b[k]) <= 1e-12, k
+    # sws: spectral output from the segmented kernel (single g-points, no averaging over a band: the two kernels'
+    # different association of the adding recurrence shows a little more)
+    for k in ("sws.gpt_flux_up", "sws.gpt_flux_dn", "sws.gpt_flux_dir"):
+        assert cases.rel_err(a[k], b[k]) <= 1e-11, k
     # direct call: night columns + diffuse boundary condition, broadband, against the oracle
     rng = np.random.default_rng(11)
     F = lambda *sh: np.asfortranarray(rng.random(sh))
@@ -134,7 +137,7 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
         out = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(ssa), A(g), A(mu0), A(idir), A(adir), A(adif),
                               inc_flux_dif=A(idif), do_broadband=False)
         for k in ("gpt_flux_up", "gpt_flux_dn", "gpt_flux_dir"):
-            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-11, (k, nlay, top_at_1)
         # the LW two-stream solver on the same optical properties (segmented kernel) against the oracle
         lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
         emis, sfc, inc = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10, F(ncol, ngpt)
