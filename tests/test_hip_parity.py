@@ -112,10 +112,11 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
         hiplib.ext_call(hip, "rte_hip_force_generic_sw", ["i"], 0)
     for k in ("sw.flux_up", "sw.flux_dn", "sw.flux_dir", "swc.flux_up", "swc.flux_dn", "swc.flux_dir"):
         assert cases.rel_err(a[k], b[k]) <= 1e-12, k
-    # sws: spectral output from the segmented kernel (single g-points, no averaging over a band: the two kernels'
-    # different association of the adding recurrence shows a little more)
+    # sws: spectral output from the segmented kernel.  Single g-points of clear-sky gas optics: optically very thin
+    # layers make 1 - exp(-2 k tau) lose digits (inherent in the reference's formulas, :1028-1031), and the two kernels'
+    # exponentials differ by an ulp -- a few 1e-11 of the largest flux, where the band sums above agree to 1e-12
     for k in ("sws.gpt_flux_up", "sws.gpt_flux_dn", "sws.gpt_flux_dir"):
-        assert cases.rel_err(a[k], b[k]) <= 1e-11, k
+        assert cases.rel_err(a[k], b[k]) <= 1e-10, k
     # direct call: night columns + diffuse boundary condition, broadband, against the oracle
     rng = np.random.default_rng(11)
     F = lambda *sh: np.asfortranarray(rng.random(sh))
