@@ -534,6 +534,233 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   }
 }
 
+// seg_load with the row offsets formed where they are used: base + (clamped slot) * step, two integer operations per load
+// instead of a register per row (the two-sub-segment kernel below has no registers to spare for 4 L + 2 offsets)
+template <int L, bool do_jac, bool SFC>
+__device__ __forceinline__ void seg_load2(SegTile<L>& t, unsigned lay0, unsigned lev0, unsigned step, unsigned cg, int np_off, int np,
+                                          int igpt, int ncol, int nlay, const Float* __restrict__ Dsec,
+                                          const Float* __restrict__ tau_, const Float* __restrict__ lay_source_,
+                                          const Float* __restrict__ lev_source_, const Float* __restrict__ sfc_emis,
+                                          const Float* __restrict__ sfc_src, const Float* __restrict__ inc_flux,
+                                          const Float* __restrict__ sfc_srcJac) {
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1), ncg = (size_t)ncol * igpt;
+  auto at = [](const Float* plane, unsigned off) {  // plane is wave-uniform
+    asm volatile("" : "+v"(off));
+    return __builtin_nontemporal_load(reinterpret_cast<const Float*>(reinterpret_cast<const char*>(plane) + off));
+  };
+  const Float* tau = tau_ + ncl * igpt;
+  const Float* lay = lay_source_ + ncl * igpt;
+  const Float* lev = lev_source_ + nclv * igpt;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    const unsigned o = lay0 + (unsigned)min(i, np_off - 1) * step;
+    const Float tv = at(tau, o);
+    t.tau[i] = i < np ? tv : (Float)0;  // neutral slot (see seg_load)
+    t.lay[i] = at(lay, o);
+  }
+#pragma unroll
+  for (int i = 0; i <= L; ++i) t.lev[i] = at(lev, lev0 + (unsigned)min(i, np_off) * step);
+  if (SFC) {
+    t.D = at(Dsec + ncg, cg);
+    t.emis = at(sfc_emis + ncg, cg);
+    t.ssrc = at(sfc_src + ncg, cg);
+    t.inc = at(inc_flux + ncg, cg);
+    t.sjac = do_jac ? at(sfc_srcJac + ncg, cg) : (Float)0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LW no-scattering, segmented, TWO sub-segments per wave: 81 ... 160 layers (host models at 91 / 128 / 137 levels).
+//
+// The reference has no layer limit (:697-743); the kernel above holds one segment's (trans, src_dn, src_up) in
+// registers and cannot take more than 10 layers per wave without spilling.  Here wave s owns 2 L consecutive layers as
+// sub-segments A (upper) and B (lower): pass 1 evaluates A, parks its 3 L values per thread in the thread's own LDS
+// slots (98 ... 123 KB per block: the reason the surface arrays are not shared through LDS here), evaluates B into the
+// registers A just left, and publishes the composite of A followed by B; after the exchange pass 2 sweeps A from LDS
+// and B from registers.  Same arithmetic per layer as the one-segment kernel, same composites across waves.
+// ---------------------------------------------------------------------------------------------
+template <int L, bool do_jac, bool SPEC>
+__global__ void __launch_bounds__(64 * 8)
+lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
+                      const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
+                      const Float* __restrict__ lay_source_, const Float* __restrict__ lev_source_,
+                      const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
+                      const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
+                      Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac,
+                      Float* __restrict__ spec_up, Float* __restrict__ spec_dn, bool spec_add) {
+#pragma clang fp contract(fast)
+  constexpr int LT = 2 * L, MAXS = 8;
+  extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][MAXS][64], then A's parked values [3][L][512]
+  const int lane = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int icol = blockIdx.x * 64 + lane;
+  const bool active = icol < ncol;
+  const int c = active ? icol : ncol - 1;
+  const int nlev = nlay + 1;
+  const size_t nclv = (size_t)ncol * nlev;
+  const int p0 = s * LT;
+  const int np = min(LT, nlay - p0);  // layers of this wave (>= 1 by construction)
+  const bool last = (s == S - 1);
+  const Float piw = kPi * weight;
+  const Float inv_piw = (Float)1 / piw;
+  const int g_begin = blockIdx.y * g_per_block;
+  const int g_end = min(ngpt, g_begin + g_per_block);
+  Float* const PARK = lds + 2 * 3 * MAXS * 64 + threadIdx.x;  // value k of layer i at PARK[(k * L + i) * 512]
+  for (int i = threadIdx.x; i < 2 * 3 * MAXS * 64; i += blockDim.x) {
+    const int q = (i >> 6) % MAXS, k = (i >> 6) / MAXS % 3;
+    if (q >= S) lds[i] = k == 0 ? (Float)1 : (Float)0;  // neutral composites of the segment slots no wave owns
+  }
+  // the wider variants are a dozen registers over the budget: the LAST NL upward-flux accumulators live in the thread's own
+  // LDS slots (ds_add_f64), as many as the LDS left beside the parked values holds (L = 9: 6 of 38, L = 10: 3 of 42)
+  constexpr int NL = SPEC ? 0 : (L == 9 ? 6 : (L == 10 ? 3 : 0));
+  Float* const ACCL = lds + 2 * 3 * MAXS * 64 + 3 * L * 512 + threadIdx.x;  // slot k at ACCL[k * 512]
+  Float acc_dn[SPEC ? 1 : LT + 1], acc_up[SPEC ? 1 : LT + 1 - NL], acc_j[do_jac ? LT + 1 : 1];
+#pragma unroll
+  for (int i = 0; i <= LT; ++i) {
+    if (!SPEC) { acc_dn[i] = 0; if (i <= LT - NL) acc_up[i] = 0; else ACCL[(i - (LT + 1 - NL)) * 512] = 0; }
+    if (do_jac) acc_j[i] = 0;
+  }
+  auto put_up = [&](int i, Float v) {  // broadband upward accumulation (compile-time i)
+    if (i <= LT - NL) acc_up[i <= LT - NL ? i : 0] += v;
+    else atomicAdd(&ACCL[(i - (LT + 1 - NL)) * 512], v);
+  };
+  // sub-segment A: layers p0 .. p0 + L - 1, B: the L after it.  A B without layers (the wave's last layers all in A)
+  // points at valid rows and is neutral (tau = 0, see seg_load)
+  const int npA = min(L, np), npB = max(0, np - L);
+  // byte offsets inside one g-point plane: the wave's first level row, the step to the next row (layers and levels
+  // advance alike), first layer / level rows of A and B
+  const unsigned dlev = (top_at_1 ? (unsigned)ncol : 0u - (unsigned)ncol) * (unsigned)sizeof(Float);
+  auto lay_row = [&](int p) { return ((unsigned)c + (unsigned)ncol * (unsigned)(top_at_1 ? p : nlay - 1 - p)) * (unsigned)sizeof(Float); };
+  auto lev_row = [&](int p) { return ((unsigned)c + (unsigned)ncol * (unsigned)(top_at_1 ? p : nlay - p)) * (unsigned)sizeof(Float); };
+  const int pB = min(p0 + L, nlay - 1);
+  unsigned olev0 = lev_row(p0), layA = lay_row(p0), layB = lay_row(pB), levB = lev_row(pB), ocg = (unsigned)c * (unsigned)sizeof(Float);
+  asm volatile("" : "+v"(olev0), "+v"(layA), "+v"(layB), "+v"(levB), "+v"(ocg));
+  auto put = [&](Float* acc, Float* __restrict__ spec, int i, Float v, int ig) {
+    if constexpr (SPEC) {
+      if (active && (i < np || (last && i == np))) {
+        Float* q = reinterpret_cast<Float*>(reinterpret_cast<char*>(spec + nclv * ig) + (olev0 + (unsigned)i * dlev));
+        const Float f = v * piw;
+        if (spec_add) *q = *q + f; else rte::store_stream(q, f);
+      }
+    } else {
+      if (acc == acc_up) put_up(i, v); else acc[i] += v;
+    }
+  };
+  auto loadA = [&](SegTile<L>& tile, int igpt) {
+    seg_load2<L, do_jac, true>(tile, layA, olev0, dlev, ocg, npA, npA, min(igpt, g_end - 1), ncol, nlay, Dsec, tau_, lay_source_,
+                               lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac);
+  };
+  auto loadB = [&](SegTile<L>& tile, int igpt) {
+    seg_load2<L, do_jac, false>(tile, layB, levB, dlev, ocg, max(npB, 1), npB, min(igpt, g_end - 1), ncol, nlay, Dsec, tau_,
+                                lay_source_, lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac);
+  };
+  // One g-point.  The inputs of a sub-segment are dead after its pass 1: the next g-point's are requested into the same
+  // registers right there (in flight during the rest of this g-point) -- one set of input registers, not two
+  auto process = [&](SegTile<L>& ta, SegTile<L>& tb, int buf, int ig) {
+#pragma clang fp contract(fast)
+    Float t[L], sd[L], su[L];
+    const Float D = ta.D, emis = ta.emis, ssrc = ta.ssrc, inc = ta.inc, sjac = ta.sjac;
+    auto pass1 = [&](const SegTile<L>& x, Float& Td, Float& Sd, Float& Su) {
+      Td = 1; Sd = 0;
+#pragma unroll
+      for (int i = 0; i < L; ++i) {
+        const Float tau_loc = x.tau[i] * D;
+        const Float tr = rte::exp_nonpos(-tau_loc);
+        lw_source_layer_fast(tau_loc, tr, x.lay[i], x.lev[i], x.lev[i + 1], sd[i], su[i]);
+        t[i] = tr;
+        Sd = tr * Sd + sd[i];
+        Td = Td * tr;
+        __builtin_amdgcn_sched_barrier(0);  // one layer at a time: this kernel has no registers for interleaved layers
+      }
+      Su = 0;
+#pragma unroll
+      for (int i = L - 1; i >= 0; --i) Su = t[i] * Su + su[i];
+    };
+    Float TdA, SdA, SuA, TdB, SdB, SuB;
+    // Register budget (a double is two VGPRs): accumulators 4 L + 2, a sub-segment's inputs 3 L + 1, its (t, sd, su) 3 L.
+    // Only ONE set of inputs may be in flight besides the one being consumed: A's next are requested after pass 1 of B
+    // (in flight during the exchange and pass 2), B's next at the very end (in flight during the next pass 1 of A).
+    pass1(ta, TdA, SdA, SuA);
+#pragma unroll
+    for (int i = 0; i < L; ++i) { PARK[(0 * L + i) * 512] = t[i]; PARK[(1 * L + i) * 512] = sd[i]; PARK[(2 * L + i) * 512] = su[i]; }
+    __builtin_amdgcn_sched_barrier(0);
+    pass1(tb, TdB, SdB, SuB);
+    __builtin_amdgcn_sched_barrier(0);
+    loadA(ta, ig + 1);
+    // A above B: down through A then B; up through B then A
+    Float* X = lds + (size_t)buf * 3 * MAXS * 64;
+    X[(0 * MAXS + s) * 64 + lane] = TdA * TdB;
+    X[(1 * MAXS + s) * 64 + lane] = TdB * SdA + SdB;
+    X[(2 * MAXS + s) * 64 + lane] = TdA * SuB + SuA;
+    __syncthreads();
+    Float r = inc * inv_piw;  // radiance entering segment 0 from above (:144)
+    Float r_in = r;
+    for (int q = 0; q < S; ++q) {
+      if (q == s) r_in = r;
+      r = X[(0 * MAXS + q) * 64 + lane] * r + X[(1 * MAXS + q) * 64 + lane];
+    }
+    Float u = r * ((Float)1 - emis) + emis * ssrc;  // :198-200
+    Float jv = do_jac ? emis * sjac : (Float)0;
+    for (int q = S - 1; q > s; --q) {
+      const Float Tq = X[(0 * MAXS + q) * 64 + lane];
+      u = Tq * u + X[(2 * MAXS + q) * 64 + lane];
+      jv = Tq * jv;
+    }
+    put(acc_up, spec_up, LT, u, ig);  // the level below the wave's last slot (a FULL last wave: the surface)
+    if (do_jac) acc_j[LT] += jv;
+    // ---- pass 2, down: A from LDS, B from registers (neutral slots carry the value on: slot np gets the surface value)
+    r = r_in;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      put(acc_dn, spec_dn, i, r, ig);
+      r = PARK[(0 * L + i) * 512] * r + PARK[(1 * L + i) * 512];
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      put(acc_dn, spec_dn, L + i, r, ig);
+      r = t[i] * r + sd[i];
+    }
+    put(acc_dn, spec_dn, LT, r, ig);
+    // ---- pass 2, up (+ Jacobian, :729-743): B, then A
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      u = t[i] * u + su[i];
+      put(acc_up, spec_up, L + i, u, ig);
+      if (do_jac) { jv = t[i] * jv; acc_j[L + i] += jv; }
+    }
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      const Float ta_ = PARK[(0 * L + i) * 512];
+      u = ta_ * u + PARK[(2 * L + i) * 512];
+      put(acc_up, spec_up, i, u, ig);
+      if (do_jac) { jv = ta_ * jv; acc_j[i] += jv; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    loadB(tb, ig + 1);
+  };
+  SegTile<L> ta, tb;
+  loadA(ta, g_begin);
+  loadB(tb, g_begin);
+  int buf = 0;
+#pragma unroll 1
+  for (int igpt = g_begin; igpt < g_end; ++igpt, buf ^= 1) process(ta, tb, buf, igpt);
+  if (active && (!SPEC || do_jac)) {
+    const size_t base = icol + nclv * blockIdx.y;
+#pragma unroll
+    for (int i = 0; i <= LT; ++i) {
+      if (i < np || (last && i == np)) {
+        const int p = p0 + i;
+        const int ilev = top_at_1 ? p : nlay - p;
+        if constexpr (!SPEC) {
+          part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
+          part_up[base + (size_t)ncol * ilev] = i <= LT - NL ? acc_up[i <= LT - NL ? i : 0] : ACCL[(i - (LT + 1 - NL)) * 512];
+        }
+        if (do_jac) part_jac[base + (size_t)ncol * ilev] = acc_j[i];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LW two-stream, generic: reference :377-440 (lw_two_stream :854-909, lw_source_2str :917-967,
 // adding :1135-1245).  ws: 4 layer slabs (ncol, nlay, gchunk): Rdif, Tdif, src_dn, denom.
@@ -1608,6 +1835,52 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
         const Float piw = (Float)3.14159265358979323846264338327950288 * w_h[imu];
         hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_jac, d_jac, piw, imu > 0);
       }
+    }
+    return;
+  }
+
+  if (!do_rescaling && nlay > 80 && nlay <= 160 && !g_lw_force_generic && nclv < ((size_t)1 << 29)) {
+    // ---------------------------------------------------------------- production path, 81 ... 160 layers: two sub-segments
+    // of 8 / 9 / 10 layers per wave (lw_noscat_seg2_kernel), broadband or spectral output
+    const int L2 = nlay <= 128 ? 8 : nlay <= 144 ? 9 : 10;
+    const int S2 = (nlay + 2 * L2 - 1) / (2 * L2);
+    const int col_tiles = cdiv(ncol, 64);
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    const int nparts = (do_broadband ? 2 : 0) + (do_jac ? 1 : 0);
+    Float* parts = nparts ? (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * nparts) : nullptr;
+    Float* part_up = do_broadband ? parts : nullptr;
+    Float* part_dn = do_broadband ? parts + nclv * ngroups : nullptr;
+    Float* part_jac = do_jac ? parts + nclv * ngroups * (do_broadband ? 2 : 0) : nullptr;
+    const size_t lds_bytes = sizeof(Float) * (2 * 3 * 8 * 64 + 3 * L2 * 512 + (L2 == 9 ? 6 : L2 == 10 ? 3 : 0) * 512);
+    for (int imu = 0; imu < nmus; ++imu) {
+      {
+        rte::ProfScope p("lw_noscat_seg2_kernel");
+#define RTE_LAUNCH_SEG2(LL, JJ, SS)                                                                                       \
+  do {                                                                                                                    \
+    HIP_CHECK(hipFuncSetAttribute((const void*)lw_noscat_seg2_kernel<LL, JJ, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds_bytes));                                                                       \
+    hipLaunchKernelGGL((lw_noscat_seg2_kernel<LL, JJ, SS>), dim3(col_tiles, ngroups), dim3(64 * S2), lds_bytes, st, ncol, \
+                       nlay, ngpt, S2, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev,     \
+                       d_emis, d_sfc, d_inc, d_srcJac, part_up, part_dn, part_jac, d_flux_up, d_flux_dn, imu > 0);        \
+  } while (0)
+#define RTE_LAUNCH_SEG2_(LL)                                                                     \
+  do {                                                                                           \
+    if (do_broadband) { if (do_jac) RTE_LAUNCH_SEG2(LL, true, false); else RTE_LAUNCH_SEG2(LL, false, false); } \
+    else              { if (do_jac) RTE_LAUNCH_SEG2(LL, true, true); else RTE_LAUNCH_SEG2(LL, false, true); }   \
+  } while (0)
+        if (L2 == 8) RTE_LAUNCH_SEG2_(8); else if (L2 == 9) RTE_LAUNCH_SEG2_(9); else RTE_LAUNCH_SEG2_(10);
+#undef RTE_LAUNCH_SEG2_
+#undef RTE_LAUNCH_SEG2
+      }
+      rte::ProfScope p("lw_reduce_parts");
+      const Float piw = (Float)3.14159265358979323846264338327950288 * w_h[imu];
+      if (do_broadband) {
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_up, d_bb_up, piw, imu > 0);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_dn, d_bb_dn, piw, imu > 0);
+      }
+      if (do_jac)
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_jac, d_jac, piw, imu > 0);
     }
     return;
   }

@@ -167,6 +167,32 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
 
 
+@pytest.mark.parametrize("nlay,top_at_1", [(81, True), (91, False), (128, True), (137, False), (144, True), (160, False)])
+def test_lw_noscat_with_more_than_80_layers(hip, oracle_c, nlay, top_at_1):
+    """Host models at 91 / 128 / 137 levels: the reference has no layer limit (rte/kernels/mo_rte_solver_kernels.F90:697-743).
+    81 ... 160 layers run on the two-sub-segment kernel (8 waves x 2 x 8 / 9 / 10 layers): broadband with three angles,
+    incident flux and Jacobian, and spectral output, against the oracle; partial last waves (81, 91, 137) included."""
+    import numpy as np
+
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    rng = np.random.default_rng(nlay)
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    ncol, ngpt = 70, 16
+    tau = F(ncol, nlay, ngpt) * 2.0
+    lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
+    emis, sfc, inc, sj = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10, F(ncol, ngpt), F(ncol, ngpt)
+    for kw, keys in ((dict(n_gauss_angles=3, do_jacobians=True), ("flux_up", "flux_dn", "flux_up_jac")),
+                     (dict(n_gauss_angles=2, do_broadband=False), ("gpt_flux_up", "gpt_flux_dn")),
+                     (dict(), ("flux_up", "flux_dn"))):
+        ref = frontend.rte_lw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, lay, lev, emis, sfc, inc_flux=inc,
+                              sfc_src_jac=sj, **kw)
+        out = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(lay), A(lev), A(emis), A(sfc), inc_flux=A(inc),
+                              sfc_src_jac=A(sj), **kw)
+        for k in keys:
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1, kw)
+
+
 @pytest.mark.parametrize("name", ["lw_mid_ragged", "lw_mid_top1", "lw_g256"])
 def test_segmented_and_generic_lw_solvers_agree(hip, name):
     """The production (segmented) and the generic LW kernels are two implementations of one
