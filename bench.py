@@ -351,6 +351,8 @@ def main():
                     help="ragged: the synthetic table's minor-absorber intervals spread unevenly over the bands (0 ... 8 per band and "
                          "regime, same totals), as in real coefficient files; even (default): 4 per band lower, 2-3 upper")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plain-abi", action="store_true",
+                    help="skip the untimed plain-ABI steps (for rocprofv3 passes: their kernel variants would mix into the per-kernel averages)")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
     ap.add_argument("--seg-groups", type=int, default=0, help="experiment: g-point groups per column tile of the segmented solvers (0 = automatic)")
     ap.add_argument("--no-aux-stream", action="store_true",
@@ -569,7 +571,8 @@ def main():
 
     plain_abi_ms = None
     try:
-        plain_abi_ms = timed_ms(step_plain, reps=3)
+        if not args.no_plain_abi:
+            plain_abi_ms = timed_ms(step_plain, reps=3)
     except Exception as e:  # noqa: BLE001  (e.g. not enough memory for the unfused all-sky chain beside the fused one)
         plain_abi_ms = f"failed: {e}"
     bufs_p.clear(); rb_p.clear(); st_p.clear()
