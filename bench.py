@@ -235,6 +235,32 @@ def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw")
     from rte_rrtmgp_amd import synth
 
     cores, cores_note = _usable_cores()
+    # beside it: the reference's UNCHANGED Fortran frontend on pageable host arrays (oracle/_ref/bin/ref_frontend_driver, the
+    # program of tests/test_extern_frontend.py) -- on the HIP library in host-mirror mode and staged, and on the reference's CPU
+    # kernels -- i.e. what a host model that keeps its arrays on the host gets from the drop-in.  Never `value`.
+    host_arrays = None
+    if workload == "lw" and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "bin", "ref_frontend_driver")):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import stream_io
+
+            nt = max(1, min(8, cores))
+            m = stream_io.measure_frontend_driver("lw", 98304, 16384, ("mirror", "staged", "cpuref"), nrep=2)
+            mt = stream_io.measure_frontend_driver("lw", 98304, 4096, ("mirror",), nrep=3, threads=nt) if nt > 1 else m
+            host_arrays = {"hip_host_mirror_columns_per_s": round(mt["mirror"]["columns_per_s"], 1),
+                           "hip_host_mirror_host_threads": nt,
+                           "hip_host_mirror_1thread_columns_per_s": round(m["mirror"]["columns_per_s"], 1),
+                           "hip_staged_columns_per_s": round(m["staged"]["columns_per_s"], 1),
+                           "reference_cpu_kernels_1core_columns_per_s": round(m["cpuref"]["columns_per_s"], 1),
+                           "what": "reference Fortran frontend (load -> gas_optics -> rte_lw, ty_fluxes_broadband) on pageable host arrays, "
+                                   "value checks off, 98304 columns: one host thread in blocks of 16384 (mirror, staged), and the OpenMP "
+                                   f"build with {nt} host threads in blocks of 4096, every thread on its own library context "
+                                   "(RTE_HIP_THREAD_CONTEXTS=1, host-mirror mode)",
+                           "pcie_bound_note": "about 20.6 KB per column cross PCIe in host-mirror mode (19.6 in, 1.0 out)",
+                           "passes_threads": mt["mirror"]["passes"], "passes_1thread": m["mirror"]["passes"],
+                           "staging_report": m["mirror"]["report"]}
+        except Exception as e:  # noqa: BLE001
+            host_arrays = {"failed": str(e)[-300:]}
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     # the k-distribution tables once, in shared memory, mapped read-only by every worker
     shm_dir = tempfile.mkdtemp(prefix="rte_kdist_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -284,31 +310,6 @@ def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw")
     except OSError:
         pass
     gpt = gpt.replace("+", " + ")
-    # beside it: the reference's UNCHANGED Fortran frontend on pageable host arrays (oracle/_ref/bin/ref_frontend_driver, the
-    # program of tests/test_extern_frontend.py) -- on the HIP library in host-mirror mode and staged, and on the reference's CPU
-    # kernels -- i.e. what a host model that keeps its arrays on the host gets from the drop-in.  Never `value`.
-    host_arrays = None
-    if workload == "lw" and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "bin", "ref_frontend_driver")):
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import stream_io
-
-            nt = max(1, min(8, cores))
-            m = stream_io.measure_frontend_driver("lw", 98304, 16384, ("mirror", "staged", "cpuref"), nrep=2)
-            mt = stream_io.measure_frontend_driver("lw", 98304, 4096, ("mirror",), nrep=3, threads=nt) if nt > 1 else m
-            host_arrays = {"hip_host_mirror_columns_per_s": round(mt["mirror"]["columns_per_s"], 1),
-                           "hip_host_mirror_host_threads": nt,
-                           "hip_host_mirror_1thread_columns_per_s": round(m["mirror"]["columns_per_s"], 1),
-                           "hip_staged_columns_per_s": round(m["staged"]["columns_per_s"], 1),
-                           "reference_cpu_kernels_1core_columns_per_s": round(m["cpuref"]["columns_per_s"], 1),
-                           "what": "reference Fortran frontend (load -> gas_optics -> rte_lw, ty_fluxes_broadband) on pageable host arrays, "
-                                   "value checks off, 98304 columns: one host thread in blocks of 16384 (mirror, staged), and the OpenMP "
-                                   f"build with {nt} host threads in blocks of 4096, every thread on its own library context "
-                                   "(RTE_HIP_THREAD_CONTEXTS=1, host-mirror mode)",
-                           "pcie_bound_note": "about 20.6 KB per column cross PCIe in host-mirror mode (19.6 in, 1.0 out)",
-                           "staging_report": m["mirror"]["report"]}
-        except Exception as e:  # noqa: BLE001
-            host_arrays = {"failed": str(e)[-300:]}
     return {"value": rate, "reference_frontend_host_arrays": host_arrays, "unit": "columns/s", "cores": cores, "kind": kind,
             "value_1core": rate1, "per_core_at_full_load": rate / cores, "cpu_model": model, "cores_note": cores_note,
             "sample": f"{blocks * ncol_block} columns in {dt:.1f} s ({cores} single-threaded processes, one per core, "
