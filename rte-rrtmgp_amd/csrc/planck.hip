@@ -1,0 +1,781 @@
+// planck.hip -- rrtmgp_compute_Planck_source (reference rrtmgp/kernels/mo_gas_optics_rrtmgp_kernels.F90:568-710) for gfx950.
+// Each (column tile, band) block walks the layers so that the geometric mean of adjacent layers' Planck fractions needs
+// no second gather; the production kernel splits loader and compute waves like the tau kernel (gas_optics_common.h).
+#include "gas_optics_common.h"
+
+namespace {
+// -------------------------------------------------------------------------------------------
+// compute_Planck_source: reference :568-710 (+ interpolate1D :715-737)
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ Float planck_1d(Float val, Float offset, Float delta_r, const Float* __restrict__ table,
+                                           int ntab) {
+  const Float val0 = (val - offset) * delta_r;
+  const Float frac = val0 - trunc(val0);
+  const int index = min(ntab - 1, max(1, (int)val0 + 1));  // 1-based
+  const Float t0 = table[index - 1], t1 = table[index];
+  return t0 + frac * (t1 - t0);
+}
+
+struct PlanckArgs {
+  int ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, sfc_lay;
+  const Float *tlay, *tlev, *tsfc, *fmajor;
+  const int* jeta;
+  const Bool* tropo;
+  const int *jtemp, *jpress, *band_lims_gpt;
+  const Float* pfracin;
+  Float temp_ref_min, totplnk_delta_r;
+  const Float* totplnk;
+  const int* gpoint_flavor;
+  Float *sfc_src, *lay_src, *lev_src, *sfc_source_Jac;
+};
+
+// one column, one band, native table layout: always applicable
+__device__ __forceinline__ void planck_direct_column(const PlanckArgs& q, const int icol, const int ibnd) {
+  const int ncol = q.ncol, nlay = q.nlay, neta = q.neta, npres = q.npres, ntemp = q.ntemp,
+            nPlanckTemp = q.nPlanckTemp, sfc_lay = q.sfc_lay;
+  const Float *tlay = q.tlay, *tlev = q.tlev, *tsfc = q.tsfc, *fmajor = q.fmajor, *pfracin = q.pfracin, *totplnk = q.totplnk;
+  const int *jeta = q.jeta, *jtemp = q.jtemp, *jpress = q.jpress, *band_lims_gpt = q.band_lims_gpt,
+            *gpoint_flavor = q.gpoint_flavor;
+  const Bool* tropo = q.tropo;
+  const Float temp_ref_min = q.temp_ref_min, totplnk_delta_r = q.totplnk_delta_r;
+  Float *sfc_src = q.sfc_src, *lay_src = q.lay_src, *lev_src = q.lev_src, *sfc_source_Jac = q.sfc_source_Jac;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const int gptS = band_lims_gpt[2 * ibnd] - 1, gptE = band_lims_gpt[2 * ibnd + 1] - 1;
+  const Float* tp = totplnk + (size_t)nPlanckTemp * ibnd;
+  const size_t tn = (size_t)ntemp * neta;
+  const size_t gstride = tn * (npres + 1);
+  // :641-656 surface Planck function at tsfc and tsfc + 1 K
+  const Float pl_sfc = planck_1d(tsfc[icol], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
+  const Float pl_sfc1 = planck_1d(tsfc[icol] + (Float)1, temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
+
+  for (int g0 = gptS; g0 <= gptE; g0 += GC) {
+    Float pf_prev[GC];
+#pragma unroll
+    for (int j = 0; j < GC; ++j) pf_prev[j] = 0;
+    for (int ilay = 0; ilay < nlay; ++ilay) {
+      const size_t cl = icol + (size_t)ncol * ilay;
+      const int itropo = tropo[cl] ? 0 : 1;
+      const int iflav = gpoint_flavor[itropo + 2 * gptS] - 1;
+      const size_t clf = cl + ncl * iflav;
+      const int jT = jtemp[cl];
+      const int jp = jpress[cl] + itropo + 1;
+      const int je1 = jeta[2 * clf], je2 = jeta[2 * clf + 1];
+      Float fm[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fm[i] = fmajor[8 * clf + i];
+      const size_t a0 = (size_t)(jT - 1) + (size_t)ntemp * (je1 - 1) + tn * (size_t)(jp - 2);
+      const size_t b0 = (size_t)jT + (size_t)ntemp * (je2 - 1) + tn * (size_t)(jp - 2);
+      const Float pl_lay = planck_1d(tlay[cl], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
+      const Float pl_lev = planck_1d(tlev[icol + (size_t)ncol * ilay], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
+#pragma unroll
+      for (int j = 0; j < GC; ++j) {
+        const int g = g0 + j;
+        if (g <= gptE) {
+          const Float* ka = pfracin + gstride * (size_t)g + a0;
+          const Float* kb = pfracin + gstride * (size_t)g + b0;
+          // interpolate3D_byflav with scaling = (1,1), :791-801
+          const Float pf =
+              (Float)1 * (fm[0] * ka[0] + fm[1] * ka[ntemp] + fm[2] * ka[tn] + fm[3] * ka[tn + ntemp]) +
+              (Float)1 * (fm[4] * kb[0] + fm[5] * kb[ntemp] + fm[6] * kb[tn] + fm[7] * kb[tn + ntemp]);
+          lay_src[cl + ncl * (size_t)g] = pf * pl_lay;                                   // :674
+          const Float lv = (ilay == 0) ? pf : sqrt(pf_prev[j] * pf);                      // :695,:699
+          lev_src[icol + (size_t)ncol * ilay + nclv * (size_t)g] = lv * pl_lev;
+          if (ilay == sfc_lay - 1) {                                                      // :651-653
+            sfc_src[icol + (size_t)ncol * g] = pf * pl_sfc;
+            sfc_source_Jac[icol + (size_t)ncol * g] = pf * (pl_sfc1 - pl_sfc);
+          }
+          pf_prev[j] = pf;
+        }
+      }
+    }
+    const Float pl_top = planck_1d(tlev[icol + (size_t)ncol * nlay], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
+#pragma unroll
+    for (int j = 0; j < GC; ++j)
+      if (g0 + j <= gptE) lev_src[icol + (size_t)ncol * nlay + nclv * (size_t)(g0 + j)] = pf_prev[j] * pl_top;  // :705
+  }
+}
+
+__global__ void __launch_bounds__(256) planck_source_kernel(PlanckArgs q, const int* __restrict__ run_if) {
+  if (run_if && *run_if == 0) return;
+  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
+  if (icol < q.ncol) planck_direct_column(q, icol, blockIdx.y);
+}
+
+// (tile, band) pairs the slab kernel handed over (worklist[0] = count)
+__global__ void __launch_bounds__(256)
+planck_source_worklist_kernel(PlanckArgs q, const int* __restrict__ worklist, int tile, int* __restrict__ stat) {
+  const int n = worklist[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *stat = n;  // rte_hip_stat(1)
+  for (int w = blockIdx.x; w < n; w += gridDim.x)
+    for (int c = threadIdx.x; c < tile; c += 256) {
+      const int icol = worklist[1 + 2 * w] * tile + c;
+      if (icol < q.ncol) planck_direct_column(q, icol, worklist[2 + 2 * w]);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// compute_Planck_source, production kernel: same scheme as tau_absorption_v7_kernel.
+// block = (256 columns, one band) and walks the LAYERS, so the previous layer's Planck fractions
+// stay in registers for the geometric mean at the interface (:699).  Per layer the tile's
+// bounding box of pfrac rows is staged in LDS from the g-fastest table; the band's totplnk column
+// sits in LDS for the whole block.  Interpolation state of layer l+1 is requested while layer l
+// is computed (two-deep: indices two layers ahead, flavor-dependent weights one layer ahead).
+// -------------------------------------------------------------------------------------------
+struct PlanckV7 {
+  int ncol, nlay, ngpt, ntemp, TE, nPlanckTemp, sfc_lay;
+  Float temp_ref_min, totplnk_delta_r;
+  const int *band_lims, *gpoint_flavor, *jeta, *jtemp, *jpress;
+  const Bool* tropo;
+  const Float *pf_g, *totplnk, *fmajor, *tlay, *tlev, *tsfc;
+  Float *sfc_src, *lay_src, *lev_src, *sfc_jac;
+  int* worklist;  // [0] = count, then (tile, band) pairs for planck_source_worklist_kernel
+  const int* skip_if;  // plan guard raised: the direct kernel does the call
+};
+
+template <int BS>
+__global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
+  __shared__ int rng[2][6];  // per layer (ping-pong): Tmin, Tmax, Pmin, Pmax, emin, emax
+  constexpr int PSLAB = 8704;  // 68 KB: no minor tables here and 2 blocks per CU, so the slab can be larger
+  __shared__ __align__(16) Float slab[PSLAB];
+  extern __shared__ Float tpl[];  // totplnk(:, ibnd)
+  if (*a.skip_if) return;
+  const int tid = threadIdx.x;
+  const int ibnd = blockIdx.y;
+  const unsigned ncol = a.ncol, nlay = a.nlay;
+  const unsigned ncl = ncol * nlay, nclv = ncol * (nlay + 1);  // host guarantees < 2^31
+  const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nPT = a.nPlanckTemp;
+  const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
+  for (int i = tid; i < nPT; i += BS) tpl[i] = a.totplnk[(size_t)nPT * ibnd + i];
+  if (tid < 12) rng[tid / 6][tid % 6] = (tid % 2 == 0) ? (1 << 30) : -1;
+  __syncthreads();
+  const unsigned icol = blockIdx.x * BS + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  auto planck = [&](Float t) {  // interpolate1D :715-737 on the LDS copy of the band's column
+    const Float val0 = (t - a.temp_ref_min) * a.totplnk_delta_r;
+    const Float frac = val0 - trunc(val0);
+    const int index = min(nPT - 1, max(1, (int)val0 + 1));
+    const Float t0 = tpl[index - 1], t1 = tpl[index];
+    return t0 + frac * (t1 - t0);
+  };
+  const Float pl_sfc = planck(a.tsfc[ic]);
+  const Float pl_sfc1 = planck(a.tsfc[ic] + (Float)1);
+
+  struct Idx { int itropo, jT, jp; Float tlay, tlev; };
+  struct Wts { Float2 fm[4]; int je1, je2; };
+  auto load_idx = [&](unsigned l, Idx& x) {
+    const unsigned cl = ic + ncol * l;
+    x.itropo = a.tropo[cl] ? 0 : 1;
+    x.jT = a.jtemp[cl];
+    x.jp = a.jpress[cl] + x.itropo + 1;
+    x.tlay = a.tlay[cl];
+    x.tlev = a.tlev[cl];
+  };
+  auto load_wts = [&](unsigned l, const Idx& x, Wts& w) {
+    const unsigned cl = ic + ncol * l;
+    const int iflav = a.gpoint_flavor[x.itropo + 2 * gptS] - 1;
+    const size_t clf = cl + (size_t)ncl * iflav;
+    const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.fm[i] = fmp[i];
+    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
+    w.je1 = je.x; w.je2 = je.y;
+  };
+  Idx x0, x1;   // layers l and l+1
+  Wts w0;       // layer l
+  load_idx(0, x0);
+  load_idx(min(1u, nlay - 1), x1);
+  load_wts(0, x0, w0);
+
+  for (int g0 = gptS; g0 <= gptE; g0 += GC) {  // host guarantees whole, 16-aligned chunks (one pass per 16 g)
+    if (g0 != gptS) {  // restart the layer walk for the next chunk of a wide band
+      load_idx(0, x0); load_idx(min(1u, nlay - 1), x1); load_wts(0, x0, w0);
+    }
+    Float prev[GC];
+#pragma unroll
+    for (int j = 0; j < GC; ++j) prev[j] = 0;
+    for (unsigned l = 0; l < nlay; ++l) {
+      int* r = rng[l & 1];
+      {
+        const int big = 1 << 30;
+        const int a0 = wave_min(valid ? x0.jT : big), a1 = wave_max(valid ? x0.jT + 1 : -1);
+        const int a2 = wave_min(valid ? x0.jp - 1 : big), a3 = wave_max(valid ? x0.jp : -1);
+        const int a4 = wave_min(valid ? min(w0.je1, w0.je2) : big), a5 = wave_max(valid ? max(w0.je1, w0.je2) + 1 : -1);
+        if ((tid & 63) == 0) {
+          atomicMin(&r[0], a0); atomicMax(&r[1], a1); atomicMin(&r[2], a2); atomicMax(&r[3], a3);
+          atomicMin(&r[4], a4); atomicMax(&r[5], a5);
+        }
+      }
+      __syncthreads();  // ranges complete; previous layer's compute finished (slab is free)
+      const int Tmin = r[0], nT = r[1] - r[0] + 1, Pmin = r[2], nP = r[3] - r[2] + 1, emin = r[4], nE = r[5] - r[4] + 1;
+      const int rows = nP * nT * nE;
+      if (rows * RS > PSLAB) {  // block-uniform: this (tile, band) goes to the direct kernel as a whole
+        if (tid == 0) {
+          const int w = atomicAdd(&a.worklist[0], 1);
+          a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = ibnd;
+        }
+        return;
+      }
+      constexpr bool use_lds = true;
+      if (tid < 6) rng[(l + 1) & 1][tid] = (tid % 2 == 0) ? (1 << 30) : -1;
+      if (use_lds) {
+        // 16-byte pieces of the bounding box, SB per thread requested back to back (index clamped, so the
+        // count is fixed): the tile pays the L2 latency once per batch
+        constexpr int SB = 4;
+        const int nAll = rows * (GC / 2);
+        const float inv_nE = 1.0f / (float)nE, inv_nT = 1.0f / (float)nT;
+        auto piece = [&](int idx) -> Float2 {
+          const int j = idx & 7, rr = idx >> 3;
+          const int rest = (int)(((float)rr + 0.5f) * inv_nE), e = rr - rest * nE;  // rows < 2^12: exact
+          const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
+          return *reinterpret_cast<const Float2*>(
+              a.pf_g + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
+        };
+#pragma unroll 1
+        for (int base = tid; base < nAll; base += SB * BS) {
+          Float2 v[SB];
+#pragma unroll
+          for (int u = 0; u < SB; ++u) v[u] = piece(min(base + u * BS, nAll - 1));
+#pragma unroll
+          for (int u = 0; u < SB; ++u) {
+            const int idx = base + u * BS;
+            if (idx < nAll) *reinterpret_cast<Float2*>(slab + (idx >> 3) * RS + 2 * (idx & 7)) = v[u];
+          }
+        }
+      }
+      // this layer's values into locals, then request the following layers' inputs
+      const Float f0 = w0.fm[0].x, f1 = w0.fm[0].y, f2 = w0.fm[1].x, f3 = w0.fm[1].y, f4 = w0.fm[2].x, f5 = w0.fm[2].y,
+                  f6 = w0.fm[3].x, f7 = w0.fm[3].y;
+      const int je1 = w0.je1, je2 = w0.je2, jT = x0.jT, jp = x0.jp;
+      const Float tl = x0.tlay, tv = x0.tlev;
+      x0 = x1;
+      if (l + 1 < nlay) load_wts(l + 1, x0, w0);
+      if (l + 2 < nlay) load_idx(l + 2, x1);
+      __syncthreads();
+      if (!valid) continue;
+      const Float pl_lay = planck(tl), pl_lev = planck(tv);
+      const unsigned cl = ic + ncol * l;
+      Float* lay = a.lay_src + cl + (size_t)ncl * g0;
+      Float* lev = a.lev_src + (ic + ncol * l) + (size_t)nclv * g0;
+      const bool sfc = (int)l == a.sfc_lay - 1;
+      // one body, instantiated separately for LDS and for global rows (a merged pointer would be a
+      // generic one and every gather a slow flat load)
+      auto body = [&](const Float* __restrict__ A0, const Float* __restrict__ B0, const int sE, const int sP) {
+#pragma unroll
+        for (int jj = 0; jj < GC; jj += 2) {
+          // interpolate3D_byflav with scaling (1,1), :791-801; one 16-byte read feeds two g-points
+          const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + sE + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + sE + jj),
+                       k4 = ld2(B0 + jj), k5 = ld2(B0 + sE + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + sE + jj);
+          Float pfv[2], pgv[2];
+          pfv[0] = f0 * k0.x; pfv[1] = f0 * k0.y;
+          pfv[0] = fma(f1, k1.x, pfv[0]); pfv[1] = fma(f1, k1.y, pfv[1]);
+          pfv[0] = fma(f2, k2.x, pfv[0]); pfv[1] = fma(f2, k2.y, pfv[1]);
+          pfv[0] = fma(f3, k3.x, pfv[0]); pfv[1] = fma(f3, k3.y, pfv[1]);
+          pgv[0] = f4 * k4.x; pgv[1] = f4 * k4.y;
+          pgv[0] = fma(f5, k5.x, pgv[0]); pgv[1] = fma(f5, k5.y, pgv[1]);
+          pgv[0] = fma(f6, k6.x, pgv[0]); pgv[1] = fma(f6, k6.y, pgv[1]);
+          pgv[0] = fma(f7, k7.x, pgv[0]); pgv[1] = fma(f7, k7.y, pgv[1]);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int j = jj + u;
+            const Float pf = pfv[u] + pgv[u];
+            lay[(size_t)ncl * j] = pf * pl_lay;                                  // :674
+            lev[(size_t)nclv * j] = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;  // :695,:699
+            if (sfc) {                                                           // :651-653
+              a.sfc_src[ic + (size_t)ncol * (g0 + j)] = pf * pl_sfc;
+              a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = pf * (pl_sfc1 - pl_sfc);
+            }
+            prev[j] = pf;
+          }
+          asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));  // keep the pair's arithmetic here (see tau kernel)
+          if ((jj & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads (64 VGPRs) in flight
+        }
+      };
+      body(slab + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS,
+           slab + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS, RS, nT * nE * RS);
+    }
+    if (valid) {
+      const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
+#pragma unroll
+      for (int j = 0; j < GC; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
+    }
+    __syncthreads();
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------
+// compute_Planck_source, specialised-wave kernel: the loader / compute split of tau_absorption_v9_kernel.
+// Block = (NCW*64 columns, one band): NCW compute waves (lanes = columns) walk the LAYERS, so the previous
+// layer's Planck fractions stay in registers for the geometric mean at the interface (:699); NLW loader
+// waves stage the bounding box of pfrac rows of layer l+1 into the other half of a double-buffered LDS slab
+// while layer l is computed; one barrier per layer.  planck_geom_kernel provides the boxes and sends
+// (tile, band) pairs that do not fit the slab at some layer to the direct kernel.
+// -------------------------------------------------------------------------------------------
+template <int TILE, int G>
+__global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd, TileGeom* __restrict__ geom,
+                                                           int* __restrict__ flags, int slab_floats) {
+  constexpr int RS = G + 2;
+  __shared__ int rng[4];
+  __shared__ int erng[MAXB][2];
+  __shared__ int flav[MAXB][2];  // flavor (0-based) of band b per tropo regime
+  if (*a.skip_if) return;
+  const int tid = threadIdx.x;
+  const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
+  const unsigned ncl = ncol * nlay;
+  if (tid == 0) { rng[0] = 1 << 30; rng[1] = -1; rng[2] = 1 << 30; rng[3] = -1; }
+  if (tid < MAXB) { erng[tid][0] = 1 << 30; erng[tid][1] = -1; }
+  if (tid < 2 * nbnd) flav[tid >> 1][tid & 1] = a.gpoint_flavor[(tid & 1) + 2 * (a.band_lims[2 * (tid >> 1)] - 1)] - 1;
+  __syncthreads();
+  const unsigned icol = blockIdx.x * TILE + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  const unsigned cl = ic + ncol * ilay;
+  const int itropo = a.tropo[cl] ? 0 : 1;
+  const int jT = a.jtemp[cl];
+  const int jp = a.jpress[cl] + itropo + 1;
+  const int big = 1 << 30;
+  {
+    const int a0 = wave_min(valid ? jT : big), a1 = wave_max(valid ? jT + 1 : -1);
+    const int a2 = wave_min(valid ? jp - 1 : big), a3 = wave_max(valid ? jp : -1);
+    if ((tid & 63) == 0) { atomicMin(&rng[0], a0); atomicMax(&rng[1], a1); atomicMin(&rng[2], a2); atomicMax(&rng[3], a3); }
+  }
+  for (int b = 0; b < nbnd; ++b) {
+    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * flav[b][itropo]));
+    const int e0 = wave_min(valid ? min(je.x, je.y) : big), e1 = wave_max(valid ? max(je.x, je.y) + 1 : -1);
+    if ((tid & 63) == 0) { atomicMin(&erng[b][0], e0); atomicMax(&erng[b][1], e1); }
+  }
+  __syncthreads();
+  TileGeom* out = geom + (blockIdx.x + (size_t)gridDim.x * ilay);
+  const int nT = rng[1] - rng[0] + 1, nP = rng[3] - rng[2] + 1;
+  if (tid == 0) {
+    out->Tmin = rng[0]; out->nT = nT; out->Pmin = rng[2]; out->nP = nP; out->has_lo = 0; out->has_up = 0;
+    out->pad0 = 0; out->pad1 = 0;
+  }
+  if (tid < nbnd) {
+    const int emin = erng[tid][0], nE = erng[tid][1] - erng[tid][0] + 1;
+    const bool fits = nP * nT * nE * RS <= slab_floats;
+    if (!fits && atomicCAS(&flags[blockIdx.x * nbnd + tid], 0, 1) == 0) {  // once per (tile, band)
+      const int w = atomicAdd(&a.worklist[0], 1);
+      a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = tid;
+    }
+    out->eg[tid] = make_int2(emin, nE);
+  }
+}
+
+// Planck on a geometry left by compute_tau_absorption (rte_hip_share_geometry): which (tile, band) pairs do not fit
+// the slab at some layer.  One wave per pair, lanes = layers (one thread walking the layers was 60 dependent latencies).
+__global__ void __launch_bounds__(256)
+planck_flags_kernel(const TileGeom* __restrict__ geom, int tiles, int nlay, int nbnd, int slab_floats, int RS,
+                    int* __restrict__ flags, int* __restrict__ worklist, const int* __restrict__ valid,
+                    const int* __restrict__ guard) {
+  if (!*valid || *guard) return;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= tiles * nbnd) return;
+  const int tile = i / nbnd, b = i - tile * nbnd;
+  bool fits = true;
+  for (int l = lane; l < nlay; l += 64) {
+    const TileGeom* g = geom + (tile + (size_t)tiles * l);
+    fits = fits && g->nP * g->nT * abs(g->eg[b].y) * RS <= slab_floats;
+  }
+  if (__ballot(!fits) != 0ull && lane == 0) {
+    flags[i] = 1;
+    const int w = atomicAdd(&worklist[0], 1);
+    worklist[1 + 2 * w] = tile; worklist[2 + 2 * w] = b;
+  }
+}
+
+template <int NCW, int NLW, int SLAB, int G>
+__global__ void __launch_bounds__((NCW + NLW) * 64, (NCW + NLW + 3) / 4)
+planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* __restrict__ geom,
+                        const int* __restrict__ flags) {
+  constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
+  constexpr int RS = G + 2, PPR = G / 2, PSH = G == 16 ? 3 : 2;  // row stride, 16-byte pieces per row, log2(PPR)
+  constexpr int MAXL = 256;  // layers per block held in the LDS geometry table (host checks nlay <= MAXL)
+  __shared__ __align__(16) Float slab[2][SLAB];
+  __shared__ int gl[MAXL][6];       // per layer: Tmin, nT, Pmin, nP, emin, nE
+  extern __shared__ Float tpl[];    // totplnk(:, ibnd)
+  if (*a.skip_if) return;
+  const int tid = threadIdx.x;
+  // the bands of one column tile are neighbours in launch order (band = fast grid index): they run at about the
+  // same time and share the tile's index arrays and, per flavor, its interpolation weights in the caches
+  // XCD-aware: workgroups go to the 8 XCDs round-robin by linear id, so (id % 8) picks the XCD and the
+  // sequence id / 8 on one XCD walks the bands of one tile before the next tile
+  const unsigned lin = blockIdx.x, xcd = lin % 8, seq = lin / 8;
+  const int ibnd = (int)(seq % (unsigned)nbnd);
+  const unsigned tile = (seq / (unsigned)nbnd) * 8 + xcd;
+  if (tile >= ntiles) return;  // block-uniform (grid padded to a multiple of 8 tiles)
+  if (flags[tile * nbnd + ibnd]) return;  // block-uniform: the direct kernel does this (tile, band)
+  const unsigned ncol = a.ncol, nlay = a.nlay;
+  const unsigned ncl = ncol * nlay, nclv = ncol * (nlay + 1);  // host guarantees 8 * nclv < 2^32
+  const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nPT = a.nPlanckTemp;
+  const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
+  for (int i = tid; i < nPT; i += NT) tpl[i] = a.totplnk[(size_t)nPT * ibnd + i];
+  for (int l = tid; l < (int)nlay; l += NT) {
+    const TileGeom* g = geom + (tile + (size_t)ntiles * l);
+    gl[l][0] = g->Tmin; gl[l][1] = g->nT; gl[l][2] = g->Pmin; gl[l][3] = g->nP;
+    gl[l][4] = g->eg[ibnd].x; gl[l][5] = abs(g->eg[ibnd].y);  // (negative in a geometry shared with compute_tau_absorption)
+  }
+  __syncthreads();
+  const int nchunk = (gptE - gptS + 1) / G;  // host guarantees whole, 16-aligned chunks
+  // stages of a chunk: the layers in order, then -- unless the surface layer is the last one, whose Planck
+  // fractions are still in registers -- the surface layer once more for sfc_source (keeps those stores and
+  // their addresses out of the layer loop)
+  const int lsfc = a.sfc_lay - 1;
+  const int spc = (int)nlay + (lsfc == (int)nlay - 1 ? 0 : 1);
+  const int nstage = nchunk * spc;
+
+  if (tid >= TILE) {
+    // ================================ loader waves ================================
+    // the loaders issue little and mostly wait for memory: a raised issue priority lets their requests and LDS writes go
+    // out ahead of the eight compute waves' FMAs, so that the next slab is complete a little earlier (tau 5.34 -> 5.28 ms
+    // in one process, no change for Planck)
+    __builtin_amdgcn_s_setprio(1);
+    const int lt = tid - TILE;
+    constexpr int SB = 8;  // 16-byte pieces per lane requested back to back
+#pragma unroll 1
+    for (int s = 0; s < nstage; ++s) {
+      const int ls = s % spc, l = ls < (int)nlay ? ls : lsfc, g0 = gptS + (s / spc) * G;
+      const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], nP = gl[l][3], emin = gl[l][4], nE = gl[l][5];
+      const float inv_nE = 1.0f / (float)nE, inv_nT = 1.0f / (float)nT;
+      const int nAll = nP * nT * nE * (G / 2);
+      Float* sl = slab[s & 1];
+      auto piece = [&](int idx) -> Float2 {  // rows ordered [p][t][eta]
+        const int j = idx & (PPR - 1), r = idx >> PSH;
+        const int rest = (int)(((float)r + 0.5f) * inv_nE), e = r - rest * nE;  // rows < 2^12: exact
+        const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
+        return *reinterpret_cast<const Float2*>(
+            a.pf_g + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
+      };
+#pragma unroll 1
+      for (int base = lt; base < nAll; base += SB * NLT) {
+        Float2 v[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) v[u] = piece(min(base + u * NLT, nAll - 1));
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int idx = base + u * NLT;
+          if (idx < nAll) *reinterpret_cast<Float2*>(sl + (idx >> PSH) * RS + 2 * (idx & (PPR - 1))) = v[u];
+        }
+      }
+      __syncthreads();  // B(s): slab(s) complete; the compute waves are done with the other buffer
+    }
+    return;
+  }
+
+  // ================================ compute waves (lanes = columns) ================================
+  const unsigned icol = tile * TILE + tid;
+  const bool valid = icol < ncol;
+  const unsigned ic = min(icol, ncol - 1);
+  const int flav0 = a.gpoint_flavor[2 * gptS] - 1, flav1 = a.gpoint_flavor[1 + 2 * gptS] - 1;
+  auto planck = [&](Float t) {  // interpolate1D :715-737 on the LDS copy of the band's column
+    const Float val0 = (t - a.temp_ref_min) * a.totplnk_delta_r;
+    const Float frac = val0 - trunc(val0);
+    const int index = min(nPT - 1, max(1, (int)val0 + 1));
+    const Float t0 = tpl[index - 1], t1 = tpl[index];
+    return t0 + frac * (t1 - t0);
+  };
+  const Float pl_sfc = planck(a.tsfc[ic]);
+  const Float pl_sfc1 = planck(a.tsfc[ic] + (Float)1);
+
+  struct Idx { Bool tropo; int jT, jpress; Float tlay, tlev; };  // raw loaded values: nothing is derived at load
+  struct Wts { Float2 fm[4]; int je1, je2; };                     // time, so no request waits for another
+  auto load_idx = [&](unsigned l, Idx& x) {
+    const unsigned cl = ic + ncol * l;
+    x.tropo = a.tropo[cl];
+    x.jT = a.jtemp[cl];
+    x.jpress = a.jpress[cl];
+    x.tlay = a.tlay[cl];
+    x.tlev = a.tlev[cl];
+  };
+  auto load_wts = [&](unsigned l, const Idx& x, Wts& w) {
+    const size_t clf = (ic + ncol * l) + (size_t)ncl * (x.tropo ? flav0 : flav1);
+    const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.fm[i] = fmp[i];
+    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
+    w.je1 = je.x; w.je2 = je.y;
+  };
+  Idx x0, x1;   // layers l and l+1
+  Wts w0;       // layer l
+  Float prev[G];
+  int s = 0;
+#pragma unroll 1
+  for (int g0 = gptS; g0 <= gptE; g0 += G) {
+    load_idx(0, x0);
+    load_idx(min(1u, nlay - 1), x1);
+    load_wts(0, x0, w0);
+#pragma unroll
+    for (int j = 0; j < G; ++j) prev[j] = 0;
+    // nothing outstanding at loop entry: the wait counts inside are then those of the steady state (requests of
+    // the following layers, then this layer's 32 stores), not their merge with this prologue
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll 1
+    for (unsigned l = 0; l < nlay; ++l, ++s) {
+      // this layer's values into locals, then request the following layers' inputs
+      const Float f0 = w0.fm[0].x, f1 = w0.fm[0].y, f2 = w0.fm[1].x, f3 = w0.fm[1].y, f4 = w0.fm[2].x, f5 = w0.fm[2].y,
+                  f6 = w0.fm[3].x, f7 = w0.fm[3].y;
+      const int je1 = w0.je1, je2 = w0.je2, jT = x0.jT, jp = x0.jpress + (x0.tropo ? 0 : 1) + 1;  // levels jp-1, jp
+      const Float tl = x0.tlay, tv = x0.tlev;
+      x0 = x1;
+      // unconditional (the last layers repeat the last one): a request made on some paths only makes the number of
+      // outstanding memory operations path-dependent, and the compiler then drains them all -- this layer's requests
+      // and the previous layer's 32 stores -- in front of every barrier
+      load_wts(min(l + 1, nlay - 1), x0, w0);
+      load_idx(min(l + 2, nlay - 1), x1);
+      const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], emin = gl[l][4], nE = gl[l][5];
+      const Float pl_lay = planck(tl), pl_lev = planck(tv);
+      __syncthreads();  // B(s): slab(s) is complete
+      const Float* sl = slab[s & 1];
+      const Float* A0 = sl + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS;
+      const Float* B0 = sl + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
+      const int sP = nT * nE * RS;
+      // byte offsets of this column in the (col, lay, g) / (col, lev, g) planes; scalar plane bases
+      unsigned olay = (ic + ncol * l) * (unsigned)sizeof(Float);
+      asm volatile("" : "+v"(olay));  // keep 64-bit addresses out of the loop-invariant registers
+      char* const play_ = reinterpret_cast<char*>(a.lay_src + (size_t)ncl * g0);
+      char* const plev_ = reinterpret_cast<char*>(a.lev_src + (size_t)nclv * g0);
+      const size_t slay = (size_t)ncl * sizeof(Float), slev = (size_t)nclv * sizeof(Float);
+#pragma unroll
+      for (int jj = 0; jj < G; jj += 2) {
+        // interpolate3D_byflav with scaling (1,1), :791-801; one 16-byte read feeds two g-points
+        const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + RS + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + RS + jj),
+                     k4 = ld2(B0 + jj), k5 = ld2(B0 + RS + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + RS + jj);
+        Float pfv[2], pgv[2];
+        pfv[0] = f0 * k0.x; pfv[1] = f0 * k0.y;
+        pfv[0] = fma(f1, k1.x, pfv[0]); pfv[1] = fma(f1, k1.y, pfv[1]);
+        pfv[0] = fma(f2, k2.x, pfv[0]); pfv[1] = fma(f2, k2.y, pfv[1]);
+        pfv[0] = fma(f3, k3.x, pfv[0]); pfv[1] = fma(f3, k3.y, pfv[1]);
+        pgv[0] = f4 * k4.x; pgv[1] = f4 * k4.y;
+        pgv[0] = fma(f5, k5.x, pgv[0]); pgv[1] = fma(f5, k5.y, pgv[1]);
+        pgv[0] = fma(f6, k6.x, pgv[0]); pgv[1] = fma(f6, k6.y, pgv[1]);
+        pgv[0] = fma(f7, k7.x, pgv[0]); pgv[1] = fma(f7, k7.y, pgv[1]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = jj + u;
+          const Float pf = pfv[u] + pgv[u];
+          const Float vlay = pf * pl_lay;                                      // :674
+          const Float vlev = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;      // :695,:699
+          // lanes past the last column repeat it (ic is clamped) and store the same values to the same
+          // addresses: unconditional stores keep the number of outstanding memory operations static, so the
+          // wait for the next layer's weights is a counted one instead of a drain of these stores
+          store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), vlay);
+          store_stream(reinterpret_cast<Float*>(plev_ + slev * j + olay), vlev);  // level l of (ncol, nlay+1): same column offset
+          prev[j] = pf;
+        }
+        asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));  // keep the pair's arithmetic here
+        __builtin_amdgcn_sched_barrier(0);   // at most 8 row reads (32 VGPRs) in flight
+      }
+    }
+    if (valid) {
+      const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
+#pragma unroll
+      for (int j = 0; j < G; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
+    }
+    // ---- surface source (:651-653) from the Planck fractions of the surface layer
+    if (lsfc != (int)nlay - 1) {
+      load_idx(lsfc, x0);
+      load_wts(lsfc, x0, w0);
+      const int Tmin = gl[lsfc][0], nT = gl[lsfc][1], Pmin = gl[lsfc][2], emin = gl[lsfc][4], nE = gl[lsfc][5];
+      __syncthreads();  // B(s): the surface layer's slab is complete
+      const Float* sl = slab[s & 1];
+      ++s;
+      const int jps = x0.jpress + (x0.tropo ? 0 : 1) + 1;
+      const Float* A0 = sl + (((jps - 1 - Pmin) * nT + (x0.jT - Tmin)) * nE + (w0.je1 - emin)) * RS;
+      const Float* B0 = sl + (((jps - 1 - Pmin) * nT + (x0.jT + 1 - Tmin)) * nE + (w0.je2 - emin)) * RS;
+      const int sP = nT * nE * RS;
+#pragma unroll
+      for (int jj = 0; jj < G; jj += 2) {
+        const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + RS + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + RS + jj),
+                     k4 = ld2(B0 + jj), k5 = ld2(B0 + RS + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + RS + jj);
+        Float pa = w0.fm[0].x * k0.x, pb = w0.fm[0].x * k0.y, qa = w0.fm[2].x * k4.x, qb = w0.fm[2].x * k4.y;
+        pa = fma(w0.fm[0].y, k1.x, pa); pb = fma(w0.fm[0].y, k1.y, pb); qa = fma(w0.fm[2].y, k5.x, qa); qb = fma(w0.fm[2].y, k5.y, qb);
+        pa = fma(w0.fm[1].x, k2.x, pa); pb = fma(w0.fm[1].x, k2.y, pb); qa = fma(w0.fm[3].x, k6.x, qa); qb = fma(w0.fm[3].x, k6.y, qb);
+        pa = fma(w0.fm[1].y, k3.x, pa); pb = fma(w0.fm[1].y, k3.y, pb); qa = fma(w0.fm[3].y, k7.x, qa); qb = fma(w0.fm[3].y, k7.y, qb);
+        prev[jj] = pa + qa; prev[jj + 1] = pb + qb;
+        asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        a.sfc_src[ic + (size_t)ncol * (g0 + j)] = prev[j] * pl_sfc;
+        a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = prev[j] * (pl_sfc1 - pl_sfc);
+      }
+    }
+  }
+}
+
+
+}  // namespace
+
+extern "C" {
+void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int* nbnd_,
+                                  const int* ngpt_, const int* nflav_, const int* neta_,
+                                  const int* npres_, const int* ntemp_, const int* nPlanckTemp_,
+                                  const Float* tlay, const Float* tlev, const Float* tsfc,
+                                  const int* sfc_lay_, const Float* fmajor, const int* jeta,
+                                  const Bool* tropo, const int* jtemp, const int* jpress,
+                                  const int* gpoint_bands, const int* band_lims_gpt,
+                                  const Float* pfracin, const Float* temp_ref_min,
+                                  const Float* totplnk_delta, const Float* totplnk,
+                                  const int* gpoint_flavor, Float* sfc_src, Float* lay_src,
+                                  Float* lev_src, Float* sfc_source_Jac) {
+  const int ncol = *ncol_, nlay = *nlay_, nbnd = *nbnd_, ngpt = *ngpt_, nflav = *nflav_, neta = *neta_,
+            npres = *npres_, ntemp = *ntemp_, nPlanckTemp = *nPlanckTemp_;
+  (void)gpoint_bands;
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
+  RTE_TRY
+  rte::Call c("rrtmgp_compute_Planck_source");
+  const size_t ncl = (size_t)ncol * nlay;
+  const Float* d_tlay = c.in(tlay, ncl);
+  const Float* d_tlev = c.in(tlev, (size_t)ncol * (nlay + 1));
+  const Float* d_tsfc = c.in(tsfc, (size_t)ncol);
+  const Float* d_fmajor = c.in(fmajor, 8 * ncl * nflav);
+  const int* d_jeta = c.in(jeta, 2 * ncl * nflav);
+  const Bool* d_tropo = c.in(tropo, ncl);
+  const int* d_jtemp = c.in(jtemp, ncl);
+  const int* d_jpress = c.in(jpress, ncl);
+  const int* d_band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
+  const Float* d_pfracin = c.in(pfracin, (size_t)ntemp * neta * (npres + 1) * ngpt);
+  const Float* d_totplnk = c.in(totplnk, (size_t)nPlanckTemp * nbnd);
+  const int* d_gpoint_flavor = c.in(gpoint_flavor, (size_t)2 * ngpt);
+  Float* d_sfc_src = c.out_lazy(sfc_src, (size_t)ncol * ngpt);  // (lazy: host-mirror mode keeps the sources on the device)
+  Float* d_lay_src = c.out_lazy(lay_src, ncl * ngpt);
+  Float* d_lev_src = c.out_lazy(lev_src, (size_t)ncol * (nlay + 1) * ngpt);
+  Float* d_sfc_jac = c.out_lazy(sfc_source_Jac, (size_t)ncol * ngpt);
+  const Float totplnk_delta_r = (Float)1 / *totplnk_delta;  // :636
+  {
+    const void* outs[4] = {d_sfc_src, d_lay_src, d_lev_src, d_sfc_jac};
+    const size_t ob[4] = {sizeof(Float) * (size_t)ncol * ngpt, sizeof(Float) * ncl * ngpt,
+                          sizeof(Float) * (size_t)ncol * (nlay + 1) * ngpt, sizeof(Float) * (size_t)ncol * ngpt};
+    c.try_fork(outs, ob, 4);  // opt-in: concurrently with the compute_tau_absorption call this one follows
+  }
+  hipStream_t st = rte::stream();
+  int* d_stale = stale_flag();
+  stale_poll();
+  // production kernel: 16-aligned whole-chunk bands (checked once per table pointer), aligned inputs
+  BandCheck& bc_ = gs().planck_bands;
+  const void*& bl_key = bc_.key;
+  int &bl_n = bc_.n, &bl_epoch = bc_.epoch;
+  bool& bl_ok = bc_.ok;
+  int& bl_gw = bc_.gw;
+  unsigned bl_fp = 0;
+  if (!rte::is_device_pointer(band_lims_gpt))  // host tables: fingerprint the contents (see compute_tau_absorption)
+    for (int i = 0; i < 2 * nbnd; ++i) bl_fp = (bl_fp ^ (unsigned)band_lims_gpt[i]) * 16777619u;
+  unsigned& bl_fp_seen = bc_.fp_seen;
+  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != gs().plan_epoch || bl_fp != bl_fp_seen) {
+    bl_fp_seen = bl_fp;
+    const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
+    auto aligned = [&](int w) {
+      bool al_ = ngpt % w == 0;
+      for (int b = 0; b < nbnd; ++b) al_ = al_ && (bl[2 * b] - 1) % w == 0 && bl[2 * b + 1] % w == 0;
+      return al_;
+    };
+    bl_gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);  // g-points per stage of the production kernel
+    bl_ok = bl_gw > 0;
+    bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = gs().plan_epoch;
+  }
+  auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
+  const bool fast = bl_ok && ncol >= 512 && !g_tau_force_direct && (size_t)ncol * (nlay + 1) < ((size_t)1 << 31) &&
+                    al(d_fmajor, 16) && al(d_jeta, 8);
+  PlanckArgs q;
+  q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.neta = neta; q.npres = npres; q.ntemp = ntemp; q.nPlanckTemp = nPlanckTemp;
+  q.sfc_lay = *sfc_lay_; q.tlay = d_tlay; q.tlev = d_tlev; q.tsfc = d_tsfc; q.fmajor = d_fmajor; q.jeta = d_jeta;
+  q.tropo = d_tropo; q.jtemp = d_jtemp; q.jpress = d_jpress; q.band_lims_gpt = d_band_lims; q.pfracin = d_pfracin;
+  q.temp_ref_min = *temp_ref_min; q.totplnk_delta_r = totplnk_delta_r; q.totplnk = d_totplnk;
+  q.gpoint_flavor = d_gpoint_flavor; q.sfc_src = d_sfc_src; q.lay_src = d_lay_src; q.lev_src = d_lev_src;
+  q.sfc_source_Jac = d_sfc_jac;
+  if (!fast) {
+    rte::ProfScope p("planck_source_kernel");
+    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)nullptr);
+    return;
+  }
+  // plan guard: the band limits on the device must have the alignment the cached stage width assumes
+  int* guard = (int*)rte::scratch(sizeof(int));
+  constexpr int BS = 256;
+  int* const worklist = (int*)rte::scratch(sizeof(int) * (1 + 2 * (size_t)cdiv(ncol, BS) * nbnd));
+  const unsigned nflags = cdiv(ncol, 512) * (unsigned)nbnd;  // (512-column tile, band) flags of the specialised-wave kernel
+  int* const d_flags = (int*)rte::scratch(sizeof(int) * (size_t)nflags);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(cdiv(nflags + 2, 256)), dim3(256), 0, st, guard, 1u, worklist, 1u, d_flags, nflags);
+  hipLaunchKernelGGL(bands_guard_kernel, dim3(1), dim3(64), 0, st, nbnd, ngpt, d_band_lims, bl_gw, guard, d_stale);
+  const int TE = ntemp * neta;
+  Float* pf_g = (Float*)rte::scratch(sizeof(Float) * (size_t)TE * (npres + 1) * ngpt);
+  {
+    rte::ProfScope p("relayout_gfast_kernel");
+    hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(ngpt, 32), npres + 1), dim3(256), sizeof(Float) * TE * 33, st,
+                       TE, npres + 1, ngpt, d_pfracin, pf_g);
+  }
+  PlanckV7 v;
+  v.ncol = ncol; v.nlay = nlay; v.ngpt = ngpt; v.ntemp = ntemp; v.TE = TE; v.nPlanckTemp = nPlanckTemp;
+  v.sfc_lay = *sfc_lay_; v.temp_ref_min = *temp_ref_min; v.totplnk_delta_r = totplnk_delta_r;
+  v.band_lims = d_band_lims; v.gpoint_flavor = d_gpoint_flavor; v.jeta = d_jeta; v.jtemp = d_jtemp;
+  v.jpress = d_jpress; v.tropo = d_tropo; v.pf_g = pf_g; v.totplnk = d_totplnk; v.fmajor = d_fmajor;
+  v.tlay = d_tlay; v.tlev = d_tlev; v.tsfc = d_tsfc;
+  v.sfc_src = d_sfc_src; v.lay_src = d_lay_src; v.lev_src = d_lev_src; v.sfc_jac = d_sfc_jac;
+  v.skip_if = guard;
+  v.worklist = worklist;
+  int wl_tile = BS;
+  const bool planck9 = (g_planck_variant == 9 || bl_gw != 16) && nlay <= 256 && nbnd <= MAXB &&
+                       (size_t)ncol * (nlay + 1) < ((size_t)1 << 29);
+  if (!planck9 && bl_gw != 16) {  // 8-wide stages exist only in the specialised-wave kernel
+    rte::ProfScope p("planck_source_kernel");
+    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)nullptr);
+    return;
+  }
+  if (planck9) {
+    constexpr int NCW = 8, NLW = 2, SLAB9 = 8704;  // 8 compute + 2 loader waves, 2 x 68 KB slab: one block per CU
+    wl_tile = NCW * 64;
+    const unsigned tiles = cdiv(ncol, NCW * 64);
+    // the geometry of the compute_tau_absorption call immediately before this one, if it is for the same arrays
+    const bool shared = share_boxes() && gs().shared.seq >= 0 && gs().shared.seq + 1 == rte::call_seq() && gs().shared.jeta == jeta &&
+                        gs().shared.jtemp == jtemp && gs().shared.jpress == jpress && gs().shared.tropo == tropo &&
+                        gs().shared.ncol == ncol && gs().shared.nlay == nlay && gs().shared.nflav == nflav &&
+                        gs().shared.nbnd == nbnd && gs().shared.gw == bl_gw && !c.any_host() &&
+                        !c.forked();  // (on the side stream this call does not wait for that call's kernels)
+    gs().shared.seq = -1;
+    TileGeom* d_geom = shared ? gs().shared.geom : (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
+    static_assert(NCW * 64 == 512, "d_flags is sized for 512-column tiles");
+    const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
+    Geom2Args ga{};
+    ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = true;
+    ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.band_lims = d_band_lims;
+    ga.gpoint_flavor = d_gpoint_flavor; ga.worklist = v.worklist; ga.flags = d_flags; ga.skip_if = guard;
+    ga.skip_if2 = shared ? gs().shared.valid : nullptr;  // (set on the device by that call's geometry kernel, if it ran)
+#define RTE_LAUNCH_PLANCK9(GW)                                                                                    \
+  do {                                                                                                            \
+    {                                                                                                             \
+      rte::ProfScope p("planck_source_setup");                                                                    \
+      if (shared) hipLaunchKernelGGL(planck_flags_kernel, dim3(cdiv(tiles * nbnd, 4)), dim3(256), 0, st, (const TileGeom*)d_geom, \
+                                     (int)tiles, nlay, nbnd, SLAB9, GW + 2, d_flags, v.worklist, (const int*)gs().shared.valid, \
+                                     (const int*)guard);                                                          \
+      if (geom2) hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, ga, d_geom); \
+      else hipLaunchKernelGGL((planck_geom_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, \
+                              d_flags, SLAB9);                                                                    \
+    }                                                                                                             \
+    rte::ProfScope p("planck_source_kernel");                                                                     \
+    hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW>), dim3(nbnd * 8 * cdiv(tiles, 8)),          \
+                       dim3((NCW + NLW) * 64), sizeof(Float) * nPlanckTemp, st, v, nbnd, tiles,                   \
+                       (const TileGeom*)d_geom, (const int*)d_flags);                                             \
+  } while (0)
+    if (bl_gw == 16) RTE_LAUNCH_PLANCK9(16); else RTE_LAUNCH_PLANCK9(8);
+#undef RTE_LAUNCH_PLANCK9
+  } else {
+    rte::ProfScope p("planck_source_kernel");
+    hipLaunchKernelGGL((planck_source_v7_kernel<BS>), dim3(cdiv(ncol, BS), nbnd), dim3(BS), sizeof(Float) * nPlanckTemp, st,
+                       v);
+  }
+  {
+    // (tile, band) pairs whose pfrac bounding box exceeded the LDS slab at some layer
+    rte::ProfScope p("planck_source_fallback");
+    hipLaunchKernelGGL(planck_source_worklist_kernel, dim3(1024), dim3(256), 0, st, q, (const int*)v.worklist, wl_tile,
+                       stats_dev() + 1);
+    // the whole call on the direct kernel if the guard fired
+    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)guard);
+  }
+  RTE_CATCH("rrtmgp_compute_Planck_source")
+}
+
+}  // extern "C"
+

@@ -1,0 +1,29 @@
+// plans.hip -- process-wide switches of the gas-optics kernels and the extension entry points that set them or read the
+// per-context state (gas_optics_common.h); the plans themselves are built where they are used (tau_absorption.hip).
+#include "gas_optics_common.h"
+
+// process-wide tuning switches (set from any thread: relaxed atomics)
+std::atomic<int> g_tau_force_direct{0};
+std::atomic<int> g_tau_variant{9};
+std::atomic<int> g_planck_variant{9};  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
+std::atomic<int> g_geom_variant{2};  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
+std::atomic<int> g_share_geom_default{0};  // what a context starts with (the last rte_hip_share_geometry of any context)
+
+extern "C" {
+
+int rte_hip_share_geometry(int on) { g_share_geom_default = on; gs().share_geom = on; gs().shared.seq = -1; gs().imask.seq = -1; return 0; }
+int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
+int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
+int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
+int rte_hip_invalidate_plans(void) { ++gs().plan_epoch; return 0; }
+int rte_hip_geom_variant(int v) { g_geom_variant = v; return 0; }
+// diagnostics (synchronises): 0 = (column tile, layer, band) triples the last compute_tau_absorption call handed to the
+// direct-gather worklist, 1 = (column tile, band) pairs of the last compute_Planck_source call
+int rte_hip_stat(int which) {
+  if (which < 0 || which > 3) return -1;
+  int v = 0;
+  HIP_CHECK(hipStreamSynchronize(rte::stream()));
+  HIP_CHECK(hipMemcpy(&v, stats_dev() + which, sizeof(int), hipMemcpyDeviceToHost));
+  return v;
+}
+}  // extern "C"

@@ -390,18 +390,10 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       const Float tau_loc = cur_.tau[i] * cur.D;
-#ifdef LWX_NOEXP
-      const Float tr = (Float)1 - tau_loc * (Float)0.001;
-#else
       const Float tr = rte::exp_nonpos(-tau_loc);
-#endif
       // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo): "toward bottom" uses the
       // bottom level source, "toward top" the top level source
-#ifdef LWX_NOSRC
-      sd[i] = tr * cur_.lev[i + 1] + cur_.lay[i]; su[i] = tr * cur_.lev[i] + cur_.lay[i];
-#else
       lw_source_layer_fast(tau_loc, tr, cur_.lay[i], cur_.lev[i], cur_.lev[i + 1], sd[i], su[i]);
-#endif
       t[i] = tr;
       Sd = tr * Sd + sd[i];
       Td = Td * tr;
@@ -410,10 +402,6 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     Float Su = 0;
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) Su = t[i] * Su + su[i];
-#ifdef LWX_NOPASS2
-    acc_dn[0] += Td + Sd + Su;
-    return;
-#endif
     // ---- exchange segment composites: slots [buffer][Td, Sd, Su][MAXS segments][64 lanes]; slots of segments
     // that do not exist hold the neutral composite (1, 0, 0), so the chains below have a fixed length and all
     // their LDS reads are issued back to back (a read per chain step costs one LDS latency per step)
@@ -421,9 +409,7 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     X[(0 * MAXS + s) * 64 + lane] = Td;
     X[(1 * MAXS + s) * 64 + lane] = Sd;
     X[(2 * MAXS + s) * 64 + lane] = Su;
-#ifndef LWX_NOBARRIER
     __syncthreads();
-#endif
     Float r = cur.inc * inv_piw;  // radiance entering segment 0 from above (:144)
     Float r_in = r;
     Float u, jv;

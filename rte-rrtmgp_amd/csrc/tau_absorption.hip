@@ -1,4 +1,5 @@
-// gas_optics.hip -- RRTMGP gas-optics kernels for gfx950 (MI355X), hand-written HIP.
+// tau_absorption.hip -- rrtmgp_compute_tau_absorption and rrtmgp_compute_tau_rayleigh (with their fused extension forms)
+// for gfx950 (MI355X), hand-written HIP.  rrtmgp_interpolation: interpolation.hip, rrtmgp_compute_Planck_source: planck.hip.
 //
 // Entry points (C ABI = the reference's bind(C) interface, include/rte_rrtmgp_kernels.h):
 //   rrtmgp_interpolation, rrtmgp_compute_tau_absorption, rrtmgp_compute_tau_rayleigh,
@@ -14,231 +15,11 @@
 //     major, then lower minors in interval order, then upper minors);
 //   * Planck: each thread owns one (column, band) and walks the layers sequentially so the
 //     geometric mean of adjacent layers' Planck fractions needs no second gather.
-#include <math.h>
+#include "gas_optics_common.h"
 
-#include <vector>
-
-#include <type_traits>
-
-#include <atomic>
-
-#include "common.h"
+static const bool g_worklist_native = getenv("RTE_WORKLIST_NATIVE") != nullptr;  // A/B: worklist entries from the native-layout tables
 
 namespace {
-
-using rte::cdiv;
-using rte::store_stream;
-
-constexpr int GC = 16;  // g-points held in registers per chunk
-
-// OR over the 64 lanes of a wave, result returned as a wave-uniform value: inclusive scan inside each row of 16
-// lanes (row_shr 1, 2, 4, 8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15), then rows 0-1 -> rows 2-3
-// (row_bcast:31); lane 63 holds the total
-__device__ __forceinline__ unsigned wave_or(unsigned v) {
-  int x = (int)v;
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-  return (unsigned)__builtin_amdgcn_readlane(x, 63);
-}
-
-constexpr int MAXFLAV = 32;
-
-// -------------------------------------------------------------------------------------------
-// interpolation: reference mo_gas_optics_rrtmgp_kernels.F90:37-170
-// -------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npres, int ntemp,
-                     const int* __restrict__ flavor, const Float* __restrict__ temp_ref,
-                     const Float* __restrict__ press_ref_log, Float press_ref_log_delta_inv, Float temp_ref_min,
-                     Float temp_ref_delta, Float temp_ref_delta_inv, Float press_ref_trop,
-                     const Float* __restrict__ vmr_ref, const Float* __restrict__ play,
-                     const Float* __restrict__ tlay, const Float* __restrict__ col_gas,
-                     int* __restrict__ jtemp, Float* __restrict__ fmajor, Float* __restrict__ fminor,
-                     Float* __restrict__ col_mix, Bool* __restrict__ tropo, int* __restrict__ jeta,
-                     int* __restrict__ jpress, unsigned* __restrict__ masks, int cg_lds) {
-  // block = (256 columns, one layer); the flavors are walked INSIDE the block: pressure / temperature terms (one log)
-  // are formed once per (column, layer), and play, tlay and the column amounts are read once instead of once per flavor
-  // (as a grid dimension the flavors' blocks ran far apart: 1.9 GB of reads for 0.5 GB of inputs)
-  const int icol_raw = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ilay = blockIdx.y;
-  const bool in_range = icol_raw < ncol;
-  const int icol = in_range ? icol_raw : ncol - 1;  // ragged last block: compute on a valid column, store nothing
-  const size_t ncl = (size_t)ncol * nlay;
-  const size_t cl = icol + (size_t)ncol * ilay;
-  const Float T = tlay[cl], P = play[cl];
-  // :106-108 (INT truncates toward zero; ftemp uses the unclamped index)
-  const int jtemp_ = (int)((T - (temp_ref_min - temp_ref_delta)) * temp_ref_delta_inv);
-  const int jt = min(ntemp - 1, max(1, jtemp_));
-  const int jt_read = min(ntemp, max(1, jtemp_));  // reference reads out of bounds outside the table
-  const Float ftemp = (T - temp_ref[jt_read - 1]) * temp_ref_delta_inv;
-  // :111-114
-  const Float locpress = (Float)1 + (log(P) - press_ref_log[0]) * press_ref_log_delta_inv;
-  const Float jpress_aint = fmin((Float)(npres - 1), fmax((Float)1, trunc(locpress)));
-  const Float fpress = locpress - jpress_aint;
-  const bool trop = P > press_ref_trop;  // :117
-  if (in_range) {
-    jtemp[cl] = jt;
-    jpress[cl] = (int)jpress_aint;
-    tropo[cl] = trop;
-  }
-  const int itropo = trop ? 0 : 1;
-  // masks != nullptr: the block also leaves bit masks of the LUT rows its columns touch (temperature, pressure, regime,
-  // and per flavor and regime the eta rows) -- what tile_geom2_kernel would otherwise derive by reading jtemp, jpress,
-  // tropo and all of jeta again in the compute_tau_absorption call that follows (InterpMasks below)
-  __shared__ unsigned s_mask[4 + 2 * MAXFLAV];
-  const int mask_w = 4 + 2 * nflav;
-  if (masks) {
-    if ((int)threadIdx.x < mask_w) s_mask[threadIdx.x] = 0;
-    __syncthreads();
-    const int jp = (int)jpress_aint + itropo + 1;
-    const unsigned long long pm = in_range ? (3ull << (jp - 1)) : 0ull;
-    const unsigned tm = wave_or(in_range ? (3u << jt) : 0u);
-    const unsigned p0 = wave_or((unsigned)pm), p1 = wave_or((unsigned)(pm >> 32));
-    const unsigned rg = wave_or(in_range ? (trop ? 1u : 2u) : 0u);
-    if ((threadIdx.x & 63) == 0) { atomicOr(&s_mask[0], tm); atomicOr(&s_mask[1], p0); atomicOr(&s_mask[2], p1); atomicOr(&s_mask[3], rg); }
-  }
-  // this column's amounts of every gas, parked in LDS (lane-private slots; the flavor's two gases are block-uniform indices)
-  // (tables with many gases -- the real files have ~20 -- would need more LDS than a block may have beside the transpose
-  //  buffers: `cg_lds` == 0 then reads the two amounts of a flavor from global memory, L2-resident after the first touch)
-  extern __shared__ Float s_cg[];  // [ngas + 1][256]
-  const int t = threadIdx.x;
-  if (cg_lds)
-    for (int ig = 0; ig <= ngas; ++ig) s_cg[ig * 256 + t] = col_gas[cl + ncl * ig];
-  // The outputs are interleaved records per column (8, 4, 2, 2 values): written straight from the
-  // registers every store instruction would scatter 8-16 bytes per lane over kilobytes.  Transpose
-  // through LDS instead, so each store instruction of the block writes one contiguous 2-4 KB run.
-  __shared__ Float s_fmj[256 * 9], s_fmn[256 * 5], s_cm[256 * 3];
-  __shared__ int s_je[256 * 3];
-  const int c0 = blockIdx.x * blockDim.x;
-  const int nc = min((int)blockDim.x, ncol - c0);  // columns of this block
-#pragma unroll 1
-  for (int iflav = 0; iflav < nflav; ++iflav) {
-    // :121-168
-    const int igas_1 = flavor[2 * iflav], igas_2 = flavor[2 * iflav + 1];
-    const Float cg1 = cg_lds ? s_cg[igas_1 * 256 + t] : col_gas[cl + ncl * igas_1];
-    const Float cg2 = cg_lds ? s_cg[igas_2 * 256 + t] : col_gas[cl + ncl * igas_2];
-    Float fmn[4], fmj[8], cm[2];
-    int je[2];
-#pragma unroll
-    for (int itemp = 0; itemp < 2; ++itemp) {
-      const int tt = jt + itemp;  // 1-based
-      const size_t v = (size_t)itropo + 2 * ((size_t)0 + (size_t)(ngas + 1) * (tt - 1));
-      const Float ratio_eta_half = vmr_ref[v + 2 * (size_t)igas_1] / vmr_ref[v + 2 * (size_t)igas_2];
-      const Float c = cg1 + ratio_eta_half * cg2;
-      cm[itemp] = c;
-      Float eta;
-#ifdef RTE_USE_SP
-      if (c > (Float)2 * (Float)1.17549435e-38f)
-#else
-      if (c > (Float)2 * (Float)2.2250738585072014e-308)
-#endif
-        eta = cg1 / c;
-      else
-        eta = (Float)0.5;
-      const Float loceta = eta * (Float)(neta - 1);
-      je[itemp] = min((int)loceta + 1, neta - 1);
-      const Float feta = loceta - trunc(loceta);
-      const Float ftemp_term = ((Float)(1 - itemp) + (Float)(2 * itemp - 1) * ftemp);
-      const Float f1 = ((Float)1 - feta) * ftemp_term;
-      const Float f2 = feta * ftemp_term;
-      fmn[0 + 2 * itemp] = f1;
-      fmn[1 + 2 * itemp] = f2;
-      fmj[0 + 4 * itemp] = ((Float)1 - fpress) * f1;
-      fmj[1 + 4 * itemp] = ((Float)1 - fpress) * f2;
-      fmj[2 + 4 * itemp] = fpress * f1;
-      fmj[3 + 4 * itemp] = fpress * f2;
-    }
-    if (masks) {
-      const unsigned m = (3u << je[0]) | (3u << je[1]);  // rows eta, eta + 1 of both temperature corners
-      const unsigned w0 = wave_or(in_range && trop ? m : 0u), w1 = wave_or(in_range && !trop ? m : 0u);
-      if ((t & 63) == 0) { atomicOr(&s_mask[4 + 2 * iflav], w0); atomicOr(&s_mask[5 + 2 * iflav], w1); }
-    }
-    __syncthreads();  // the previous flavor's records have been stored
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s_fmj[t * 9 + i] = fmj[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s_fmn[t * 5 + i] = fmn[i];
-    s_cm[t * 3] = cm[0]; s_cm[t * 3 + 1] = cm[1];
-    s_je[t * 3] = je[0]; s_je[t * 3 + 1] = je[1];
-    __syncthreads();
-    const size_t rec0 = (size_t)c0 + (size_t)ncol * ilay + ncl * iflav;  // record index of the block's first column
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int e = t + 256 * k;
-      if (e < 8 * nc) fmajor[8 * rec0 + e] = s_fmj[(e >> 3) * 9 + (e & 7)];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int e = t + 256 * k;
-      if (e < 4 * nc) fminor[4 * rec0 + e] = s_fmn[(e >> 2) * 5 + (e & 3)];
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int e = t + 256 * k;
-      if (e < 2 * nc) {
-        col_mix[2 * rec0 + e] = s_cm[(e >> 1) * 3 + (e & 1)];
-        jeta[2 * rec0 + e] = s_je[(e >> 1) * 3 + (e & 1)];
-      }
-    }
-  }
-  if (masks) {
-    __syncthreads();
-    if (t < mask_w) masks[((size_t)blockIdx.x + (size_t)gridDim.x * ilay) * mask_w + t] = s_mask[t];
-  }
-}
-
-// -------------------------------------------------------------------------------------------
-// Plan guards.  The host-side plans of the production kernels (band / minor-interval metadata, stage width) are
-// cached per table address; device-resident tables cannot be inspected by the host without draining the stream.
-// Instead of trusting the addresses, every call re-checks the tables ON THE DEVICE against the cached plan: an
-// order-independent weighted checksum of the index tables (tau) or the band alignment (Planck, Rayleigh).  On a
-// mismatch the guard flag is raised, the production kernels return at once and the direct kernels -- which read the
-// caller's tables themselves -- do the call; the host learns about it at its next plan look-up.  So tables changed in
-// place, or re-uploaded at the same addresses, give correct results without rte_hip_invalidate_plans().
-// -------------------------------------------------------------------------------------------
-__host__ __device__ inline unsigned guard_term(unsigned value, unsigned index) {
-  return (value + 0x9e3779b9u) * (2u * index + 1u);
-}
-struct GuardTables {
-  const int* ip[10];    // int tables
-  int in[10];
-  const Bool* bp[4];    // logical tables
-  int bn[4];
-};
-__device__ __forceinline__ void tables_guard_body(const GuardTables& t, unsigned expected, int* __restrict__ flag,
-                                                  int* __restrict__ stale) {
-  __shared__ unsigned acc;
-  if (threadIdx.x == 0) acc = 0;
-  __syncthreads();
-  unsigned h = 0, base = 0;
-  for (int a = 0; a < 10; ++a) {
-    for (int i = threadIdx.x; i < t.in[a]; i += 256) h += guard_term((unsigned)t.ip[a][i], base + (unsigned)i);
-    base += (unsigned)t.in[a];
-  }
-  for (int a = 0; a < 4; ++a) {
-    for (int i = threadIdx.x; i < t.bn[a]; i += 256) h += guard_term(t.bp[a][i] ? 1u : 0u, base + (unsigned)i);
-    base += (unsigned)t.bn[a];
-  }
-  atomicAdd(&acc, h);
-  __syncthreads();
-  if (threadIdx.x == 0 && acc != expected) { *flag = 1; *stale = 1; }
-}
-__global__ void __launch_bounds__(256) tables_guard_kernel(GuardTables t, unsigned expected, int* __restrict__ flag,
-                                                           int* __restrict__ stale) {
-  tables_guard_body(t, expected, flag, stale);
-}
-// band limits: whole chunks of gw g-points, ngpt a multiple of gw (what the stage loops of the production kernels assume)
-__global__ void bands_guard_kernel(int nbnd, int ngpt, const int* __restrict__ band_lims, int gw, int* __restrict__ flag,
-                                   int* __restrict__ stale) {
-  bool ok = gw > 0 && ngpt % gw == 0;
-  for (int b = threadIdx.x; b < nbnd; b += 64) ok = ok && (band_lims[2 * b] - 1) % gw == 0 && band_lims[2 * b + 1] % gw == 0;
-  if (!ok) { *flag = 1; *stale = 1; }
-}
-
 // -------------------------------------------------------------------------------------------
 // layer limits of the lower / upper atmosphere: reference :274-285 (minloc/maxloc with mask,
 // first extremal location; 0 = no such layer)
@@ -401,7 +182,6 @@ __device__ __forceinline__ void minor_chunk(const MinorTables& mt, int flav_row,
 // -------------------------------------------------------------------------------------------
 // compute_tau_absorption: reference :176-338 (driver), :345-396 (major), :402-501 (minor)
 // -------------------------------------------------------------------------------------------
-struct alignas(2 * sizeof(Float)) Float2 { Float x, y; };
 
 // Output planes are written once and never read by the kernel that writes them: stored non-temporally they do not
 // push the interpolation weights and index arrays, which the bands of a tile share, out of the 4 MB L2 of the XCD.
@@ -610,32 +390,6 @@ __global__ void __launch_bounds__(256) tau_absorption_kernel(TauArgs a, int nbnd
   }
 }
 
-// -------------------------------------------------------------------------------------------
-// LUT re-layout (per call, into the scratch arena): (TE = ntemp*neta, nouter, ng) with the
-// (temperature, eta) plane fastest  ->  rows of g-points: out[(o*TE + te)*ng + g].
-// A band's g-points of one (T, eta, p) corner become one contiguous 128-byte row, which is what
-// the LDS staging below copies.  ~35 MB moved per call (L2 / Infinity-Cache resident): ~10 us.
-// -------------------------------------------------------------------------------------------
-__device__ __forceinline__ void relayout_gfast_body(unsigned bx, unsigned by, int TE, int nouter, int ng,
-                                                    const Float* __restrict__ in, Float* __restrict__ out) {
-  extern __shared__ Float tile[];  // [TE][33]
-  const int g0 = bx * 32, o = by;
-  const int ngc = min(32, ng - g0);
-  for (int idx = threadIdx.x; idx < TE * ngc; idx += blockDim.x) {
-    const int te = idx % TE, gg = idx / TE;
-    tile[te * 33 + gg] = in[(size_t)te + (size_t)TE * ((size_t)o + (size_t)nouter * (g0 + gg))];
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < TE * ngc; idx += blockDim.x) {
-    const int gg = idx % ngc, te = idx / ngc;
-    out[((size_t)o * TE + te) * ng + g0 + gg] = tile[te * 33 + gg];
-  }
-}
-__global__ void __launch_bounds__(256)
-relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, Float* __restrict__ out) {
-  relayout_gfast_body(blockIdx.x, blockIdx.y, TE, nouter, ng, in, out);
-}
-
 // Everything compute_tau_absorption's production path prepares before its geometry pre-pass, in ONE launch: the
 // blocks take roles by index -- layer limits per column, the two minor-interval plans of the stand-by direct kernel,
 // the g-fastest copies of up to five tables, the plan guard.  The roles do not depend on each other; as seven
@@ -667,121 +421,6 @@ __global__ void __launch_bounds__(256) tau_setup_kernel(TauSetupArgs a) {
     tables_guard_body(a.gt, a.guard_expected, a.overlap, a.stale);
   }
 }
-
-// -------------------------------------------------------------------------------------------
-// compute_tau_absorption, production kernels (LDS slab).
-//
-// What the measurements on MI355X said (tools/membench.hip): kernels that gather
-// LUT values straight from global memory with lanes = columns run at ~20 ms per 1e5 columns whatever the
-// table layout, because each lane pulls its own cache line and the vector L1 retires about one distinct
-// line per clock.  Both kernels below therefore
-//   * copy the tables to a g-point-fastest layout per call (relayout_gfast_kernel), so that the 16 g-points
-//     of a stage are one 128-byte row piece;
-//   * stage, per (column tile, layer, band), the BOUNDING BOX of the rows the tile's columns need --
-//     pressure x temperature x eta ranges for kmajor, temperature x eta per minor interval -- into an LDS
-//     slab with a row stride of 18 doubles;
-//   * keep lanes = columns: every thread gathers its 8 major + 4-per-interval minor corner rows with
-//     16-byte LDS reads (two g-points per read) and writes tau with coalesced 512-byte wave stores.
-// tau_absorption_v7_kernel does all of it with one kind of wave and two barriers per band;
-// tau_absorption_v9_kernel (default) splits the roles: loader waves stage the next stage's slab into the
-// other half of a double-buffered slab while compute waves gather, one barrier per stage.
-// Tiles whose box does not fit the slab go to a worklist for the direct-gather kernel.
-// Arithmetic: the same products and sums as the reference (:791-801, :757-760) evaluated with
-// fused multiply-adds and col_mix folded into the major weights; differences from the reference
-// association are a few ulp (tests: 1e-12 relative).
-// -------------------------------------------------------------------------------------------
-constexpr int MAXM = 12;   // minor intervals per (band, regime) handled by the production kernels; more -> native kernel
-constexpr int MAXB = 32;   // bands
-
-struct MinorMeta {  // one minor interval
-  int mS, mE, idx_minor, idx_scaling, kstart, flags /*1: scales with density, 2: by complement*/;
-};
-struct BandMeta {  // built on the host from the small index tables, uploaded per call
-  int cnt[2];
-  int gS, gE;   // g-point range of the band (0-based)
-  int flav[2];  // flavor (0-based) of the band per tropo regime: gpoint_flavor(:, gS)
-  MinorMeta m[2][MAXM];  // [0]: lower-regime intervals of the band, [1]: upper
-};
-
-// combine_abs_and_rayleigh, 2-stream branch (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:1983-2002), applied to one value,
-// optionally followed by increment_2stream_by_2stream_bybnd (rte/kernels/mo_optical_props_kernels.F90: the by-band
-// form of :159-181) with a second set of 2-stream properties given per band (clouds): the same operations in the same
-// order as the separate kernels, on values that are doubles in registers instead of doubles in memory -- bit-identical.
-struct RaylCombine {
-  const Float* tau_abs;  // nullptr: plain compute_tau_rayleigh
-  Float *tau, *ssa, *g;  // tau may alias tau_abs
-  const Float *cld_tau, *cld_ssa, *cld_g;  // (ncol, nlay, nbnd) or nullptr
-};
-#ifdef RTE_USE_SP
-#define RTE_TINY 1.17549435e-38f
-#else
-#define RTE_TINY 2.2250738585072014e-308
-#endif
-__device__ __forceinline__ void rayl_finish(Float ta, Float tr, bool cld, Float t2, Float s2, Float g2, Float& tau, Float& ssa,
-                                            Float& g) {
-  const Float tiny2 = (Float)2 * (Float)RTE_TINY;
-  const Float t = ta + tr;
-  ssa = t > tiny2 ? tr / t : (Float)0;
-  tau = t;
-  g = (Float)0;
-  if (cld) {
-    const Float eps = (Float)3 * (Float)RTE_TINY;  // mo_optical_props_kernels.F90:38
-    const Float tau12 = tau + t2;
-    const Float tauscat12 = tau * ssa + t2 * s2;
-    g = (tau * ssa * g + t2 * s2 * g2) / fmax(eps, tauscat12);
-    ssa = tauscat12 / fmax(eps, tau12);
-    tau = tau12;
-  }
-}
-// compute_tau_absorption fused with compute_tau_rayleigh and the 2-stream combine (rte_hip_gas_optics_sw_2str): the
-// Rayleigh table rows are staged like one more pair of minor planes, and a stage writes tau, ssa, g instead of tau_abs
-struct RaylFuse {
-  const Float* krayl_g[2];  // g-fastest copies of krayl(:, :, :, regime)
-  const Float* col_dry;
-  const Float *cld_tau, *cld_ssa, *cld_g;  // (ncol, nlay, nbnd) or nullptr: increment by band-wise 2-stream properties
-  Float *ssa, *g;           // (tau goes to TauV5::tau)
-};
-
-struct TauV5 {
-  int ncol, nlay, ngpt, nbnd, ntemp, TE, idx_h2o, nk_lo, nk_up;
-  const int* band_lims;      // (2,nbnd)
-  const int* gpoint_flavor;  // (2,ngpt)
-  const BandMeta* bmeta;     // [nbnd]
-  const Float *kmaj, *klo, *kup;  // g-fastest tables
-  const int *lim, *jeta, *jtemp, *jpress;
-  const Bool* tropo;
-  const Float *col_mix, *fmajor, *fminor, *play, *tlay, *col_gas;
-  Float* tau;
-  const int* skip_if;  // device flag: some column has overlapping regimes -> the fallback kernel does the call
-  int* worklist;       // [0] = count, then (tile, layer, band) triples for tau_absorption_worklist_kernel
-  bool overwrite;      // tau is known to be zero (deferred zero_array): do not read it
-  bool atomic_ok;      // tau is device memory proper: hardware floating-point atomics are defined on it (not on host-visible memory)
-  const Float* add_bybnd;  // (ncol, nlay, nbnd) or nullptr: see TauArgs
-  RaylFuse rf;             // used by the RAYL instantiations only
-#ifdef EXP_CLOCKS
-  unsigned long long* clocks;
-#endif
-};
-
-// wave-wide min / max by butterfly shuffles (LDS atomics on one address serialise lane by lane)
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ Float2 ld2(const Float* p) { return *reinterpret_cast<const Float2*>(p); }
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
-}
-
-// LDS slab row stride in Floats: 18 = nine 16-byte quads.  Rows are read with ds_read_b128 (two g-points per
-// read), which the LDS serves in groups of 16 lanes x 4 banks: an odd quad stride puts the rows of a group on
-// distinct banks (MI355X_MICROARCH.md, LDS), and b128 reaches the LDS peak with one wave per SIMD where
-// 8-byte reads need four.
-constexpr int RS = GC + 2;
-constexpr int SLAB_FLOATS = 8704;  // 68 KB of LUT slab per block (2 blocks per CU); tiles that need more go to the direct kernel
 
 // lanes = columns; block = (256 columns, one layer), walks the bands.  Per band the block stages the
 // bounding box of LUT rows its columns need (pressure x temperature x eta ranges of the tile) from the
@@ -904,9 +543,6 @@ __global__ void __launch_bounds__(BS, MINW) tau_absorption_v7_kernel(TauV5 a) {
       // ---- stage the slab; rows ordered [p][t][eta] (+ minor: [interval][t][eta]); 16-byte pieces.
       // Up to SB pieces per thread are requested back to back and only then written to LDS, so a tile
       // pays the L2 latency once per batch, not once per piece.
-#ifdef EXP_NOSTAGE
-      if (a.ncol == -12345)
-#endif
       {
         constexpr int SB = 8;
         const int nMaj = rowsMaj * (GC / 2), nAll = (rowsMaj + rowsLo + rowsUp) * (GC / 2);
@@ -950,9 +586,6 @@ __global__ void __launch_bounds__(BS, MINW) tau_absorption_v7_kernel(TauV5 a) {
       }
       __syncthreads();
       if (!valid) continue;
-#ifdef EXP_NOCOMPUTE
-      if (a.ncol != -12345) continue;
-#endif
       if (g0 == gptS) {
         // col_mix folded into the major weights
         w0 = cm.x * fm[0].x; w1 = cm.x * fm[0].y; w2 = cm.x * fm[1].x; w3 = cm.x * fm[1].y;
@@ -964,9 +597,6 @@ __global__ void __launch_bounds__(BS, MINW) tau_absorption_v7_kernel(TauV5 a) {
       const int sP = nT * nE * RS;
       const Float* M0_ = slab + (rowsMaj + (regime == 2 ? rowsLo : 0)) * RS;
       const Float *A0 = A0_, *B0 = B0_, *M0 = M0_;
-#ifdef EXP_BCAST
-      A0 = slab + (a.ncol == -12345 ? tid : 0) * RS; B0 = A0 + 2 * RS; M0 = A0 - ((jT - Tmin) * nE + (em1 - emin)) * RS;
-#endif
 #pragma unroll 1
       for (int h = 0; h < GC; h += HW) {  // HW g-points at a time: bounded register footprint
         Float acc[HW];
@@ -1034,53 +664,13 @@ __global__ void __launch_bounds__(BS, MINW) tau_absorption_v7_kernel(TauV5 a) {
             acc[j + 1] = fma(scaling, t_, acc[j + 1]);
           }
         }
-#ifdef EXP_NOSTORE
-        Float sum = 0;
-#pragma unroll
-        for (int j = 0; j < HW; ++j) sum += acc[j];
-        if (sum == (Float)-12345.678) tp[0] = sum;
-#else
 #pragma unroll
         for (int j = 0; j < HW; ++j) tp[(size_t)ncl * j] = acc[j];
-#endif
       }
     }
   }
 }
 
-
-#ifndef V9_NCW  // shape of the specialised-wave kernel (overridable for experiments: tools/variants.py)
-#define V9_NCW 8
-#define V9_NLW 2
-#endif
-#ifndef V9_SB
-#define V9_SB 8
-#endif
-#ifndef V9_SLAB
-#define V9_SLAB 8704   // floats per slab buffer (two buffers per block)
-#endif
-#ifndef V9_MINW
-#define V9_MINW ((V9_NCW + V9_NLW + 3) / 4)  // waves per SIMD the register budget must allow
-#endif
-// -------------------------------------------------------------------------------------------
-// compute_tau_absorption, specialised-wave kernel ("v9").
-//
-// Measured on the slab kernel above (tools/variants.py, per-phase cycle counters): staging, compute and
-// the tau stores of a stage run back to back -- vector-memory operations of a wave retire in order, so a
-// staging load issued after the previous stage's stores waits for them, and the range reductions, the
-// dependent index loads and two barriers per stage sit on the same critical path.  Here the work is split:
-//   * tau_geom_kernel (tiny pre-pass) computes, per (column tile, layer), the bounding box of LUT rows
-//     every band needs, and sends oversized (tile, layer, band) triples to the direct-gather worklist;
-//   * the main kernel runs one block per CU with NCW compute waves (lanes = columns) and NLW loader
-//     waves.  The loaders know the whole schedule from the geometry table: they stage the slab of stage
-//     s+1 into the other half of a double-buffered LDS slab while the compute waves work on stage s, with
-//     ONE barrier per stage.  The loaders' memory queue holds only table reads; the compute waves' queue
-//     holds weights (requested one stage ahead) and tau stores, so neither waits for the other's traffic.
-// -------------------------------------------------------------------------------------------
-struct TileGeom {   // one per (column tile, layer)
-  int Tmin, nT, Pmin, nP, has_lo, has_up, pad0, pad1;
-  int2 eg[MAXB];    // per band: (emin, nE); nE = 0 -> band handled by the direct kernel (or no work)
-};
 
 template <int TILE, int G>
 __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __restrict__ geom, int slab_floats) {
@@ -1153,160 +743,6 @@ __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __res
       a.worklist[1 + 3 * w] = blockIdx.x; a.worklist[2 + 3 * w] = ilay; a.worklist[3 + 3 * w] = tid;
     }
     out->eg[tid] = make_int2(emin, fits ? nE : 0);
-  }
-}
-
-// -------------------------------------------------------------------------------------------
-// Tile geometry by bit masks ("geom2"): the pre-pass of both specialised-wave kernels.
-//
-// The first version walked the bands, loading the band's eta indices and reducing them with 12 cross-lane
-// shuffles per band -- 16 dependent load -> reduce steps per block (0.31 + 0.27 ms per step of the LW chain).
-// Here every thread requests the eta indices of ALL flavors up front (4 at a time), turns each index pair into a
-// bit mask of the LUT rows it touches (row r -> bit r; neta, ntemp < 31, npres + 1 < 63 checked by the host),
-// and masks are OR-reduced: six DPP steps inside the wave (no LDS traffic), one LDS atomic per wave and word.
-// A band's eta range is then the span of the masks of its two flavors, keyed by the regime of the columns
-// that use them -- the same box as before.
-// -------------------------------------------------------------------------------------------
-struct Geom2Args {
-  int ncol, nlay, nbnd, nflav, slab_floats;
-  bool planck;               // Planck: box = pressure x temperature x eta of pfrac; no minor rows, no regime ranges
-  const int* lim;            // (ncol, 4) regime layer limits (tau only)
-  const int *jeta, *jtemp, *jpress;
-  const Bool* tropo;
-  const BandMeta* bmeta;     // tau: band flavors and minor counts
-  const int *band_lims, *gpoint_flavor;  // Planck: band flavors
-  const int* skip_if;        // tau: the direct kernel does the whole call
-  const int* skip_if2;       // Planck: the geometry left by the compute_tau_absorption call before is valid (shared)
-  int* valid_out;            // tau: set to 1 once this geometry is (being) written, for a Planck call that shares it
-  int extra_planes;          // tau: more (T, eta) planes staged per stage (2 with the fused Rayleigh rows)
-  int* worklist;             // tau: (tile, layer, band) triples; Planck: (tile, band) pairs
-  int* flags;                // Planck: one worklist entry per (tile, band)
-  const unsigned* imask;     // tau: masks per (256-column block, layer) left by the interpolation call (InterpMasks), or nullptr
-  int imask_nblk;            //      blocks per layer
-  const int* irregular;      //      != 0: some column's layer ranges are not those of its tropo flags -> derive the masks here
-  int* stat;                 //      rte_hip_stat(2): 1 = masks taken from the interpolation call, 2 = derived here
-};
-
-template <int TILE, int G>
-__global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom* __restrict__ geom) {
-  constexpr int RS = G + 2;
-  __shared__ unsigned mT, mP[2], mReg;
-  __shared__ unsigned mE[MAXFLAV][2];
-  __shared__ int flav[MAXB][2], cnt[MAXB][2];
-  if (a.skip_if && *a.skip_if) return;
-  if (a.skip_if2 && *a.skip_if2) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
-  const unsigned ncl = ncol * nlay;
-  const int nbnd = a.nbnd, nflav = a.nflav;
-  if (a.valid_out && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *a.valid_out = 1;  // (read by later launches only)
-  if (tid == 0) { mT = 0; mP[0] = 0; mP[1] = 0; mReg = 0; }
-  if (tid < 2 * MAXFLAV) mE[tid >> 1][tid & 1] = 0;
-  if (tid < 2 * nbnd) {
-    const int b = tid >> 1, r = tid & 1;
-    if (a.planck) {
-      flav[b][r] = a.gpoint_flavor[r + 2 * (a.band_lims[2 * b] - 1)] - 1;
-      cnt[b][r] = 0;
-    } else {
-      flav[b][r] = a.bmeta[b].flav[r];
-      cnt[b][r] = a.bmeta[b].cnt[r];
-    }
-  }
-  __syncthreads();
-  static_assert(TILE % 256 == 0, "the interpolation kernel leaves one mask record per 256 columns");
-  const bool pre = a.imask != nullptr && *a.irregular == 0;
-  if (a.stat && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *a.stat = pre ? 1 : 2;
-  if (pre && tid >= 128) return;  // two waves do the rest (4 + 2 * nflav <= 68 words; finished waves no longer count at the barrier)
-  if (pre) {
-    const int W = 4 + 2 * nflav;
-    if (tid < W) {
-      unsigned m = 0;
-      for (int k = 0; k < TILE / 256; ++k) {
-        const unsigned blk = blockIdx.x * (TILE / 256) + k;
-        if (blk < (unsigned)a.imask_nblk) m |= a.imask[((size_t)blk + (size_t)a.imask_nblk * ilay) * W + tid];
-      }
-      if (tid == 0) mT = m;
-      else if (tid == 1) mP[0] = m;
-      else if (tid == 2) mP[1] = m;
-      else if (tid == 3) mReg = m;
-      else mE[(tid - 4) >> 1][(tid - 4) & 1] = m;
-    }
-  } else {
-  const unsigned icol = blockIdx.x * TILE + tid;
-  const bool valid = icol < ncol;
-  const unsigned ic = min(icol, ncol - 1);
-  const unsigned cl = ic + ncol * ilay;
-  const int itropo = a.tropo[cl] ? 0 : 1;
-  const int jT = a.jtemp[cl];
-  const int jp = a.jpress[cl] + itropo + 1;  // levels jp-1, jp (1-based)
-  int regime = 0;
-  if (!a.planck) {
-    const int lay1 = ilay + 1;
-    const int lo1 = a.lim[ic], lo2 = a.lim[ic + ncol];
-    const int up1 = a.lim[ic + 2 * (size_t)ncol], up2 = a.lim[ic + 3 * (size_t)ncol];
-    regime = ((lo1 > 0 && lay1 >= lo1 && lay1 <= lo2) ? 1 : 0) | ((up1 > 0 && lay1 >= up1 && lay1 <= up2) ? 2 : 0);
-  }
-  const int rsel = regime == 2 ? 1 : 0;  // regime whose flavor the minor absorbers use
-  // a column's eta rows count for the regimes whose flavor table it uses: itropo (major species, Planck
-  // fractions) and rsel (minor species; differs from itropo only for non-contiguous tropo masks)
-  const bool key0 = valid && (itropo == 0 || (!a.planck && rsel == 0));
-  const bool key1 = valid && (itropo == 1 || (!a.planck && rsel == 1));
-  {
-    const unsigned long long pm = valid ? (3ull << (jp - 1)) : 0ull;
-    const unsigned t = wave_or(valid ? (3u << jT) : 0u);
-    const unsigned p0 = wave_or((unsigned)pm), p1 = wave_or((unsigned)(pm >> 32));
-    const unsigned rg = wave_or(valid ? (unsigned)regime : 0u);
-    if (lane == 0) { atomicOr(&mT, t); atomicOr(&mP[0], p0); atomicOr(&mP[1], p1); atomicOr(&mReg, rg); }
-  }
-  for (int f0 = 0; f0 < nflav; f0 += 4) {
-    int2 je[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      je[k] = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * min(f0 + k, nflav - 1)));
-    unsigned w[4][2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned m = (3u << je[k].x) | (3u << je[k].y);  // rows eta, eta + 1 of both temperature corners
-      w[k][0] = wave_or(key0 ? m : 0u);
-      w[k][1] = wave_or(key1 ? m : 0u);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (f0 + k < nflav) { atomicOr(&mE[f0 + k][0], w[k][0]); atomicOr(&mE[f0 + k][1], w[k][1]); }
-    }
-  }
-  }  // !pre
-  __syncthreads();
-  TileGeom* out = geom + (blockIdx.x + (size_t)gridDim.x * ilay);
-  const int Tmin = __ffs(mT) - 1, nT = (32 - __clz(mT)) - Tmin;
-  const unsigned long long pmask = ((unsigned long long)mP[1] << 32) | mP[0];
-  const int Pmin = __ffsll((long long)pmask) - 1, nP = (64 - __clzll((long long)pmask)) - Pmin;
-  const int has_lo = mReg & 1, has_up = (mReg >> 1) & 1;
-  if (tid == 0) {
-    out->Tmin = Tmin; out->nT = nT; out->Pmin = Pmin; out->nP = nP; out->has_lo = has_lo; out->has_up = has_up;
-    out->pad0 = 0; out->pad1 = 0;
-  }
-  if (tid < nbnd) {
-    const unsigned me = mE[flav[tid][0]][0] | mE[flav[tid][1]][1];
-    const int emin = me ? __ffs(me) - 1 : 1, nE = me ? (32 - __clz(me)) - emin : 0;
-    const int n_lo = has_lo ? cnt[tid][0] : 0, n_up = has_up ? cnt[tid][1] : 0;
-    const int rows = (nP + n_lo + n_up + (a.planck ? 0 : a.extra_planes)) * nT * nE;
-    const bool fits = rows * RS <= a.slab_floats;
-    if (a.planck) {
-      if (!fits && atomicCAS(&a.flags[blockIdx.x * nbnd + tid], 0, 1) == 0) {  // once per (tile, band)
-        const int w = atomicAdd(&a.worklist[0], 1);
-        a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = tid;
-      }
-      out->eg[tid] = make_int2(emin, nE);
-    } else {
-      if (!fits) {  // hand (tile, layer, band) to the direct kernel
-        const int w = atomicAdd(&a.worklist[0], 1);
-        a.worklist[1 + 3 * w] = blockIdx.x; a.worklist[2 + 3 * w] = ilay; a.worklist[3 + 3 * w] = tid;
-      }
-      // (nE <= 0: not a stage of the slab kernel; the magnitude is kept for a Planck call that shares this geometry)
-      out->eg[tid] = make_int2(emin, fits ? nE : -nE);
-    }
   }
 }
 
@@ -1395,9 +831,6 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
           return *reinterpret_cast<const Float2*>(
               kg + ((size_t)((emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * nk + (unsigned)m.kstart + (on ? g0 - m.mS : 0) + 2 * j));
         };
-#ifdef X9_NOSTAGE
-        if (a.ncol < 0)
-#endif
 #pragma unroll 1
         for (int base = lt; base < nAll; base += SB * NLT) {
           Float2 v[SB];
@@ -1595,12 +1028,8 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
     for (int j = 0; j < G; j += 2) {
       // :791-801 with col_mix folded into the weights; one 16-byte LDS read feeds two g-points
-#ifdef X9_NOGATHER
-      const Float2 k0{w1, w2}, k1{w2, w3}, k2{w3, w4}, k3{w4, w5}, k4{w5, w6}, k5{w6, w7}, k6{w7, w0}, k7{w0, w1};
-#else
       const Float2 k0 = ld2(A0 + j), k1 = ld2(A0 + RS + j), k2 = ld2(A0 + sP + j), k3 = ld2(A0 + sP + RS + j),
                    k4 = ld2(B0 + j), k5 = ld2(B0 + RS + j), k6 = ld2(B0 + sP + j), k7 = ld2(B0 + sP + RS + j);
-#endif
       Float m = w0 * k0.x, n = w0 * k0.y;
       m = fma(w1, k1.x, m); n = fma(w1, k1.y, n);
       m = fma(w2, k2.x, m); n = fma(w2, k2.y, n);
@@ -1617,13 +1046,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     }
     // next stage's major weights: their registers are free now, and the request is a minor pass ahead of its use
     // (requested with the minor weights at the end of the stage, their latency is exposed: 5.5 -> 5.9 ms)
-#if defined(X9_NOLOAD) || defined(X9_NOLOAD_MAJ)
-    if (a.ncol < 0)
-#endif
     load_major(nq.flav_major, mj);
-#if defined(X9_NOLOAD) || defined(X9_NOLOAD_MIN)
-    if (a.ncol < 0)
-#endif
     load_minor_w(nq, mw);
     __builtin_amdgcn_sched_barrier(0);
     // ---- minor absorbers of this regime; scalings (:461-480)
@@ -1642,13 +1065,6 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         }
       }
     }
-#ifdef X9_EARLY_SC
-#if defined(X9_NOLOAD) || defined(X9_NOLOAD_MIN)
-    if (a.ncol < 0)
-#endif
-    load_minor(ibnd_n, nq, mn);  // this stage's amounts are scaled copies by now
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     const Float f0 = fn0.x, f1 = fn0.y, f2 = fn1.x, f3 = fn1.y;
     // one minor interval's contribution (:757-760, :493): 4 corner rows of its plane, 2 g-points per LDS read
     auto minor_rows = [&](int k, Float scaling) {
@@ -1656,12 +1072,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       const Float* r2 = M0 + ((k * nT + (jT + 1 - Tmin)) * nE + (em.y - emin)) * RS;
 #pragma unroll
       for (int j = 0; j < G; j += 2) {
-#ifdef X9_NOGATHER
-        const Float2 q0{f1, f2}, q1{f2, f3}, q2{f3, scaling}, q3{scaling, f0};
-        (void)r1; (void)r2;
-#else
         const Float2 q0 = ld2(r1 + j), q1 = ld2(r1 + RS + j), q2 = ld2(r2 + j), q3 = ld2(r2 + RS + j);
-#endif
         Float s_ = f0 * q0.x, t_ = f0 * q0.y;
         s_ = fma(f1, q1.x, s_); t_ = fma(f1, q1.y, t_);
         s_ = fma(f2, q2.x, s_); t_ = fma(f2, q2.y, t_);
@@ -1702,22 +1113,8 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         minor_rows(k, scaling);
       }
     }
-#ifndef X9_EARLY_SC
-#if defined(X9_NOLOAD) || defined(X9_NOLOAD_MIN)
-    if (a.ncol < 0)
-#endif
     load_minor(ibnd_n, nq, mn);
-#endif
     __builtin_amdgcn_sched_barrier(0);  // keep these requests ahead of the stores that follow
-#ifdef X9_NOSTORE
-    {
-      Float t_ = 0;
-#pragma unroll
-      for (int j = 0; j < G; ++j) t_ += acc[j];
-      if (t_ == (Float)-1.2345) *tau_at(0) = t_;
-    }
-    if (a.ncol < 0)
-#endif
     if constexpr (RAYL != 0) {
       // compute_tau_rayleigh (:548-555: interpolate2D with the reference's association) on the staged table rows,
       // combine_abs_and_rayleigh and the optional by-band increment on the values in registers (rayl_finish), and
@@ -1764,11 +1161,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
         for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
       }
-#ifdef X9_RMW
-      const bool use_atomics = false;
-#else
       const bool use_atomics = a.atomic_ok;  // host-visible (pinned / managed) buffers: load - add - store
-#endif
       if (use_atomics) {
 #pragma unroll
         for (int j = 0; j < G; ++j) unsafeAtomicAdd(tau_at(j), acc[j]);
@@ -1784,19 +1177,6 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   if (all_run) run_stages(std::true_type{}); else run_stages(std::false_type{});
 }
 
-// the few flag / counter words a call needs zeroed, in ONE launch (each hipMemsetAsync is a launch of its own)
-__global__ void __launch_bounds__(256) zero_words_kernel(int* a, unsigned na, int* b, unsigned nb, int* c, unsigned nc) {
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < na + nb + nc; i += gridDim.x * 256) {
-    if (i < na) a[i] = 0;
-    else if (i < na + nb) b[i - na] = 0;
-    else c[i - na - nb] = 0;
-  }
-}
-
-// (tile, layer, band) triples the slab kernel could not hold, done by the direct-gather code
-// (work item = one entry x one 64-column chunk, taken by waves in grid stride: the few hundred entries of a call
-// spread over all CUs instead of one block walking an entry's 512 columns)
-// (<= 168 registers: three waves per SIMD, so that a wave of it fits beside two waves of the slab kernel's blocks)
 template <bool GFAST>
 __global__ void __launch_bounds__(256, 3) tau_absorption_worklist_kernel(TauArgs a, GfastTabs gt, const int* __restrict__ worklist,
                                                                       int tile, int* __restrict__ stat) {
@@ -1875,629 +1255,6 @@ tau_rayleigh_kernel(int ncol, int nlay, int nbnd, int ngpt, int neta, int ntemp,
     }
   }
 }
-
-// -------------------------------------------------------------------------------------------
-// compute_Planck_source: reference :568-710 (+ interpolate1D :715-737)
-// -------------------------------------------------------------------------------------------
-__device__ __forceinline__ Float planck_1d(Float val, Float offset, Float delta_r, const Float* __restrict__ table,
-                                           int ntab) {
-  const Float val0 = (val - offset) * delta_r;
-  const Float frac = val0 - trunc(val0);
-  const int index = min(ntab - 1, max(1, (int)val0 + 1));  // 1-based
-  const Float t0 = table[index - 1], t1 = table[index];
-  return t0 + frac * (t1 - t0);
-}
-
-struct PlanckArgs {
-  int ncol, nlay, ngpt, neta, npres, ntemp, nPlanckTemp, sfc_lay;
-  const Float *tlay, *tlev, *tsfc, *fmajor;
-  const int* jeta;
-  const Bool* tropo;
-  const int *jtemp, *jpress, *band_lims_gpt;
-  const Float* pfracin;
-  Float temp_ref_min, totplnk_delta_r;
-  const Float* totplnk;
-  const int* gpoint_flavor;
-  Float *sfc_src, *lay_src, *lev_src, *sfc_source_Jac;
-};
-
-// one column, one band, native table layout: always applicable
-__device__ __forceinline__ void planck_direct_column(const PlanckArgs& q, const int icol, const int ibnd) {
-  const int ncol = q.ncol, nlay = q.nlay, neta = q.neta, npres = q.npres, ntemp = q.ntemp,
-            nPlanckTemp = q.nPlanckTemp, sfc_lay = q.sfc_lay;
-  const Float *tlay = q.tlay, *tlev = q.tlev, *tsfc = q.tsfc, *fmajor = q.fmajor, *pfracin = q.pfracin, *totplnk = q.totplnk;
-  const int *jeta = q.jeta, *jtemp = q.jtemp, *jpress = q.jpress, *band_lims_gpt = q.band_lims_gpt,
-            *gpoint_flavor = q.gpoint_flavor;
-  const Bool* tropo = q.tropo;
-  const Float temp_ref_min = q.temp_ref_min, totplnk_delta_r = q.totplnk_delta_r;
-  Float *sfc_src = q.sfc_src, *lay_src = q.lay_src, *lev_src = q.lev_src, *sfc_source_Jac = q.sfc_source_Jac;
-  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
-  const int gptS = band_lims_gpt[2 * ibnd] - 1, gptE = band_lims_gpt[2 * ibnd + 1] - 1;
-  const Float* tp = totplnk + (size_t)nPlanckTemp * ibnd;
-  const size_t tn = (size_t)ntemp * neta;
-  const size_t gstride = tn * (npres + 1);
-  // :641-656 surface Planck function at tsfc and tsfc + 1 K
-  const Float pl_sfc = planck_1d(tsfc[icol], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
-  const Float pl_sfc1 = planck_1d(tsfc[icol] + (Float)1, temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
-
-  for (int g0 = gptS; g0 <= gptE; g0 += GC) {
-    Float pf_prev[GC];
-#pragma unroll
-    for (int j = 0; j < GC; ++j) pf_prev[j] = 0;
-    for (int ilay = 0; ilay < nlay; ++ilay) {
-      const size_t cl = icol + (size_t)ncol * ilay;
-      const int itropo = tropo[cl] ? 0 : 1;
-      const int iflav = gpoint_flavor[itropo + 2 * gptS] - 1;
-      const size_t clf = cl + ncl * iflav;
-      const int jT = jtemp[cl];
-      const int jp = jpress[cl] + itropo + 1;
-      const int je1 = jeta[2 * clf], je2 = jeta[2 * clf + 1];
-      Float fm[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fm[i] = fmajor[8 * clf + i];
-      const size_t a0 = (size_t)(jT - 1) + (size_t)ntemp * (je1 - 1) + tn * (size_t)(jp - 2);
-      const size_t b0 = (size_t)jT + (size_t)ntemp * (je2 - 1) + tn * (size_t)(jp - 2);
-      const Float pl_lay = planck_1d(tlay[cl], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
-      const Float pl_lev = planck_1d(tlev[icol + (size_t)ncol * ilay], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
-#pragma unroll
-      for (int j = 0; j < GC; ++j) {
-        const int g = g0 + j;
-        if (g <= gptE) {
-          const Float* ka = pfracin + gstride * (size_t)g + a0;
-          const Float* kb = pfracin + gstride * (size_t)g + b0;
-          // interpolate3D_byflav with scaling = (1,1), :791-801
-          const Float pf =
-              (Float)1 * (fm[0] * ka[0] + fm[1] * ka[ntemp] + fm[2] * ka[tn] + fm[3] * ka[tn + ntemp]) +
-              (Float)1 * (fm[4] * kb[0] + fm[5] * kb[ntemp] + fm[6] * kb[tn] + fm[7] * kb[tn + ntemp]);
-          lay_src[cl + ncl * (size_t)g] = pf * pl_lay;                                   // :674
-          const Float lv = (ilay == 0) ? pf : sqrt(pf_prev[j] * pf);                      // :695,:699
-          lev_src[icol + (size_t)ncol * ilay + nclv * (size_t)g] = lv * pl_lev;
-          if (ilay == sfc_lay - 1) {                                                      // :651-653
-            sfc_src[icol + (size_t)ncol * g] = pf * pl_sfc;
-            sfc_source_Jac[icol + (size_t)ncol * g] = pf * (pl_sfc1 - pl_sfc);
-          }
-          pf_prev[j] = pf;
-        }
-      }
-    }
-    const Float pl_top = planck_1d(tlev[icol + (size_t)ncol * nlay], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
-#pragma unroll
-    for (int j = 0; j < GC; ++j)
-      if (g0 + j <= gptE) lev_src[icol + (size_t)ncol * nlay + nclv * (size_t)(g0 + j)] = pf_prev[j] * pl_top;  // :705
-  }
-}
-
-__global__ void __launch_bounds__(256) planck_source_kernel(PlanckArgs q, const int* __restrict__ run_if) {
-  if (run_if && *run_if == 0) return;
-  const int icol = blockIdx.x * blockDim.x + threadIdx.x;
-  if (icol < q.ncol) planck_direct_column(q, icol, blockIdx.y);
-}
-
-// (tile, band) pairs the slab kernel handed over (worklist[0] = count)
-__global__ void __launch_bounds__(256)
-planck_source_worklist_kernel(PlanckArgs q, const int* __restrict__ worklist, int tile, int* __restrict__ stat) {
-  const int n = worklist[0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *stat = n;  // rte_hip_stat(1)
-  for (int w = blockIdx.x; w < n; w += gridDim.x)
-    for (int c = threadIdx.x; c < tile; c += 256) {
-      const int icol = worklist[1 + 2 * w] * tile + c;
-      if (icol < q.ncol) planck_direct_column(q, icol, worklist[2 + 2 * w]);
-    }
-}
-
-// -------------------------------------------------------------------------------------------
-// compute_Planck_source, production kernel: same scheme as tau_absorption_v7_kernel.
-// block = (256 columns, one band) and walks the LAYERS, so the previous layer's Planck fractions
-// stay in registers for the geometric mean at the interface (:699).  Per layer the tile's
-// bounding box of pfrac rows is staged in LDS from the g-fastest table; the band's totplnk column
-// sits in LDS for the whole block.  Interpolation state of layer l+1 is requested while layer l
-// is computed (two-deep: indices two layers ahead, flavor-dependent weights one layer ahead).
-// -------------------------------------------------------------------------------------------
-struct PlanckV7 {
-  int ncol, nlay, ngpt, ntemp, TE, nPlanckTemp, sfc_lay;
-  Float temp_ref_min, totplnk_delta_r;
-  const int *band_lims, *gpoint_flavor, *jeta, *jtemp, *jpress;
-  const Bool* tropo;
-  const Float *pf_g, *totplnk, *fmajor, *tlay, *tlev, *tsfc;
-  Float *sfc_src, *lay_src, *lev_src, *sfc_jac;
-  int* worklist;  // [0] = count, then (tile, band) pairs for planck_source_worklist_kernel
-  const int* skip_if;  // plan guard raised: the direct kernel does the call
-#ifdef EXP_CLOCKS
-  unsigned long long* clocks;
-#endif
-};
-
-template <int BS>
-__global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
-  __shared__ int rng[2][6];  // per layer (ping-pong): Tmin, Tmax, Pmin, Pmax, emin, emax
-  constexpr int PSLAB = 8704;  // 68 KB: no minor tables here and 2 blocks per CU, so the slab can be larger
-  __shared__ __align__(16) Float slab[PSLAB];
-  extern __shared__ Float tpl[];  // totplnk(:, ibnd)
-  if (*a.skip_if) return;
-  const int tid = threadIdx.x;
-  const int ibnd = blockIdx.y;
-  const unsigned ncol = a.ncol, nlay = a.nlay;
-  const unsigned ncl = ncol * nlay, nclv = ncol * (nlay + 1);  // host guarantees < 2^31
-  const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nPT = a.nPlanckTemp;
-  const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
-  for (int i = tid; i < nPT; i += BS) tpl[i] = a.totplnk[(size_t)nPT * ibnd + i];
-  if (tid < 12) rng[tid / 6][tid % 6] = (tid % 2 == 0) ? (1 << 30) : -1;
-  __syncthreads();
-  const unsigned icol = blockIdx.x * BS + tid;
-  const bool valid = icol < ncol;
-  const unsigned ic = min(icol, ncol - 1);
-  auto planck = [&](Float t) {  // interpolate1D :715-737 on the LDS copy of the band's column
-    const Float val0 = (t - a.temp_ref_min) * a.totplnk_delta_r;
-    const Float frac = val0 - trunc(val0);
-    const int index = min(nPT - 1, max(1, (int)val0 + 1));
-    const Float t0 = tpl[index - 1], t1 = tpl[index];
-    return t0 + frac * (t1 - t0);
-  };
-  const Float pl_sfc = planck(a.tsfc[ic]);
-  const Float pl_sfc1 = planck(a.tsfc[ic] + (Float)1);
-
-  struct Idx { int itropo, jT, jp; Float tlay, tlev; };
-  struct Wts { Float2 fm[4]; int je1, je2; };
-  auto load_idx = [&](unsigned l, Idx& x) {
-    const unsigned cl = ic + ncol * l;
-    x.itropo = a.tropo[cl] ? 0 : 1;
-    x.jT = a.jtemp[cl];
-    x.jp = a.jpress[cl] + x.itropo + 1;
-    x.tlay = a.tlay[cl];
-    x.tlev = a.tlev[cl];
-  };
-  auto load_wts = [&](unsigned l, const Idx& x, Wts& w) {
-    const unsigned cl = ic + ncol * l;
-    const int iflav = a.gpoint_flavor[x.itropo + 2 * gptS] - 1;
-    const size_t clf = cl + (size_t)ncl * iflav;
-    const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w.fm[i] = fmp[i];
-    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
-    w.je1 = je.x; w.je2 = je.y;
-  };
-  Idx x0, x1;   // layers l and l+1
-  Wts w0;       // layer l
-  load_idx(0, x0);
-  load_idx(min(1u, nlay - 1), x1);
-  load_wts(0, x0, w0);
-
-  for (int g0 = gptS; g0 <= gptE; g0 += GC) {  // host guarantees whole, 16-aligned chunks (one pass per 16 g)
-    if (g0 != gptS) {  // restart the layer walk for the next chunk of a wide band
-      load_idx(0, x0); load_idx(min(1u, nlay - 1), x1); load_wts(0, x0, w0);
-    }
-    Float prev[GC];
-#pragma unroll
-    for (int j = 0; j < GC; ++j) prev[j] = 0;
-    for (unsigned l = 0; l < nlay; ++l) {
-      int* r = rng[l & 1];
-      {
-        const int big = 1 << 30;
-        const int a0 = wave_min(valid ? x0.jT : big), a1 = wave_max(valid ? x0.jT + 1 : -1);
-        const int a2 = wave_min(valid ? x0.jp - 1 : big), a3 = wave_max(valid ? x0.jp : -1);
-        const int a4 = wave_min(valid ? min(w0.je1, w0.je2) : big), a5 = wave_max(valid ? max(w0.je1, w0.je2) + 1 : -1);
-        if ((tid & 63) == 0) {
-          atomicMin(&r[0], a0); atomicMax(&r[1], a1); atomicMin(&r[2], a2); atomicMax(&r[3], a3);
-          atomicMin(&r[4], a4); atomicMax(&r[5], a5);
-        }
-      }
-      __syncthreads();  // ranges complete; previous layer's compute finished (slab is free)
-      const int Tmin = r[0], nT = r[1] - r[0] + 1, Pmin = r[2], nP = r[3] - r[2] + 1, emin = r[4], nE = r[5] - r[4] + 1;
-      const int rows = nP * nT * nE;
-      if (rows * RS > PSLAB) {  // block-uniform: this (tile, band) goes to the direct kernel as a whole
-        if (tid == 0) {
-          const int w = atomicAdd(&a.worklist[0], 1);
-          a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = ibnd;
-        }
-        return;
-      }
-      constexpr bool use_lds = true;
-      if (tid < 6) rng[(l + 1) & 1][tid] = (tid % 2 == 0) ? (1 << 30) : -1;
-      if (use_lds) {
-        // 16-byte pieces of the bounding box, SB per thread requested back to back (index clamped, so the
-        // count is fixed): the tile pays the L2 latency once per batch
-        constexpr int SB = 4;
-        const int nAll = rows * (GC / 2);
-        const float inv_nE = 1.0f / (float)nE, inv_nT = 1.0f / (float)nT;
-        auto piece = [&](int idx) -> Float2 {
-          const int j = idx & 7, rr = idx >> 3;
-          const int rest = (int)(((float)rr + 0.5f) * inv_nE), e = rr - rest * nE;  // rows < 2^12: exact
-          const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
-          return *reinterpret_cast<const Float2*>(
-              a.pf_g + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
-        };
-#pragma unroll 1
-        for (int base = tid; base < nAll; base += SB * BS) {
-          Float2 v[SB];
-#pragma unroll
-          for (int u = 0; u < SB; ++u) v[u] = piece(min(base + u * BS, nAll - 1));
-#pragma unroll
-          for (int u = 0; u < SB; ++u) {
-            const int idx = base + u * BS;
-            if (idx < nAll) *reinterpret_cast<Float2*>(slab + (idx >> 3) * RS + 2 * (idx & 7)) = v[u];
-          }
-        }
-      }
-      // this layer's values into locals, then request the following layers' inputs
-      const Float f0 = w0.fm[0].x, f1 = w0.fm[0].y, f2 = w0.fm[1].x, f3 = w0.fm[1].y, f4 = w0.fm[2].x, f5 = w0.fm[2].y,
-                  f6 = w0.fm[3].x, f7 = w0.fm[3].y;
-      const int je1 = w0.je1, je2 = w0.je2, jT = x0.jT, jp = x0.jp;
-      const Float tl = x0.tlay, tv = x0.tlev;
-      x0 = x1;
-      if (l + 1 < nlay) load_wts(l + 1, x0, w0);
-      if (l + 2 < nlay) load_idx(l + 2, x1);
-      __syncthreads();
-      if (!valid) continue;
-      const Float pl_lay = planck(tl), pl_lev = planck(tv);
-      const unsigned cl = ic + ncol * l;
-      Float* lay = a.lay_src + cl + (size_t)ncl * g0;
-      Float* lev = a.lev_src + (ic + ncol * l) + (size_t)nclv * g0;
-      const bool sfc = (int)l == a.sfc_lay - 1;
-      // one body, instantiated separately for LDS and for global rows (a merged pointer would be a
-      // generic one and every gather a slow flat load)
-      auto body = [&](const Float* __restrict__ A0, const Float* __restrict__ B0, const int sE, const int sP) {
-#pragma unroll
-        for (int jj = 0; jj < GC; jj += 2) {
-          // interpolate3D_byflav with scaling (1,1), :791-801; one 16-byte read feeds two g-points
-          const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + sE + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + sE + jj),
-                       k4 = ld2(B0 + jj), k5 = ld2(B0 + sE + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + sE + jj);
-          Float pfv[2], pgv[2];
-          pfv[0] = f0 * k0.x; pfv[1] = f0 * k0.y;
-          pfv[0] = fma(f1, k1.x, pfv[0]); pfv[1] = fma(f1, k1.y, pfv[1]);
-          pfv[0] = fma(f2, k2.x, pfv[0]); pfv[1] = fma(f2, k2.y, pfv[1]);
-          pfv[0] = fma(f3, k3.x, pfv[0]); pfv[1] = fma(f3, k3.y, pfv[1]);
-          pgv[0] = f4 * k4.x; pgv[1] = f4 * k4.y;
-          pgv[0] = fma(f5, k5.x, pgv[0]); pgv[1] = fma(f5, k5.y, pgv[1]);
-          pgv[0] = fma(f6, k6.x, pgv[0]); pgv[1] = fma(f6, k6.y, pgv[1]);
-          pgv[0] = fma(f7, k7.x, pgv[0]); pgv[1] = fma(f7, k7.y, pgv[1]);
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int j = jj + u;
-            const Float pf = pfv[u] + pgv[u];
-            lay[(size_t)ncl * j] = pf * pl_lay;                                  // :674
-            lev[(size_t)nclv * j] = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;  // :695,:699
-            if (sfc) {                                                           // :651-653
-              a.sfc_src[ic + (size_t)ncol * (g0 + j)] = pf * pl_sfc;
-              a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = pf * (pl_sfc1 - pl_sfc);
-            }
-            prev[j] = pf;
-          }
-          asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));  // keep the pair's arithmetic here (see tau kernel)
-          if ((jj & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads (64 VGPRs) in flight
-        }
-      };
-      body(slab + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS,
-           slab + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS, RS, nT * nE * RS);
-    }
-    if (valid) {
-      const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
-#pragma unroll
-      for (int j = 0; j < GC; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
-    }
-    __syncthreads();
-  }
-}
-
-
-// -------------------------------------------------------------------------------------------
-// compute_Planck_source, specialised-wave kernel: the loader / compute split of tau_absorption_v9_kernel.
-// Block = (NCW*64 columns, one band): NCW compute waves (lanes = columns) walk the LAYERS, so the previous
-// layer's Planck fractions stay in registers for the geometric mean at the interface (:699); NLW loader
-// waves stage the bounding box of pfrac rows of layer l+1 into the other half of a double-buffered LDS slab
-// while layer l is computed; one barrier per layer.  planck_geom_kernel provides the boxes and sends
-// (tile, band) pairs that do not fit the slab at some layer to the direct kernel.
-// -------------------------------------------------------------------------------------------
-template <int TILE, int G>
-__global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd, TileGeom* __restrict__ geom,
-                                                           int* __restrict__ flags, int slab_floats) {
-  constexpr int RS = G + 2;
-  __shared__ int rng[4];
-  __shared__ int erng[MAXB][2];
-  __shared__ int flav[MAXB][2];  // flavor (0-based) of band b per tropo regime
-  if (*a.skip_if) return;
-  const int tid = threadIdx.x;
-  const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
-  const unsigned ncl = ncol * nlay;
-  if (tid == 0) { rng[0] = 1 << 30; rng[1] = -1; rng[2] = 1 << 30; rng[3] = -1; }
-  if (tid < MAXB) { erng[tid][0] = 1 << 30; erng[tid][1] = -1; }
-  if (tid < 2 * nbnd) flav[tid >> 1][tid & 1] = a.gpoint_flavor[(tid & 1) + 2 * (a.band_lims[2 * (tid >> 1)] - 1)] - 1;
-  __syncthreads();
-  const unsigned icol = blockIdx.x * TILE + tid;
-  const bool valid = icol < ncol;
-  const unsigned ic = min(icol, ncol - 1);
-  const unsigned cl = ic + ncol * ilay;
-  const int itropo = a.tropo[cl] ? 0 : 1;
-  const int jT = a.jtemp[cl];
-  const int jp = a.jpress[cl] + itropo + 1;
-  const int big = 1 << 30;
-  {
-    const int a0 = wave_min(valid ? jT : big), a1 = wave_max(valid ? jT + 1 : -1);
-    const int a2 = wave_min(valid ? jp - 1 : big), a3 = wave_max(valid ? jp : -1);
-    if ((tid & 63) == 0) { atomicMin(&rng[0], a0); atomicMax(&rng[1], a1); atomicMin(&rng[2], a2); atomicMax(&rng[3], a3); }
-  }
-  for (int b = 0; b < nbnd; ++b) {
-    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * flav[b][itropo]));
-    const int e0 = wave_min(valid ? min(je.x, je.y) : big), e1 = wave_max(valid ? max(je.x, je.y) + 1 : -1);
-    if ((tid & 63) == 0) { atomicMin(&erng[b][0], e0); atomicMax(&erng[b][1], e1); }
-  }
-  __syncthreads();
-  TileGeom* out = geom + (blockIdx.x + (size_t)gridDim.x * ilay);
-  const int nT = rng[1] - rng[0] + 1, nP = rng[3] - rng[2] + 1;
-  if (tid == 0) {
-    out->Tmin = rng[0]; out->nT = nT; out->Pmin = rng[2]; out->nP = nP; out->has_lo = 0; out->has_up = 0;
-    out->pad0 = 0; out->pad1 = 0;
-  }
-  if (tid < nbnd) {
-    const int emin = erng[tid][0], nE = erng[tid][1] - erng[tid][0] + 1;
-    const bool fits = nP * nT * nE * RS <= slab_floats;
-    if (!fits && atomicCAS(&flags[blockIdx.x * nbnd + tid], 0, 1) == 0) {  // once per (tile, band)
-      const int w = atomicAdd(&a.worklist[0], 1);
-      a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = tid;
-    }
-    out->eg[tid] = make_int2(emin, nE);
-  }
-}
-
-// Planck on a geometry left by compute_tau_absorption (rte_hip_share_geometry): which (tile, band) pairs do not fit
-// the slab at some layer.  One wave per pair, lanes = layers (one thread walking the layers was 60 dependent latencies).
-__global__ void __launch_bounds__(256)
-planck_flags_kernel(const TileGeom* __restrict__ geom, int tiles, int nlay, int nbnd, int slab_floats, int RS,
-                    int* __restrict__ flags, int* __restrict__ worklist, const int* __restrict__ valid,
-                    const int* __restrict__ guard) {
-  if (!*valid || *guard) return;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= tiles * nbnd) return;
-  const int tile = i / nbnd, b = i - tile * nbnd;
-  bool fits = true;
-  for (int l = lane; l < nlay; l += 64) {
-    const TileGeom* g = geom + (tile + (size_t)tiles * l);
-    fits = fits && g->nP * g->nT * abs(g->eg[b].y) * RS <= slab_floats;
-  }
-  if (__ballot(!fits) != 0ull && lane == 0) {
-    flags[i] = 1;
-    const int w = atomicAdd(&worklist[0], 1);
-    worklist[1 + 2 * w] = tile; worklist[2 + 2 * w] = b;
-  }
-}
-
-template <int NCW, int NLW, int SLAB, int G>
-__global__ void __launch_bounds__((NCW + NLW) * 64, (NCW + NLW + 3) / 4)
-planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* __restrict__ geom,
-                        const int* __restrict__ flags) {
-  constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
-  constexpr int RS = G + 2, PPR = G / 2, PSH = G == 16 ? 3 : 2;  // row stride, 16-byte pieces per row, log2(PPR)
-  constexpr int MAXL = 256;  // layers per block held in the LDS geometry table (host checks nlay <= MAXL)
-  __shared__ __align__(16) Float slab[2][SLAB];
-  __shared__ int gl[MAXL][6];       // per layer: Tmin, nT, Pmin, nP, emin, nE
-  extern __shared__ Float tpl[];    // totplnk(:, ibnd)
-  if (*a.skip_if) return;
-  const int tid = threadIdx.x;
-  // the bands of one column tile are neighbours in launch order (band = fast grid index): they run at about the
-  // same time and share the tile's index arrays and, per flavor, its interpolation weights in the caches
-  // XCD-aware: workgroups go to the 8 XCDs round-robin by linear id, so (id % 8) picks the XCD and the
-  // sequence id / 8 on one XCD walks the bands of one tile before the next tile
-  const unsigned lin = blockIdx.x, xcd = lin % 8, seq = lin / 8;
-  const int ibnd = (int)(seq % (unsigned)nbnd);
-  const unsigned tile = (seq / (unsigned)nbnd) * 8 + xcd;
-  if (tile >= ntiles) return;  // block-uniform (grid padded to a multiple of 8 tiles)
-  if (flags[tile * nbnd + ibnd]) return;  // block-uniform: the direct kernel does this (tile, band)
-  const unsigned ncol = a.ncol, nlay = a.nlay;
-  const unsigned ncl = ncol * nlay, nclv = ncol * (nlay + 1);  // host guarantees 8 * nclv < 2^32
-  const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nPT = a.nPlanckTemp;
-  const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
-  for (int i = tid; i < nPT; i += NT) tpl[i] = a.totplnk[(size_t)nPT * ibnd + i];
-  for (int l = tid; l < (int)nlay; l += NT) {
-    const TileGeom* g = geom + (tile + (size_t)ntiles * l);
-    gl[l][0] = g->Tmin; gl[l][1] = g->nT; gl[l][2] = g->Pmin; gl[l][3] = g->nP;
-    gl[l][4] = g->eg[ibnd].x; gl[l][5] = abs(g->eg[ibnd].y);  // (negative in a geometry shared with compute_tau_absorption)
-  }
-  __syncthreads();
-  const int nchunk = (gptE - gptS + 1) / G;  // host guarantees whole, 16-aligned chunks
-  // stages of a chunk: the layers in order, then -- unless the surface layer is the last one, whose Planck
-  // fractions are still in registers -- the surface layer once more for sfc_source (keeps those stores and
-  // their addresses out of the layer loop)
-  const int lsfc = a.sfc_lay - 1;
-  const int spc = (int)nlay + (lsfc == (int)nlay - 1 ? 0 : 1);
-  const int nstage = nchunk * spc;
-
-  if (tid >= TILE) {
-    // ================================ loader waves ================================
-    // the loaders issue little and mostly wait for memory: a raised issue priority lets their requests and LDS writes go
-    // out ahead of the eight compute waves' FMAs, so that the next slab is complete a little earlier (tau 5.34 -> 5.28 ms
-    // in one process, no change for Planck)
-    __builtin_amdgcn_s_setprio(1);
-    const int lt = tid - TILE;
-    constexpr int SB = 8;  // 16-byte pieces per lane requested back to back
-#pragma unroll 1
-    for (int s = 0; s < nstage; ++s) {
-      const int ls = s % spc, l = ls < (int)nlay ? ls : lsfc, g0 = gptS + (s / spc) * G;
-      const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], nP = gl[l][3], emin = gl[l][4], nE = gl[l][5];
-      const float inv_nE = 1.0f / (float)nE, inv_nT = 1.0f / (float)nT;
-      const int nAll = nP * nT * nE * (G / 2);
-      Float* sl = slab[s & 1];
-      auto piece = [&](int idx) -> Float2 {  // rows ordered [p][t][eta]
-        const int j = idx & (PPR - 1), r = idx >> PSH;
-        const int rest = (int)(((float)r + 0.5f) * inv_nE), e = r - rest * nE;  // rows < 2^12: exact
-        const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
-        return *reinterpret_cast<const Float2*>(
-            a.pf_g + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
-      };
-#pragma unroll 1
-      for (int base = lt; base < nAll; base += SB * NLT) {
-        Float2 v[SB];
-#pragma unroll
-        for (int u = 0; u < SB; ++u) v[u] = piece(min(base + u * NLT, nAll - 1));
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-          const int idx = base + u * NLT;
-          if (idx < nAll) *reinterpret_cast<Float2*>(sl + (idx >> PSH) * RS + 2 * (idx & (PPR - 1))) = v[u];
-        }
-      }
-      __syncthreads();  // B(s): slab(s) complete; the compute waves are done with the other buffer
-    }
-    return;
-  }
-
-  // ================================ compute waves (lanes = columns) ================================
-  const unsigned icol = tile * TILE + tid;
-  const bool valid = icol < ncol;
-  const unsigned ic = min(icol, ncol - 1);
-  const int flav0 = a.gpoint_flavor[2 * gptS] - 1, flav1 = a.gpoint_flavor[1 + 2 * gptS] - 1;
-  auto planck = [&](Float t) {  // interpolate1D :715-737 on the LDS copy of the band's column
-    const Float val0 = (t - a.temp_ref_min) * a.totplnk_delta_r;
-    const Float frac = val0 - trunc(val0);
-    const int index = min(nPT - 1, max(1, (int)val0 + 1));
-    const Float t0 = tpl[index - 1], t1 = tpl[index];
-    return t0 + frac * (t1 - t0);
-  };
-  const Float pl_sfc = planck(a.tsfc[ic]);
-  const Float pl_sfc1 = planck(a.tsfc[ic] + (Float)1);
-
-  struct Idx { Bool tropo; int jT, jpress; Float tlay, tlev; };  // raw loaded values: nothing is derived at load
-  struct Wts { Float2 fm[4]; int je1, je2; };                     // time, so no request waits for another
-  auto load_idx = [&](unsigned l, Idx& x) {
-    const unsigned cl = ic + ncol * l;
-    x.tropo = a.tropo[cl];
-    x.jT = a.jtemp[cl];
-    x.jpress = a.jpress[cl];
-    x.tlay = a.tlay[cl];
-    x.tlev = a.tlev[cl];
-  };
-  auto load_wts = [&](unsigned l, const Idx& x, Wts& w) {
-    const size_t clf = (ic + ncol * l) + (size_t)ncl * (x.tropo ? flav0 : flav1);
-    const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w.fm[i] = fmp[i];
-    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
-    w.je1 = je.x; w.je2 = je.y;
-  };
-  Idx x0, x1;   // layers l and l+1
-  Wts w0;       // layer l
-  Float prev[G];
-  int s = 0;
-#ifdef EXP_CLOCKS
-  unsigned long long tk = clock64(), tacc[4] = {0, 0, 0, 0};
-#undef TICK
-#define TICK(i) do { const unsigned long long t2_ = clock64(); tacc[i] += t2_ - tk; tk = t2_; } while (0)
-#else
-#undef TICK
-#define TICK(i)
-#endif
-#pragma unroll 1
-  for (int g0 = gptS; g0 <= gptE; g0 += G) {
-    load_idx(0, x0);
-    load_idx(min(1u, nlay - 1), x1);
-    load_wts(0, x0, w0);
-#pragma unroll
-    for (int j = 0; j < G; ++j) prev[j] = 0;
-    // nothing outstanding at loop entry: the wait counts inside are then those of the steady state (requests of
-    // the following layers, then this layer's 32 stores), not their merge with this prologue
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#pragma unroll 1
-    for (unsigned l = 0; l < nlay; ++l, ++s) {
-      TICK(0);
-      // this layer's values into locals, then request the following layers' inputs
-      const Float f0 = w0.fm[0].x, f1 = w0.fm[0].y, f2 = w0.fm[1].x, f3 = w0.fm[1].y, f4 = w0.fm[2].x, f5 = w0.fm[2].y,
-                  f6 = w0.fm[3].x, f7 = w0.fm[3].y;
-      const int je1 = w0.je1, je2 = w0.je2, jT = x0.jT, jp = x0.jpress + (x0.tropo ? 0 : 1) + 1;  // levels jp-1, jp
-      const Float tl = x0.tlay, tv = x0.tlev;
-      x0 = x1;
-      // unconditional (the last layers repeat the last one): a request made on some paths only makes the number of
-      // outstanding memory operations path-dependent, and the compiler then drains them all -- this layer's requests
-      // and the previous layer's 32 stores -- in front of every barrier
-      load_wts(min(l + 1, nlay - 1), x0, w0);
-      load_idx(min(l + 2, nlay - 1), x1);
-      const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], emin = gl[l][4], nE = gl[l][5];
-      const Float pl_lay = planck(tl), pl_lev = planck(tv);
-      TICK(1);
-      __syncthreads();  // B(s): slab(s) is complete
-      TICK(2);
-      const Float* sl = slab[s & 1];
-      const Float* A0 = sl + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS;
-      const Float* B0 = sl + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
-      const int sP = nT * nE * RS;
-      // byte offsets of this column in the (col, lay, g) / (col, lev, g) planes; scalar plane bases
-      unsigned olay = (ic + ncol * l) * (unsigned)sizeof(Float);
-      asm volatile("" : "+v"(olay));  // keep 64-bit addresses out of the loop-invariant registers
-      char* const play_ = reinterpret_cast<char*>(a.lay_src + (size_t)ncl * g0);
-      char* const plev_ = reinterpret_cast<char*>(a.lev_src + (size_t)nclv * g0);
-      const size_t slay = (size_t)ncl * sizeof(Float), slev = (size_t)nclv * sizeof(Float);
-#pragma unroll
-      for (int jj = 0; jj < G; jj += 2) {
-        // interpolate3D_byflav with scaling (1,1), :791-801; one 16-byte read feeds two g-points
-        const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + RS + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + RS + jj),
-                     k4 = ld2(B0 + jj), k5 = ld2(B0 + RS + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + RS + jj);
-        Float pfv[2], pgv[2];
-        pfv[0] = f0 * k0.x; pfv[1] = f0 * k0.y;
-        pfv[0] = fma(f1, k1.x, pfv[0]); pfv[1] = fma(f1, k1.y, pfv[1]);
-        pfv[0] = fma(f2, k2.x, pfv[0]); pfv[1] = fma(f2, k2.y, pfv[1]);
-        pfv[0] = fma(f3, k3.x, pfv[0]); pfv[1] = fma(f3, k3.y, pfv[1]);
-        pgv[0] = f4 * k4.x; pgv[1] = f4 * k4.y;
-        pgv[0] = fma(f5, k5.x, pgv[0]); pgv[1] = fma(f5, k5.y, pgv[1]);
-        pgv[0] = fma(f6, k6.x, pgv[0]); pgv[1] = fma(f6, k6.y, pgv[1]);
-        pgv[0] = fma(f7, k7.x, pgv[0]); pgv[1] = fma(f7, k7.y, pgv[1]);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int j = jj + u;
-          const Float pf = pfv[u] + pgv[u];
-          const Float vlay = pf * pl_lay;                                      // :674
-          const Float vlev = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;      // :695,:699
-          // lanes past the last column repeat it (ic is clamped) and store the same values to the same
-          // addresses: unconditional stores keep the number of outstanding memory operations static, so the
-          // wait for the next layer's weights is a counted one instead of a drain of these stores
-          store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), vlay);
-          store_stream(reinterpret_cast<Float*>(plev_ + slev * j + olay), vlev);  // level l of (ncol, nlay+1): same column offset
-          prev[j] = pf;
-        }
-        asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));  // keep the pair's arithmetic here
-        __builtin_amdgcn_sched_barrier(0);   // at most 8 row reads (32 VGPRs) in flight
-      }
-      TICK(3);
-    }
-    if (valid) {
-      const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
-#pragma unroll
-      for (int j = 0; j < G; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
-    }
-    // ---- surface source (:651-653) from the Planck fractions of the surface layer
-    if (lsfc != (int)nlay - 1) {
-      load_idx(lsfc, x0);
-      load_wts(lsfc, x0, w0);
-      const int Tmin = gl[lsfc][0], nT = gl[lsfc][1], Pmin = gl[lsfc][2], emin = gl[lsfc][4], nE = gl[lsfc][5];
-      __syncthreads();  // B(s): the surface layer's slab is complete
-      const Float* sl = slab[s & 1];
-      ++s;
-      const int jps = x0.jpress + (x0.tropo ? 0 : 1) + 1;
-      const Float* A0 = sl + (((jps - 1 - Pmin) * nT + (x0.jT - Tmin)) * nE + (w0.je1 - emin)) * RS;
-      const Float* B0 = sl + (((jps - 1 - Pmin) * nT + (x0.jT + 1 - Tmin)) * nE + (w0.je2 - emin)) * RS;
-      const int sP = nT * nE * RS;
-#pragma unroll
-      for (int jj = 0; jj < G; jj += 2) {
-        const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + RS + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + RS + jj),
-                     k4 = ld2(B0 + jj), k5 = ld2(B0 + RS + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + RS + jj);
-        Float pa = w0.fm[0].x * k0.x, pb = w0.fm[0].x * k0.y, qa = w0.fm[2].x * k4.x, qb = w0.fm[2].x * k4.y;
-        pa = fma(w0.fm[0].y, k1.x, pa); pb = fma(w0.fm[0].y, k1.y, pb); qa = fma(w0.fm[2].y, k5.x, qa); qb = fma(w0.fm[2].y, k5.y, qb);
-        pa = fma(w0.fm[1].x, k2.x, pa); pb = fma(w0.fm[1].x, k2.y, pb); qa = fma(w0.fm[3].x, k6.x, qa); qb = fma(w0.fm[3].x, k6.y, qb);
-        pa = fma(w0.fm[1].y, k3.x, pa); pb = fma(w0.fm[1].y, k3.y, pb); qa = fma(w0.fm[3].y, k7.x, qa); qb = fma(w0.fm[3].y, k7.y, qb);
-        prev[jj] = pa + qa; prev[jj + 1] = pb + qb;
-        asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (valid) {
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        a.sfc_src[ic + (size_t)ncol * (g0 + j)] = prev[j] * pl_sfc;
-        a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = prev[j] * (pl_sfc1 - pl_sfc);
-      }
-    }
-  }
-#ifdef EXP_CLOCKS
-  if (tid == 0)
-    for (int i = 0; i < 4; ++i) atomicAdd(&a.clocks[i], tacc[i]);
-#endif
-}
-
 
 // -------------------------------------------------------------------------------------------
 // compute_tau_rayleigh, production kernel.  The Rayleigh table has no pressure dimension: the whole
@@ -2618,218 +1375,6 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
 
 }  // namespace
 
-// ===============================================================================================
-// C ABI
-// ===============================================================================================
-// process-wide tuning switches (set from any thread: relaxed atomics)
-static std::atomic<int> g_tau_force_direct{0};
-static std::atomic<int> g_tau_variant{9};
-static const bool g_worklist_native = getenv("RTE_WORKLIST_NATIVE") != nullptr;  // A/B: worklist entries from the native-layout tables
-static std::atomic<int> g_planck_variant{9};  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
-static std::atomic<int> g_geom_variant{2};  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
-// Every piece of mutable host-side state of this file lives in the calling thread's current CONTEXT (runtime.hip):
-// plan caches, the geometry shared between consecutive calls, the guards' flag words.  Tuning switches (rte_hip_*_variant)
-// are process-wide.
-namespace {
-struct TauPlanCache {
-  const void* key[14] = {};
-  int dims[7] = {};
-  int epoch = -1;
-  bool fast_ok = false;
-  int gw = 0;  // g-points per stage of the production kernels (16 or 8)
-  bool uploads_pending = false;  // bands changed since the last upload to the device
-  unsigned guard = 0;            // checksum of the index tables the plan was built from (tables_guard_kernel)
-  std::vector<BandMeta> bands;
-  bool matches(const void* const* k, const int* d, int e) const {
-    if (e != epoch) return false;
-    for (int i = 0; i < 14; ++i)
-      if (k[i] != key[i]) return false;
-    for (int i = 0; i < 7; ++i)
-      if (d[i] != dims[i]) return false;
-    return true;
-  }
-  void set(const void* const* k, const int* d, int e) {
-    for (int i = 0; i < 14; ++i) key[i] = k[i];
-    for (int i = 0; i < 7; ++i) dims[i] = d[i];
-    epoch = e;
-  }
-};
-}  // namespace
-
-// Geometry shared between compute_tau_absorption and the compute_Planck_source call that directly follows it
-// (opt-in, rte_hip_share_geometry): both derive the same per-(tile, layer) bounding boxes from the same interpolation
-// indices, each by reading all of jeta (0.13 ms).  Like the deferred zero fill, for callers that touch the
-// interpolation arrays only through this library between the two calls; keyed by the arrays' addresses, the
-// dimensions and the library's call sequence (the Planck call must be the very next one).
-struct SharedGeom {
-  const void *jeta = nullptr, *jtemp = nullptr, *jpress = nullptr, *tropo = nullptr;
-  int ncol = 0, nlay = 0, nflav = 0, nbnd = 0, gw = 0;
-  long seq = -1;            // call sequence number of the compute_tau_absorption call that wrote it
-  TileGeom* geom = nullptr;  // persistent: lives across calls
-  int* valid = nullptr;      // device word: 1 once that call's geometry kernel ran (it does not when the call is rerouted)
-  size_t cap = 0;
-};
-// The same option also lets rrtmgp_interpolation leave, per (256-column block, layer), the bit masks of the LUT rows
-// its columns touch (it has every index in registers), and the compute_tau_absorption call that is the very next
-// library call on the same interpolation arrays builds its tile geometry from these few megabytes instead of reading
-// jtemp, jpress, tropo and all of jeta again (0.13 ms).  Masks are keyed by the tropo flag; the geometry kernel's own
-// are keyed by the layer ranges derived from it, which is the same thing unless a column's pressure is not monotone in
-// the layer index -- tropo_limits_kernel raises `irregular` then and the geometry kernel derives its masks itself.
-struct InterpMasks {
-  const void *jeta = nullptr, *jtemp = nullptr, *jpress = nullptr, *tropo = nullptr;
-  int ncol = 0, nlay = 0, nflav = 0;
-  long seq = -1;             // call sequence number of the interpolation call that wrote them
-  unsigned* buf = nullptr;   // persistent
-  size_t cap = 0;
-};
-// "are this table's bands whole aligned chunks of 16 or 8 g-points" -- checked once per table pointer and contents
-struct BandCheck {
-  const void* key = nullptr;
-  int n = -1, epoch = -1;
-  bool ok = false;
-  int gw = 0;
-  unsigned fp_seen = 0;
-};
-constexpr int NPLAN = 4;  // a few plans are kept (e.g. an LW and an SW k-distribution used alternately), least recently built evicted
-struct GasState {
-  int plan_epoch = 0;  // bumped by rte_hip_invalidate_plans(): forget cached host-side plans
-  // Raised ON THE DEVICE by the plan guards when a cached plan no longer matches the caller's tables: one int in pinned,
-  // device-mapped host memory that the guard kernels write directly.  The host looks at it at every plan look-up and then
-  // drops the cached plans, so that they are rebuilt instead of the direct kernels doing every later call.
-  volatile int* stale_host = nullptr;
-  int* stale_dev = nullptr;
-  int* stats_dev = nullptr;  // diagnostics: entries handed to the direct-gather worklists by the last tau / Planck call (rte_hip_stat)
-  int share_geom = 0;        // 0 off, 1 on; 2 = tau -> Planck only, 3 = interpolation -> tau only (A/B)
-  SharedGeom shared;
-  InterpMasks imask;
-  TauPlanCache plans[NPLAN];
-  int plan_next = 0;
-  BandCheck rayl_bands, planck_bands;
-};
-static std::atomic<int> g_share_geom_default{0};  // what a context starts with (the last rte_hip_share_geometry of any context)
-static void* make_gas_state() {
-  auto* g = new GasState();
-  g->share_geom = g_share_geom_default;
-  return g;
-}
-static void free_gas_state(void* p) {
-  auto* g = (GasState*)p;
-  if (g->shared.geom) (void)hipFree(g->shared.geom);
-  if (g->shared.valid) (void)hipFree(g->shared.valid);
-  if (g->imask.buf) (void)hipFree(g->imask.buf);
-  if (g->stats_dev) (void)hipFree(g->stats_dev);
-  if (g->stale_host) (void)hipHostFree((void*)g->stale_host);
-  delete g;
-}
-static GasState& gs() { return *(GasState*)rte::gas_state(make_gas_state, free_gas_state); }
-static int* stats_dev() {
-  GasState& g = gs();
-  if (!g.stats_dev) {
-    HIP_CHECK(hipMalloc((void**)&g.stats_dev, 4 * sizeof(int)));
-    HIP_CHECK(hipMemset(g.stats_dev, 0, 4 * sizeof(int)));
-  }
-  return g.stats_dev;
-}
-static int* stale_flag() {
-  GasState& g = gs();
-  if (!g.stale_dev) {
-    HIP_CHECK(hipHostMalloc((void**)&g.stale_host, sizeof(int), hipHostMallocMapped));
-    *g.stale_host = 0;
-    HIP_CHECK(hipHostGetDevicePointer((void**)&g.stale_dev, (void*)g.stale_host, 0));
-  }
-  return g.stale_dev;
-}
-static void stale_poll() {
-  (void)stale_flag();
-  GasState& g = gs();
-  if (*g.stale_host) {  // a guard fired in an earlier call: forget every plan
-    ++g.plan_epoch;
-    *g.stale_host = 0;
-  }
-}
-static bool share_boxes() { const int v = gs().share_geom; return v == 1 || v == 2; }
-static bool share_masks() { const int v = gs().share_geom; return v == 1 || v == 3; }
-
-extern "C" {
-
-int rte_hip_share_geometry(int on) { g_share_geom_default = on; gs().share_geom = on; gs().shared.seq = -1; gs().imask.seq = -1; return 0; }
-int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
-int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
-int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
-int rte_hip_invalidate_plans(void) { ++gs().plan_epoch; return 0; }
-int rte_hip_geom_variant(int v) { g_geom_variant = v; return 0; }
-// diagnostics (synchronises): 0 = (column tile, layer, band) triples the last compute_tau_absorption call handed to the
-// direct-gather worklist, 1 = (column tile, band) pairs of the last compute_Planck_source call
-int rte_hip_stat(int which) {
-  if (which < 0 || which > 3) return -1;
-  int v = 0;
-  HIP_CHECK(hipStreamSynchronize(rte::stream()));
-  HIP_CHECK(hipMemcpy(&v, stats_dev() + which, sizeof(int), hipMemcpyDeviceToHost));
-  return v;
-}
-
-
-void rrtmgp_interpolation(const int* ncol_, const int* nlay_, const int* ngas_, const int* nflav_,
-                          const int* neta_, const int* npres_, const int* ntemp_, const int* flavor,
-                          const Float* press_ref_log, const Float* temp_ref,
-                          const Float* press_ref_log_delta, const Float* temp_ref_min,
-                          const Float* temp_ref_delta, const Float* press_ref_trop_log,
-                          const Float* vmr_ref, const Float* play, const Float* tlay,
-                          const Float* col_gas, int* jtemp, Float* fmajor, Float* fminor,
-                          Float* col_mix, Bool* tropo, int* jeta, int* jpress) {
-  const int ncol = *ncol_, nlay = *nlay_, ngas = *ngas_, nflav = *nflav_, neta = *neta_,
-            npres = *npres_, ntemp = *ntemp_;
-  if (ncol <= 0 || nlay <= 0 || nflav <= 0) return;
-  RTE_TRY
-  rte::Call c("rrtmgp_interpolation");
-  const size_t ncl = (size_t)ncol * nlay;
-  // scalar preparation exactly as reference :99-102
-  const Float press_ref_trop = exp(*press_ref_trop_log);
-  const Float temp_ref_delta_inv = (Float)1 / *temp_ref_delta;
-  const Float press_ref_log_delta_inv = (Float)1 / *press_ref_log_delta;
-  const int* d_flavor = c.in(flavor, (size_t)2 * nflav);
-  const Float* d_temp_ref = c.in(temp_ref, (size_t)ntemp);
-  const Float* d_press_ref_log = c.in(press_ref_log, (size_t)npres);
-  const Float* d_vmr_ref = c.in(vmr_ref, (size_t)2 * (ngas + 1) * ntemp);
-  const Float* d_play = c.in(play, ncl);
-  const Float* d_tlay = c.in(tlay, ncl);
-  const Float* d_col_gas = c.in(col_gas, ncl * (ngas + 1));
-  int* d_jtemp = c.out_lazy(jtemp, ncl);  // (lazy: host-mirror mode keeps the interpolation state on the device)
-  Float* d_fmajor = c.out_lazy(fmajor, 8 * ncl * nflav);
-  Float* d_fminor = c.out_lazy(fminor, 4 * ncl * nflav);
-  Float* d_col_mix = c.out_lazy(col_mix, 2 * ncl * nflav);
-  Bool* d_tropo = c.out_lazy(tropo, ncl);
-  int* d_jeta = c.out_lazy(jeta, 2 * ncl * nflav);
-  int* d_jpress = c.out_lazy(jpress, ncl);
-  dim3 grid(cdiv(ncol, 256), nlay), block(256);
-  // masks for the compute_tau_absorption call that follows (InterpMasks): row numbers must fit the mask words
-  unsigned* d_masks = nullptr;
-  gs().imask.seq = -1;
-  if (share_masks() && !c.any_host() && rte::is_device_memory(jeta) && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63) {
-    const size_t need = sizeof(unsigned) * (size_t)grid.x * nlay * (4 + 2 * nflav);
-    if (gs().imask.cap < need) {
-      HIP_CHECK(hipStreamSynchronize(rte::stream()));
-      if (gs().imask.buf) HIP_CHECK(hipFree(gs().imask.buf));
-      HIP_CHECK(hipMalloc((void**)&gs().imask.buf, need));
-      gs().imask.cap = need;
-    }
-    d_masks = gs().imask.buf;
-    gs().imask.jeta = jeta; gs().imask.jtemp = jtemp; gs().imask.jpress = jpress; gs().imask.tropo = tropo;
-    gs().imask.ncol = ncol; gs().imask.nlay = nlay; gs().imask.nflav = nflav;
-    gs().imask.seq = rte::call_seq();
-  }
-  rte::ProfScope p("interpolation_kernel");
-  // the gas amounts of a (column, layer) in LDS while they fit beside the 38 KB of transpose buffers in the 64 KB a block
-  // gets without asking for more (ngas <= 11); larger tables read them through L2
-  const int cg_lds = (ngas + 1) <= 12 ? 1 : 0;
-  hipLaunchKernelGGL(interpolation_kernel, grid, block, cg_lds ? sizeof(Float) * 256 * (ngas + 1) : 0, rte::stream(), ncol, nlay, ngas, nflav, neta,
-                     npres, ntemp, d_flavor, d_temp_ref, d_press_ref_log, press_ref_log_delta_inv,
-                     *temp_ref_min, *temp_ref_delta, temp_ref_delta_inv, press_ref_trop, d_vmr_ref, d_play,
-                     d_tlay, d_col_gas, d_jtemp, d_fmajor, d_fminor, d_col_mix, d_tropo, d_jeta, d_jpress, d_masks, cg_lds);
-  RTE_CATCH("rrtmgp_interpolation")
-}
-
-}  // extern "C"
 // compute_tau_absorption; add_bybnd != nullptr: the band-wise increment of the result by a second optical depth given
 // per band (clouds as absorbers) is applied in the same pass
 // fused SW gas optics (rte_hip_gas_optics_sw_2str): what compute_tau_rayleigh and the combine need besides the
@@ -3158,10 +1703,6 @@ static void tau_absorption_impl(
   hipStream_t aux = nullptr;
   const bool use_v9 = g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr || rh != nullptr;  // the single-role kernel exists for 16-wide stages only
   if (use_v9) {
-#ifdef EXP_CLOCKS
-    v.clocks = (unsigned long long*)rte::scratch(64);
-    HIP_CHECK(hipMemsetAsync(v.clocks, 0, 64, st));
-#endif
     constexpr int NCW = V9_NCW, NLW = V9_NLW, SLAB9 = V9_SLAB;  // compute + loader waves, 2 x 68 KB slab: one block per CU
     const unsigned tiles = cdiv(ncol, NCW * 64);
     const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
@@ -3233,16 +1774,6 @@ static void tau_absorption_impl(
     hipLaunchKernelGGL((tau_absorption_v7_kernel<BS, V7_MINW, V7_HW, V7_SLAB>), dim3(cdiv(ncol, BS), nlay), dim3(BS), sizeof(BandMeta) * nbnd, st,
                        v);
   }
-#ifdef EXP_CLOCKS
-  if (use_v9) {
-    unsigned long long h[8];
-    HIP_CHECK(hipMemcpyAsync(h, v.clocks, 64, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    const double n = (double)cdiv(ncol, V9_NCW * 64) * nlay * (ngpt / 16);
-    fprintf(stderr, "clocks/stage: looptop %.0f requests %.0f barrier %.0f major %.0f minor %.0f stores %.0f\n", h[0] / n, h[1] / n, h[2] / n,
-            h[3] / n, h[4] / n, h[5] / n);
-  }
-#endif
   {
     // runs only when *overlap != 0 (some column's lower and upper layer ranges intersect)
     rte::ProfScope p("tau_absorption_fallback");
@@ -3473,185 +2004,6 @@ int rte_hip_tau_rayleigh_combine_2str(int ncol, int nlay, int nbnd, int ngpt, in
                     band_lims_gpt, krayl, idx_h2o, col_dry, col_gas, fminor, jeta, tropo, jtemp, nullptr, tau_abs, tau, ssa, g,
                     cld_tau, cld_tau ? cld_ssa : nullptr, cld_tau ? cld_g : nullptr);
   return 0;
-}
-
-void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int* nbnd_,
-                                  const int* ngpt_, const int* nflav_, const int* neta_,
-                                  const int* npres_, const int* ntemp_, const int* nPlanckTemp_,
-                                  const Float* tlay, const Float* tlev, const Float* tsfc,
-                                  const int* sfc_lay_, const Float* fmajor, const int* jeta,
-                                  const Bool* tropo, const int* jtemp, const int* jpress,
-                                  const int* gpoint_bands, const int* band_lims_gpt,
-                                  const Float* pfracin, const Float* temp_ref_min,
-                                  const Float* totplnk_delta, const Float* totplnk,
-                                  const int* gpoint_flavor, Float* sfc_src, Float* lay_src,
-                                  Float* lev_src, Float* sfc_source_Jac) {
-  const int ncol = *ncol_, nlay = *nlay_, nbnd = *nbnd_, ngpt = *ngpt_, nflav = *nflav_, neta = *neta_,
-            npres = *npres_, ntemp = *ntemp_, nPlanckTemp = *nPlanckTemp_;
-  (void)gpoint_bands;
-  if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
-  RTE_TRY
-  rte::Call c("rrtmgp_compute_Planck_source");
-  const size_t ncl = (size_t)ncol * nlay;
-  const Float* d_tlay = c.in(tlay, ncl);
-  const Float* d_tlev = c.in(tlev, (size_t)ncol * (nlay + 1));
-  const Float* d_tsfc = c.in(tsfc, (size_t)ncol);
-  const Float* d_fmajor = c.in(fmajor, 8 * ncl * nflav);
-  const int* d_jeta = c.in(jeta, 2 * ncl * nflav);
-  const Bool* d_tropo = c.in(tropo, ncl);
-  const int* d_jtemp = c.in(jtemp, ncl);
-  const int* d_jpress = c.in(jpress, ncl);
-  const int* d_band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
-  const Float* d_pfracin = c.in(pfracin, (size_t)ntemp * neta * (npres + 1) * ngpt);
-  const Float* d_totplnk = c.in(totplnk, (size_t)nPlanckTemp * nbnd);
-  const int* d_gpoint_flavor = c.in(gpoint_flavor, (size_t)2 * ngpt);
-  Float* d_sfc_src = c.out_lazy(sfc_src, (size_t)ncol * ngpt);  // (lazy: host-mirror mode keeps the sources on the device)
-  Float* d_lay_src = c.out_lazy(lay_src, ncl * ngpt);
-  Float* d_lev_src = c.out_lazy(lev_src, (size_t)ncol * (nlay + 1) * ngpt);
-  Float* d_sfc_jac = c.out_lazy(sfc_source_Jac, (size_t)ncol * ngpt);
-  const Float totplnk_delta_r = (Float)1 / *totplnk_delta;  // :636
-  {
-    const void* outs[4] = {d_sfc_src, d_lay_src, d_lev_src, d_sfc_jac};
-    const size_t ob[4] = {sizeof(Float) * (size_t)ncol * ngpt, sizeof(Float) * ncl * ngpt,
-                          sizeof(Float) * (size_t)ncol * (nlay + 1) * ngpt, sizeof(Float) * (size_t)ncol * ngpt};
-    c.try_fork(outs, ob, 4);  // opt-in: concurrently with the compute_tau_absorption call this one follows
-  }
-  hipStream_t st = rte::stream();
-  int* d_stale = stale_flag();
-  stale_poll();
-  // production kernel: 16-aligned whole-chunk bands (checked once per table pointer), aligned inputs
-  BandCheck& bc_ = gs().planck_bands;
-  const void*& bl_key = bc_.key;
-  int &bl_n = bc_.n, &bl_epoch = bc_.epoch;
-  bool& bl_ok = bc_.ok;
-  int& bl_gw = bc_.gw;
-  unsigned bl_fp = 0;
-  if (!rte::is_device_pointer(band_lims_gpt))  // host tables: fingerprint the contents (see compute_tau_absorption)
-    for (int i = 0; i < 2 * nbnd; ++i) bl_fp = (bl_fp ^ (unsigned)band_lims_gpt[i]) * 16777619u;
-  unsigned& bl_fp_seen = bc_.fp_seen;
-  if (bl_key != (const void*)band_lims_gpt || bl_n != nbnd || bl_epoch != gs().plan_epoch || bl_fp != bl_fp_seen) {
-    bl_fp_seen = bl_fp;
-    const int* bl = c.host(band_lims_gpt, (size_t)2 * nbnd);
-    auto aligned = [&](int w) {
-      bool al_ = ngpt % w == 0;
-      for (int b = 0; b < nbnd; ++b) al_ = al_ && (bl[2 * b] - 1) % w == 0 && bl[2 * b + 1] % w == 0;
-      return al_;
-    };
-    bl_gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);  // g-points per stage of the production kernel
-    bl_ok = bl_gw > 0;
-    bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = gs().plan_epoch;
-  }
-  auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
-  const bool fast = bl_ok && ncol >= 512 && !g_tau_force_direct && (size_t)ncol * (nlay + 1) < ((size_t)1 << 31) &&
-                    al(d_fmajor, 16) && al(d_jeta, 8);
-  PlanckArgs q;
-  q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.neta = neta; q.npres = npres; q.ntemp = ntemp; q.nPlanckTemp = nPlanckTemp;
-  q.sfc_lay = *sfc_lay_; q.tlay = d_tlay; q.tlev = d_tlev; q.tsfc = d_tsfc; q.fmajor = d_fmajor; q.jeta = d_jeta;
-  q.tropo = d_tropo; q.jtemp = d_jtemp; q.jpress = d_jpress; q.band_lims_gpt = d_band_lims; q.pfracin = d_pfracin;
-  q.temp_ref_min = *temp_ref_min; q.totplnk_delta_r = totplnk_delta_r; q.totplnk = d_totplnk;
-  q.gpoint_flavor = d_gpoint_flavor; q.sfc_src = d_sfc_src; q.lay_src = d_lay_src; q.lev_src = d_lev_src;
-  q.sfc_source_Jac = d_sfc_jac;
-  if (!fast) {
-    rte::ProfScope p("planck_source_kernel");
-    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)nullptr);
-    return;
-  }
-  // plan guard: the band limits on the device must have the alignment the cached stage width assumes
-  int* guard = (int*)rte::scratch(sizeof(int));
-  constexpr int BS = 256;
-  int* const worklist = (int*)rte::scratch(sizeof(int) * (1 + 2 * (size_t)cdiv(ncol, BS) * nbnd));
-  const unsigned nflags = cdiv(ncol, 512) * (unsigned)nbnd;  // (512-column tile, band) flags of the specialised-wave kernel
-  int* const d_flags = (int*)rte::scratch(sizeof(int) * (size_t)nflags);
-  hipLaunchKernelGGL(zero_words_kernel, dim3(cdiv(nflags + 2, 256)), dim3(256), 0, st, guard, 1u, worklist, 1u, d_flags, nflags);
-  hipLaunchKernelGGL(bands_guard_kernel, dim3(1), dim3(64), 0, st, nbnd, ngpt, d_band_lims, bl_gw, guard, d_stale);
-  const int TE = ntemp * neta;
-  Float* pf_g = (Float*)rte::scratch(sizeof(Float) * (size_t)TE * (npres + 1) * ngpt);
-  {
-    rte::ProfScope p("relayout_gfast_kernel");
-    hipLaunchKernelGGL(relayout_gfast_kernel, dim3(cdiv(ngpt, 32), npres + 1), dim3(256), sizeof(Float) * TE * 33, st,
-                       TE, npres + 1, ngpt, d_pfracin, pf_g);
-  }
-  PlanckV7 v;
-  v.ncol = ncol; v.nlay = nlay; v.ngpt = ngpt; v.ntemp = ntemp; v.TE = TE; v.nPlanckTemp = nPlanckTemp;
-  v.sfc_lay = *sfc_lay_; v.temp_ref_min = *temp_ref_min; v.totplnk_delta_r = totplnk_delta_r;
-  v.band_lims = d_band_lims; v.gpoint_flavor = d_gpoint_flavor; v.jeta = d_jeta; v.jtemp = d_jtemp;
-  v.jpress = d_jpress; v.tropo = d_tropo; v.pf_g = pf_g; v.totplnk = d_totplnk; v.fmajor = d_fmajor;
-  v.tlay = d_tlay; v.tlev = d_tlev; v.tsfc = d_tsfc;
-  v.sfc_src = d_sfc_src; v.lay_src = d_lay_src; v.lev_src = d_lev_src; v.sfc_jac = d_sfc_jac;
-  v.skip_if = guard;
-  v.worklist = worklist;
-  int wl_tile = BS;
-  const bool planck9 = (g_planck_variant == 9 || bl_gw != 16) && nlay <= 256 && nbnd <= MAXB &&
-                       (size_t)ncol * (nlay + 1) < ((size_t)1 << 29);
-  if (!planck9 && bl_gw != 16) {  // 8-wide stages exist only in the specialised-wave kernel
-    rte::ProfScope p("planck_source_kernel");
-    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)nullptr);
-    return;
-  }
-  if (planck9) {
-    constexpr int NCW = 8, NLW = 2, SLAB9 = 8704;  // 8 compute + 2 loader waves, 2 x 68 KB slab: one block per CU
-    wl_tile = NCW * 64;
-    const unsigned tiles = cdiv(ncol, NCW * 64);
-    // the geometry of the compute_tau_absorption call immediately before this one, if it is for the same arrays
-    const bool shared = share_boxes() && gs().shared.seq >= 0 && gs().shared.seq + 1 == rte::call_seq() && gs().shared.jeta == jeta &&
-                        gs().shared.jtemp == jtemp && gs().shared.jpress == jpress && gs().shared.tropo == tropo &&
-                        gs().shared.ncol == ncol && gs().shared.nlay == nlay && gs().shared.nflav == nflav &&
-                        gs().shared.nbnd == nbnd && gs().shared.gw == bl_gw && !c.any_host() &&
-                        !c.forked();  // (on the side stream this call does not wait for that call's kernels)
-    gs().shared.seq = -1;
-    TileGeom* d_geom = shared ? gs().shared.geom : (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
-    static_assert(NCW * 64 == 512, "d_flags is sized for 512-column tiles");
-#ifdef EXP_CLOCKS
-    v.clocks = (unsigned long long*)rte::scratch(64);
-    HIP_CHECK(hipMemsetAsync(v.clocks, 0, 64, st));
-#endif
-    const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
-    Geom2Args ga{};
-    ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = true;
-    ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.band_lims = d_band_lims;
-    ga.gpoint_flavor = d_gpoint_flavor; ga.worklist = v.worklist; ga.flags = d_flags; ga.skip_if = guard;
-    ga.skip_if2 = shared ? gs().shared.valid : nullptr;  // (set on the device by that call's geometry kernel, if it ran)
-#define RTE_LAUNCH_PLANCK9(GW)                                                                                    \
-  do {                                                                                                            \
-    {                                                                                                             \
-      rte::ProfScope p("planck_source_setup");                                                                    \
-      if (shared) hipLaunchKernelGGL(planck_flags_kernel, dim3(cdiv(tiles * nbnd, 4)), dim3(256), 0, st, (const TileGeom*)d_geom, \
-                                     (int)tiles, nlay, nbnd, SLAB9, GW + 2, d_flags, v.worklist, (const int*)gs().shared.valid, \
-                                     (const int*)guard);                                                          \
-      if (geom2) hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, ga, d_geom); \
-      else hipLaunchKernelGGL((planck_geom_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, \
-                              d_flags, SLAB9);                                                                    \
-    }                                                                                                             \
-    rte::ProfScope p("planck_source_kernel");                                                                     \
-    hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW>), dim3(nbnd * 8 * cdiv(tiles, 8)),          \
-                       dim3((NCW + NLW) * 64), sizeof(Float) * nPlanckTemp, st, v, nbnd, tiles,                   \
-                       (const TileGeom*)d_geom, (const int*)d_flags);                                             \
-  } while (0)
-    if (bl_gw == 16) RTE_LAUNCH_PLANCK9(16); else RTE_LAUNCH_PLANCK9(8);
-#undef RTE_LAUNCH_PLANCK9
-  } else {
-    rte::ProfScope p("planck_source_kernel");
-    hipLaunchKernelGGL((planck_source_v7_kernel<BS>), dim3(cdiv(ncol, BS), nbnd), dim3(BS), sizeof(Float) * nPlanckTemp, st,
-                       v);
-  }
-#ifdef EXP_CLOCKS
-  if (wl_tile != BS) {
-    unsigned long long h[8];
-    HIP_CHECK(hipMemcpyAsync(h, v.clocks, 64, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    const double n = (double)cdiv(ncol, wl_tile) * nbnd * nlay;
-    fprintf(stderr, "planck clocks/stage: top %.0f requests %.0f barrier %.0f compute+stores %.0f\n", h[0] / n, h[1] / n, h[2] / n, h[3] / n);
-  }
-#endif
-  {
-    // (tile, band) pairs whose pfrac bounding box exceeded the LDS slab at some layer
-    rte::ProfScope p("planck_source_fallback");
-    hipLaunchKernelGGL(planck_source_worklist_kernel, dim3(1024), dim3(256), 0, st, q, (const int*)v.worklist, wl_tile,
-                       stats_dev() + 1);
-    // the whole call on the direct kernel if the guard fired
-    hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)guard);
-  }
-  RTE_CATCH("rrtmgp_compute_Planck_source")
 }
 
 }  // extern "C"

@@ -352,7 +352,7 @@ class HipGlue:
 
         ext_call(self.lib, "rte_hip_broadcast_gpt", ["i", "i", "a", "a"], ncol, ngpt, per_gpt, out)
 
-    # compute_tau_rayleigh fused with the 2-stream combine (csrc/gas_optics.hip: rte_hip_tau_rayleigh_combine_2str)
+    # compute_tau_rayleigh fused with the 2-stream combine (csrc/tau_absorption.hip: rte_hip_tau_rayleigh_combine_2str)
     def tau_rayleigh_combine_2str(self, ncol, nlay, nbnd, ngpt, ngas, nflav, neta, ntemp, gpoint_flavor, band_lims_gpt, krayl,
                                   idx_h2o, col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_abs, tau, ssa, g, clouds_bybnd=None):
         from .hiplib import ext_call
@@ -362,7 +362,7 @@ class HipGlue:
                  ncol, nlay, nbnd, ngpt, ngas, nflav, neta, ntemp, gpoint_flavor, band_lims_gpt, krayl, idx_h2o,
                  col_dry, col_gas, fminor, jeta, tropo, jtemp, tau_abs, tau, ssa, g, ct, cs, cg)
 
-    # the whole SW gas optics in one pass (csrc/gas_optics.hip: rte_hip_gas_optics_sw_2str)
+    # the whole SW gas optics in one pass (csrc/tau_absorption.hip: rte_hip_gas_optics_sw_2str)
     def gas_optics_sw_2str(self, go, ncol, nlay, st, play, tlay, col_gas, col_dry, tau, ssa, g, clouds_bybnd=None):
         from .hiplib import ext_call
 
