@@ -44,6 +44,7 @@ hipStream_t stream();
 // per-context state owned by another translation unit (the gas-optics plan caches): created on first use with `make`,
 // released with `destroy` when the context releases its buffers
 void* gas_state(void* (*make)(), void (*destroy)(void*));
+void drop_table_copies();  // host-mirror mode: forget the cached device copies of host tables (rte_hip_invalidate_plans)
 // device scratch that lives until the end of the current API call (bump allocator; grows)
 void* scratch(size_t bytes);
 // persistent named device buffers (LUT re-layouts etc.), keyed by a caller-chosen id
@@ -69,6 +70,12 @@ class Call {
   template <class T> T* inout_lazy(T* p, size_t n, bool* zero_fill = nullptr) {
     return (T*)stage((void*)p, n * sizeof(T), true, true, true, zero_fill);
   }
+  // a k-distribution TABLE (kmajor, kminor_*, krayl, planck_frac, totplnk): in host-mirror mode a host table is uploaded once
+  // per context and reused while its address, size and a sampled fingerprint of its contents (head, tail, 256 strided
+  // words) stay the same -- the 33 MB of tables are a quarter of what a 4096-column block sends otherwise.  Part of the
+  // mode's contract: tables are not modified in place while it is on (rte_hip_invalidate_plans drops the copies).
+  // Without the mode: in().
+  template <class T> const T* in_table(const T* p, size_t n) { return (const T*)stage_table((const void*)p, n * sizeof(T)); }
   // zero_array on a host array in host-mirror mode: recorded on the device copy (true) or not handled (false)
   bool lazy_zero(void* p, size_t bytes);
   // copy the device-resident arrays last written by the library entry `producer` back to their host addresses at the
@@ -84,6 +91,7 @@ class Call {
 
  private:
   void* stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy = false, bool* zero_fill = nullptr);
+  const void* stage_table(const void* p, size_t bytes);
   const void* to_host(const void* p, size_t bytes);
   struct Back { void* host; void* dev; size_t bytes; };
   Back back_[16];

@@ -638,7 +638,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   const int* d_jtemp = c.in(jtemp, ncl);
   const int* d_jpress = c.in(jpress, ncl);
   const int* d_band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
-  const Float* d_pfracin = c.in(pfracin, (size_t)ntemp * neta * (npres + 1) * ngpt);
+  const Float* d_pfracin = c.in_table(pfracin, (size_t)ntemp * neta * (npres + 1) * ngpt);
   const Float* d_totplnk = c.in(totplnk, (size_t)nPlanckTemp * nbnd);
   const int* d_gpoint_flavor = c.in(gpoint_flavor, (size_t)2 * ngpt);
   Float* d_sfc_src = c.out_lazy(sfc_src, (size_t)ncol * ngpt);  // (lazy: host-mirror mode keeps the sources on the device)

@@ -15,7 +15,13 @@ int rte_hip_share_geometry(int on) { g_share_geom_default = on; gs().share_geom 
 int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
 int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
 int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
-int rte_hip_invalidate_plans(void) { ++gs().plan_epoch; return 0; }
+int rte_hip_invalidate_plans(void) {
+  RTE_TRY
+  ++gs().plan_epoch;
+  rte::drop_table_copies();  // (host-mirror mode: cached device copies of host tables)
+  RTE_CATCH("rte_hip_invalidate_plans")
+  return 0;
+}
 int rte_hip_geom_variant(int v) { g_geom_variant = v; return 0; }
 // diagnostics (synchronises): 0 = (column tile, layer, band) triples the last compute_tau_absorption call handed to the
 // direct-gather worklist, 1 = (column tile, band) pairs of the last compute_Planck_source call

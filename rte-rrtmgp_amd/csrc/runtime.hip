@@ -40,6 +40,7 @@ struct Mirror {
   bool zero_pending;  // entirely zero by a recorded zero_array; the device copy has not been filled yet
 };
 struct FreeBuf { char* dev; size_t cap; };
+struct TableCopy { const char* host; size_t bytes; unsigned long long fp; char* dev; long last_use; };
 struct ProfEntry { std::string name; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms = 0; long n = 0; };
 
 struct Context {
@@ -69,6 +70,7 @@ struct Context {
   // ---- host-mirror mode
   std::vector<Mirror> mirrors;
   std::vector<FreeBuf> mirror_free;
+  std::vector<TableCopy> tables;  // host-mirror mode: device copies of host k-distribution tables
   int mirror_mode = -1;          // -1: take RTE_HIP_HOST_MIRROR at the first call
   size_t mirror_total = 0;       // device bytes held by mirrors and the free list
   size_t mirror_limit = 0;
@@ -76,6 +78,7 @@ struct Context {
   unsigned long long magic_state = 0x9E3779B97F4A7C15ull;
   hipEvent_t ev_h2d = nullptr;
   long long mstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hits, mirrors made, H2D bytes, D2H bytes, dropped (host changed), dropped (overlap), aged out, zero fills elided
+  long long table_hits = 0, table_uploads = 0;
   double t_call = 0, t_h2d = 0, t_wait = 0, t_find = 0;  // host wall-clock inside the host-array path
   long n_calls = 0;
   std::chrono::steady_clock::time_point call_t0;
@@ -348,8 +351,9 @@ static void staging_report() {
   for (Context* c : g_report_contexts) {
     fprintf(stderr, "rte_rrtmgp_hip staging report (context %d): %ld calls, %.3f s inside the library (host-to-device copies %.3f s for %.3f GB, "
             "waits + device-to-host %.3f s for %.3f GB, mirror look-ups %.3f s); mirrors made %lld, hits %lld, dropped %lld + %lld, aged %lld, "
-            "zero fills elided %lld, device bytes held %.2f GB\n", i++, c->n_calls, c->t_call, c->t_h2d, c->mstat[2] * 1e-9, c->t_wait,
-            c->mstat[3] * 1e-9, c->t_find, c->mstat[1], c->mstat[0], c->mstat[4], c->mstat[5], c->mstat[6], c->mstat[7], c->mirror_total * 1e-9);
+            "zero fills elided %lld, device bytes held %.2f GB; host tables uploaded %lld, reused %lld\n", i++, c->n_calls, c->t_call, c->t_h2d, c->mstat[2] * 1e-9, c->t_wait,
+            c->mstat[3] * 1e-9, c->t_find, c->mstat[1], c->mstat[0], c->mstat[4], c->mstat[5], c->mstat[6], c->mstat[7], c->mirror_total * 1e-9,
+            c->table_uploads, c->table_hits);
   }
 }
 static bool mirror_on() {
@@ -615,6 +619,60 @@ bool Call::lazy_zero(void* p, size_t bytes) {
   return true;
 }
 
+// sampled fingerprint of a host table: 4 KB at either end and 256 eight-byte words in between
+static unsigned long long table_fingerprint(const char* p, size_t bytes) {
+  unsigned long long h = 1469598103934665603ull ^ bytes;
+  auto mix = [&](const char* q, size_t n) {
+    for (size_t i = 0; i + 8 <= n; i += 8) { unsigned long long w; memcpy(&w, q + i, 8); h = (h ^ w) * 1099511628211ull; }
+  };
+  const size_t edge = bytes < 4096 ? bytes : 4096;
+  mix(p, edge);
+  if (bytes > edge) mix(p + bytes - edge, edge);
+  if (bytes > 2 * edge) {
+    const size_t step = ((bytes - 2 * edge) / 256) & ~size_t(7);
+    if (step) for (size_t i = 0; i < 256; ++i) mix(p + edge + i * step, 8);
+  }
+  return h;
+}
+void drop_table_copies() {
+  Context& c = C;
+  if (c.tables.empty()) return;
+  HIP_CHECK(hipStreamSynchronize(c.stream));
+  for (auto& t : c.tables) HIP_CHECK(hipFree(t.dev));
+  c.tables.clear();
+}
+const void* Call::stage_table(const void* p, size_t bytes) {
+  void* dv;
+  if (!p || bytes < (size_t(64) << 10) || !mirror_on() || classify(p, &dv) != 0) return stage(const_cast<void*>(p), bytes, true, false);
+  Context& c = C;
+  const unsigned long long fp = table_fingerprint((const char*)p, bytes);
+  for (auto& t : c.tables)
+    if (t.host == (const char*)p && t.bytes == bytes && t.fp == fp) { t.last_use = c.seq; ++c.table_hits; return t.dev; }
+  for (size_t i = c.tables.size(); i-- > 0;)  // same range, other contents (or more than 24 copies): replace
+    if (c.tables[i].host == (const char*)p || c.tables.size() >= 24) {
+      size_t victim = i;
+      if (c.tables[i].host != (const char*)p) {  // least recently used
+        victim = 0;
+        for (size_t k = 1; k < c.tables.size(); ++k) if (c.tables[k].last_use < c.tables[victim].last_use) victim = k;
+      }
+      HIP_CHECK(hipStreamSynchronize(c.stream));
+      HIP_CHECK(hipFree(c.tables[victim].dev));
+      c.tables.erase(c.tables.begin() + victim);
+      break;
+    }
+  char* d = nullptr;
+  HIP_CHECK(hipMalloc((void**)&d, bytes));
+  const auto t0 = std::chrono::steady_clock::now();
+  HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c.stream));
+  c.t_h2d += secs_since(t0);
+  staged_in_ = true;
+  c.mstat[2] += (long long)bytes;
+  mark_h2d();
+  c.tables.push_back(TableCopy{(const char*)p, bytes, fp, d, c.seq});
+  ++c.table_uploads;
+  return d;
+}
+
 void Call::writeback_produced_by(const char* producer) {
   if (!mirror_on()) return;
   Context& c = C;
@@ -730,6 +788,7 @@ static void release_context_buffers() {
   if (c.side) HIP_CHECK(hipStreamSynchronize(c.side));
   if (c.aux) HIP_CHECK(hipStreamSynchronize(c.aux));
   mirror_drop_all();
+  drop_table_copies();
   if (c.gas) { c.gas_free(c.gas); c.gas = nullptr; }
   for (auto* v : {&c.blocks_main, &c.blocks_side}) {
     for (auto& b : *v) HIP_CHECK(hipFree(b.base));

@@ -1408,12 +1408,12 @@ static void tau_absorption_impl(
   const Float* d_add = add_bybnd ? c.in(add_bybnd, ncl * nbnd) : nullptr;
   const int* d_gpoint_flavor = c.in(gpoint_flavor, (size_t)2 * ngpt);
   const int* d_band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
-  const Float* d_kmajor = c.in(kmajor, tn * (npres + 1) * ngpt);
-  MinorTables lo{c.in(kminor_lower, tn * *nminorklower_), c.in(minor_limits_gpt_lower, (size_t)2 * nlo),
+  const Float* d_kmajor = c.in_table(kmajor, tn * (npres + 1) * ngpt);
+  MinorTables lo{c.in_table(kminor_lower, tn * *nminorklower_), c.in(minor_limits_gpt_lower, (size_t)2 * nlo),
                  c.in(minor_scales_with_density_lower, (size_t)nlo), c.in(scale_by_complement_lower, (size_t)nlo),
                  c.in(idx_minor_lower, (size_t)nlo), c.in(idx_minor_scaling_lower, (size_t)nlo),
                  c.in(kminor_start_lower, (size_t)nlo), nullptr, nullptr, nlo};
-  MinorTables up{c.in(kminor_upper, tn * *nminorkupper_), c.in(minor_limits_gpt_upper, (size_t)2 * nup),
+  MinorTables up{c.in_table(kminor_upper, tn * *nminorkupper_), c.in(minor_limits_gpt_upper, (size_t)2 * nup),
                  c.in(minor_scales_with_density_upper, (size_t)nup), c.in(scale_by_complement_upper, (size_t)nup),
                  c.in(idx_minor_upper, (size_t)nup), c.in(idx_minor_scaling_upper, (size_t)nup),
                  c.in(kminor_start_upper, (size_t)nup), nullptr, nullptr, nup};
@@ -1434,7 +1434,7 @@ static void tau_absorption_impl(
   RaylCombine cb{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const Float *d_krayl = nullptr, *d_col_dry = nullptr;
   if (rh) {
-    d_krayl = c.in(rh->krayl, (size_t)ntemp * neta * ngpt * 2);
+    d_krayl = c.in_table(rh->krayl, (size_t)ntemp * neta * ngpt * 2);
     d_col_dry = c.in(rh->col_dry, ncl);
     if (rh->cld_tau) { cb.cld_tau = c.in(rh->cld_tau, ncl * nbnd); cb.cld_ssa = c.in(rh->cld_ssa, ncl * nbnd); cb.cld_g = c.in(rh->cld_g, ncl * nbnd); }
     cb.tau_abs = d_tau; cb.tau = d_tau;  // the direct kernels combine in place
@@ -1893,7 +1893,7 @@ static void tau_rayleigh_impl(const char* api_name, int ncol, int nlay, int nbnd
   const size_t ncl = (size_t)ncol * nlay;
   const int* d_gpoint_flavor = c.in(gpoint_flavor, (size_t)2 * ngpt);
   const int* d_band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
-  const Float* d_krayl = c.in(krayl, (size_t)ntemp * neta * ngpt * 2);
+  const Float* d_krayl = c.in_table(krayl, (size_t)ntemp * neta * ngpt * 2);
   const Float* d_col_dry = c.in(col_dry, ncl);
   const Float* d_col_gas = c.in(col_gas, ncl * (ngas + 1));
   const Float* d_fminor = c.in(fminor, 4 * ncl * nflav);

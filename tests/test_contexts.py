@@ -118,3 +118,54 @@ def test_sticky_error_mode_records_instead_of_aborting():
         hiplib.ext_call(hip, "rte_hip_error_mode", ["i"], 0)
         setc(None)
         destroy(ctx)
+
+
+def test_host_mirror_mode_with_numpy_arrays_and_table_copies():
+    """Host-mirror mode driven from Python with pageable numpy arrays (the arrays persist, unlike Fortran automatics): the LW
+    chain gives the staged mode's arrays bit for bit, intermediates are readable after rte_hip_writeback, and the cached device
+    copy of a host table follows a table that is replaced in place (fingerprint of the contents)."""
+    hip = hiplib.load()
+    create, setc, destroy = _ctx_api(hip)
+    xp = frontend.NumpyArrays()
+    kd = synth.make_kdist("lw", ngpt=64, nbnd=4)
+    ncol = 600
+    atm = synth.make_atmosphere(ncol, NLAY, seed=9, kdist=kd)
+    stat = hip.raw("rte_hip_mirror_stat")
+    stat.restype = ctypes.c_longlong
+    wb = hip.raw("rte_hip_writeback")
+    wb.argtypes = [ctypes.c_void_p]
+
+    def chain(go):
+        b = go.gas_optics_lw(ncol, NLAY, atm.play, atm.plev, atm.tlay, atm.tsfc, atm.col_gas, atm.tlev, atm.top_at_1)
+        r = frontend.rte_lw(hip, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"], xp.full((ncol, kd.ngpt), 0.98), b["sfc_src"])
+        return b, r
+
+    ctx = create(-1, None)
+    setc(ctx)
+    try:
+        go = frontend.GasOptics(hip, kd, xp)
+        b0, r0 = chain(go)                       # staged
+        up0, tau0 = r0["flux_up"].copy(), b0["tau"].copy()
+        hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 1)
+        stat(ctypes.c_int(-1))
+        b1, r1 = chain(go)
+        assert np.array_equal(r1["flux_up"], up0)
+        assert stat(ctypes.c_int(0)) > 10 and stat(ctypes.c_int(3)) < 8 * ncol * (NLAY + 1) * 4  # hits; only the fluxes came back
+        assert not np.array_equal(b1["tau"], tau0)           # the host copy is unspecified (canaries) ...
+        assert wb(b1["tau"].ctypes.data) == 1                 # ... until it is written back
+        assert np.array_equal(b1["tau"], tau0)
+        assert wb(b1["tau"].ctypes.data) == 0
+        # the k-distribution replaced in place: the cached device copy must not be used
+        kmajor = go.t["kmajor"]
+        kmajor *= 2.0
+        hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 0)
+        b2, r2 = chain(go)
+        up2 = r2["flux_up"].copy()
+        hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 1)
+        b3, r3 = chain(go)
+        assert np.array_equal(r3["flux_up"], up2) and not np.array_equal(up2, up0)
+        kmajor *= 0.5
+    finally:
+        hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 0)
+        setc(None)
+        destroy(ctx)
