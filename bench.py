@@ -245,7 +245,7 @@ def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw")
             import stream_io
 
             nt = max(1, min(8, cores))
-            m = stream_io.measure_frontend_driver("lw", 98304, 16384, ("mirror", "staged", "cpuref"), nrep=2)
+            m = stream_io.measure_frontend_driver("lw", 98304, 4096, ("mirror", "staged", "cpuref"), nrep=3)
             mt = stream_io.measure_frontend_driver("lw", 98304, 4096, ("mirror",), nrep=3, threads=nt) if nt > 1 else m
             host_arrays = {"hip_host_mirror_columns_per_s": round(mt["mirror"]["columns_per_s"], 1),
                            "hip_host_mirror_host_threads": nt,
@@ -253,8 +253,8 @@ def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw")
                            "hip_staged_columns_per_s": round(m["staged"]["columns_per_s"], 1),
                            "reference_cpu_kernels_1core_columns_per_s": round(m["cpuref"]["columns_per_s"], 1),
                            "what": "reference Fortran frontend (load -> gas_optics -> rte_lw, ty_fluxes_broadband) on pageable host arrays, "
-                                   "value checks off, 98304 columns: one host thread in blocks of 16384 (mirror, staged), and the OpenMP "
-                                   f"build with {nt} host threads in blocks of 4096, every thread on its own library context "
+                                   "value checks off, 98304 columns in blocks of 4096: one host thread (mirror, staged), and the OpenMP "
+                                   f"build with {nt} host threads, every thread on its own library context "
                                    "(RTE_HIP_THREAD_CONTEXTS=1, host-mirror mode)",
                            "pcie_bound_note": "about 20.6 KB per column cross PCIe in host-mirror mode (19.6 in, 1.0 out)",
                            "passes_threads": mt["mirror"]["passes"], "passes_1thread": m["mirror"]["passes"],
