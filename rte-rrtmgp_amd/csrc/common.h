@@ -44,6 +44,8 @@ hipStream_t stream();
 // per-context state owned by another translation unit (the gas-optics plan caches): created on first use with `make`,
 // released with `destroy` when the context releases its buffers
 void* gas_state(void* (*make)(), void (*destroy)(void*));
+// holds the current context's mutex (extension entry points that read or write per-context state outside a Call)
+struct CtxLock { CtxLock(); ~CtxLock(); void* ctx_; };
 void drop_table_copies();  // host-mirror mode: forget the cached device copies of host tables (rte_hip_invalidate_plans)
 // device scratch that lives until the end of the current API call (bump allocator; grows)
 void* scratch(size_t bytes);

@@ -11,12 +11,17 @@ std::atomic<int> g_share_geom_default{0};  // what a context starts with (the la
 
 extern "C" {
 
-int rte_hip_share_geometry(int on) { g_share_geom_default = on; gs().share_geom = on; gs().shared.seq = -1; gs().imask.seq = -1; return 0; }
+int rte_hip_share_geometry(int on) {
+  rte::CtxLock l;
+  g_share_geom_default = on; gs().share_geom = on; gs().shared.seq = -1; gs().imask.seq = -1;
+  return 0;
+}
 int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
 int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
 int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
 int rte_hip_invalidate_plans(void) {
   RTE_TRY
+  rte::CtxLock l;
   ++gs().plan_epoch;
   rte::drop_table_copies();  // (host-mirror mode: cached device copies of host tables)
   RTE_CATCH("rte_hip_invalidate_plans")
@@ -27,9 +32,13 @@ int rte_hip_geom_variant(int v) { g_geom_variant = v; return 0; }
 // direct-gather worklist, 1 = (column tile, band) pairs of the last compute_Planck_source call
 int rte_hip_stat(int which) {
   if (which < 0 || which > 3) return -1;
+  RTE_TRY
+  rte::CtxLock l;
   int v = 0;
   HIP_CHECK(hipStreamSynchronize(rte::stream()));
   HIP_CHECK(hipMemcpy(&v, stats_dev() + which, sizeof(int), hipMemcpyDeviceToHost));
   return v;
+  RTE_CATCH("rte_hip_stat")
+  return -1;
 }
 }  // extern "C"

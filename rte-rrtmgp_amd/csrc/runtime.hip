@@ -133,6 +133,9 @@ void* gas_state(void* (*make)(), void (*destroy)(void*)) {
   return c.gas;
 }
 
+CtxLock::CtxLock() : ctx_(&C) { ((Context*)ctx_)->mutex.lock(); }
+CtxLock::~CtxLock() { ((Context*)ctx_)->mutex.unlock(); }
+
 // ---- error channel ---------------------------------------------------------------------------------
 // The reference kernel interface has no error channel (all entry points are void).  A failing HIP call throws rte::Error;
 // the entry point's handler (RTE_CATCH) either prints and abort()s (default: a host model must not continue on garbage) or,
