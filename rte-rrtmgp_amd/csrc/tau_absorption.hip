@@ -17,6 +17,17 @@
 //     geometric mean of adjacent layers' Planck fractions needs no second gather.
 #include "gas_optics_common.h"
 
+// shape of the specialised-wave tau kernel (defaults: that of gas_optics_common.h; overridable for experiments)
+#ifndef TAU_NCW
+#define TAU_NCW V9_NCW
+#define TAU_NLW V9_NLW
+#endif
+#ifndef TAU_SLAB
+#define TAU_SLAB V9_SLAB
+#endif
+#ifndef TAU_MINW
+#define TAU_MINW ((TAU_NCW + TAU_NLW + 3) / 4)
+#endif
 static const bool g_worklist_native = getenv("RTE_WORKLIST_NATIVE") != nullptr;  // A/B: worklist entries from the native-layout tables
 
 namespace {
@@ -755,7 +766,7 @@ __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __res
 // then waits for (nearly) all of them, i.e. for the previous stage's stores, at the top of every stage.
 // RAYL: fused with compute_tau_rayleigh + combine_abs_and_rayleigh (2-stream) [+ by-band 2-stream increment]: see RaylFuse
 template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G, int MM, bool ADDB, int RAYL = 0 /* 1: fused, 2: + by-band clouds */>
-__global__ void __launch_bounds__((NCW + NLW) * 64, V9_MINW)
+__global__ void __launch_bounds__((NCW + NLW) * 64, TAU_MINW)
 tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
   constexpr int RS = G + 2, PPR = G / 2, PSH = G == 16 ? 3 : 2;  // row stride, 16-byte pieces per row, log2(PPR)
@@ -1521,7 +1532,11 @@ static void tau_absorption_impl(
         for (int i = 0; i < nn[r]; ++i) al_ = al_ && (ml[r][2 * i] - 1) % w == 0 && ml[r][2 * i + 1] % w == 0;
       return al_;
     };
+#ifdef TAU_FORCE_GW8
+    const int gw = aligned(8) ? 8 : 0;
+#else
     const int gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);
+#endif
     bool ok = gw > 0 && nbnd <= MAXB;
     cache.bands.assign(nbnd > 0 ? nbnd : 1, BandMeta{});
     {
@@ -1703,7 +1718,7 @@ static void tau_absorption_impl(
   hipStream_t aux = nullptr;
   const bool use_v9 = g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr || rh != nullptr;  // the single-role kernel exists for 16-wide stages only
   if (use_v9) {
-    constexpr int NCW = V9_NCW, NLW = V9_NLW, SLAB9 = V9_SLAB;  // compute + loader waves, 2 x 68 KB slab: one block per CU
+    constexpr int NCW = TAU_NCW, NLW = TAU_NLW, SLAB9 = TAU_SLAB;  // compute + loader waves, 2 x 68 KB slab: one block per CU
     const unsigned tiles = cdiv(ncol, NCW * 64);
     const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
     const bool share = share_boxes() && geom2 && NCW * 64 == 512 && !c.any_host() && !rh;
@@ -1792,11 +1807,11 @@ static void tau_absorption_impl(
     if (!g_worklist_native && offsets_fit) { gft.kmaj = kmaj_g; gft.klo = klo_g; gft.kup = kup_g; gft.nkl = nkl; gft.nku = nku; }
     if (gft.kmaj)
       hipLaunchKernelGGL(tau_absorption_worklist_kernel<true>, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw, gft,
-                         (const int*)v.worklist, use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
+                         (const int*)v.worklist, use_v9 ? TAU_NCW * 64 : BS, stats_dev() + 0);
     else
       hipLaunchKernelGGL(tau_absorption_worklist_kernel<false>, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw, gft,
-                         (const int*)v.worklist, use_v9 ? V9_NCW * 64 : BS, stats_dev() + 0);
-    if (rh) rayleigh_direct(nullptr, (const int*)v.worklist, V9_NCW * 64);  // (lambda launches on st)
+                         (const int*)v.worklist, use_v9 ? TAU_NCW * 64 : BS, stats_dev() + 0);
+    if (rh) rayleigh_direct(nullptr, (const int*)v.worklist, TAU_NCW * 64);  // (lambda launches on st)
     st = main_st;
     if (aux) rte::aux_join();
   }
