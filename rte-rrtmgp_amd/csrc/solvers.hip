@@ -320,7 +320,10 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, 
 // other than ty_fluxes_broadband, rte/frontend/mo_rte_lw.F90:297-321): every wave stores pi * weight * radiance at the
 // levels it owns, per g-point, instead of accumulating; `spec_add` (angles after the first, :343-361) adds to what is
 // there.  The Jacobian stays a broadband quantity (partial slabs as before).
-template <int L, bool do_jac, bool SFCLDS, bool SPEC = false>
+// BYBAND (extension rte_hip_lw_solver_noscat_byband): one block per (column tile, BAND) -- grid.y = band, the g-point range
+// comes from band_lims_gpt -- and the block's sums leave as the by-band fluxes themselves, pi * weight applied (what
+// rte_sum_byband of the spectral arrays gives, rte/extensions/mo_fluxes_byband.F90:46-137, without the spectral arrays).
+template <int L, bool do_jac, bool SFCLDS, bool SPEC = false, bool BYBAND = false>
 __global__ void __launch_bounds__(64 * 8)
 lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
                      const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
@@ -328,7 +331,8 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
                      const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
                      const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
                      Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac,
-                     Float* __restrict__ spec_up = nullptr, Float* __restrict__ spec_dn = nullptr, bool spec_add = false) {
+                     Float* __restrict__ spec_up = nullptr, Float* __restrict__ spec_dn = nullptr, bool spec_add = false,
+                     const int* __restrict__ band_lims = nullptr) {
 #pragma clang fp contract(fast)  // this kernel is fp64-issue bound: fuse the recurrences' a*b+c
   extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][MAXS][64]
   const int lane = threadIdx.x & 63;
@@ -345,8 +349,8 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   const bool last = (s == S - 1);
   const Float piw = kPi * weight;
   const Float inv_piw = (Float)1 / piw;
-  const int g_begin = blockIdx.y * g_per_block;
-  const int g_end = min(ngpt, g_begin + g_per_block);
+  const int g_begin = BYBAND ? band_lims[2 * blockIdx.y] - 1 : blockIdx.y * g_per_block;
+  const int g_end = BYBAND ? band_lims[2 * blockIdx.y + 1] : min(ngpt, g_begin + g_per_block);
   constexpr int MAXS = 8;  // waves per block at most
   constexpr int CH = 16, NA = do_jac ? 5 : 4, RPW = 2 * NA;  // chunk of g-points, arrays, rows loaded per wave and chunk
   Float* const SFCB = lds + 2 * 3 * MAXS * 64;  // [2 buffers][CH][NA][64]
@@ -510,7 +514,12 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       if (i < np || (last && i == np)) {
         const int p = p0 + i;  // level position from the top
         const int ilev = top_at_1 ? p : nlay - p;
-        if constexpr (!SPEC) {
+        if constexpr (BYBAND) {  // the by-band fluxes themselves (angles after the first add)
+          Float* qd = part_dn + base + (size_t)ncol * ilev;
+          Float* qu = part_up + base + (size_t)ncol * ilev;
+          *qd = spec_add ? *qd + acc_dn[i] * piw : acc_dn[i] * piw;
+          *qu = spec_add ? *qu + acc_up[i] * piw : acc_up[i] * piw;
+        } else if constexpr (!SPEC) {
           part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
           part_up[base + (size_t)ncol * ilev] = acc_up[i];
         }
@@ -1005,6 +1014,7 @@ struct Sw2SegArgs {
   const Float *tau, *ssa, *g, *mu0, *sfc_alb_dir, *sfc_alb_dif, *inc_flux_dir, *inc_flux_dif;
   Float *part_up, *part_dn, *part_dir;  // (ncol, nlev, ngroups)
   Float *spec_up, *spec_dn, *spec_dir;  // SPEC: the interface's spectral flux arrays (ncol, nlev, ngpt)
+  const int* band_lims;                 // non-null (rte_hip_sw_solver_2stream_byband): grid.y = band, part_* are the by-band fluxes
 };
 
 // SPEC: spectral output (rte_sw with a ty_fluxes other than ty_fluxes_broadband, rte/frontend/mo_rte_sw.F90): every wave
@@ -1027,8 +1037,8 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   const int p0 = s * L;
   const int np = min(L, nlay - p0);  // layers in this segment (>= 1 by construction)
   const bool last = (s == S - 1);
-  const int g_begin = blockIdx.y * a.g_per_block;
-  const int g_end = min(a.ngpt, g_begin + a.g_per_block);
+  const int g_begin = a.band_lims ? a.band_lims[2 * blockIdx.y] - 1 : blockIdx.y * a.g_per_block;
+  const int g_end = a.band_lims ? a.band_lims[2 * blockIdx.y + 1] : min(a.ngpt, g_begin + a.g_per_block);
   const Float min_k = (Float)1.e4 * (Float)RTE_EPS;
   const Float min_mu0 = sqrt((Float)RTE_EPS);
   auto layer_of = [&](int i) {  // array index of the segment's i-th layer from the top (clamped to a valid one)
@@ -2044,7 +2054,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     q.part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * 3);
     q.part_dn = q.part_up + nclv * ngroups;
     q.part_dir = q.part_dn + nclv * ngroups;
-    q.spec_up = q.spec_dn = q.spec_dir = nullptr;
+    q.spec_up = q.spec_dn = q.spec_dir = nullptr; q.band_lims = nullptr;
     // composites, flux maps, mu0 (clamped, reciprocal; L == 9: one value), direct-flux (L == 9: and upward-flux) accumulators
     const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + (L == 9 ? 1 : 2) * 8 * L + (L <= 9 ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
     {
@@ -2073,7 +2083,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     q.tau = a.tau; q.ssa = a.ssa; q.g = a.g; q.mu0 = a.mu0; q.sfc_alb_dir = a.sfc_alb_dir; q.sfc_alb_dif = a.sfc_alb_dif;
     q.inc_flux_dir = a.inc_flux_dir; q.inc_flux_dif = a.inc_flux_dif;
     q.part_up = q.part_dn = q.part_dir = nullptr;
-    q.spec_up = d_up; q.spec_dn = d_dn; q.spec_dir = d_dir;
+    q.spec_up = d_up; q.spec_dn = d_dn; q.spec_dir = d_dir; q.band_lims = nullptr;
     const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 2 * 8 * L);  // composites, flux maps, mu0 (clamped, reciprocal)
     rte::ProfScope p("sw_2stream_seg_spectral_kernel");
     if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
@@ -2108,6 +2118,74 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     }
   }
   RTE_CATCH("rte_sw_solver_2stream")
+}
+
+// ---- by-band fluxes straight from the segmented kernels (extensions; what rte_lw / rte_sw + ty_fluxes_byband%reduce produce
+//      through the spectral arrays and rte_sum_byband, rte/extensions/mo_fluxes_byband.F90:46-137, without those arrays)
+int rte_hip_lw_solver_noscat_byband(int ncol, int nlay, int ngpt, int nbnd, int top_at_1, int nmus, const Float* Ds,
+                                    const Float* weights, const int* band_lims_gpt, const Float* tau, const Float* lay_source,
+                                    const Float* lev_source, const Float* sfc_emis, const Float* sfc_src, const Float* inc_flux,
+                                    Float* byband_up, Float* byband_dn) {
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0 || nbnd <= 0 || nmus <= 0) return 0;
+  const int nlev = nlay + 1;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev, ncg = (size_t)ncol * ngpt;
+  if (nlay > 80 || nclv >= ((size_t)1 << 29)) return -2;  // (callers fall back to spectral output + rte_sum_byband)
+  RTE_TRY
+  rte::Call c("rte_hip_lw_solver_noscat_byband");
+  const Float* w_h = c.host(weights, (size_t)nmus);
+  const Float* d_Ds = c.in(Ds, ncg * nmus);
+  const int* d_bl = c.in(band_lims_gpt, (size_t)2 * nbnd);
+  const Float *d_tau = c.in(tau, ncl * ngpt), *d_lay = c.in(lay_source, ncl * ngpt), *d_lev = c.in(lev_source, nclv * ngpt);
+  const Float *d_emis = c.in(sfc_emis, ncg), *d_sfc = c.in(sfc_src, ncg), *d_inc = c.in(inc_flux, ncg);
+  Float *d_up = c.out(byband_up, nclv * nbnd), *d_dn = c.out(byband_dn, nclv * nbnd);
+  hipStream_t st = rte::stream();
+  const int L = nlay <= 64 ? 8 : nlay <= 72 ? 9 : 10;
+  const int S = (nlay + L - 1) / L;
+  const size_t lds_bytes = sizeof(Float) * (2 * 3 * 8 * 64);
+  rte::ProfScope p("lw_noscat_seg_byband_kernel");
+  for (int imu = 0; imu < nmus; ++imu) {
+#define RTE_LAUNCH_SEGB(LL)                                                                                              \
+  hipLaunchKernelGGL((lw_noscat_seg_kernel<LL, false, false, false, true>), dim3(cdiv(ncol, 64), nbnd), dim3(64 * S), lds_bytes, st, \
+                     ncol, nlay, ngpt, S, 0, top_at_1 != 0, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev, d_emis, d_sfc, \
+                     d_inc, (const Float*)nullptr, d_up, d_dn, (Float*)nullptr, (Float*)nullptr, (Float*)nullptr, imu > 0, d_bl)
+    if (L == 8) RTE_LAUNCH_SEGB(8); else if (L == 9) RTE_LAUNCH_SEGB(9); else RTE_LAUNCH_SEGB(10);
+#undef RTE_LAUNCH_SEGB
+  }
+  return 0;
+  RTE_CATCH("rte_hip_lw_solver_noscat_byband")
+  return -1;
+}
+
+int rte_hip_sw_solver_2stream_byband(int ncol, int nlay, int ngpt, int nbnd, int top_at_1, const int* band_lims_gpt,
+                                     const Float* tau, const Float* ssa, const Float* g, const Float* mu0,
+                                     const Float* sfc_alb_dir, const Float* sfc_alb_dif, const Float* inc_flux_dir,
+                                     int has_dif_bc, const Float* inc_flux_dif, Float* byband_up, Float* byband_dn,
+                                     Float* byband_dir) {
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0 || nbnd <= 0) return 0;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1), ncg = (size_t)ncol * ngpt;
+  if (nlay > 80 || nclv >= ((size_t)1 << 29)) return -2;
+  RTE_TRY
+  rte::Call c("rte_hip_sw_solver_2stream_byband");
+  Sw2SegArgs q;
+  const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);
+  q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = (nlay + L - 1) / L; q.g_per_block = 0;
+  q.top_at_1 = top_at_1 != 0; q.has_dif_bc = has_dif_bc != 0;
+  q.band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
+  q.tau = c.in(tau, ncl * ngpt); q.ssa = c.in(ssa, ncl * ngpt); q.g = c.in(g, ncl * ngpt); q.mu0 = c.in(mu0, ncl);
+  q.sfc_alb_dir = c.in(sfc_alb_dir, ncg); q.sfc_alb_dif = c.in(sfc_alb_dif, ncg); q.inc_flux_dir = c.in(inc_flux_dir, ncg);
+  q.inc_flux_dif = has_dif_bc ? c.in(inc_flux_dif, ncg) : nullptr;
+  q.part_up = c.out(byband_up, nclv * nbnd); q.part_dn = c.out(byband_dn, nclv * nbnd); q.part_dir = c.out(byband_dir, nclv * nbnd);
+  q.spec_up = q.spec_dn = q.spec_dir = nullptr;
+  const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + (L == 9 ? 1 : 2) * 8 * L + (L <= 9 ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
+  rte::ProfScope p("sw_2stream_seg_byband_kernel");
+  hipStream_t st = rte::stream();
+  const dim3 grid(cdiv(ncol, 64), nbnd), blk(64 * q.S);
+  if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8>), grid, blk, lds_bytes, st, q);
+  else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9>), grid, blk, lds_bytes, st, q);
+  else hipLaunchKernelGGL((sw_2stream_seg_kernel<10>), grid, blk, lds_bytes, st, q);
+  return 0;
+  RTE_CATCH("rte_hip_sw_solver_2stream_byband")
+  return -1;
 }
 
 }  // extern "C"

@@ -595,3 +595,60 @@ def rte_sw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, inc_flux_dir, 
                               sfc_alb_dif_gpt, inc_flux_dir, gfu, gfd, gfdir, has_dif_bc,
                               inc_flux_dif, do_broadband, fu, fd, fdir)
     return b
+
+
+# --------------------------------------------------------------------------------------
+# by-band fluxes (rte/extensions/mo_fluxes_byband.F90: ty_fluxes_byband%reduce)
+# --------------------------------------------------------------------------------------
+def rte_lw_byband(lib, xp, ncol, nlay, ngpt, nbnd, band_lims_gpt, top_at_1, tau, lay_src, lev_src, sfc_emis_gpt, sfc_src,
+                  n_gauss_angles: int = 1, inc_flux=None, buffers: Optional[Dict[str, object]] = None):
+    """``rte_lw`` with a ``ty_fluxes_byband`` flux object: by-band fluxes (ncol, nlay+1, nbnd).  The reference computes the
+    spectral arrays and reduces them (mo_rte_lw.F90:297-321 -> mo_fluxes_byband.F90:46-137: ``rte_sum_byband``); with the HIP
+    library's extension ``rte_hip_lw_solver_noscat_byband`` the segmented kernel accumulates per band and the spectral arrays
+    never exist.  Libraries without the extension (the oracle) take the reference's route."""
+    b = buffers if buffers is not None else {}
+    if "bb_up" not in b:
+        b["bb_up"], b["bb_dn"] = xp.empty((ncol, nlay + 1, nbnd)), xp.empty((ncol, nlay + 1, nbnd))
+    if lib.has("rte_hip_lw_solver_noscat_byband") and nlay <= 80:
+        from . import hiplib
+
+        nmus = n_gauss_angles
+        sec = np.empty((ncol, ngpt, nmus), order="F")
+        for imu in range(nmus):
+            sec[:, :, imu] = GAUSS_DS[nmus - 1][imu]
+        if inc_flux is None:
+            inc_flux = xp.zeros((ncol, ngpt))
+        weights = np.array(GAUSS_WTS[nmus - 1], dtype=xp.ftype)
+        rc = hiplib.ext_call(lib, "rte_hip_lw_solver_noscat_byband", "iiiiiiaaaaaaaaaaa", ncol, nlay, ngpt, nbnd, int(top_at_1), nmus,
+                             xp.asarray(sec), weights, band_lims_gpt, tau, lay_src, lev_src, sfc_emis_gpt, sfc_src, inc_flux,
+                             b["bb_up"], b["bb_dn"])
+        assert rc == 0, rc
+        return b
+    r = rte_lw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, lay_src, lev_src, sfc_emis_gpt, sfc_src, n_gauss_angles=n_gauss_angles,
+               inc_flux=inc_flux, do_broadband=False, buffers=b)
+    lib.rte_sum_byband(ncol, nlay + 1, ngpt, nbnd, band_lims_gpt, r["gpt_flux_up"], b["bb_up"])
+    lib.rte_sum_byband(ncol, nlay + 1, ngpt, nbnd, band_lims_gpt, r["gpt_flux_dn"], b["bb_dn"])
+    return b
+
+
+def rte_sw_byband(lib, xp, ncol, nlay, ngpt, nbnd, band_lims_gpt, top_at_1, tau, ssa, g, mu0, inc_flux_dir, sfc_alb_dir_gpt,
+                  sfc_alb_dif_gpt, inc_flux_dif=None, buffers: Optional[Dict[str, object]] = None):
+    """``rte_sw`` with a ``ty_fluxes_byband`` flux object (mo_rte_sw.F90 -> mo_fluxes_byband.F90): by-band up / down / direct
+    fluxes; ``rte_hip_sw_solver_2stream_byband`` where the library has it, the spectral arrays + ``rte_sum_byband`` otherwise."""
+    b = buffers if buffers is not None else {}
+    if "bb_up" not in b:
+        b["bb_up"], b["bb_dn"], b["bb_dir"] = (xp.empty((ncol, nlay + 1, nbnd)) for _ in range(3))
+    if lib.has("rte_hip_sw_solver_2stream_byband") and nlay <= 80:
+        from . import hiplib
+
+        dif = inc_flux_dif if inc_flux_dif is not None else inc_flux_dir
+        rc = hiplib.ext_call(lib, "rte_hip_sw_solver_2stream_byband", "iiiiiaaaaaaaaiaaaa", ncol, nlay, ngpt, nbnd, int(top_at_1),
+                             band_lims_gpt, tau, ssa, g, mu0, sfc_alb_dir_gpt, sfc_alb_dif_gpt, inc_flux_dir,
+                             1 if inc_flux_dif is not None else 0, dif, b["bb_up"], b["bb_dn"], b["bb_dir"])
+        assert rc == 0, rc
+        return b
+    r = rte_sw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, inc_flux_dir, sfc_alb_dir_gpt, sfc_alb_dif_gpt,
+               inc_flux_dif=inc_flux_dif, do_broadband=False, buffers=b)
+    for k_in, k_out in (("gpt_flux_up", "bb_up"), ("gpt_flux_dn", "bb_dn"), ("gpt_flux_dir", "bb_dir")):
+        lib.rte_sum_byband(ncol, nlay + 1, ngpt, nbnd, band_lims_gpt, r[k_in], b[k_out])
+    return b

@@ -193,6 +193,38 @@ def test_lw_noscat_with_more_than_80_layers(hip, oracle_c, nlay, top_at_1):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1, kw)
 
 
+@pytest.mark.parametrize("nlay,top_at_1", [(27, False), (60, True), (72, False), (75, True)])
+def test_byband_fluxes_from_the_segmented_kernels(hip, oracle_c, nlay, top_at_1):
+    """By-band fluxes (ty_fluxes_byband, rte/extensions/mo_fluxes_byband.F90:46-137): the reference reduces the spectral
+    arrays with rte_sum_byband; the extensions rte_hip_lw_solver_noscat_byband / rte_hip_sw_solver_2stream_byband accumulate per
+    band inside the segmented kernels (one block per column tile and band).  Bands of unequal width, LW with two angles and an
+    incident flux, SW with night columns and a diffuse boundary condition, against the oracle's spectral arrays reduced by the
+    oracle's rte_sum_byband."""
+    import numpy as np
+
+    xp, xo = frontend.TorchArrays("cuda:0"), frontend.NumpyArrays()
+    A = xp.asarray
+    rng = np.random.default_rng(100 + nlay)
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    ncol, ngpt, nbnd = 70, 40, 3
+    bl = np.asfortranarray(np.array([[1, 9, 25], [8, 24, 40]], dtype=np.int32))  # 8 + 16 + 16 g-points
+    tau, ssa, g = F(ncol, nlay, ngpt) * 3.0, F(ncol, nlay, ngpt) * 0.999, F(ncol, nlay, ngpt) * 0.9 - 0.1
+    lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
+    emis, sfc, inc = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10, F(ncol, ngpt)
+    ref = frontend.rte_lw_byband(oracle_c, xo, ncol, nlay, ngpt, nbnd, bl, top_at_1, tau, lay, lev, emis, sfc, n_gauss_angles=2, inc_flux=inc)
+    out = frontend.rte_lw_byband(hip, xp, ncol, nlay, ngpt, nbnd, A(bl), top_at_1, A(tau), A(lay), A(lev), A(emis), A(sfc),
+                                 n_gauss_angles=2, inc_flux=A(inc))
+    for k in ("bb_up", "bb_dn"):
+        assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, ("lw", k)
+    mu0 = np.asfortranarray(np.repeat((rng.random(ncol) * 1.2 - 0.2)[:, None], nlay, axis=1))  # some <= 0
+    adir, adif, idir, idif = F(ncol, ngpt), F(ncol, ngpt), F(ncol, ngpt) * 100, F(ncol, ngpt) * 10
+    ref = frontend.rte_sw_byband(oracle_c, xo, ncol, nlay, ngpt, nbnd, bl, top_at_1, tau, ssa, g, mu0, idir, adir, adif, inc_flux_dif=idif)
+    out = frontend.rte_sw_byband(hip, xp, ncol, nlay, ngpt, nbnd, A(bl), top_at_1, A(tau), A(ssa), A(g), A(mu0), A(idir), A(adir), A(adif),
+                                 inc_flux_dif=A(idif))
+    for k in ("bb_up", "bb_dn", "bb_dir"):
+        assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, ("sw", k)
+
+
 @pytest.mark.parametrize("name", ["lw_mid_ragged", "lw_mid_top1", "lw_g256"])
 def test_segmented_and_generic_lw_solvers_agree(hip, name):
     """The production (segmented) and the generic LW kernels are two implementations of one

@@ -34,3 +34,19 @@ for kind, ngpt in (("lw", 256), ("sw", 224)):
     print(f"{kind} spectral {ncol} x {nlay} x {ngpt}: segmented {t_seg:.2f} ms ({(in_gb + out_gb) / t_seg:.2f} TB/s on {in_gb + out_gb:.1f} GB; "
           f"outputs alone {out_gb:.1f} GB = {out_gb / 5.5:.2f} ms at 5.5 TB/s), generic {t_gen:.2f} ms")
     del tau, ssa, g, bufs; torch.cuda.empty_cache()
+# by-band fluxes (16 bands) straight from the segmented kernels against spectral output + rte_sum_byband
+for kind, ngpt, nbnd in (("lw", 256, 16), ("sw", 224, 14)):
+    gpb = ngpt // nbnd
+    bl = xp.asarray(np.asfortranarray(np.stack([1 + gpb * np.arange(nbnd), gpb * (1 + np.arange(nbnd))]).astype(np.int32)))
+    tau, ssa, g = rnd(ncol, nlay, ngpt, scale=2.0), rnd(ncol, nlay, ngpt, scale=0.9), rnd(ncol, nlay, ngpt, scale=0.8)
+    if kind == "lw":
+        lay, lev = rnd(ncol, nlay, ngpt, scale=10, off=1), rnd(ncol, nlay + 1, ngpt, scale=10, off=1)
+        emis, sfc = rnd(ncol, ngpt, scale=0.2, off=0.8), rnd(ncol, ngpt, scale=10)
+        bufs = {}
+        fn = lambda: frontend.rte_lw_byband(lib, xp, ncol, nlay, ngpt, nbnd, bl, False, tau, lay, lev, emis, sfc, buffers=bufs)
+    else:
+        mu0 = xp.full((ncol, nlay), 0.86); idir, alb = rnd(ncol, ngpt, scale=100), rnd(ncol, ngpt, scale=0.5)
+        bufs = {}
+        fn = lambda: frontend.rte_sw_byband(lib, xp, ncol, nlay, ngpt, nbnd, bl, False, tau, ssa, g, mu0, idir, alb, alb, buffers=bufs)
+    print(f"{kind} by-band {ncol} x {nlay} x {ngpt} ({nbnd} bands): {timed(fn):.2f} ms (spectral output + rte_sum_byband: the spectral time above plus the reduction)")
+    del tau, ssa, g, bufs; torch.cuda.empty_cache()
