@@ -613,14 +613,18 @@ def rte_lw_byband(lib, xp, ncol, nlay, ngpt, nbnd, band_lims_gpt, top_at_1, tau,
         from . import hiplib
 
         nmus = n_gauss_angles
-        sec = np.empty((ncol, ngpt, nmus), order="F")
-        for imu in range(nmus):
-            sec[:, :, imu] = GAUSS_DS[nmus - 1][imu]
+        if ("secants", nmus) not in b:  # mo_rte_lw.F90:357-365
+            sec = np.empty((ncol, ngpt, nmus), order="F")
+            for imu in range(nmus):
+                sec[:, :, imu] = GAUSS_DS[nmus - 1][imu]
+            b[("secants", nmus)] = xp.asarray(sec)
         if inc_flux is None:
-            inc_flux = xp.zeros((ncol, ngpt))
+            if "inc_flux_zero" not in b:
+                b["inc_flux_zero"] = xp.zeros((ncol, ngpt))
+            inc_flux = b["inc_flux_zero"]
         weights = np.array(GAUSS_WTS[nmus - 1], dtype=xp.ftype)
         rc = hiplib.ext_call(lib, "rte_hip_lw_solver_noscat_byband", "iiiiiiaaaaaaaaaaa", ncol, nlay, ngpt, nbnd, int(top_at_1), nmus,
-                             xp.asarray(sec), weights, band_lims_gpt, tau, lay_src, lev_src, sfc_emis_gpt, sfc_src, inc_flux,
+                             b[("secants", nmus)], weights, band_lims_gpt, tau, lay_src, lev_src, sfc_emis_gpt, sfc_src, inc_flux,
                              b["bb_up"], b["bb_dn"])
         assert rc == 0, rc
         return b
