@@ -18,6 +18,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <exception>
 #include <mutex>
@@ -342,6 +343,10 @@ void flush_pending_zeros() {
 constexpr int kCanaries = 34;
 constexpr size_t kLazyMinBytes = 4096;
 static int g_procmem_fd = -2;
+// device bytes held by the mirrors (and their free lists) of ALL contexts, and the limit they share: with one context per
+// host thread, per-context limits of "60 % of what is free" would add up to several times the device
+static std::atomic<size_t> g_mirror_all{0};
+static std::atomic<size_t> g_mirror_limit_all{0};
 static std::mutex g_report_mutex;
 static std::vector<Context*> g_report_contexts;
 
@@ -414,7 +419,7 @@ static void mirror_trim_free_list() {
   Context& c = C;
   if (c.mirror_free.empty()) return;
   HIP_CHECK(hipStreamSynchronize(c.stream));  // kernels of earlier calls may still use them
-  for (auto& f : c.mirror_free) { HIP_CHECK(hipFree(f.dev)); c.mirror_total -= f.cap; }
+  for (auto& f : c.mirror_free) { HIP_CHECK(hipFree(f.dev)); c.mirror_total -= f.cap; g_mirror_all -= f.cap; }
   c.mirror_free.clear();
 }
 static char* mirror_alloc(size_t bytes, size_t* cap_out) {
@@ -430,19 +435,24 @@ static char* mirror_alloc(size_t bytes, size_t* cap_out) {
     *cap_out = f.cap;
     return f.dev;
   }
-  if (c.mirror_limit == 0) {
-    if (const char* e = getenv("RTE_HIP_MIRROR_MAX_GB")) c.mirror_limit = (size_t)(atof(e) * 1073741824.0);
-    if (c.mirror_limit == 0) {
+  if (g_mirror_limit_all.load() == 0) {
+    size_t lim = 0;
+    if (const char* e = getenv("RTE_HIP_MIRROR_MAX_GB")) lim = (size_t)(atof(e) * 1073741824.0);
+    if (lim == 0) {
       size_t fr = 0, tot = 0;
       HIP_CHECK(hipMemGetInfo(&fr, &tot));
-      c.mirror_limit = fr / 10 * 6;
+      lim = fr / 10 * 6;
     }
+    size_t expect = 0;
+    g_mirror_limit_all.compare_exchange_strong(expect, lim);
   }
+  c.mirror_limit = g_mirror_limit_all.load();
   const size_t cap = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
-  if (c.mirror_total + cap > c.mirror_limit) mirror_trim_free_list();
+  if (g_mirror_all.load() + cap > c.mirror_limit) mirror_trim_free_list();  // (this context's idle buffers; others trim theirs in turn)
   char* d = nullptr;
   HIP_CHECK(hipMalloc((void**)&d, cap));
   c.mirror_total += cap;
+  g_mirror_all += cap;
   *cap_out = cap;
   return d;
 }
