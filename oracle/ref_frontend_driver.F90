@@ -39,10 +39,15 @@ program ref_frontend_driver
   logical :: is_lw
   integer, allocatable :: opts(:)
   integer :: ncol, nlay, bs, nblocks, nrep, n_ang, ngpt, nbnd, ngas
-  logical :: use_col_dry, use_tlev, checks
+  logical :: use_col_dry, use_tlev, checks, timing_lines
+  character(len=8) :: envv
   real(wp), allocatable :: p_lay(:,:), p_lev(:,:), t_lay(:,:), t_lev(:,:), vmr(:,:,:), col_dry(:,:), t_sfc(:), sfc_emis(:), &
                            mu0(:), sfc_alb(:)
   real(wp), allocatable, target :: flux_up(:,:), flux_dn(:,:), flux_dir(:,:)
+  ! blocked as in the RFMIP drivers (examples/rfmip-clear-sky/rrtmgp_rfmip_lw.F90:113-120: (block_size, nlay, nblocks)):
+  ! a block is a contiguous slab that is passed to the frontend as it lies, no copies inside the block loop
+  real(wp), allocatable :: bp_lay(:,:,:), bp_lev(:,:,:), bt_lay(:,:,:), bt_lev(:,:,:), bcol_dry(:,:,:), bsfc(:,:,:), bt_sfc(:,:), bmu0(:,:)
+  real(wp), allocatable, target :: bup(:,:,:), bdn(:,:,:), bdir(:,:,:)
   type(ty_gas_concs), allocatable :: concs(:)
   integer :: u, b, c0, c1, ig, irep, nth
   integer(8) :: t0, t1, rate
@@ -85,6 +90,30 @@ program ref_frontend_driver
 
   allocate(flux_up(ncol, nlay+1), flux_dn(ncol, nlay+1))
   if (.not. is_lw) allocate(flux_dir(ncol, nlay+1))
+  allocate(bp_lay(bs, nlay, nblocks), bp_lev(bs, nlay+1, nblocks), bt_lay(bs, nlay, nblocks), bt_lev(bs, nlay+1, nblocks), &
+           bcol_dry(bs, nlay, nblocks), bsfc(nbnd, bs, nblocks), bup(bs, nlay+1, nblocks), bdn(bs, nlay+1, nblocks))
+  if (is_lw) then
+    allocate(bt_sfc(bs, nblocks))
+  else
+    allocate(bmu0(bs, nblocks), bdir(bs, nlay+1, nblocks))
+  end if
+  do b = 1, nblocks
+    c0 = (b - 1) * bs + 1; c1 = b * bs
+    bp_lay(:, :, b) = p_lay(c0:c1, :); bp_lev(:, :, b) = p_lev(c0:c1, :); bt_lay(:, :, b) = t_lay(c0:c1, :)
+    bt_lev(:, :, b) = t_lev(c0:c1, :); bcol_dry(:, :, b) = col_dry(c0:c1, :)
+    do ig = 1, nbnd
+      if (is_lw) then
+        bsfc(ig, :, b) = sfc_emis(c0:c1)
+      else
+        bsfc(ig, :, b) = sfc_alb(c0:c1)
+      end if
+    end do
+    if (is_lw) then
+      bt_sfc(:, b) = t_sfc(c0:c1)
+    else
+      bmu0(:, b) = mu0(c0:c1)
+    end if
+  end do
 
   ! The block loop of the RFMIP drivers; with OpenMP (the same source built with -fopenmp: ref_frontend_driver_omp) the
   ! blocks are dealt round-robin to the threads, each with its own optical-property / source / flux objects -- concurrent
@@ -93,6 +122,8 @@ program ref_frontend_driver
   !$ nth = omp_get_max_threads()
   best = huge(best)
   call system_clock(count_rate=rate)
+  call get_environment_variable('REF_DRIVER_TIMING', envv)
+  timing_lines = len_trim(envv) > 0 .and. envv(1:1) /= '0'
   do irep = 1, nrep
     call system_clock(t0)
     !$omp parallel default(shared)
@@ -105,6 +136,11 @@ program ref_frontend_driver
   end do
   print '(a,f12.1)', 'best columns/s: ', real(ncol, 8) / best
 
+  do b = 1, nblocks
+    c0 = (b - 1) * bs + 1; c1 = b * bs
+    flux_up(c0:c1, :) = bup(:, :, b); flux_dn(c0:c1, :) = bdn(:, :, b)
+    if (.not. is_lw) flux_dir(c0:c1, :) = bdir(:, :, b)
+  end do
   open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
   write(u) flux_up; write(u) flux_dn
   if (.not. is_lw) write(u) flux_dir
@@ -113,63 +149,60 @@ program ref_frontend_driver
 contains
   ! one thread's share of the blocks: its own work arrays and frontend objects (all local, i.e. private)
   subroutine worker()
-    real(wp), allocatable, target :: bup(:,:), bdn(:,:), bdir(:,:)   ! one block's fluxes (contiguous, as in the RFMIP drivers)
-    real(wp), allocatable :: bp_lay(:,:), bp_lev(:,:), bt_lay(:,:), bt_lev(:,:), bcol_dry(:,:), bsfc(:,:), toa(:,:)
+    real(wp), allocatable :: toa(:,:)
     type(ty_optical_props_1scl) :: op1
     type(ty_optical_props_2str) :: op2
     type(ty_source_func_lw) :: src
     type(ty_fluxes_broadband) :: fluxes
-    integer :: b, c0, c1, ibnd, tid, nthr
+    integer :: b, tid, nthr
+    integer(8) :: tb, tc, td, tick_go, tick_rte
     character(len=128) :: e
+    tick_go = 0; tick_rte = 0
     tid = 0; nthr = 1
     !$ tid = omp_get_thread_num()
     !$ nthr = omp_get_num_threads()
-    allocate(bup(bs, nlay+1), bdn(bs, nlay+1))
-    allocate(bp_lay(bs, nlay), bp_lev(bs, nlay+1), bt_lay(bs, nlay), bt_lev(bs, nlay+1), bcol_dry(bs, nlay), bsfc(nbnd, bs))
-    fluxes%flux_up => bup; fluxes%flux_dn => bdn
     if (is_lw) then
       call stop_on_err(op1%alloc_1scl(bs, nlay, k))
       call stop_on_err(src%alloc(bs, nlay, k))
     else
-      allocate(bdir(bs, nlay+1), toa(bs, ngpt))
-      fluxes%flux_dn_dir => bdir
+      allocate(toa(bs, ngpt))
       call stop_on_err(op2%alloc_2str(bs, nlay, k))
     end if
     do b = 1 + tid, nblocks, nthr
-      c0 = (b - 1) * bs + 1; c1 = b * bs
-      bp_lay = p_lay(c0:c1, :); bp_lev = p_lev(c0:c1, :); bt_lay = t_lay(c0:c1, :)
-      if (use_tlev) bt_lev = t_lev(c0:c1, :)
-      if (use_col_dry) bcol_dry = col_dry(c0:c1, :)
+      fluxes%flux_up => bup(:, :, b); fluxes%flux_dn => bdn(:, :, b)   ! (rrtmgp_rfmip_lw.F90:259-260)
+      call system_clock(tb)
       if (is_lw) then
-        do ibnd = 1, nbnd
-          bsfc(ibnd, :) = sfc_emis(c0:c1)
-        end do
         if (use_col_dry .and. use_tlev) then
-          e = k%gas_optics(bp_lay, bp_lev, bt_lay, t_sfc(c0:c1), concs(b), op1, src, col_dry=bcol_dry, tlev=bt_lev)
+          e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), bt_sfc(:,b), concs(b), op1, src, &
+                           col_dry=bcol_dry(:,:,b), tlev=bt_lev(:,:,b))
         else if (use_col_dry) then
-          e = k%gas_optics(bp_lay, bp_lev, bt_lay, t_sfc(c0:c1), concs(b), op1, src, col_dry=bcol_dry)
+          e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), bt_sfc(:,b), concs(b), op1, src, col_dry=bcol_dry(:,:,b))
         else if (use_tlev) then
-          e = k%gas_optics(bp_lay, bp_lev, bt_lay, t_sfc(c0:c1), concs(b), op1, src, tlev=bt_lev)
+          e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), bt_sfc(:,b), concs(b), op1, src, tlev=bt_lev(:,:,b))
         else
-          e = k%gas_optics(bp_lay, bp_lev, bt_lay, t_sfc(c0:c1), concs(b), op1, src)
+          e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), bt_sfc(:,b), concs(b), op1, src)
         end if
         call stop_on_err(e)
-        call stop_on_err(rte_lw(op1, src, bsfc, fluxes, n_gauss_angles=n_ang))
+        call system_clock(tc)
+        call stop_on_err(rte_lw(op1, src, bsfc(:,:,b), fluxes, n_gauss_angles=n_ang))
+        call system_clock(td)
       else
-        do ibnd = 1, nbnd
-          bsfc(ibnd, :) = sfc_alb(c0:c1)
-        end do
+        fluxes%flux_dn_dir => bdir(:, :, b)
         if (use_col_dry) then
-          e = k%gas_optics(bp_lay, bp_lev, bt_lay, concs(b), op2, toa, col_dry=bcol_dry)
+          e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), concs(b), op2, toa, col_dry=bcol_dry(:,:,b))
         else
-          e = k%gas_optics(bp_lay, bp_lev, bt_lay, concs(b), op2, toa)
+          e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), concs(b), op2, toa)
         end if
         call stop_on_err(e)
-        call stop_on_err(rte_sw(op2, mu0(c0:c1), toa, bsfc, bsfc, fluxes))
-        flux_dir(c0:c1, :) = bdir
+        call system_clock(tc)
+        call stop_on_err(rte_sw(op2, bmu0(:,b), toa, bsfc(:,:,b), bsfc(:,:,b), fluxes))
+        call system_clock(td)
       end if
-      flux_up(c0:c1, :) = bup; flux_dn(c0:c1, :) = bdn
+      tick_go = tick_go + (tc - tb); tick_rte = tick_rte + (td - tc)
     end do
+    ! where a thread's time went (wall clock of the frontend calls, the library's share of them is in its own report)
+    if (tid == 0 .and. timing_lines) print '(a,f9.4,a,f9.4,a)', '  thread 0: gas_optics ', real(tick_go, 8) / real(rate, 8), &
+      ' s, rte ', real(tick_rte, 8) / real(rate, 8), ' s'
   end subroutine
   subroutine stop_on_err(msg)
     character(len=*), intent(in) :: msg

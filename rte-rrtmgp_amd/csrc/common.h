@@ -99,6 +99,7 @@ class Call {
   Back back_[16];
   int n_back_ = 0;
   bool staged_in_ = false;
+  bool staged_plain_ = false;  // ... by the runtime's own pageable copy (the source may still be in use when it returns)
   bool host_visible_ = false;  // some array is pinned / registered / managed host memory used in place
   void* host_tmp_[24];
   int n_host_tmp_ = 0;

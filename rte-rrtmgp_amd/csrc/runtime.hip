@@ -23,6 +23,7 @@
 #include <exception>
 #include <mutex>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -78,11 +79,21 @@ struct Context {
   long mirror_max_age = 64;
   unsigned long long magic_state = 0x9E3779B97F4A7C15ull;
   hipEvent_t ev_h2d = nullptr;
+  // pinned staging ring for host-to-device copies of pageable arrays (h2d())
+  static constexpr int kRing = 4;
+  static constexpr size_t kRingChunk = size_t(4) << 20;
+  char* ring[kRing] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
+  bool ring_busy[kRing] = {false, false, false, false};
+  unsigned ring_next = 0;
+  int ring_mode = -1;  // -1: take RTE_HIP_H2D_RING at the first copy (default on)
   long long mstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hits, mirrors made, H2D bytes, D2H bytes, dropped (host changed), dropped (overlap), aged out, zero fills elided
   long long table_hits = 0, table_uploads = 0;
   double t_call = 0, t_h2d = 0, t_wait = 0, t_find = 0;  // host wall-clock inside the host-array path
   long n_calls = 0;
   std::chrono::steady_clock::time_point call_t0;
+  bool report_on = false;        // RTE_HIP_STAGING_REPORT: also keep the wall-clock per entry point
+  std::vector<std::pair<const char*, std::pair<double, long>>> t_entry;
   // ---- timing
   bool prof_on = false;
   std::string prof_only;  // non-empty: only this scope is timed
@@ -362,6 +373,10 @@ static void staging_report() {
             "zero fills elided %lld, device bytes held %.2f GB; host tables uploaded %lld, reused %lld\n", i++, c->n_calls, c->t_call, c->t_h2d, c->mstat[2] * 1e-9, c->t_wait,
             c->mstat[3] * 1e-9, c->t_find, c->mstat[1], c->mstat[0], c->mstat[4], c->mstat[5], c->mstat[6], c->mstat[7], c->mirror_total * 1e-9,
             c->table_uploads, c->table_hits);
+    auto v = c->t_entry;
+    std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.first > b.second.first; });
+    for (size_t k = 0; k < v.size() && k < 12; ++k)
+      fprintf(stderr, "    %-44s %6ld calls %9.4f s\n", v[k].first, v[k].second.second, v[k].second.first);
   }
 }
 static bool mirror_on() {
@@ -375,6 +390,7 @@ static bool mirror_on() {
         std::lock_guard<std::mutex> l(g_report_mutex);
         if (g_report_contexts.empty()) atexit(staging_report);
         g_report_contexts.push_back(&c);
+        c.report_on = true;
       }
   }
   return c.mirror_mode == 1;
@@ -404,6 +420,38 @@ static bool canaries_intact(const Mirror& m) {
     canary_value(m.magic, k, v);
     if (pread(g_procmem_fd, w, 16, (off_t)(uintptr_t)(m.host + canary_offset(m.bytes, k))) != 16) return false;
     if (w[0] != v[0] || w[1] != v[1]) return false;
+  }
+  return true;
+}
+// Host-to-device copy of a PAGEABLE array on the context's stream.  For a copy of 1 MB or more the HIP runtime pins the
+// caller's pages: fast when the same pages come again (55 GB/s: its pin cache), but the Fortran frontend's arrays are
+// automatic / allocatable arrays, freshly mapped for every call -- measured 0.7 ... 40 GB/s and erratic
+// (tools/h2d_bench.hip).  Large copies therefore go through the context's own pinned ring: memcpy of a 4 MB chunk while
+// the DMA engine takes the chunk before it, 27-38 GB/s whatever the age of the pages.  Like the runtime's pageable copy
+// the call returns when the source has been read.  Arrays above 128 MB stay with the runtime: in the frontend those are
+// the 3-D members of optical-property objects (SW: tau, ssa, g after the host-side combine_abs_and_rayleigh), allocated
+// once per object, and their pages are found pinned again.
+static bool h2d(Context& c, void* d, const void* p, size_t bytes) {  // true: the source has been read when it returns
+  if (c.ring_mode < 0) {
+    const char* e = getenv("RTE_HIP_H2D_RING");
+    c.ring_mode = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  if (!c.ring_mode || bytes < (size_t(512) << 10) || bytes > (size_t(128) << 20)) {
+    HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c.stream));
+    return false;
+  }
+  for (size_t o = 0; o < bytes; o += Context::kRingChunk) {
+    const size_t len = bytes - o < Context::kRingChunk ? bytes - o : Context::kRingChunk;
+    const unsigned slot = c.ring_next++ % Context::kRing;
+    if (!c.ring[slot]) {
+      HIP_CHECK(hipHostMalloc((void**)&c.ring[slot], Context::kRingChunk, hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&c.ring_ev[slot], hipEventDisableTiming));
+    }
+    if (c.ring_busy[slot]) HIP_CHECK(hipEventSynchronize(c.ring_ev[slot]));
+    memcpy(c.ring[slot], (const char*)p + o, len);
+    HIP_CHECK(hipMemcpyAsync((char*)d + o, c.ring[slot], len, hipMemcpyHostToDevice, c.stream));
+    HIP_CHECK(hipEventRecord(c.ring_ev[slot], c.stream));
+    c.ring_busy[slot] = true;
   }
   return true;
 }
@@ -577,7 +625,7 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
       char* d = mirror_alloc(bytes, &cap);
       if (copy_in) {
         const auto t0 = std::chrono::steady_clock::now();
-        HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c.stream));
+        if (!h2d(c, d, p, bytes)) staged_plain_ = true;
         c.t_h2d += secs_since(t0);
         staged_in_ = true;
         c.mstat[2] += (long long)bytes;
@@ -594,7 +642,7 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
   void* d = scratch(bytes);
   if (copy_in) {
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c.stream));
+    if (!h2d(c, d, p, bytes)) staged_plain_ = true;
     c.t_h2d += secs_since(t0);
     staged_in_ = true;
     c.mstat[2] += (long long)bytes;
@@ -676,7 +724,7 @@ const void* Call::stage_table(const void* p, size_t bytes) {
   char* d = nullptr;
   HIP_CHECK(hipMalloc((void**)&d, bytes));
   const auto t0 = std::chrono::steady_clock::now();
-  HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c.stream));
+  if (!h2d(c, d, p, bytes)) staged_plain_ = true;
   c.t_h2d += secs_since(t0);
   staged_in_ = true;
   c.mstat[2] += (long long)bytes;
@@ -730,7 +778,7 @@ Call::~Call() noexcept(false) {
       // In host-mirror mode a call that staged inputs only waits for those copies (mark_h2d), not for its kernels: they
       // run while the host program prepares the next call.
       if (n_back_ > 0 || host_visible_ || (staged_in_ && !mirror)) HIP_CHECK(hipStreamSynchronize(c.stream));
-      else if (staged_in_) HIP_CHECK(hipEventSynchronize(c.ev_h2d));
+      else if (staged_plain_) HIP_CHECK(hipEventSynchronize(c.ev_h2d));
       c.t_wait += secs_since(tw);
       for (int i = 0; i < n_lazy_; ++i) write_canaries(lazy_[i].host, lazy_[i].bytes, lazy_[i].magic);
       if (forked_) {  // join: the library stream (and whatever is queued on it from now on) waits for this call
@@ -750,7 +798,15 @@ Call::~Call() noexcept(false) {
   for (int i = 0; i < n_recycle_; ++i) c.mirror_free.push_back(FreeBuf{(char*)recycle_[i].dev, recycle_[i].cap});
   for (int i = 0; i < n_host_tmp_; ++i) free(host_tmp_[i]);
   c.on_side = false;
-  c.t_call += secs_since(c.call_t0);
+  const double dt_call = secs_since(c.call_t0);
+  c.t_call += dt_call;
+  if (c.report_on) {
+    size_t i = 0;
+    while (i < c.t_entry.size() && c.t_entry[i].first != name) ++i;  // (entry names are string literals: one address each)
+    if (i == c.t_entry.size()) c.t_entry.push_back({name, {0.0, 0L}});
+    c.t_entry[i].second.first += dt_call;
+    c.t_entry[i].second.second += 1;
+  }
   c.mutex.unlock();
 }
 
@@ -862,6 +918,10 @@ int rte_hip_ctx_destroy(void* ctx) {
     if (c->aux) HIP_CHECK(hipStreamDestroy(c->aux));
     for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_aux_fork, c->ev_aux_join, c->ev_h2d})
       if (e) HIP_CHECK(hipEventDestroy(e));
+    for (int i = 0; i < rte::Context::kRing; ++i) {
+      if (c->ring_ev[i]) HIP_CHECK(hipEventDestroy(c->ring_ev[i]));
+      if (c->ring[i]) HIP_CHECK(hipHostFree(c->ring[i]));
+    }
   }
   {
     std::lock_guard<std::mutex> l(rte::g_report_mutex);

@@ -965,8 +965,59 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // second instance of the loop (ALLRUN = false) that pays the drains.
   bool all_run = true;
   for (int b = 0; b < nbnd; ++b) all_run = all_run && tg.eg[b].y > 0;
-  auto run_stages = [&](auto allrun_tag) {
+  auto run_stages = [&](auto allrun_tag, auto rot_tag) {
   constexpr bool ALLRUN = decltype(allrun_tag)::value;
+  // ROT: this wave issues a stage's tau stores AFTER the next stage's barrier (while the other half of the compute
+  // waves gathers from the LDS) instead of at the end of the stage (when every wave of the block stores)
+  constexpr bool ROT = decltype(rot_tag)::value;
+  static_assert(!ROT || RAYL == 0, "the fused variants finish a stage from its own slab");
+  Float acc[G];
+  bool have_prev = false;
+  int g0_prev = 0;
+  Float addv_prev = 0;
+  // tau(:, :, g) = scalar plane base + this column's 32-bit byte offset (host guarantees 8*ncol*nlay < 2^32)
+  const size_t gstride = (size_t)ncl * sizeof(Float);
+  // the stage's G stores (RAYL == 0)
+  auto flush = [&](int g0f, Float addvf) {
+    char* const tplane = reinterpret_cast<char*>(a.tau + (size_t)ncl * g0f);
+    unsigned toff = cl8;
+    asm volatile("" : "+v"(toff));  // keep the 64-bit address out of the loop-invariant registers
+    auto tau_at = [&](int j) { return reinterpret_cast<Float*>(tplane + gstride * j + toff); };
+    if (OVERWRITE) {
+      if (ADDB) {  // by-band increment fused in (tau = tau_gas + tau_2 of the band)
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = acc[j] + addvf;
+      }
+      // lanes past the last column repeat it (ic is clamped): same values to the same addresses.  Unconditional
+      // stores keep the count of outstanding memory operations static (counted waits instead of drains).
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        store_stream(tau_at(j), acc[j]);
+      }
+    } else if (valid) {
+      // tau is inout (the reference accumulates onto it, :637,:679).  The stage's sum is added to the incoming
+      // value at the end: identical to the reference when tau comes in as zero (always, in the frontend),
+      // otherwise the same terms in a different order (1 ulp)
+      // ... as a hardware floating-point atomic add performed in L2 (global_atomic_add, no return value): the same
+      // single addition tau_in + sum, but the wave neither waits for tau_in nor holds it in registers (a load - add -
+      // store sequence needed `vmcnt(0)` 15 times per stage).  Every element is touched by exactly one thread of
+      // one block per call, so the result does not depend on any order.
+      if (ADDB) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = acc[j] + addvf;
+      }
+      const bool use_atomics = a.atomic_ok;  // host-visible (pinned / managed) buffers: load - add - store
+      if (use_atomics) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) unsafeAtomicAdd(tau_at(j), acc[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
+#pragma unroll
+        for (int j = 0; j < G; ++j) *tau_at(j) = acc[j];
+      }
+    }
+  };
   Major mj;
   Minor mn;
   MinorIdx nq;
@@ -1013,6 +1064,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
     const int je1 = mj.je.x, je2 = mj.je.y;
     __syncthreads();  // B(s): slab(s) is complete
+    if constexpr (ROT) {
+      if (ALLRUN ? s > 0 : have_prev) flush(g0_prev, addv_prev);
+      have_prev = false;
+    }
     peek_minor(ibnd_n, n_minor(ibnd_n), nq);
     if (!ALLRUN && !run) {
       load_major(nq.flav_major, mj);
@@ -1027,12 +1082,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const Float* B0 = sl + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
     const int sP = nT * nE * RS;
     const Float* M0 = sl + (rowsMaj + (regime == 2 ? rowsLo : 0)) * RS;
-    Float acc[G];
-    // tau(:, :, g) = scalar plane base + this column's 32-bit byte offset (host guarantees 8*ncol*nlay < 2^32)
+    // (RAYL: the stage's stores are issued here, see below)
     char* const tplane = reinterpret_cast<char*>(a.tau + (size_t)ncl * g0);
-    const size_t gstride = (size_t)ncl * sizeof(Float);
     unsigned toff = cl8;
-    asm volatile("" : "+v"(toff));  // keep the 64-bit address out of the loop-invariant registers
+    if (RAYL) asm volatile("" : "+v"(toff));  // keep the 64-bit address out of the loop-invariant registers
     auto tau_at = [&](int j) { return reinterpret_cast<Float*>(tplane + gstride * j + toff); };
 #pragma unroll
     for (int j = 0; j < G; ++j) acc[j] = 0;
@@ -1149,43 +1202,33 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
           store_stream(reinterpret_cast<Float*>(gplane + gstride * (j + u) + toff), g_);
         }
       }
-    } else if (OVERWRITE) {
-      if (ADDB) {  // by-band increment fused in (tau = tau_gas + tau_2 of the band)
-#pragma unroll
-        for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
-      }
-      // lanes past the last column repeat it (ic is clamped): same values to the same addresses.  Unconditional
-      // stores keep the count of outstanding memory operations static (counted waits instead of drains).
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        store_stream(tau_at(j), acc[j]);
-      }
-    } else if (valid) {
-      // tau is inout (the reference accumulates onto it, :637,:679).  The stage's sum is added to the incoming
-      // value at the end: identical to the reference when tau comes in as zero (always, in the frontend),
-      // otherwise the same terms in a different order (1 ulp)
-      // ... as a hardware floating-point atomic add performed in L2 (global_atomic_add, no return value): the same
-      // single addition tau_in + sum, but the wave neither waits for tau_in nor holds it in registers (a load - add -
-      // store sequence needed `vmcnt(0)` 15 times per stage).  Every element is touched by exactly one thread of
-      // one block per call, so the result does not depend on any order.
-      if (ADDB) {
-#pragma unroll
-        for (int j = 0; j < G; ++j) acc[j] = acc[j] + addv;
-      }
-      const bool use_atomics = a.atomic_ok;  // host-visible (pinned / managed) buffers: load - add - store
-      if (use_atomics) {
-#pragma unroll
-        for (int j = 0; j < G; ++j) unsafeAtomicAdd(tau_at(j), acc[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
-#pragma unroll
-        for (int j = 0; j < G; ++j) *tau_at(j) = acc[j];
-      }
+    } else if constexpr (ROT) {
+      have_prev = true; g0_prev = g0; addv_prev = addv;
+    } else {
+      flush(g0, addv);
     }
   }
+  if constexpr (ROT) {
+    if (ALLRUN ? nstage > 0 : have_prev) flush(g0_prev, addv_prev);
+  }
   };
-  if (all_run) run_stages(std::true_type{}); else run_stages(std::false_type{});
+  // (round 3: 5.30 -> 5.19 ms at 1e5 x 60 x 256; -DTAU_NO_ROT for the A/B.  The fused variants end a stage with LDS
+  // reads of their own slab and stay as they were.)
+#ifdef TAU_NO_ROT
+  constexpr bool ROTATE = false;
+#else
+  constexpr bool ROTATE = RAYL == 0;
+#endif
+  bool rotated = false;
+  if constexpr (ROTATE) rotated = tid >= TILE / 2;  // (wave-uniform)
+  if constexpr (ROTATE) {
+    if (rotated) {
+      if (all_run) run_stages(std::true_type{}, std::true_type{}); else run_stages(std::false_type{}, std::true_type{});
+      return;
+    }
+  }
+  if (all_run) run_stages(std::true_type{}, std::false_type{}); else run_stages(std::false_type{}, std::false_type{});
+
 }
 
 template <bool GFAST>

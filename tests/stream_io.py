@@ -155,7 +155,9 @@ def measure_frontend_driver(kind="lw", ncol=98304, block=8192, modes=("mirror",)
                     assert np.array_equal(fl[k], ref[k]), (mode, k, float(np.max(np.abs(fl[k] - ref[k]))))
             best = float([ln for ln in log.splitlines() if "best columns/s" in ln][0].split(":")[1])
             rep = [ln.strip() for ln in last_stderr.splitlines() if "staging report" in ln]
-            out[mode] = {"columns_per_s": best, "report": rep[0] if rep else None, "reports": rep,
+            detail = [ln.rstrip() for ln in last_stderr.splitlines() if ln.startswith("    ")]  # per-entry wall clock
+            detail += [ln.rstrip() for ln in log.splitlines() if ln.startswith("  thread 0:")]     # REF_DRIVER_TIMING=1
+            out[mode] = {"columns_per_s": best, "report": rep[0] if rep else None, "reports": rep, "detail": detail,
                          "passes": [ln.split(":", 1)[1].strip() for ln in log.splitlines() if ln.startswith("pass")]}
     finally:
         shutil.rmtree(d, ignore_errors=True)

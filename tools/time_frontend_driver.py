@@ -15,7 +15,10 @@ for bs in blocks:
     if ncol % bs:
         continue
     for nt in threads:
-        for mode, r in stream_io.measure_frontend_driver(kind, ncol, bs, modes, threads=nt).items():
+        for mode, r in stream_io.measure_frontend_driver(kind, ncol, bs, modes, threads=nt, env_extra={"REF_DRIVER_TIMING": "1"}).items():
             for rep in r.get("reports", [])[:2]:
                 print("   ", rep)
+            if nt == 1:
+                for ln in r.get("detail", []):
+                    print("   ", ln)
             print(f"{kind} {mode:7s} threads {nt:2d} block {bs:6d}: best {r['columns_per_s']:12.0f} columns/s   ({' | '.join(r['passes'])})", flush=True)
