@@ -970,6 +970,15 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // ROT: this wave issues a stage's tau stores AFTER the next stage's barrier (while the other half of the compute
   // waves gathers from the LDS) instead of at the end of the stage (when every wave of the block stores)
   constexpr bool ROT = decltype(rot_tag)::value;
+  // ROLL: the LDS gathers as a rolling pipeline -- the next four rows are requested BEFORE the FMAs on the four that have
+  // arrived, at most 8 row reads in flight per wave (the batched form: 16 reads, wait, 32 FMAs, with the LDS idle during
+  // the FMAs and the SIMD idle during the reads).  5.19 -> 5.05 ms at 1e5 x 60 x 256 (-DTAU_BATCHED_GATHER for the A/B).
+  // The fused variants are at the register limit and keep the batched form.
+#ifdef TAU_BATCHED_GATHER
+  constexpr bool ROLL = false;
+#else
+  constexpr bool ROLL = RAYL == 0 && !ADDB;
+#endif
   static_assert(!ROT || RAYL == 0, "the fused variants finish a stage from its own slab");
   Float acc[G];
   bool have_prev = false;
@@ -1089,6 +1098,39 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     auto tau_at = [&](int j) { return reinterpret_cast<Float*>(tplane + gstride * j + toff); };
 #pragma unroll
     for (int j = 0; j < G; ++j) acc[j] = 0;
+    if constexpr (ROLL) {
+      // rolling: the next four rows are requested BEFORE the FMAs on the four that arrived (at most 8 row reads in flight
+      // per wave; the LDS serves the other waves' and this wave's next rows while the SIMD works on these)
+      Float2 kb[2][4];
+      auto rd = [&](Float2 (&k)[4], int h) {  // h: half-step index, (pair, lower / upper temperature)
+        const Float* base = ((h & 1) ? B0 : A0) + 2 * (h >> 1);
+        k[0] = ld2(base); k[1] = ld2(base + RS); k[2] = ld2(base + sP); k[3] = ld2(base + sP + RS);
+      };
+      rd(kb[0], 0);
+      Float m = 0, n = 0;
+#pragma unroll
+      for (int h = 0; h < G; ++h) {
+        Float2 (&k)[4] = kb[h & 1];
+        if (h + 1 < G) rd(kb[(h & 1) ^ 1], h + 1);
+        if ((h & 1) == 0) {
+          m = w0 * k[0].x; n = w0 * k[0].y;
+          m = fma(w1, k[1].x, m); n = fma(w1, k[1].y, n);
+          m = fma(w2, k[2].x, m); n = fma(w2, k[2].y, n);
+          m = fma(w3, k[3].x, m); n = fma(w3, k[3].y, n);
+          asm volatile("" : "+v"(m), "+v"(n));
+        } else {
+          m = fma(w4, k[0].x, m); n = fma(w4, k[0].y, n);
+          m = fma(w5, k[1].x, m); n = fma(w5, k[1].y, n);
+          m = fma(w6, k[2].x, m); n = fma(w6, k[2].y, n);
+          m = fma(w7, k[3].x, m); n = fma(w7, k[3].y, n);
+          const int j = h & ~1;
+          acc[j] = acc[j] + m;
+          acc[j + 1] = acc[j + 1] + n;
+          asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < G; j += 2) {
       // :791-801 with col_mix folded into the weights; one 16-byte LDS read feeds two g-points
@@ -1107,6 +1149,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       // pin the accumulation here: otherwise the FMA chains are sunk below the whole loop and all 64 reads stay live
       asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
       if ((j & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads (64 VGPRs) in flight
+    }
     }
     // next stage's major weights: their registers are free now, and the request is a minor pass ahead of its use
     // (requested with the minor weights at the end of the stage, their latency is exposed: 5.5 -> 5.9 ms)
@@ -1134,6 +1177,24 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     auto minor_rows = [&](int k, Float scaling) {
       const Float* r1 = M0 + ((k * nT + (jT - Tmin)) * nE + (em.x - emin)) * RS;
       const Float* r2 = M0 + ((k * nT + (jT + 1 - Tmin)) * nE + (em.y - emin)) * RS;
+      if constexpr (ROLL) {
+      Float2 qb[2][4];  // one g-point pair (4 row reads) per step, the next step's requested ahead
+      auto rdm = [&](Float2 (&q)[4], int j) { q[0] = ld2(r1 + j); q[1] = ld2(r1 + RS + j); q[2] = ld2(r2 + j); q[3] = ld2(r2 + RS + j); };
+      rdm(qb[0], 0);
+#pragma unroll
+      for (int j = 0; j < G; j += 2) {
+        Float2 (&q)[4] = qb[(j >> 1) & 1];
+        if (j + 2 < G) rdm(qb[((j >> 1) & 1) ^ 1], j + 2);
+        Float s_ = f0 * q[0].x, t_ = f0 * q[0].y;
+        s_ = fma(f1, q[1].x, s_); t_ = fma(f1, q[1].y, t_);
+        s_ = fma(f2, q[2].x, s_); t_ = fma(f2, q[2].y, t_);
+        s_ = fma(f3, q[3].x, s_); t_ = fma(f3, q[3].y, t_);
+        acc[j] = fma(scaling, s_, acc[j]);
+        acc[j + 1] = fma(scaling, t_, acc[j + 1]);
+        asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      } else {
 #pragma unroll
       for (int j = 0; j < G; j += 2) {
         const Float2 q0 = ld2(r1 + j), q1 = ld2(r1 + RS + j), q2 = ld2(r2 + j), q3 = ld2(r2 + RS + j);
@@ -1145,6 +1206,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         acc[j + 1] = fma(scaling, t_, acc[j + 1]);
         asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
         if ((j & 6) == 6) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads in flight
+      }
       }
     };
     const int n_reg = n_my < MM ? n_my : MM;
@@ -1217,7 +1279,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #ifdef TAU_NO_ROT
   constexpr bool ROTATE = false;
 #else
-  constexpr bool ROTATE = RAYL == 0;
+  constexpr bool ROTATE = RAYL == 0 && !ADDB;  // (the by-band operand's variant would spill)
 #endif
   bool rotated = false;
   if constexpr (ROTATE) rotated = tid >= TILE / 2;  // (wave-uniform)
