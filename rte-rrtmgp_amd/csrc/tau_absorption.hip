@@ -1015,16 +1015,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
         for (int j = 0; j < G; ++j) acc[j] = acc[j] + addvf;
       }
-      const bool use_atomics = a.atomic_ok;  // host-visible (pinned / managed) buffers: load - add - store
-      if (use_atomics) {
+      // (tau is device memory proper here: the host sends host-visible buffers to the direct kernels)
 #pragma unroll
-        for (int j = 0; j < G; ++j) unsafeAtomicAdd(tau_at(j), acc[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < G; ++j) acc[j] = *tau_at(j) + acc[j];
-#pragma unroll
-        for (int j = 0; j < G; ++j) *tau_at(j) = acc[j];
-      }
+      for (int j = 0; j < G; ++j) unsafeAtomicAdd(tau_at(j), acc[j]);
     }
   };
   Major mj;
@@ -1702,8 +1695,11 @@ static void tau_absorption_impl(
     if (!overwrite_ok) HIP_CHECK(hipMemsetAsync(d_tau, 0, sizeof(Float) * ncl * ngpt, st));
   }
   auto al = [](const void* q, size_t n) { return ((uintptr_t)q % n) == 0; };
+  // (accumulating onto a host-visible -- pinned / managed -- tau: hardware floating-point atomics are not defined there,
+  //  the direct kernels' plain read - add - write is)
   const bool fast = cache.fast_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) &&
                     al(d_fmajor, 16) && al(d_fminor, 16) && al(d_col_mix, 16) && al(d_jeta, 8) &&
+                    (overwrite_ok || rte::is_device_memory(d_tau)) &&
                     (!rh || (overwrite_ok && g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 &&
                              npres + 1 < 63));  // (fused: the bands tile the g-points -- else tau was zero-filled above --
                                                 //  and the bit-mask geometry, which counts the Rayleigh rows)

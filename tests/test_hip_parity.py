@@ -497,9 +497,9 @@ def test_pinned_host_arrays_are_synchronous(hip, oracle_c):
 
 def test_tau_accumulates_onto_device_and_pinned_buffers(hip):
     """compute_tau_absorption is intent(inout): it adds to what `tau` holds.  On device memory the production kernel
-    does that with a hardware floating-point atomic add, on host-visible (pinned) memory -- where such atomics are not
-    defined -- with load, add, store.  Both must equal (incoming value + the optical depth computed onto zeros), bit for
-    bit: it is one addition of the same two numbers."""
+    does that with a hardware floating-point atomic add: (incoming value + the optical depth computed onto zeros), bit for
+    bit -- one addition of the same two numbers.  Host-visible (pinned) memory, where such atomics are not defined, goes
+    to the direct kernels (plain read - add - write, the reference's association): the same sum to rounding."""
     import torch
     from rte_rrtmgp_amd import synth
 
@@ -522,7 +522,7 @@ def test_tau_accumulates_onto_device_and_pinned_buffers(hip):
     pinned = t.numpy().T
     pinned[...] = incoming
     go_n.compute_tau_absorption(ncol, nlay, st, F(atm.play), F(atm.tlay), F(atm.col_gas), pinned)
-    assert np.array_equal(pinned, expect)
+    assert cases.rel_err(pinned, expect) <= 1e-13
     # (3) onto the incoming values in device memory
     go_d = frontend.GasOptics(hip, kd, xp)
     A = xp.asarray
