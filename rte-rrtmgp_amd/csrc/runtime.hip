@@ -85,7 +85,8 @@ struct Context {
   char* ring[kRing] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
   bool ring_busy[kRing] = {false, false, false, false};
-  unsigned ring_next = 0;
+  int ring_cur = -1;       // slot being filled
+  size_t ring_fill = 0;    // bytes of it handed to the DMA engine so far
   int ring_mode = -1;  // -1: take RTE_HIP_H2D_RING at the first copy (default on)
   long long mstat[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hits, mirrors made, H2D bytes, D2H bytes, dropped (host changed), dropped (overlap), aged out, zero fills elided
   long long table_hits = 0, table_uploads = 0;
@@ -436,22 +437,40 @@ static bool h2d(Context& c, void* d, const void* p, size_t bytes) {  // true: th
     const char* e = getenv("RTE_HIP_H2D_RING");
     c.ring_mode = (e && atoi(e) == 0) ? 0 : 1;
   }
-  if (!c.ring_mode || bytes < (size_t(512) << 10) || bytes > (size_t(128) << 20)) {
+  if (bytes == 0) return true;
+  if (!c.ring_mode || bytes > (size_t(128) << 20)) {
     HIP_CHECK(hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c.stream));
     return false;
   }
-  for (size_t o = 0; o < bytes; o += Context::kRingChunk) {
-    const size_t len = bytes - o < Context::kRingChunk ? bytes - o : Context::kRingChunk;
-    const unsigned slot = c.ring_next++ % Context::kRing;
-    if (!c.ring[slot]) {
-      HIP_CHECK(hipHostMalloc((void**)&c.ring[slot], Context::kRingChunk, hipHostMallocDefault));
-      HIP_CHECK(hipEventCreateWithFlags(&c.ring_ev[slot], hipEventDisableTiming));
+  // Small arrays are packed into the current slot one after the other (the runtime's pageable copy of some sizes -- 64 KB,
+  // 2 MB -- returns only when everything queued on the stream before it has run, i.e. it would make the host wait for the
+  // previous calls' kernels: tools/h2d_bench.hip); a slot's event is recorded when the ring moves on, and waited for when
+  // the ring comes round to the slot again.
+  size_t o = 0;
+  while (o < bytes) {
+    if (c.ring_cur < 0 || c.ring_fill >= Context::kRingChunk) {
+      if (c.ring_cur >= 0) {
+        HIP_CHECK(hipEventRecord(c.ring_ev[c.ring_cur], c.stream));
+        c.ring_busy[c.ring_cur] = true;
+      }
+      c.ring_cur = (c.ring_cur + 1) % Context::kRing;
+      c.ring_fill = 0;
+      if (!c.ring[c.ring_cur]) {
+        HIP_CHECK(hipHostMalloc((void**)&c.ring[c.ring_cur], Context::kRingChunk, hipHostMallocDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&c.ring_ev[c.ring_cur], hipEventDisableTiming));
+      }
+      if (c.ring_busy[c.ring_cur]) {
+        HIP_CHECK(hipEventSynchronize(c.ring_ev[c.ring_cur]));
+        c.ring_busy[c.ring_cur] = false;
+      }
     }
-    if (c.ring_busy[slot]) HIP_CHECK(hipEventSynchronize(c.ring_ev[slot]));
-    memcpy(c.ring[slot], (const char*)p + o, len);
-    HIP_CHECK(hipMemcpyAsync((char*)d + o, c.ring[slot], len, hipMemcpyHostToDevice, c.stream));
-    HIP_CHECK(hipEventRecord(c.ring_ev[slot], c.stream));
-    c.ring_busy[slot] = true;
+    const size_t room = Context::kRingChunk - c.ring_fill;
+    const size_t len = bytes - o < room ? bytes - o : room;
+    char* slot = c.ring[c.ring_cur] + c.ring_fill;
+    memcpy(slot, (const char*)p + o, len);
+    HIP_CHECK(hipMemcpyAsync((char*)d + o, slot, len, hipMemcpyHostToDevice, c.stream));
+    c.ring_fill += (len + 255) & ~size_t(255);
+    o += len;
   }
   return true;
 }
