@@ -75,6 +75,14 @@ if [ -f "$OUT/librefkernels.so" ]; then
   $FC -o "$OUT/bin/ref_frontend_driver_cpuref" ref_frontend_driver.o mo_raw_stream.o $FRONT_OBJS shim.o \
       -L"$OUT" -lrefkernels -L"$HERE" -loracle -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../..'
 fi
+# the invariances of the reference's tests/check_equivalence.F90 on the synthetic streams (oracle/ref_equivalence_driver.F90, ours)
+$FC $FFLAGS -c "$HERE/ref_equivalence_driver.F90" 2> err.log || { cat err.log >&2; exit 1; }
+$FC -o "$OUT/bin/ref_equivalence_driver" ref_equivalence_driver.o mo_raw_stream.o $FRONT_OBJS shim.o \
+    -L"$LIBDIR" -lrte_rrtmgp_hip -Wl,-rpath,'$ORIGIN/../../../rte-rrtmgp_amd' -Wl,-rpath,/opt/rocm/lib
+if [ -f "$OUT/librefkernels.so" ]; then
+  $FC -o "$OUT/bin/ref_equivalence_driver_cpuref" ref_equivalence_driver.o mo_raw_stream.o $FRONT_OBJS shim.o \
+      -L"$OUT" -lrefkernels -L"$HERE" -loracle -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../..'
+fi
 # the same driver with OpenMP: blocks of columns spread over host threads (concurrent calls on distinct buffers)
 $FC $FFLAGS -fopenmp -c "$HERE/ref_frontend_driver.F90" -o ref_frontend_driver_omp.o 2> err.log || { cat err.log >&2; exit 1; }
 $FC -fopenmp -o "$OUT/bin/ref_frontend_driver_omp" ref_frontend_driver_omp.o mo_raw_stream.o $FRONT_OBJS shim.o \

@@ -110,6 +110,22 @@ def run_frontend_driver(binary, kfile, afile, ofile, gases, ncol, nlay, is_lw, e
     return {k: raw[i * n:(i + 1) * n].reshape((ncol, nlay + 1), order="F") for i, k in enumerate(names)}, r.stdout
 
 
+def run_equivalence_driver(binary, kfile, afile, gases, env=None, timeout=1800):
+    """Run oracle/_ref/bin/<binary> (ref_equivalence_driver[_cpuref]); returns (returncode, {check name: (worst deviation in
+    spacings, limit, ok)}, stdout)."""
+    path = os.path.join(BIN, binary)
+    r = subprocess.run(f"ulimit -s unlimited 2>/dev/null; exec '{path}' '{kfile}' '{afile}' '{','.join(gases)}'",
+                       shell=True, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
+    checks = {}
+    for ln in r.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith("check ") and "spacings" in ln:
+            name, rest = ln[6:].rsplit(":", 1)
+            w = rest.split()
+            checks[name] = (float(w[0]), float(w[3].rstrip(")")), ln.endswith("ok"))
+    return r.returncode, checks, r.stdout + r.stderr
+
+
 def measure_frontend_driver(kind="lw", ncol=98304, block=8192, modes=("mirror",), nlay=60, nrep=3, seed=42, env_extra=None, threads=1):
     """Columns/s of the reference's UNCHANGED Fortran frontend (oracle/_ref/bin/ref_frontend_driver: k%load -> k%gas_optics
     -> rte_lw / rte_sw per block, pageable host arrays) on the HIP library in the given modes ("mirror": host-mirror mode,

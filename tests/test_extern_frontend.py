@@ -204,3 +204,39 @@ def test_openmp_frontend_threads_on_their_own_contexts(kind, tmp_path):
     assert "4 host threads" in log
     for k in ser:
         assert np.array_equal(ser[k], omp[k]), (k, float(np.max(np.abs(ser[k] - omp[k]))))
+
+
+# ---- the invariances of the reference's tests/check_equivalence.F90 (which needs rrtmgp-data) on synthetic streams:
+#      oracle/ref_equivalence_driver.F90, through the reference's unchanged frontend classes
+N_EQUIV_CHECKS = {"lw": 18, "sw": 18}
+
+
+def _equivalence(tmp_path, binary, kind, ncol, nlay, top_at_1, env=None):
+    raw, kd, atm, kf, af = _frontend_case(tmp_path, kind, ncol, nlay, ncol, top_at_1, False, True)
+    rc, checks, log = stream_io.run_equivalence_driver(binary, kf, af, GASES, env=env)
+    return rc, checks, log
+
+
+@pytest.mark.parametrize("kind,top_at_1", [("lw", False), ("sw", True)])
+def test_equivalence_driver_on_the_reference_kernels(kind, top_at_1, tmp_path):
+    """The driver itself, on the reference's own CPU kernels: every invariance holds within the reference's tolerances
+    (2 ... 30 spacings) -- the baseline for the same program on the HIP library."""
+    if not _have("ref_equivalence_driver_cpuref"):
+        pytest.skip("oracle/_ref/bin/ref_equivalence_driver_cpuref absent (needs /root/reference + flang)")
+    rc, checks, log = _equivalence(tmp_path, "ref_equivalence_driver_cpuref", kind, 24, 20, top_at_1)
+    assert rc == 0 and "ref_equivalence_driver ok" in log, log[-3000:]
+    assert len(checks) == N_EQUIV_CHECKS[kind] and all(ok for _, _, ok in checks.values()), checks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,top_at_1,ncol", [("lw", False, 96), ("lw", True, 40), ("sw", False, 96), ("sw", True, 40),
+                                                 ("lw", False, 1024), ("sw", True, 1024)])  # 1024: the production kernels
+def test_equivalence_invariances_on_the_hip_library(kind, top_at_1, ncol, tmp_path):
+    """check_equivalence's invariances through the reference's frontend ON THE HIP LIBRARY, with the reference's own
+    tolerances: net fluxes, vertical flip, column subsets through get_subset (extract_subset kernels), halving + self-increment,
+    transparent 1scl / 2str / nstr increments, Jacobian; SW: flip, TSI scaling, increments."""
+    if not _have("ref_equivalence_driver"):
+        pytest.skip("oracle/_ref/bin/ref_equivalence_driver absent (needs /root/reference + flang at build time)")
+    rc, checks, log = _equivalence(tmp_path, "ref_equivalence_driver", kind, ncol, 24, top_at_1)
+    assert rc == 0 and "ref_equivalence_driver ok" in log, log[-3000:]
+    assert len(checks) == N_EQUIV_CHECKS[kind] and all(ok for _, _, ok in checks.values()), checks
