@@ -12,7 +12,12 @@
 ! the flux files.  The program is the same in both links: library options (host-mirror mode) are switched through
 ! environment variables of the HIP library, never through symbols the reference kernels lack.
 !
-! Usage: ref_frontend_driver <k-distribution stream> <atmosphere stream> <output file> <comma-separated gases>
+! Usage: ref_frontend_driver <k-distribution stream> <atmosphere stream> <output file> <comma-separated gases> [cloud stream]
+! With a cloud stream the block loop is the all-sky example's (examples/all-sky/rrtmgp_allsky.F90:362-404): the reference's
+! ty_cloud_optics_rrtmgp%load on the given look-up tables, then per block cloud_optics%cloud_optics (by band) ->
+! k%gas_optics -> [SW: clouds%delta_scale] -> clouds%increment(gas optical properties) -> rte_lw / rte_sw.
+! Cloud stream: radliq_lwr, radliq_upr, diamice_lwr, diamice_upr (scalars); extliq, ssaliq, asyliq (nsize_liq, nbnd);
+!   extice, ssaice, asyice (nsize_ice, nbnd, nrghice); ice roughness to select (int); lwp, iwp, rel, dei (ncol, nlay).
 ! Atmosphere stream (records as in oracle/mo_raw_stream.F90):
 !   opts  int(8): ncol, nlay, block size, use_col_dry, use_tlev, checks on/off, repetitions of the block loop, n_gauss_angles
 !   p_lay, p_lev, t_lay, t_lev (ncol, nlay[+1]); vmr(ncol, nlay, ngases) in the order of <gases>; col_dry(ncol, nlay);
@@ -30,10 +35,17 @@ program ref_frontend_driver
   use mo_fluxes,             only: ty_fluxes_broadband
   use mo_rte_lw,             only: rte_lw
   use mo_rte_sw,             only: rte_sw
-  use mo_raw_stream,         only: split_names, load_kdist_stream, rd_i1, rd_r1, rd_r2, rd_r3
+  use mo_cloud_optics_rrtmgp,only: ty_cloud_optics_rrtmgp
+  use mo_raw_stream,         only: split_names, load_kdist_stream, rd_i0, rd_r0, rd_i1, rd_r1, rd_r2, rd_r3
   !$ use omp_lib
   implicit none
-  character(len=512) :: fk, fatm, fout, gases_arg
+  character(len=512) :: fk, fatm, fout, gases_arg, fcld
+  logical :: with_clouds
+  type(ty_cloud_optics_rrtmgp) :: cloud_spec
+  real(wp) :: radliq_lwr, radliq_upr, diamice_lwr, diamice_upr
+  real(wp), allocatable :: extliq(:,:), ssaliq(:,:), asyliq(:,:), extice(:,:,:), ssaice(:,:,:), asyice(:,:,:)
+  real(wp), allocatable :: lwp(:,:), iwp(:,:), rel(:,:), dei(:,:), blwp(:,:,:), biwp(:,:,:), brel(:,:,:), bdei(:,:,:)
+  integer :: irgh
   character(len=32), allocatable :: gases(:)
   type(ty_gas_optics_rrtmgp) :: k
   logical :: is_lw
@@ -55,6 +67,8 @@ program ref_frontend_driver
 
   call get_command_argument(1, fk); call get_command_argument(2, fatm)
   call get_command_argument(3, fout); call get_command_argument(4, gases_arg)
+  with_clouds = command_argument_count() >= 5
+  if (with_clouds) call get_command_argument(5, fcld)
   call split_names(gases_arg, gases)
   ngas = size(gases)
   call load_kdist_stream(fk, gases, k, is_lw)
@@ -72,6 +86,19 @@ program ref_frontend_driver
     call rd_r1(u, mu0); call rd_r1(u, sfc_alb)
   end if
   close(u)
+  if (with_clouds) then
+    open(newunit=u, file=trim(fcld), access='stream', form='unformatted', status='old')
+    call rd_r0(u, radliq_lwr); call rd_r0(u, radliq_upr); call rd_r0(u, diamice_lwr); call rd_r0(u, diamice_upr)
+    call rd_r2(u, extliq); call rd_r2(u, ssaliq); call rd_r2(u, asyliq)
+    call rd_r3(u, extice); call rd_r3(u, ssaice); call rd_r3(u, asyice)
+    call rd_i0(u, irgh)
+    call rd_r2(u, lwp); call rd_r2(u, iwp); call rd_r2(u, rel); call rd_r2(u, dei)
+    close(u)
+    ! by-band cloud optics (no band_lims_gpt: one "g-point" per band), examples/all-sky/mo_load_cloud_coefficients.F90
+    call stop_on_err(cloud_spec%load(k%get_band_lims_wavenumber(), radliq_lwr, radliq_upr, diamice_lwr, diamice_upr, &
+                                     extliq, ssaliq, asyliq, extice, ssaice, asyice))
+    call stop_on_err(cloud_spec%set_ice_roughness(irgh))
+  end if
   if (mod(ncol, bs) /= 0) error stop 'ref_frontend_driver: ncol is not a multiple of the block size'
   nblocks = ncol / bs
   ! rte/frontend/mo_rte_config.F90:25-49 (the all-sky example switches the checks off after its first pass,
@@ -96,6 +123,13 @@ program ref_frontend_driver
     allocate(bt_sfc(bs, nblocks))
   else
     allocate(bmu0(bs, nblocks), bdir(bs, nlay+1, nblocks))
+  end if
+  if (with_clouds) then
+    allocate(blwp(bs, nlay, nblocks), biwp(bs, nlay, nblocks), brel(bs, nlay, nblocks), bdei(bs, nlay, nblocks))
+    do b = 1, nblocks
+      c0 = (b - 1) * bs + 1; c1 = b * bs
+      blwp(:, :, b) = lwp(c0:c1, :); biwp(:, :, b) = iwp(c0:c1, :); brel(:, :, b) = rel(c0:c1, :); bdei(:, :, b) = dei(c0:c1, :)
+    end do
   end if
   do b = 1, nblocks
     c0 = (b - 1) * bs + 1; c1 = b * bs
@@ -154,6 +188,8 @@ contains
     type(ty_optical_props_2str) :: op2
     type(ty_source_func_lw) :: src
     type(ty_fluxes_broadband) :: fluxes
+    type(ty_optical_props_1scl) :: cld1
+    type(ty_optical_props_2str) :: cld2
     integer :: b, tid, nthr
     integer(8) :: tb, tc, td, tick_go, tick_rte
     character(len=128) :: e
@@ -164,7 +200,9 @@ contains
     if (is_lw) then
       call stop_on_err(op1%alloc_1scl(bs, nlay, k))
       call stop_on_err(src%alloc(bs, nlay, k))
+      if (with_clouds) call stop_on_err(cld1%alloc_1scl(bs, nlay, cloud_spec))
     else
+      if (with_clouds) call stop_on_err(cld2%alloc_2str(bs, nlay, cloud_spec))
       allocate(toa(bs, ngpt))
       call stop_on_err(op2%alloc_2str(bs, nlay, k))
     end if
@@ -183,6 +221,10 @@ contains
           e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), bt_sfc(:,b), concs(b), op1, src)
         end if
         call stop_on_err(e)
+        if (with_clouds) then   ! rrtmgp_allsky.F90:362-375: clouds as absorbers, added band by band
+          call stop_on_err(cloud_spec%cloud_optics(blwp(:,:,b), biwp(:,:,b), brel(:,:,b), bdei(:,:,b), cld1))
+          call stop_on_err(cld1%increment(op1))
+        end if
         call system_clock(tc)
         call stop_on_err(rte_lw(op1, src, bsfc(:,:,b), fluxes, n_gauss_angles=n_ang))
         call system_clock(td)
@@ -194,6 +236,11 @@ contains
           e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), concs(b), op2, toa)
         end if
         call stop_on_err(e)
+        if (with_clouds) then   ! :382-396: two-stream clouds, delta-scaled, added band by band
+          call stop_on_err(cloud_spec%cloud_optics(blwp(:,:,b), biwp(:,:,b), brel(:,:,b), bdei(:,:,b), cld2))
+          call stop_on_err(cld2%delta_scale())
+          call stop_on_err(cld2%increment(op2))
+        end if
         call system_clock(tc)
         call stop_on_err(rte_sw(op2, bmu0(:,b), toa, bsfc(:,:,b), bsfc(:,:,b), fluxes))
         call system_clock(td)

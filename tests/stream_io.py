@@ -91,14 +91,32 @@ def write_atmosphere_stream(path, atm, is_lw, block, use_col_dry=True, use_tlev=
             _rec(f, "sfc_alb", sfc_alb if sfc_alb is not None else np.full(ncol, 0.06), kind="r")
 
 
-def run_frontend_driver(binary, kfile, afile, ofile, gases, ncol, nlay, is_lw, env=None, timeout=1800):
+def write_cloud_stream(path, tb, clouds, nrough=2, rough=1):
+    """Cloud look-up tables (rte-rrtmgp_amd/synth.py::make_cloud_optics, by band) + cloud field (make_cloud_field) for the
+    all-sky flow of oracle/ref_frontend_driver.F90.  The reference's tables carry an ice-roughness axis: the synthetic ice
+    tables become roughness ``rough`` (1-based) of ``nrough``, the others are perturbed copies that must not be used."""
+    with open(path, "wb") as f:
+        for k in ("radliq_lwr", "radliq_upr", "diamice_lwr", "diamice_upr"):
+            _rec(f, k, scalar=float(tb[k]), kind="r")
+        for k in ("extliq", "ssaliq", "asyliq"):
+            _rec(f, k, tb[k], kind="r")
+        for k in ("extice", "ssaice", "asyice"):
+            a = np.stack([tb[k] if r == rough - 1 else 0.5 * tb[k] for r in range(nrough)], axis=2)
+            _rec(f, k, a, kind="r")
+        _rec(f, "ice_roughness", scalar=int(rough), kind="i")
+        for k in ("lwp", "iwp", "rel", "dei"):
+            _rec(f, k, clouds[k], kind="r")
+
+
+def run_frontend_driver(binary, kfile, afile, ofile, gases, ncol, nlay, is_lw, env=None, timeout=1800, cloud_file=None):
     """Run oracle/_ref/bin/<binary>; returns (fluxes dict of (ncol, nlay+1) arrays, stdout)."""
     path = os.path.join(BIN, binary)
     env = dict(env or {})
     if "_omp" in binary:  # ... and OpenMP worker threads have stacks of their own (virtual reservation only)
         env.setdefault("OMP_STACKSIZE", "24G")
     # flang keeps automatic arrays on the stack
-    r = subprocess.run(f"ulimit -s unlimited 2>/dev/null; exec '{path}' '{kfile}' '{afile}' '{ofile}' '{','.join(gases)}'",
+    r = subprocess.run(f"ulimit -s unlimited 2>/dev/null; exec '{path}' '{kfile}' '{afile}' '{ofile}' '{','.join(gases)}'"
+                       + (f" '{cloud_file}'" if cloud_file else ""),
                        shell=True, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
     global last_stderr
     last_stderr = r.stderr

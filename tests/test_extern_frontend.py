@@ -240,3 +240,70 @@ def test_equivalence_invariances_on_the_hip_library(kind, top_at_1, ncol, tmp_pa
     rc, checks, log = _equivalence(tmp_path, "ref_equivalence_driver", kind, ncol, 24, top_at_1)
     assert rc == 0 and "ref_equivalence_driver ok" in log, log[-3000:]
     assert len(checks) == N_EQUIV_CHECKS[kind] and all(ok for _, _, ok in checks.values()), checks
+
+
+# ---- all-sky (BASELINE configs[3]) through the reference's frontend: ty_cloud_optics_rrtmgp%load /
+#      %cloud_optics (rrtmgp_compute_cld_from_table) -> gas_optics -> delta_scale -> increment (by band) -> rte_lw / rte_sw
+def _allsky_case(tmp_path, kind, ncol, nlay, block, top_at_1, checks=True, **kw):
+    raw, kd, atm, kf, af = _frontend_case(tmp_path, kind, ncol, nlay, block, top_at_1, True, True, checks=checks, **kw)
+    tb = synth.make_cloud_optics(kd.nbnd)
+    clouds = synth.make_cloud_field(atm, tb)
+    cf = str(tmp_path / "c.bin")
+    stream_io.write_cloud_stream(cf, tb, clouds)
+    return raw, kd, atm, tb, clouds, kf, af, cf
+
+
+@pytest.mark.parametrize("kind,top_at_1", [("lw", False), ("sw", True)])
+def test_python_allsky_mirror_matches_the_reference_allsky_frontend(kind, top_at_1, tmp_path):
+    """frontend.allsky_lw / allsky_sw (unfused, on the C oracle) against the reference's own cloud-optics class, delta scaling
+    and by-band increments driven by oracle/ref_frontend_driver.F90 on the reference's CPU kernels."""
+    if not _have("ref_frontend_driver_cpuref"):
+        pytest.skip("oracle/_ref/bin/ref_frontend_driver_cpuref absent (needs /root/reference + flang)")
+    from oracle import oracle as O
+
+    ncol, nlay = 48, 24
+    raw, kd, atm, tb, clouds, kf, af, cf = _allsky_case(tmp_path, kind, ncol, nlay, 16, top_at_1)
+    assert clouds["lwp"].max() > 0 and clouds["iwp"].max() > 0
+    ref, _ = stream_io.run_frontend_driver("ref_frontend_driver_cpuref", kf, af, str(tmp_path / "o.bin"), GASES, ncol, nlay, kind == "lw",
+                                           cloud_file=cf)
+    clr, _ = stream_io.run_frontend_driver("ref_frontend_driver_cpuref", kf, af, str(tmp_path / "o2.bin"), GASES, ncol, nlay, kind == "lw")
+    assert np.max(np.abs(ref["flux_dn"] - clr["flux_dn"])) > 1.0  # the clouds matter
+    c, xp = O.load_c(), frontend.NumpyArrays()
+    A = xp.asarray
+    go, co = frontend.GasOptics(c, kd, xp), frontend.CloudOptics(c, tb, xp)
+    a = {k: A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry")}
+    a["top_at_1"] = atm.top_at_1
+    cl = {k: A(v) for k, v in clouds.items()}
+    if kind == "lw":
+        _, _, r = frontend.allsky_lw(c, xp, go, co, ncol, nlay, a, cl, xp.full((ncol, kd.ngpt), 0.98), fuse=False)
+        pairs = {"flux_up": "flux_up", "flux_dn": "flux_dn"}
+    else:
+        _, _, r = frontend.allsky_sw(c, xp, go, co, ncol, nlay, a, cl, xp.full((ncol, nlay), 0.86), xp.full((ncol, kd.ngpt), 0.06), fuse=False)
+        pairs = {"flux_up": "flux_up", "flux_dn": "flux_dn", "flux_dn_dir": "flux_dir"}
+    for k, kk in pairs.items():
+        assert np.max(np.abs(ref[k] - r[kk])) <= 1e-13 * np.max(np.abs(ref[k])), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,top_at_1,block", [("lw", False, 8), ("lw", True, 512), ("sw", False, 512), ("sw", True, 8)])
+@pytest.mark.parametrize("mirror", [False, True], ids=["staged", "host-mirror"])
+def test_reference_allsky_frontend_on_the_hip_library(kind, top_at_1, block, mirror, tmp_path):
+    """The all-sky example's block loop through the UNCHANGED frontend on librte_rrtmgp_hip.so against the same program on
+    the reference's CPU kernels: 512 columns x 72 layers, g256 / g224-shaped tables, clouds in two columns out of three
+    (rrtmgp_compute_cld_from_table, rte_delta_scale_2str_k, rte_inc_*_bybnd behind the reference's classes)."""
+    assert _have("ref_frontend_driver"), "oracle/_ref/bin/ref_frontend_driver missing: run oracle/build_extern.sh"
+    if not _have("ref_frontend_driver_cpuref"):
+        pytest.skip("reference CPU build of the driver absent")
+    ncol, nlay = 512, 72
+    ngpt, nbnd = (256, 16) if kind == "lw" else (224, 14)
+    raw, kd, atm, tb, clouds, kf, af, cf = _allsky_case(tmp_path, kind, ncol, nlay, block, top_at_1, checks=not mirror, ngpt=ngpt,
+                                                       nbnd=nbnd, nminor_lower=4 * nbnd, nminor_upper=2 * nbnd + 3, seed=13)
+    ref, _ = stream_io.run_frontend_driver("ref_frontend_driver_cpuref", kf, af, str(tmp_path / "ref.bin"), GASES, ncol, nlay, kind == "lw",
+                                           cloud_file=cf)
+    env = {"RTE_HIP_HOST_MIRROR": "1" if mirror else "0"}
+    out, _ = stream_io.run_frontend_driver("ref_frontend_driver", kf, af, str(tmp_path / "hip.bin"), GASES, ncol, nlay, kind == "lw", env=env,
+                                           cloud_file=cf)
+    for k in ref:
+        assert np.all(np.isfinite(out[k])), k
+        err = float(np.max(np.abs(out[k] - ref[k])) / np.max(np.abs(ref[k])))
+        assert err <= 1e-10, (k, err)
