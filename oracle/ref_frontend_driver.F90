@@ -19,7 +19,11 @@
 ! Cloud stream: radliq_lwr, radliq_upr, diamice_lwr, diamice_upr (scalars); extliq, ssaliq, asyliq (nsize_liq, nbnd);
 !   extice, ssaice, asyice (nsize_ice, nbnd, nrghice); ice roughness to select (int); lwp, iwp, rel, dei (ncol, nlay).
 ! Atmosphere stream (records as in oracle/mo_raw_stream.F90):
-!   opts  int(8): ncol, nlay, block size, use_col_dry, use_tlev, checks on/off, repetitions of the block loop, n_gauss_angles
+!   opts  int(8 or 9): ncol, nlay, block size, use_col_dry, use_tlev, checks on/off, repetitions of the block loop, n_gauss_angles
+!         [, variant: 0 default; 1 LW optimal transport angles (k%compute_optimal_angles -> rte_lw(lw_Ds=)); 2 fluxes by band
+!         (ty_fluxes_byband: the solvers' spectral output + rte_sum_byband; the bands are summed for the output file);
+!         3 LW with two-stream clouds (needs the cloud stream): rte_lw's default for 2str properties, the Tang rescaling;
+!         4 the same through lw_solver_2stream (use_2stream=.true.)]  -- the configurations of tests/check_variants.F90
 !   p_lay, p_lev, t_lay, t_lev (ncol, nlay[+1]); vmr(ncol, nlay, ngases) in the order of <gases>; col_dry(ncol, nlay);
 !   LW: t_sfc(ncol), sfc_emis(ncol);  SW: mu0(ncol), sfc_alb(ncol)
 ! Output (stream): flux_up, flux_dn (ncol, nlay+1) [, flux_dn_dir for SW], float64, column fastest.
@@ -33,6 +37,7 @@ program ref_frontend_driver
   use mo_optical_props,      only: ty_optical_props_1scl, ty_optical_props_2str
   use mo_source_functions,   only: ty_source_func_lw
   use mo_fluxes,             only: ty_fluxes_broadband
+  use mo_fluxes_byband,      only: ty_fluxes_byband
   use mo_rte_lw,             only: rte_lw
   use mo_rte_sw,             only: rte_sw
   use mo_cloud_optics_rrtmgp,only: ty_cloud_optics_rrtmgp
@@ -45,7 +50,7 @@ program ref_frontend_driver
   real(wp) :: radliq_lwr, radliq_upr, diamice_lwr, diamice_upr
   real(wp), allocatable :: extliq(:,:), ssaliq(:,:), asyliq(:,:), extice(:,:,:), ssaice(:,:,:), asyice(:,:,:)
   real(wp), allocatable :: lwp(:,:), iwp(:,:), rel(:,:), dei(:,:), blwp(:,:,:), biwp(:,:,:), brel(:,:,:), bdei(:,:,:)
-  integer :: irgh
+  integer :: irgh, variant
   character(len=32), allocatable :: gases(:)
   type(ty_gas_optics_rrtmgp) :: k
   logical :: is_lw
@@ -78,6 +83,8 @@ program ref_frontend_driver
   call rd_i1(u, opts)
   ncol = opts(1); nlay = opts(2); bs = opts(3); use_col_dry = opts(4) /= 0; use_tlev = opts(5) /= 0
   checks = opts(6) /= 0; nrep = max(1, opts(7)); n_ang = max(1, opts(8))
+  variant = 0
+  if (size(opts) >= 9) variant = opts(9)
   call rd_r2(u, p_lay); call rd_r2(u, p_lev); call rd_r2(u, t_lay); call rd_r2(u, t_lev)
   call rd_r3(u, vmr); call rd_r2(u, col_dry)
   if (is_lw) then
@@ -190,6 +197,9 @@ contains
     type(ty_fluxes_broadband) :: fluxes
     type(ty_optical_props_1scl) :: cld1
     type(ty_optical_props_2str) :: cld2
+    type(ty_fluxes_byband) :: bfl
+    real(wp), allocatable, target :: bbu(:,:,:), bbd(:,:,:), bbdir(:,:,:)
+    real(wp), allocatable :: ds(:,:)
     integer :: b, tid, nthr
     integer(8) :: tb, tc, td, tick_go, tick_rte
     character(len=128) :: e
@@ -206,6 +216,18 @@ contains
       allocate(toa(bs, ngpt))
       call stop_on_err(op2%alloc_2str(bs, nlay, k))
     end if
+    if (variant == 1) allocate(ds(bs, ngpt))
+    if (variant == 2) then
+      allocate(bbu(bs, nlay+1, nbnd), bbd(bs, nlay+1, nbnd))
+      bfl%bnd_flux_up => bbu; bfl%bnd_flux_dn => bbd
+      if (.not. is_lw) then
+        allocate(bbdir(bs, nlay+1, nbnd)); bfl%bnd_flux_dn_dir => bbdir
+      end if
+    end if
+    if (variant >= 3) then
+      if (.not. (is_lw .and. with_clouds)) error stop 'ref_frontend_driver: variants 3 and 4 are longwave with clouds'
+      call stop_on_err(op2%alloc_2str(bs, nlay, k)); call stop_on_err(cld2%alloc_2str(bs, nlay, cloud_spec))
+    end if
     do b = 1 + tid, nblocks, nthr
       fluxes%flux_up => bup(:, :, b); fluxes%flux_dn => bdn(:, :, b)   ! (rrtmgp_rfmip_lw.F90:259-260)
       call system_clock(tb)
@@ -221,12 +243,28 @@ contains
           e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), bt_sfc(:,b), concs(b), op1, src)
         end if
         call stop_on_err(e)
-        if (with_clouds) then   ! rrtmgp_allsky.F90:362-375: clouds as absorbers, added band by band
+        if (with_clouds .and. variant < 3) then   ! rrtmgp_allsky.F90:362-375: clouds as absorbers, added band by band
           call stop_on_err(cloud_spec%cloud_optics(blwp(:,:,b), biwp(:,:,b), brel(:,:,b), bdei(:,:,b), cld1))
           call stop_on_err(cld1%increment(op1))
         end if
         call system_clock(tc)
-        call stop_on_err(rte_lw(op1, src, bsfc(:,:,b), fluxes, n_gauss_angles=n_ang))
+        select case (variant)
+        case (1)
+          call stop_on_err(k%compute_optimal_angles(op1, ds))
+          call stop_on_err(rte_lw(op1, src, bsfc(:,:,b), fluxes, lw_Ds=ds))
+        case (2)
+          call stop_on_err(rte_lw(op1, src, bsfc(:,:,b), bfl, n_gauss_angles=n_ang))
+          bup(:, :, b) = sum(bbu, dim=3); bdn(:, :, b) = sum(bbd, dim=3)
+        case (3, 4)
+          ! scattering clouds in the longwave: gas optics into two-stream properties (ssa = 0), clouds added by band
+          e = k%gas_optics(bp_lay(:,:,b), bp_lev(:,:,b), bt_lay(:,:,b), bt_sfc(:,b), concs(b), op2, src, tlev=bt_lev(:,:,b))
+          call stop_on_err(e)
+          call stop_on_err(cloud_spec%cloud_optics(blwp(:,:,b), biwp(:,:,b), brel(:,:,b), bdei(:,:,b), cld2))
+          call stop_on_err(cld2%increment(op2))
+          call stop_on_err(rte_lw(op2, src, bsfc(:,:,b), fluxes, n_gauss_angles=n_ang, use_2stream=(variant == 4)))
+        case default
+          call stop_on_err(rte_lw(op1, src, bsfc(:,:,b), fluxes, n_gauss_angles=n_ang))
+        end select
         call system_clock(td)
       else
         fluxes%flux_dn_dir => bdir(:, :, b)
@@ -242,7 +280,12 @@ contains
           call stop_on_err(cld2%increment(op2))
         end if
         call system_clock(tc)
-        call stop_on_err(rte_sw(op2, bmu0(:,b), toa, bsfc(:,:,b), bsfc(:,:,b), fluxes))
+        if (variant == 2) then
+          call stop_on_err(rte_sw(op2, bmu0(:,b), toa, bsfc(:,:,b), bsfc(:,:,b), bfl))
+          bup(:, :, b) = sum(bbu, dim=3); bdn(:, :, b) = sum(bbd, dim=3); bdir(:, :, b) = sum(bbdir, dim=3)
+        else
+          call stop_on_err(rte_sw(op2, bmu0(:,b), toa, bsfc(:,:,b), bsfc(:,:,b), fluxes))
+        end if
         call system_clock(td)
       end if
       tick_go = tick_go + (tc - tb); tick_rte = tick_rte + (td - tc)

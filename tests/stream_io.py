@@ -75,11 +75,11 @@ def write_kdist_stream(path, raw, is_lw):
 
 
 def write_atmosphere_stream(path, atm, is_lw, block, use_col_dry=True, use_tlev=True, checks=False, nrep=1, n_gauss=1,
-                            sfc_emis=None, mu0=None, sfc_alb=None):
+                            sfc_emis=None, mu0=None, sfc_alb=None, variant=0):
     """Atmosphere (rte-rrtmgp_amd/synth.py::Atmosphere) + options for oracle/ref_frontend_driver.F90."""
     ncol, nlay = atm.play.shape
     with open(path, "wb") as f:
-        _rec(f, "opts", np.array([ncol, nlay, block, int(use_col_dry), int(use_tlev), int(checks), nrep, n_gauss], np.int32), kind="i")
+        _rec(f, "opts", np.array([ncol, nlay, block, int(use_col_dry), int(use_tlev), int(checks), nrep, n_gauss, variant], np.int32), kind="i")
         for tag, a in (("p_lay", atm.play), ("p_lev", atm.plev), ("t_lay", atm.tlay), ("t_lev", atm.tlev), ("vmr", atm.vmr),
                        ("col_dry", atm.col_dry)):
             _rec(f, tag, a, kind="r")

@@ -90,7 +90,7 @@ GASES = list(synth.GAS_NAMES)
 
 
 def _frontend_case(tmp_path, kind, ncol, nlay, block, top_at_1, col_dry, tlev, ngpt=64, nbnd=4, seed=3, checks=True, nrep=1,
-                   n_gauss=1, **raw_kw):
+                   n_gauss=1, variant=0, **raw_kw):
     raw = kdist_load.synth_raw(kind, ngpt=ngpt, nbnd=nbnd, **raw_kw)
     kd = kdist_load.init_from_raw(raw, GASES)
     kd.scalars.pop("gas_names")
@@ -98,7 +98,7 @@ def _frontend_case(tmp_path, kind, ncol, nlay, block, top_at_1, col_dry, tlev, n
     kf, af = str(tmp_path / "k.bin"), str(tmp_path / "a.bin")
     stream_io.write_kdist_stream(kf, raw, kind == "lw")
     stream_io.write_atmosphere_stream(af, atm, kind == "lw", block=block, use_col_dry=col_dry, use_tlev=tlev, checks=checks,
-                                      nrep=nrep, n_gauss=n_gauss)
+                                      nrep=nrep, n_gauss=n_gauss, variant=variant)
     return raw, kd, atm, kf, af
 
 
@@ -307,3 +307,62 @@ def test_reference_allsky_frontend_on_the_hip_library(kind, top_at_1, block, mir
         assert np.all(np.isfinite(out[k])), k
         err = float(np.max(np.abs(out[k] - ref[k])) / np.max(np.abs(ref[k])))
         assert err <= 1e-10, (k, err)
+
+
+# ---- the configurations of the reference's tests/check_variants.F90 through the unchanged frontend (row f2)
+VARIANTS = [
+    # kind, variant, n_gauss, clouds, what
+    ("lw", 0, 3, False, "three quadrature angles"),
+    ("lw", 1, 1, False, "optimal transport angles (compute_optimal_angles -> lw_Ds)"),
+    ("lw", 2, 2, False, "fluxes by band, two angles (spectral output + rte_sum_byband)"),
+    ("sw", 2, 1, False, "fluxes by band"),
+    ("lw", 3, 1, True, "two-stream clouds: Tang rescaling"),
+    ("lw", 4, 1, True, "two-stream clouds: lw_solver_2stream"),
+]
+
+
+def _variant_run(tmp_path, binary, kind, variant, n_gauss, clouds, ncol, nlay, block, env=None, **kw):
+    raw, kd, atm, kf, af = _frontend_case(tmp_path, kind, ncol, nlay, block, False, True, True, n_gauss=n_gauss, variant=variant, **kw)
+    cf = None
+    if clouds:
+        tb = synth.make_cloud_optics(kd.nbnd)
+        cf = str(tmp_path / "c.bin")
+        stream_io.write_cloud_stream(cf, tb, synth.make_cloud_field(atm, tb))
+    out, _ = stream_io.run_frontend_driver(binary, kf, af, str(tmp_path / (binary + ".bin")), GASES, ncol, nlay, kind == "lw", env=env,
+                                           cloud_file=cf)
+    return out
+
+
+def test_frontend_variants_run_on_the_reference_kernels(tmp_path):
+    """The driver's variants on the reference's CPU kernels: each runs and differs from the default calculation (so the
+    GPU comparison below is not a comparison of two default runs)."""
+    if not _have("ref_frontend_driver_cpuref"):
+        pytest.skip("oracle/_ref/bin/ref_frontend_driver_cpuref absent (needs /root/reference + flang)")
+    base = {}
+    for kind in ("lw", "sw"):
+        base[kind] = _variant_run(tmp_path, "ref_frontend_driver_cpuref", kind, 0, 1, False, 24, 20, 8)
+    for kind, variant, n_gauss, clouds, what in VARIANTS:
+        out = _variant_run(tmp_path, "ref_frontend_driver_cpuref", kind, variant, n_gauss, clouds, 24, 20, 8)
+        d = float(np.max(np.abs(out["flux_up"] - base[kind]["flux_up"])) / np.max(np.abs(base[kind]["flux_up"])))
+        if variant == 2 and n_gauss == 1:  # by-band fluxes summed over the bands ARE the broadband fluxes
+            assert d <= 1e-13, (what, d)
+        else:
+            assert d > 1e-6, (what, d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,variant,n_gauss,clouds,what", VARIANTS, ids=[v[4].split(":")[0].split("(")[0].strip().replace(" ", "-") + "-" + v[0] for v in VARIANTS])
+def test_frontend_variants_on_the_hip_library(kind, variant, n_gauss, clouds, what, tmp_path):
+    """check_variants' configurations through the reference's frontend on librte_rrtmgp_hip.so against the CPU build:
+    512 columns x 60 layers in one block (production kernels) with g256 / g224-shaped tables."""
+    assert _have("ref_frontend_driver"), "oracle/_ref/bin/ref_frontend_driver missing: run oracle/build_extern.sh"
+    if not _have("ref_frontend_driver_cpuref"):
+        pytest.skip("reference CPU build of the driver absent")
+    ngpt, nbnd = (256, 16) if kind == "lw" else (224, 14)
+    kw = dict(ngpt=ngpt, nbnd=nbnd, nminor_lower=4 * nbnd, nminor_upper=2 * nbnd + 3, seed=17)
+    ref = _variant_run(tmp_path, "ref_frontend_driver_cpuref", kind, variant, n_gauss, clouds, 512, 60, 512, **kw)
+    out = _variant_run(tmp_path, "ref_frontend_driver", kind, variant, n_gauss, clouds, 512, 60, 512, env={"RTE_HIP_HOST_MIRROR": "0"}, **kw)
+    for k in ref:
+        assert np.all(np.isfinite(out[k])), (what, k)
+        err = float(np.max(np.abs(out[k] - ref[k])) / np.max(np.abs(ref[k])))
+        assert err <= 1e-10, (what, k, err)
