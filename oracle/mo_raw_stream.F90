@@ -113,7 +113,8 @@ contains
     integer, intent(in) :: uin
     real(wp), intent(out) :: a
     integer :: r, d(4)
-    call hdr(uin, r, d); read(uin) a
+    real(8) :: t   ! the streams hold float64 whatever the working precision (RTE_USE_SP builds convert here)
+    call hdr(uin, r, d); read(uin) t; a = real(t, wp)
   end subroutine
   subroutine rd_i1(uin, a)
     integer, intent(in) :: uin
@@ -142,25 +143,41 @@ contains
   subroutine rd_r1(uin, a)
     integer, intent(in) :: uin
     real(wp), allocatable, intent(out) :: a(:)
+    real(8), allocatable :: t(:)
     integer :: r, d(4)
-    call hdr(uin, r, d); allocate(a(d(1))); if (size(a) > 0) read(uin) a
+    call hdr(uin, r, d); allocate(a(d(1)), t(d(1)))
+    if (size(a) > 0) then
+      read(uin) t; a = real(t, wp)
+    end if
   end subroutine
   subroutine rd_r2(uin, a)
     integer, intent(in) :: uin
     real(wp), allocatable, intent(out) :: a(:,:)
+    real(8), allocatable :: t(:,:)
     integer :: r, d(4)
-    call hdr(uin, r, d); allocate(a(d(1), d(2))); if (size(a) > 0) read(uin) a
+    call hdr(uin, r, d); allocate(a(d(1), d(2)), t(d(1), d(2)))
+    if (size(a) > 0) then
+      read(uin) t; a = real(t, wp)
+    end if
   end subroutine
   subroutine rd_r3(uin, a)
     integer, intent(in) :: uin
     real(wp), allocatable, intent(out) :: a(:,:,:)
+    real(8), allocatable :: t(:,:,:)
     integer :: r, d(4)
-    call hdr(uin, r, d); allocate(a(d(1), d(2), d(3))); if (size(a) > 0) read(uin) a
+    call hdr(uin, r, d); allocate(a(d(1), d(2), d(3)), t(d(1), d(2), d(3)))
+    if (size(a) > 0) then
+      read(uin) t; a = real(t, wp)
+    end if
   end subroutine
   subroutine rd_r4(uin, a)
     integer, intent(in) :: uin
     real(wp), allocatable, intent(out) :: a(:,:,:,:)
+    real(8), allocatable :: t(:,:,:,:)
     integer :: r, d(4)
-    call hdr(uin, r, d); allocate(a(d(1), d(2), d(3), d(4))); if (size(a) > 0) read(uin) a
+    call hdr(uin, r, d); allocate(a(d(1), d(2), d(3), d(4)), t(d(1), d(2), d(3), d(4)))
+    if (size(a) > 0) then
+      read(uin) t; a = real(t, wp)
+    end if
   end subroutine
 end module mo_raw_stream

@@ -183,8 +183,8 @@ program ref_frontend_driver
     if (.not. is_lw) flux_dir(c0:c1, :) = bdir(:, :, b)
   end do
   open(newunit=u, file=trim(fout), access='stream', form='unformatted', status='replace')
-  write(u) flux_up; write(u) flux_dn
-  if (.not. is_lw) write(u) flux_dir
+  write(u) real(flux_up, 8); write(u) real(flux_dn, 8)   ! float64 whatever the working precision
+  if (.not. is_lw) write(u) real(flux_dir, 8)
   close(u)
   print *, 'ref_frontend_driver ok'
 contains

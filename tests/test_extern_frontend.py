@@ -366,3 +366,47 @@ def test_frontend_variants_on_the_hip_library(kind, variant, n_gauss, clouds, wh
         assert np.all(np.isfinite(out[k])), (what, k)
         err = float(np.max(np.abs(out[k] - ref[k])) / np.max(np.abs(ref[k])))
         assert err <= 1e-10, (what, k, err)
+
+
+# ---- single precision (the reference's RTE_ENABLE_SP): the frontend compiled with wp = single on librte_rrtmgp_hip_sp.so
+#      (oracle/build_extern_sp.sh)
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog", list(PROGRAMS))
+def test_reference_unit_test_programs_in_single_precision_on_the_hip_library(prog):
+    """The reference's three data-free unit-test programs, -DRTE_USE_SP, on the single-precision HIP library: they apply
+    their own (spacing-based) tolerances in single precision and must print the same lines as on the reference's SP kernels."""
+    path = os.path.join(BIN, prog + "_sp")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/bin/*_sp absent: run oracle/build_extern_sp.sh where /root/reference exists")
+    r = _run(path)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for msg in PROGRAMS[prog]:
+        assert msg in r.stdout, (msg, r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,top_at_1,block", [("lw", False, 8), ("lw", True, 512), ("sw", False, 512), ("sw", True, 8)])
+def test_reference_gas_optics_frontend_in_single_precision(kind, top_at_1, block, tmp_path):
+    """Row f4 in single precision: load -> gas_optics -> rte_lw / rte_sw with wp = single on librte_rrtmgp_hip_sp.so.  Two
+    single-precision implementations differ from each other by as much as each differs from the truth (SW upward fluxes:
+    a few 1e-2 W/m2), so the yardstick is the DOUBLE-precision run of the same program on the reference's CPU kernels: the HIP
+    SP fluxes must be within the reference's own acceptance threshold for SP results (3.5e-1 W/m2 absolute,
+    examples/compare-to-reference.py) and not further from the truth than 3x the reference's SP kernels are."""
+    need = ("ref_frontend_driver_sp", "ref_frontend_driver_sp_cpuref", "ref_frontend_driver_cpuref")
+    if not all(_have(b) for b in need):
+        pytest.skip("oracle/_ref/bin/ref_frontend_driver_sp[_cpuref] absent: run oracle/build_extern_sp.sh")
+    ncol, nlay = 512, 60
+    ngpt, nbnd = (256, 16) if kind == "lw" else (224, 14)
+    raw, kd, atm, kf, af = _frontend_case(tmp_path, kind, ncol, nlay, block, top_at_1, True, True, ngpt=ngpt, nbnd=nbnd,
+                                          nminor_lower=4 * nbnd, nminor_upper=2 * nbnd + 3, seed=19, checks=True)
+
+    def run(binary, **kw):
+        return stream_io.run_frontend_driver(binary, kf, af, str(tmp_path / (binary + ".bin")), GASES, ncol, nlay, kind == "lw", **kw)[0]
+
+    truth, cpu_sp = run("ref_frontend_driver_cpuref"), run("ref_frontend_driver_sp_cpuref")
+    out = run("ref_frontend_driver_sp", env={"RTE_HIP_HOST_MIRROR": "0"})
+    for k in truth:
+        assert np.all(np.isfinite(out[k])), k
+        e_hip, e_cpu = float(np.max(np.abs(out[k] - truth[k]))), float(np.max(np.abs(cpu_sp[k] - truth[k])))
+        assert e_hip <= 3.5e-1, (k, e_hip)
+        assert e_hip <= 3.0 * e_cpu + 1e-3, (k, e_hip, e_cpu)
