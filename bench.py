@@ -246,7 +246,13 @@ def cpu_baseline(ncol_block=32, seconds_all=8.0, seconds_one=4.0, workload="lw")
 
             nt = max(1, min(8, cores))
             m = stream_io.measure_frontend_driver("lw", 98304, 4096, ("mirror", "staged", "cpuref"), nrep=3)
-            mt = stream_io.measure_frontend_driver("lw", 98304, 4096, ("mirror",), nrep=3, threads=nt) if nt > 1 else m
+            mt = m
+            if nt > 1:
+                # (the threaded rate depends on where the process's threads and pinned buffers land -- 0.3 ... 2.3 M columns/s
+                #  from one start of the program to the next on a 256-CPU host with a 16-CPU quota: best of three starts)
+                runs = [stream_io.measure_frontend_driver("lw", 98304, 4096, ("mirror",), nrep=4, threads=nt) for _ in range(3)]
+                mt = max(runs, key=lambda r: r["mirror"]["columns_per_s"])
+                mt["mirror"]["passes"] = [p for r in runs for p in r["mirror"]["passes"]]
             host_arrays = {"hip_host_mirror_columns_per_s": round(mt["mirror"]["columns_per_s"], 1),
                            "hip_host_mirror_host_threads": nt,
                            "hip_host_mirror_1thread_columns_per_s": round(m["mirror"]["columns_per_s"], 1),
