@@ -1046,11 +1046,26 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     return a.top_at_1 ? p : nlay - 1 - p;
   };
 
-  constexpr bool DIRLDS = L <= 9 && !SPEC;  // the direct-flux accumulators in LDS (ds_add_f64 on the thread's own slots): 2L+2 registers
+  // PREF: the next g-point's inputs are requested into the registers of the current ones as soon as pass (1) has consumed
+  // them (3 L + 4 doubles in flight during passes (2) and (3)).  Worth 3 % where it fits (8 and 9 layers per wave, broadband:
+  // 12.1-12.2 against 12.5-12.6 ms at 1e5 x 60 x 224); the kernel is bound by its arithmetic and the two waves of a SIMD cover
+  // most of each other's wait for a g-point's first inputs.  Where it does not fit it costs far more than it gives: the
+  // spectral-output variants spilled (17.7 -> 15.6 ms at 60 layers, 31.1 -> 17.9 ms at 72 without it), and 10 ... 12 layers
+  // per wave (73 ... 96 layers) spilled 61-112 registers and ran at 244-320 us per layer -- without the prefetch they run at
+  // the 100-108 us per layer of the others (-DSW_PREF_ALL / -DSW_PREF_NONE for the A/B).
+#if defined(SW_PREF_ALL)
+  constexpr bool PREF = true;
+#elif defined(SW_PREF_NONE)
+  constexpr bool PREF = false;
+#else
+  constexpr bool PREF = L <= 9 && !SPEC;
+#endif
+  constexpr bool DIRLDS = (L <= 9 || L >= 11) && !SPEC;  // the direct-flux accumulators in LDS (ds_add_f64 on the thread's own slots): 2L+2 registers
   // L == 9 (72 layers) is 15 registers over: the upward-flux accumulators go to LDS as well, and to make room there
   // only ONE value per layer is parked (the reciprocal is formed again per g-point, 6 instructions per layer)
   constexpr bool UPLDS = L == 9 && !SPEC;
-  constexpr int NMU = UPLDS ? 1 : 2;
+  constexpr bool ONEMU = UPLDS || (L >= 11 && !SPEC);  // one parked value per layer (L >= 11: room for the direct-flux slots)
+  constexpr int NMU = ONEMU ? 1 : 2;
   Float* const dirs = MU + (size_t)SMAX * NMU * L * 64 + (size_t)s * (L + 1) * 64 + lane;  // acc_dir slot i at dirs[i * 64]
   Float* const ups = MU + (size_t)SMAX * NMU * L * 64 + (size_t)SMAX * (L + 1) * 64 + (size_t)s * (L + 1) * 64 + lane;
   // per-layer cosine of the solar zenith angle and what depends on it alone: independent of the g-point, parked in
@@ -1062,7 +1077,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   for (int i = 0; i < L; ++i) {
     const Float m = a.mu0[c + (size_t)ncol * layer_of(i)];
     const Float ms = fmax(min_mu0, m);
-    if constexpr (UPLDS) {
+    if constexpr (ONEMU) {
       mu0s[i * 64] = m > (Float)0 ? ms : -ms;
     } else {
       mu0s[i * 64] = ms;
@@ -1152,7 +1167,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         const Float e2 = e1 * e1;
         // RT = 1 / x (:1031) and w0 RT / om (:1054) from ONE reciprocal, of x om
         const Float xden = kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2);
-        const Float mu0_s = UPLDS ? fabs(mu0s[i * 64]) : mu0s[i * 64];
+        const Float mu0_s = ONEMU ? fabs(mu0s[i * 64]) : mu0s[i * 64];
         const Float k_mu = kk * mu0_s;
         const Float om = (Float)1 - k_mu * k_mu;
         const Float om_s = fabs(om) >= (Float)RTE_EPS ? om : (Float)RTE_EPS;
@@ -1167,7 +1182,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         const Float alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
         const Float k_gamma3 = kk * gamma3, k_gamma4 = kk * gamma4;
         Float imu;
-        if constexpr (UPLDS) { const Float r_ = rte::rcp_nr(mu0_s); imu = mu0s[i * 64] > (Float)0 ? r_ : -r_; }
+        if constexpr (ONEMU) { const Float r_ = rte::rcp_nr(mu0_s); imu = mu0s[i * 64] > (Float)0 ? r_ : -r_; }
         else imu = mu0i[i * 64];
         const Float Tnoscat = rte::exp_nonpos(-tau_s * fabs(imu));
         Float Rdir = RT * (((Float)1 - k_mu) * (alpha2 + k_gamma3) - ((Float)1 + k_mu) * (alpha2 - k_gamma3) * e2 -
@@ -1198,7 +1213,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     // the layer inputs are dead: request the next g-point's into the same registers (in flight during (2), (3);
     // spreading the requests over pass (1), layer by layer, was tried: the register allocator spills)
     const Float inc_dir = x.inc_dir, alb_dir = x.alb_dir, alb_dif = x.alb_dif, inc_dif = x.inc_dif;
-    load(x, igpt_next);
+    if constexpr (PREF) load(x, igpt_next);
     X1[(0 * SMAX + s) * 64 + lane] = P;
     X1[(1 * SMAX + s) * 64 + lane] = m00;
     X1[(2 * SMAX + s) * 64 + lane] = m02;
@@ -1276,8 +1291,12 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   };
 
   In cur;
-  load(cur, g_begin);
-  for (int igpt = g_begin; igpt < g_end; ++igpt) { gcur = igpt; process(cur, igpt + 1); }
+  if constexpr (PREF) load(cur, g_begin);
+  for (int igpt = g_begin; igpt < g_end; ++igpt) {
+    gcur = igpt;
+    if constexpr (!PREF) load(cur, igpt);
+    process(cur, igpt + 1);
+  }
   if constexpr (SPEC) return;
   if (active) {
     const size_t base = icol + nclv * blockIdx.y;
@@ -1313,6 +1332,7 @@ struct Lw2SegArgs {
 
 template <int L>
 __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
+  constexpr bool PREF = L <= 10;  // input prefetch while it fits (see sw_2stream_seg_kernel); 11 and 12 layers per wave without
   constexpr int SMAX = 8, NC1 = 7;
   extern __shared__ Float lds[];  // X1[NC1][SMAX][64] (m00, m02, m10, m11, m12, m20, m22), X2[2][SMAX][64] (A, B)
   Float* const X1 = lds;
@@ -1392,7 +1412,7 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
       m00 = n00; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m22 = n22;
     }
     const Float emis = x.emis, ssrc = x.ssrc, inc = x.inc;
-    load(x, igpt_next);  // the layer inputs are dead: the next g-point's go into the same registers
+    if constexpr (PREF) load(x, igpt_next);  // the layer inputs are dead: the next g-point's go into the same registers
     X1[(0 * SMAX + s) * 64 + lane] = m00;
     X1[(1 * SMAX + s) * 64 + lane] = m02;
     X1[(2 * SMAX + s) * 64 + lane] = m10;
@@ -1455,8 +1475,11 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
   };
 
   In cur;
-  load(cur, g_begin);
-  for (int igpt = g_begin; igpt < g_end; ++igpt) process(cur, igpt, igpt + 1);
+  if constexpr (PREF) load(cur, g_begin);
+  for (int igpt = g_begin; igpt < g_end; ++igpt) {
+    if constexpr (!PREF) load(cur, igpt);
+    process(cur, igpt, igpt + 1);
+  }
 }
 
 
@@ -1479,6 +1502,7 @@ struct LwRescArgs {
 template <int L, bool do_jac>
 __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArgs a) {
 #pragma clang fp contract(fast)
+  constexpr bool PREF = L <= 9;  // input prefetch (5 L + 6 doubles) while it fits; 10 ... 12 layers per wave without
   constexpr int SMAX = 8;
   extern __shared__ Float lds[];  // X[2 buffers (g-point parity)][4 (T, Sd1, Su2, Sd3)][SMAX][64]
   const int lane = threadIdx.x & 63;
@@ -1547,7 +1571,7 @@ __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArg
       Td = Td * t[i];
     }
     const Float emis = x.emis, ssrc = x.ssrc, inc = x.inc, sjac = x.sjac;
-    load(x, igpt_next);  // the layer inputs are dead: the next g-point's go into the same registers
+    if constexpr (PREF) load(x, igpt_next);  // the layer inputs are dead: the next g-point's go into the same registers
     X(0, s) = Td; X(1, s) = Sd;
     __syncthreads();
     // ---- sweep 1 (down) across the segments, then inside this one
@@ -1616,8 +1640,11 @@ __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArg
   };
 
   In cur;
-  load(cur, g_begin);
-  for (int igpt = g_begin; igpt < g_end; ++igpt) process(cur, igpt + 1, igpt & 1);
+  if constexpr (PREF) load(cur, g_begin);
+  for (int igpt = g_begin; igpt < g_end; ++igpt) {
+    if constexpr (!PREF) load(cur, igpt);
+    process(cur, igpt + 1, igpt & 1);
+  }
   if (active) {
     const size_t base = icol + nclv * blockIdx.y;
 #pragma unroll
@@ -1729,9 +1756,9 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
   // lose to the generic kernel (measured: 12 layers per wave 20.6 vs 18.4 ms, 16 per wave 44 vs 19 ms at 1e5 x 128)
   const int L = nlay <= 64 ? 8 : nlay <= 72 ? 9 : 10;
   const int S = (nlay + L - 1) / L;
-  if (do_broadband && do_rescaling && nlay <= 72 && !g_lw_force_generic) {
+  if (do_broadband && do_rescaling && nlay <= 96 && !g_lw_force_generic) {
     // ------------------------------------------------------------------ production path with rescaling
-    const int Lr = nlay <= 64 ? 8 : 9;
+    const int Lr = nlay <= 64 ? 8 : nlay <= 72 ? 9 : nlay <= 80 ? 10 : nlay <= 88 ? 11 : 12;
     const int Sr = (nlay + Lr - 1) / Lr;
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
@@ -1750,8 +1777,11 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
         rte::ProfScope p("lw_noscat_rescale_seg_kernel");
 #define RTE_LAUNCH_RESC(LL, JJ) \
   hipLaunchKernelGGL((lw_noscat_rescale_seg_kernel<LL, JJ>), dim3(col_tiles, ngroups), dim3(64 * Sr), lds_bytes, st, q)
-        if (Lr == 8) { if (do_jac) RTE_LAUNCH_RESC(8, true); else RTE_LAUNCH_RESC(8, false); }
-        else         { if (do_jac) RTE_LAUNCH_RESC(9, true); else RTE_LAUNCH_RESC(9, false); }
+        if (Lr == 8)       { if (do_jac) RTE_LAUNCH_RESC(8, true); else RTE_LAUNCH_RESC(8, false); }
+        else if (Lr == 9)  { if (do_jac) RTE_LAUNCH_RESC(9, true); else RTE_LAUNCH_RESC(9, false); }
+        else if (Lr == 10) { if (do_jac) RTE_LAUNCH_RESC(10, true); else RTE_LAUNCH_RESC(10, false); }
+        else if (Lr == 11) { if (do_jac) RTE_LAUNCH_RESC(11, true); else RTE_LAUNCH_RESC(11, false); }
+        else               { if (do_jac) RTE_LAUNCH_RESC(12, true); else RTE_LAUNCH_RESC(12, false); }
 #undef RTE_LAUNCH_RESC
       }
       rte::ProfScope p("lw_reduce_parts");
@@ -1963,8 +1993,8 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
   a.sfc_emis = c.in(sfc_emis, ncg); a.sfc_src = c.in(sfc_src, ncg); a.inc_flux = c.in(inc_flux, ncg);
   a.flux_up = c.out(flux_up, nclv * ngpt); a.flux_dn = c.out(flux_dn, nclv * ngpt);
   // ------------------------------------------------------------------ production path (nlay <= 64)
-  if (nlay <= 80 && !g_lw_force_generic) {
-    const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);  // layers per wave (always 8 waves), see rte_sw_solver_2stream
+  if (nlay <= 96 && !g_lw_force_generic) {
+    const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : nlay <= 80 ? 10 : nlay <= 88 ? 11 : 12);  // layers per wave (always 8 waves), see rte_sw_solver_2stream
     const int S = (nlay + L - 1) / L;
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
@@ -1978,7 +2008,9 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const size_t lds_bytes = sizeof(Float) * 64 * 8 * (7 + 2);
     if (L == 8) hipLaunchKernelGGL((lw_2stream_seg_kernel<8>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
     else if (L == 9) hipLaunchKernelGGL((lw_2stream_seg_kernel<9>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
-    else hipLaunchKernelGGL((lw_2stream_seg_kernel<10>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
+    else if (L == 10) hipLaunchKernelGGL((lw_2stream_seg_kernel<10>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
+    else if (L == 11) hipLaunchKernelGGL((lw_2stream_seg_kernel<11>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
+    else hipLaunchKernelGGL((lw_2stream_seg_kernel<12>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
     return;
   }
   const size_t gchunk = pick_gchunk(sizeof(Float) * ncl * 4, ngpt);
@@ -2039,9 +2071,10 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
   }
   hipStream_t st0 = rte::stream();
   // ------------------------------------------------------------------ production path (broadband, nlay <= 64)
-  if (do_broadband && nlay <= 80 && !g_sw_force_generic && ncl < ((size_t)1 << 29)) {  // 32-bit in-plane byte offsets
+  constexpr int kSwMaxLay = 96;  // 8 waves x up to 12 layers (11: no spill, 12: 7 spilled registers); above: generic kernel
+  if (do_broadband && nlay <= kSwMaxLay && !g_sw_force_generic && ncl < ((size_t)1 << 29)) {  // 32-bit in-plane byte offsets
     // layers per wave: 8 up to 64 layers, then 9 (72 layers: the all-sky configuration) or 10 -- always 8 waves
-    const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);
+    const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : nlay <= 80 ? 10 : nlay <= 88 ? 11 : 12);
     const int S = (nlay + L - 1) / L;
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
@@ -2056,12 +2089,14 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     q.part_dir = q.part_dn + nclv * ngroups;
     q.spec_up = q.spec_dn = q.spec_dir = nullptr; q.band_lims = nullptr;
     // composites, flux maps, mu0 (clamped, reciprocal; L == 9: one value), direct-flux (L == 9: and upward-flux) accumulators
-    const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + (L == 9 ? 1 : 2) * 8 * L + (L <= 9 ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
+    const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + ((L == 9 || L >= 11) ? 1 : 2) * 8 * L + ((L <= 9 || L >= 11) ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
     {
       rte::ProfScope p("sw_2stream_seg_kernel");
       if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
       else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
-      else hipLaunchKernelGGL((sw_2stream_seg_kernel<10>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+      else if (L == 10) hipLaunchKernelGGL((sw_2stream_seg_kernel<10>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+      else if (L == 11) hipLaunchKernelGGL((sw_2stream_seg_kernel<11>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+      else hipLaunchKernelGGL((sw_2stream_seg_kernel<12>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
     }
     rte::ProfScope p("sw_reduce_parts");
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_up, d_bu, (Float)1, false);
@@ -2069,10 +2104,10 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_dir, d_bdir, (Float)1, false);
     return;
   }
-  if (!do_broadband && nlay <= 80 && !g_sw_force_generic && nclv < ((size_t)1 << 29)) {
+  if (!do_broadband && nlay <= kSwMaxLay && !g_sw_force_generic && nclv < ((size_t)1 << 29)) {
     // ---------------------------------------------------------------- production path, spectral output: the same
     // segmented kernel, every wave storing the three fluxes of the levels it owns per g-point
-    const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);
+    const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : nlay <= 80 ? 10 : nlay <= 88 ? 11 : 12);
     const int S = (nlay + L - 1) / L;
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
@@ -2088,7 +2123,9 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     rte::ProfScope p("sw_2stream_seg_spectral_kernel");
     if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
     else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
-    else hipLaunchKernelGGL((sw_2stream_seg_kernel<10, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+    else if (L == 10) hipLaunchKernelGGL((sw_2stream_seg_kernel<10, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+    else if (L == 11) hipLaunchKernelGGL((sw_2stream_seg_kernel<11, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+    else hipLaunchKernelGGL((sw_2stream_seg_kernel<12, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
     return;
   }
   // ------------------------------------------------------------------ generic path
@@ -2163,11 +2200,11 @@ int rte_hip_sw_solver_2stream_byband(int ncol, int nlay, int ngpt, int nbnd, int
                                      Float* byband_dir) {
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0 || nbnd <= 0) return 0;
   const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1), ncg = (size_t)ncol * ngpt;
-  if (nlay > 80 || nclv >= ((size_t)1 << 29)) return -2;
+  if (nlay > 96 || nclv >= ((size_t)1 << 29)) return -2;
   RTE_TRY
   rte::Call c("rte_hip_sw_solver_2stream_byband");
   Sw2SegArgs q;
-  const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : 10);
+  const int L = nlay <= 64 ? 8 : (nlay <= 72 ? 9 : nlay <= 80 ? 10 : nlay <= 88 ? 11 : 12);
   q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = (nlay + L - 1) / L; q.g_per_block = 0;
   q.top_at_1 = top_at_1 != 0; q.has_dif_bc = has_dif_bc != 0;
   q.band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
@@ -2176,13 +2213,15 @@ int rte_hip_sw_solver_2stream_byband(int ncol, int nlay, int ngpt, int nbnd, int
   q.inc_flux_dif = has_dif_bc ? c.in(inc_flux_dif, ncg) : nullptr;
   q.part_up = c.out(byband_up, nclv * nbnd); q.part_dn = c.out(byband_dn, nclv * nbnd); q.part_dir = c.out(byband_dir, nclv * nbnd);
   q.spec_up = q.spec_dn = q.spec_dir = nullptr;
-  const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + (L == 9 ? 1 : 2) * 8 * L + (L <= 9 ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
+  const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + ((L == 9 || L >= 11) ? 1 : 2) * 8 * L + ((L <= 9 || L >= 11) ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
   rte::ProfScope p("sw_2stream_seg_byband_kernel");
   hipStream_t st = rte::stream();
   const dim3 grid(cdiv(ncol, 64), nbnd), blk(64 * q.S);
   if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8>), grid, blk, lds_bytes, st, q);
   else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9>), grid, blk, lds_bytes, st, q);
-  else hipLaunchKernelGGL((sw_2stream_seg_kernel<10>), grid, blk, lds_bytes, st, q);
+  else if (L == 10) hipLaunchKernelGGL((sw_2stream_seg_kernel<10>), grid, blk, lds_bytes, st, q);
+  else if (L == 11) hipLaunchKernelGGL((sw_2stream_seg_kernel<11>), grid, blk, lds_bytes, st, q);
+  else hipLaunchKernelGGL((sw_2stream_seg_kernel<12>), grid, blk, lds_bytes, st, q);
   return 0;
   RTE_CATCH("rte_hip_sw_solver_2stream_byband")
   return -1;

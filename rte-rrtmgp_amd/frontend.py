@@ -642,7 +642,7 @@ def rte_sw_byband(lib, xp, ncol, nlay, ngpt, nbnd, band_lims_gpt, top_at_1, tau,
     b = buffers if buffers is not None else {}
     if "bb_up" not in b:
         b["bb_up"], b["bb_dn"], b["bb_dir"] = (xp.empty((ncol, nlay + 1, nbnd)) for _ in range(3))
-    if lib.has("rte_hip_sw_solver_2stream_byband") and nlay <= 80:
+    if lib.has("rte_hip_sw_solver_2stream_byband") and nlay <= 96:
         from . import hiplib
 
         dif = inc_flux_dif if inc_flux_dif is not None else inc_flux_dir
