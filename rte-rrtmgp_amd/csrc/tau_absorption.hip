@@ -889,10 +889,16 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr bool PARK = RAYL != 0;  // (the variants that would otherwise spill)
   constexpr int NPARK = PARK ? 3 : 0;
   __shared__ Float s_park[NPARK ? NPARK : 1][NPARK ? TILE : 1];
+  // ... and the two row indices (temperature, pressure), packed into one int: the compiler kept address terms derived from
+  // them in scratch and reloaded those at the top of every stage (2 KB; the block's LDS is within 1.5 KB of the limit)
+  __shared__ int s_parki[1][PARK ? TILE : 1];
   unsigned park_at = 0;  // LDS byte address of this thread's first slot (the low half of the generic address)
+  unsigned parki_at = 0;
   if constexpr (PARK) {
     s_park[0][tid] = dens; s_park[1][tid] = vmr_fact; s_park[2][tid] = dry_fact;
+    s_parki[0][tid] = jT | (jp << 16);  // (both below 2^15: table dimensions)
     park_at = (unsigned)(uintptr_t)&s_park[0][tid];
+    parki_at = (unsigned)(uintptr_t)&s_parki[0][tid];
   }
   // read back with an explicit ds_read (a volatile access from inside the stage lambdas becomes a flat load, and an
   // ordinary one is hoisted back into a register)
@@ -905,6 +911,12 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     return v;
   };
 #define RTE_PARKED(i, in_register) (PARK ? parked(park_at, i) : (in_register))
+  auto parked_i = [](unsigned at, int i) -> int {  // i = 0: temperature index, 1: pressure index
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(at) : "memory");
+    return i == 0 ? (v & 0xFFFF) : (v >> 16);
+  };
+#define RTE_PARKED_I(i, in_register) (PARK ? parked_i(parki_at, i) : (in_register))
 
   // major weights + eta indices of band b (requested one stage ahead)
   struct Major { Float2 fm[4], cm; int2 je; };
@@ -1080,8 +1092,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const Float* sl = slab[s & 1];
     const int rowsMaj = nP * nT * nE;
     const int rowsLo = (has_lo ? bm[ibnd].cnt[0] : 0) * nT * nE;
-    const Float* A0 = sl + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS;
-    const Float* B0 = sl + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS;
+    const int jT_s = RTE_PARKED_I(0, jT), jp_s = RTE_PARKED_I(1, jp);
+    const Float* A0 = sl + (((jp_s - 1 - Pmin) * nT + (jT_s - Tmin)) * nE + (je1 - emin)) * RS;
+    const Float* B0 = sl + (((jp_s - 1 - Pmin) * nT + (jT_s + 1 - Tmin)) * nE + (je2 - emin)) * RS;
     const int sP = nT * nE * RS;
     const Float* M0 = sl + (rowsMaj + (regime == 2 ? rowsLo : 0)) * RS;
     // (RAYL: the stage's stores are issued here, see below)
@@ -1168,8 +1181,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const Float f0 = fn0.x, f1 = fn0.y, f2 = fn1.x, f3 = fn1.y;
     // one minor interval's contribution (:757-760, :493): 4 corner rows of its plane, 2 g-points per LDS read
     auto minor_rows = [&](int k, Float scaling) {
-      const Float* r1 = M0 + ((k * nT + (jT - Tmin)) * nE + (em.x - emin)) * RS;
-      const Float* r2 = M0 + ((k * nT + (jT + 1 - Tmin)) * nE + (em.y - emin)) * RS;
+      const int jT_m = RTE_PARKED_I(0, jT);
+      const Float* r1 = M0 + ((k * nT + (jT_m - Tmin)) * nE + (em.x - emin)) * RS;
+      const Float* r2 = M0 + ((k * nT + (jT_m + 1 - Tmin)) * nE + (em.y - emin)) * RS;
       if constexpr (ROLL) {
       Float2 qb[2][4];  // one g-point pair (4 row reads) per step, the next step's requested ahead
       auto rdm = [&](Float2 (&q)[4], int j) { q[0] = ld2(r1 + j); q[1] = ld2(r1 + RS + j); q[2] = ld2(r2 + j); q[3] = ld2(r2 + RS + j); };
@@ -1239,8 +1253,10 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       // combine_abs_and_rayleigh and the optional by-band increment on the values in registers (rayl_finish), and
       // the stage's 3 x G stores.  Rows [regime][t][eta] behind the minor planes; unconditional stores as below.
       const int rowsUp_ = (has_up ? bm[ibnd].cnt[1] : 0) * nT * nE;
-      const Float* R1 = sl + (rowsMaj + rowsLo + rowsUp_ + ((itropo * nT + (jT - Tmin)) * nE + (je1 - emin))) * RS;
-      const Float* R2 = sl + (rowsMaj + rowsLo + rowsUp_ + ((itropo * nT + (jT + 1 - Tmin)) * nE + (je2 - emin))) * RS;
+      const int jT_r = RTE_PARKED_I(0, jT);
+      const Float wray_s = wray;
+      const Float* R1 = sl + (rowsMaj + rowsLo + rowsUp_ + ((itropo * nT + (jT_r - Tmin)) * nE + (je1 - emin))) * RS;
+      const Float* R2 = sl + (rowsMaj + rowsLo + rowsUp_ + ((itropo * nT + (jT_r + 1 - Tmin)) * nE + (je2 - emin))) * RS;
       char* const splane = reinterpret_cast<char*>(a.rf.ssa + (size_t)ncl * g0);
       char* const gplane = reinterpret_cast<char*>(a.rf.g + (size_t)ncl * g0);
 #pragma unroll
@@ -1251,7 +1267,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           Float t_, s_, g_;
-          rayl_finish(acc[j + u], (u == 0 ? ka : kb) * wray, RAYL == 2, cld_t, cld_s, cld_g, t_, s_, g_);
+          rayl_finish(acc[j + u], (u == 0 ? ka : kb) * wray_s, RAYL == 2, cld_t, cld_s, cld_g, t_, s_, g_);
           store_stream(tau_at(j + u), t_);
           store_stream(reinterpret_cast<Float*>(splane + gstride * (j + u) + toff), s_);
           store_stream(reinterpret_cast<Float*>(gplane + gstride * (j + u) + toff), g_);
@@ -1701,7 +1717,7 @@ static void tau_absorption_impl(
                     al(d_fmajor, 16) && al(d_fminor, 16) && al(d_col_mix, 16) && al(d_jeta, 8) &&
                     (overwrite_ok || rte::is_device_memory(d_tau)) &&
                     (!rh || (overwrite_ok && g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 &&
-                             npres + 1 < 63));  // (fused: the bands tile the g-points -- else tau was zero-filled above --
+                             npres + 1 < 63 && nbnd <= 16));  // (16: the fused variants' static LDS + the band table, 160 KB)  // (fused: the bands tile the g-points -- else tau was zero-filled above --
                                                 //  and the bit-mask geometry, which counts the Rayleigh rows)
   // the direct Rayleigh + combine kernel of the fused entry: everything (run_if == nullptr), only when the guard
   // fired (run_if = the flag), or the worklist entries
