@@ -494,6 +494,8 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   }
   // software prefetch: the next g-point's loads are in flight while this one is computed.  (A ring of tiles
   // unrolled so that no tile is copied measures the same and needs 45 more registers; two g-points ahead spill.)
+  // (round 3: without this prefetch the kernel needs 179 instead of 230 registers and is 1-4 % slower, 7.5-7.7 against
+  // 7.4 ms at 1e5 x 60 x 256 -- the two waves of a SIMD cover most of each other's waits; kept, it fits)
   SegTile<L> cur;
   load(cur, g_begin);
   int buf = 0, gl = 0, chunk = 0;
@@ -585,6 +587,15 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
                       Float* __restrict__ spec_up, Float* __restrict__ spec_dn, bool spec_add) {
 #pragma clang fp contract(fast)
   constexpr int LT = 2 * L, MAXS = 8;
+  // input prefetch (see process): kept where it fits; the widest variant and the Jacobian variants spilled 39-103 registers
+  // with it and run without (-DLW2_PREF_ALL / -DLW2_PREF_NONE for the A/B)
+#if defined(LW2_PREF_ALL)
+  constexpr bool PREF2 = true;
+#elif defined(LW2_PREF_NONE)
+  constexpr bool PREF2 = false;
+#else
+  constexpr bool PREF2 = false;
+#endif
   extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][MAXS][64], then A's parked values [3][L][512]
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -653,6 +664,7 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
   // registers right there (in flight during the rest of this g-point) -- one set of input registers, not two
   auto process = [&](SegTile<L>& ta, SegTile<L>& tb, int buf, int ig) {
 #pragma clang fp contract(fast)
+    if constexpr (!PREF2) loadA(ta, ig);
     Float t[L], sd[L], su[L];
     const Float D = ta.D, emis = ta.emis, ssrc = ta.ssrc, inc = ta.inc, sjac = ta.sjac;
     auto pass1 = [&](const SegTile<L>& x, Float& Td, Float& Sd, Float& Su) {
@@ -679,9 +691,10 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
 #pragma unroll
     for (int i = 0; i < L; ++i) { PARK[(0 * L + i) * 512] = t[i]; PARK[(1 * L + i) * 512] = sd[i]; PARK[(2 * L + i) * 512] = su[i]; }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!PREF2) loadB(tb, ig);
     pass1(tb, TdB, SdB, SuB);
     __builtin_amdgcn_sched_barrier(0);
-    loadA(ta, ig + 1);
+    if constexpr (PREF2) loadA(ta, ig + 1);
     // A above B: down through A then B; up through B then A
     Float* X = lds + (size_t)buf * 3 * MAXS * 64;
     X[(0 * MAXS + s) * 64 + lane] = TdA * TdB;
@@ -731,11 +744,10 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
       if (do_jac) { jv = ta_ * jv; acc_j[i] += jv; }
     }
     __builtin_amdgcn_sched_barrier(0);
-    loadB(tb, ig + 1);
+    if constexpr (PREF2) loadB(tb, ig + 1);
   };
   SegTile<L> ta, tb;
-  loadA(ta, g_begin);
-  loadB(tb, g_begin);
+  if constexpr (PREF2) { loadA(ta, g_begin); loadB(tb, g_begin); }
   int buf = 0;
 #pragma unroll 1
   for (int igpt = g_begin; igpt < g_end; ++igpt, buf ^= 1) process(ta, tb, buf, igpt);
@@ -1865,10 +1877,10 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     return;
   }
 
-  if (!do_rescaling && nlay > 80 && nlay <= 160 && !g_lw_force_generic && nclv < ((size_t)1 << 29)) {
+  if (!do_rescaling && nlay > 80 && nlay <= 176 && !g_lw_force_generic && nclv < ((size_t)1 << 29)) {
     // ---------------------------------------------------------------- production path, 81 ... 160 layers: two sub-segments
-    // of 8 / 9 / 10 layers per wave (lw_noscat_seg2_kernel), broadband or spectral output
-    const int L2 = nlay <= 128 ? 8 : nlay <= 144 ? 9 : 10;
+    // of 8 ... 11 layers per wave (lw_noscat_seg2_kernel), broadband or spectral output
+    const int L2 = nlay <= 128 ? 8 : nlay <= 144 ? 9 : nlay <= 160 ? 10 : 11;
     const int S2 = (nlay + 2 * L2 - 1) / (2 * L2);
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
@@ -1895,7 +1907,7 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     if (do_broadband) { if (do_jac) RTE_LAUNCH_SEG2(LL, true, false); else RTE_LAUNCH_SEG2(LL, false, false); } \
     else              { if (do_jac) RTE_LAUNCH_SEG2(LL, true, true); else RTE_LAUNCH_SEG2(LL, false, true); }   \
   } while (0)
-        if (L2 == 8) RTE_LAUNCH_SEG2_(8); else if (L2 == 9) RTE_LAUNCH_SEG2_(9); else RTE_LAUNCH_SEG2_(10);
+        if (L2 == 8) RTE_LAUNCH_SEG2_(8); else if (L2 == 9) RTE_LAUNCH_SEG2_(9); else if (L2 == 10) RTE_LAUNCH_SEG2_(10); else RTE_LAUNCH_SEG2_(11);
 #undef RTE_LAUNCH_SEG2_
 #undef RTE_LAUNCH_SEG2
       }

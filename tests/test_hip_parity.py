@@ -168,10 +168,11 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
 
 
-@pytest.mark.parametrize("nlay,top_at_1", [(81, True), (91, False), (128, True), (137, False), (144, True), (160, False)])
+@pytest.mark.parametrize("nlay,top_at_1", [(81, True), (91, False), (128, True), (137, False), (144, True), (160, False), (170, True),
+                                           (176, False)])
 def test_lw_noscat_with_more_than_80_layers(hip, oracle_c, nlay, top_at_1):
     """Host models at 91 / 128 / 137 levels: the reference has no layer limit (rte/kernels/mo_rte_solver_kernels.F90:697-743).
-    81 ... 160 layers run on the two-sub-segment kernel (8 waves x 2 x 8 / 9 / 10 layers): broadband with three angles,
+    81 ... 176 layers run on the two-sub-segment kernel (8 waves x 2 x 8 ... 11 layers): broadband with three angles,
     incident flux and Jacobian, and spectral output, against the oracle; partial last waves (81, 91, 137) included."""
     import numpy as np
 
@@ -194,7 +195,7 @@ def test_lw_noscat_with_more_than_80_layers(hip, oracle_c, nlay, top_at_1):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1, kw)
 
 
-@pytest.mark.parametrize("nlay,top_at_1", [(27, False), (60, True), (72, False), (75, True)])
+@pytest.mark.parametrize("nlay,top_at_1", [(27, False), (60, True), (72, False), (75, True), (91, False)])
 def test_byband_fluxes_from_the_segmented_kernels(hip, oracle_c, nlay, top_at_1):
     """By-band fluxes (ty_fluxes_byband, rte/extensions/mo_fluxes_byband.F90:46-137): the reference reduces the spectral
     arrays with rte_sum_byband; the extensions rte_hip_lw_solver_noscat_byband / rte_hip_sw_solver_2stream_byband accumulate per
