@@ -1532,12 +1532,19 @@ __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArg
   const int g_end = min(a.ngpt, g_begin + a.g_per_block);
 
   // the level accumulators live in LDS (ds_add_f64 on the thread's own slots): 4L+4 registers the three sweeps need
-  Float* const ACC = lds + 2 * 4 * SMAX * 64 + (size_t)s * (L + 1) * 2 * 64 + lane;  // [wave][slot][dn, up][64]
-  Float acc_j[do_jac ? L + 1 : 1];
-  auto add_dn = [&](int i, Float v) { atomicAdd(&ACC[(2 * i) * 64], v); };
-  auto add_up = [&](int i, Float v) { atomicAdd(&ACC[(2 * i + 1) * 64], v); };
+  constexpr int AW = L >= 14 ? 1 : 2;  // values per level slot in LDS (from 14 layers per wave on: the upward one only)
+  Float* const ACC = lds + 2 * 4 * SMAX * 64 + (size_t)s * (L + 1) * AW * 64 + lane;  // [wave][slot][dn, up][64]
+  // (from 14 layers per wave on the LDS holds only the upward ones; the downward ones stay in registers)
+  constexpr bool DNREG = L >= 14;
+  Float acc_j[do_jac ? L + 1 : 1], acc_dn[DNREG ? L + 1 : 1];
+  auto add_dn = [&](int i, Float v) { if constexpr (DNREG) acc_dn[i] += v; else atomicAdd(&ACC[(2 * i) * 64], v); };
+  auto add_up = [&](int i, Float v) { atomicAdd(&ACC[(AW * i + AW - 1) * 64], v); };
 #pragma unroll
-  for (int i = 0; i <= L; ++i) { ACC[(2 * i) * 64] = 0; ACC[(2 * i + 1) * 64] = 0; if (do_jac) acc_j[i] = 0; }
+  for (int i = 0; i <= L; ++i) {
+    if constexpr (DNREG) acc_dn[i] = 0; else ACC[(2 * i) * 64] = 0;
+    ACC[(AW * i + AW - 1) * 64] = 0;
+    if (do_jac) acc_j[i] = 0;
+  }
 
   struct In { Float tau[L], ssa[L], g[L], lay[L], lev[L + 1], D, emis, ssrc, inc, sjac; };
   auto load = [&](In& x, int igpt_) {
@@ -1664,8 +1671,8 @@ __global__ void __launch_bounds__(64 * 8) lw_noscat_rescale_seg_kernel(LwRescArg
       if (i < np || (last && i == np)) {
         const int p = p0 + i;
         const int ilev = a.top_at_1 ? p : nlay - p;
-        a.part_dn[base + (size_t)ncol * ilev] = ACC[(2 * i) * 64];
-        a.part_up[base + (size_t)ncol * ilev] = ACC[(2 * i + 1) * 64];
+        if constexpr (DNREG) a.part_dn[base + (size_t)ncol * ilev] = acc_dn[i]; else a.part_dn[base + (size_t)ncol * ilev] = ACC[(2 * i) * 64];
+        a.part_up[base + (size_t)ncol * ilev] = ACC[(AW * i + AW - 1) * 64];
         if (do_jac) a.part_jac[base + (size_t)ncol * ilev] = acc_j[i];
       }
     }
@@ -1768,9 +1775,9 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
   // lose to the generic kernel (measured: 12 layers per wave 20.6 vs 18.4 ms, 16 per wave 44 vs 19 ms at 1e5 x 128)
   const int L = nlay <= 64 ? 8 : nlay <= 72 ? 9 : 10;
   const int S = (nlay + L - 1) / L;
-  if (do_broadband && do_rescaling && nlay <= 96 && !g_lw_force_generic) {
+  if (do_broadband && do_rescaling && nlay <= 144 && !g_lw_force_generic) {
     // ------------------------------------------------------------------ production path with rescaling
-    const int Lr = nlay <= 64 ? 8 : nlay <= 72 ? 9 : nlay <= 80 ? 10 : nlay <= 88 ? 11 : 12;
+    const int Lr = nlay <= 64 ? 8 : nlay <= 72 ? 9 : nlay <= 80 ? 10 : nlay <= 88 ? 11 : nlay <= 96 ? 12 : nlay <= 112 ? 14 : nlay <= 128 ? 16 : 18;
     const int Sr = (nlay + Lr - 1) / Lr;
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
@@ -1782,7 +1789,8 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     q.part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
     q.part_dn = q.part_up + nclv * ngroups;
     q.part_jac = do_jac ? q.part_dn + nclv * ngroups : nullptr;
-    const size_t lds_bytes = sizeof(Float) * (2 * 4 * 8 * 64 + 8 * (Lr + 1) * 2 * 64);  // composites + level accumulators
+    // composites + level accumulators (from 14 layers per wave on: the upward ones only, in the same [slot][2] layout)
+    const size_t lds_bytes = sizeof(Float) * (2 * 4 * 8 * 64 + 8 * (Lr + 1) * (Lr >= 14 ? 1 : 2) * 64);
     for (int imu = 0; imu < nmus; ++imu) {
       q.weight = w_h[imu]; q.D = d_Ds + ncg * imu;
       {
@@ -1793,7 +1801,10 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
         else if (Lr == 9)  { if (do_jac) RTE_LAUNCH_RESC(9, true); else RTE_LAUNCH_RESC(9, false); }
         else if (Lr == 10) { if (do_jac) RTE_LAUNCH_RESC(10, true); else RTE_LAUNCH_RESC(10, false); }
         else if (Lr == 11) { if (do_jac) RTE_LAUNCH_RESC(11, true); else RTE_LAUNCH_RESC(11, false); }
-        else               { if (do_jac) RTE_LAUNCH_RESC(12, true); else RTE_LAUNCH_RESC(12, false); }
+        else if (Lr == 12) { if (do_jac) RTE_LAUNCH_RESC(12, true); else RTE_LAUNCH_RESC(12, false); }
+        else if (Lr == 14) { if (do_jac) RTE_LAUNCH_RESC(14, true); else RTE_LAUNCH_RESC(14, false); }
+        else if (Lr == 16) { if (do_jac) RTE_LAUNCH_RESC(16, true); else RTE_LAUNCH_RESC(16, false); }
+        else               { if (do_jac) RTE_LAUNCH_RESC(18, true); else RTE_LAUNCH_RESC(18, false); }
 #undef RTE_LAUNCH_RESC
       }
       rte::ProfScope p("lw_reduce_parts");
@@ -2240,3 +2251,4 @@ int rte_hip_sw_solver_2stream_byband(int ncol, int nlay, int ngpt, int nbnd, int
 }
 
 }  // extern "C"
+

@@ -195,6 +195,30 @@ def test_lw_noscat_with_more_than_80_layers(hip, oracle_c, nlay, top_at_1):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1, kw)
 
 
+@pytest.mark.parametrize("nlay,top_at_1", [(100, False), (112, True), (128, False), (137, True), (144, False)])
+def test_lw_rescaling_with_up_to_144_layers(hip, oracle_c, nlay, top_at_1):
+    """rte_lw's default for two-stream (cloudy) optical properties -- lw_solver_noscat with Tang rescaling -- on the segmented
+    three-sweep kernel with 14 / 16 / 18 layers per wave (97 ... 144 layers: IFS-137-class host models), two angles, incident
+    flux and Jacobian, against the oracle."""
+    import numpy as np
+
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    rng = np.random.default_rng(1000 + nlay)
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    ncol, ngpt = 70, 16
+    tau, ssa, g = F(ncol, nlay, ngpt) * 2.0, F(ncol, nlay, ngpt) * 0.999, F(ncol, nlay, ngpt) * 0.9 - 0.1
+    lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
+    emis, sfc, inc, sj = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10, F(ncol, ngpt), F(ncol, ngpt)
+    for kw, keys in ((dict(n_gauss_angles=2, do_jacobians=True), ("flux_up", "flux_dn", "flux_up_jac")), (dict(), ("flux_up", "flux_dn"))):
+        ref = frontend.rte_lw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, lay, lev, emis, sfc, ssa=ssa, g=g,
+                              inc_flux=inc, sfc_src_jac=sj, **kw)
+        out = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(lay), A(lev), A(emis), A(sfc), ssa=A(ssa), g=A(g),
+                              inc_flux=A(inc), sfc_src_jac=A(sj), **kw)
+        for k in keys:
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1, kw)
+
+
 @pytest.mark.parametrize("nlay,top_at_1", [(27, False), (60, True), (72, False), (75, True), (91, False)])
 def test_byband_fluxes_from_the_segmented_kernels(hip, oracle_c, nlay, top_at_1):
     """By-band fluxes (ty_fluxes_byband, rte/extensions/mo_fluxes_byband.F90:46-137): the reference reduces the spectral
