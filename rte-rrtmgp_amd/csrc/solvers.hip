@@ -1027,11 +1027,19 @@ struct Sw2SegArgs {
   Float *part_up, *part_dn, *part_dir;  // (ncol, nlev, ngroups)
   Float *spec_up, *spec_dn, *spec_dir;  // SPEC: the interface's spectral flux arrays (ncol, nlev, ngpt)
   const int* band_lims;                 // non-null (rte_hip_sw_solver_2stream_byband): grid.y = band, part_* are the by-band fluxes
+  // WIN (columns of more than 96 layers, solved as an upper and a lower part): the kernel works on a WINDOW of nlay layers of
+  // arrays whose g-point planes have plane_lay / plane_lev elements (pointers already offset to the window's first row)
+  size_t plane_lay, plane_lev, plane_part;
+  int beam_mode;        // 0: beam at the window's top = inc_flux_dir * mu0 (top of the column); 1: unit beam; 2: inc_flux_dir as it is
+  bool sfc_src_given;   // the "surface" is the part below: source = beam * sfc_alb_dir without the sun test
+  bool skip_first_level;  // the window's first level belongs to the part above
+  Float *out_alb, *out_src;  // (ncol, ngpt): albedo and (relative) source at the window's top
+  Float *out_fd, *out_dir;   // (ncol, ngpt): diffuse and direct downward flux at the window's bottom
 };
 
 // SPEC: spectral output (rte_sw with a ty_fluxes other than ty_fluxes_broadband, rte/frontend/mo_rte_sw.F90): every wave
 // stores the three fluxes of the levels it owns per g-point instead of accumulating them
-template <int L, bool SPEC = false>
+template <int L, bool SPEC = false, bool WIN = false>
 __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 #pragma clang fp contract(fast)  // VALU-bound: fuse a*b+c (the segment composites already differ from the reference's rounding)
   constexpr int SMAX = 8, NC1 = 8, NC2 = 2;
@@ -1045,7 +1053,8 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   const int icol = blockIdx.x * 64 + lane;
   const bool active = icol < ncol;
   const int c = active ? icol : ncol - 1;  // clamp: inactive lanes compute on a valid column, never store
-  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const size_t ncl = WIN ? a.plane_lay : (size_t)ncol * nlay, nclv = WIN ? a.plane_lev : (size_t)ncol * (nlay + 1);
+  const size_t nclp = WIN ? a.plane_part : nclv;  // one partial slab
   const int p0 = s * L;
   const int np = min(L, nlay - p0);  // layers in this segment (>= 1 by construction)
   const bool last = (s == S - 1);
@@ -1070,7 +1079,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 #elif defined(SW_PREF_NONE)
   constexpr bool PREF = false;
 #else
-  constexpr bool PREF = L <= 9 && !SPEC;
+  constexpr bool PREF = L <= 9 && !SPEC && !WIN;
 #endif
   constexpr bool DIRLDS = (L <= 9 || L >= 11) && !SPEC;  // the direct-flux accumulators in LDS (ds_add_f64 on the thread's own slots): 2L+2 registers
   // L == 9 (72 layers) is 15 registers over: the upward-flux accumulators go to LDS as well, and to make room there
@@ -1236,7 +1245,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     X1[(7 * SMAX + s) * 64 + lane] = m22;
     __syncthreads();
     // ---- (2) beam entering every segment; adding chain from the surface up to this segment's lower edge
-    const Float dir_toa = inc_dir * mu0_top;  // :575
+    const Float dir_toa = !WIN || a.beam_mode == 0 ? inc_dir * mu0_top : (a.beam_mode == 1 ? (Float)1 : inc_dir);  // :575
     Float dir_in = dir_toa, dir_q = dir_toa;    // dir_q: beam entering segment q
     Float dq[SMAX];
 #pragma unroll
@@ -1247,7 +1256,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     }
     const Float dir_sfc = dir_q;
     Float alb = alb_dif;                                                  // :1121
-    Float src = (mu0_sfc > (Float)0) ? dir_sfc * alb_dir : (Float)0;     // :1120
+    Float src = (mu0_sfc > (Float)0 || (WIN && a.sfc_src_given)) ? dir_sfc * alb_dir : (Float)0;     // :1120
 #pragma unroll
     for (int q = SMAX - 1; q > 0; --q) {
       if (q < S && q > s) {  // wave-uniform
@@ -1277,6 +1286,12 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
       alb = alb_new; src = src_new;
       al[i] = alb; sr[i] = src;
     }
+    if constexpr (WIN) {
+      if (a.out_alb && s == 0 && active) {  // (wave 0: dir_in is the beam entering the window)
+        a.out_alb[icol + (size_t)ncol * gcur] = al[0];
+        a.out_src[icol + (size_t)ncol * gcur] = sr[0];
+      }
+    }
     Float A = 1, B = 0;
 #pragma unroll
     for (int i = 0; i < L; ++i) { B = fa[i] * B + fb[i]; A = fa[i] * A; }
@@ -1300,6 +1315,12 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     add_up(L, fd * al[L] + sr[L]);
     add_dn(L, fd + dirl);
     add_dir(L, dirl);
+    if constexpr (WIN) {
+      if (a.out_fd && last && active) {  // (neutral slots pass the values on: these are the fluxes at the window's bottom)
+        a.out_fd[icol + (size_t)ncol * gcur] = fd;
+        a.out_dir[icol + (size_t)ncol * gcur] = dirl;
+      }
+    }
   };
 
   In cur;
@@ -1311,10 +1332,10 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   }
   if constexpr (SPEC) return;
   if (active) {
-    const size_t base = icol + nclv * blockIdx.y;
+    const size_t base = icol + nclp * blockIdx.y;
 #pragma unroll
     for (int i = 0; i <= L; ++i) {
-      if (i < np || (last && i == np)) {
+      if ((i < np || (last && i == np)) && !(WIN && a.skip_first_level && s == 0 && i == 0)) {
         const int p = p0 + i;  // level position from the top
         const int ilev = a.top_at_1 ? p : nlay - p;
         if constexpr (UPLDS) a.part_up[base + (size_t)ncol * ilev] = ups[i * 64];
@@ -2125,6 +2146,51 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_up, d_bu, (Float)1, false);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_dn, d_bd, (Float)1, false);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_dir, d_bdir, (Float)1, false);
+    return;
+  }
+  if (do_broadband && nlay > kSwMaxLay && nlay <= 2 * kSwMaxLay && !g_sw_force_generic && nclv < ((size_t)1 << 29)) {
+    // ------------------------------------------------------------------ 97 ... 192 layers: the column as an upper part T and a
+    // lower part B, each on the segmented kernel (WIN).  The adding method composes: (1) B alone gives the albedo and the source
+    // (per unit of beam) it presents at its top; (2) T is solved with those as its "surface" and leaves the diffuse and the
+    // direct flux at its bottom; (3) B is solved again with these as its top boundary.  B is made as short as T's limit
+    // allows (it is evaluated twice).
+    const int nT = nlay <= 88 + kSwMaxLay ? 88 : kSwMaxLay, nB = nlay - nT;  // (11 layers per wave: the widest variant without spills)
+    const int col_tiles = cdiv(ncol, 64);
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    Float* parts = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * 3);
+    Float* side = (Float*)rte::scratch(sizeof(Float) * ncg * 4);  // albedo / source at B's top, diffuse / direct flux at T's bottom
+    const bool top = *top_at_1;
+    auto run = [&](int lay0, int nl, int phase) {
+      Sw2SegArgs q{};
+      const int L = nl <= 64 ? 8 : (nl <= 72 ? 9 : nl <= 80 ? 10 : nl <= 88 ? 11 : 12);
+      q.ncol = ncol; q.nlay = nl; q.ngpt = ngpt; q.S = (nl + L - 1) / L; q.g_per_block = g_per_block; q.top_at_1 = top;
+      // first row of the window: layer position lay0 from the top (layers), the same for levels
+      const size_t off = (size_t)ncol * (top ? lay0 : nlay - lay0 - nl);
+      q.tau = a.tau + off; q.ssa = a.ssa + off; q.g = a.g + off; q.mu0 = a.mu0 + off;
+      q.plane_lay = ncl; q.plane_lev = nclv; q.plane_part = nclv;
+      q.part_up = parts + off; q.part_dn = q.part_up + nclv * ngroups; q.part_dir = q.part_dn + nclv * ngroups;
+      q.sfc_alb_dir = a.sfc_alb_dir; q.sfc_alb_dif = a.sfc_alb_dif; q.inc_flux_dir = a.inc_flux_dir; q.inc_flux_dif = a.inc_flux_dif;
+      q.has_dif_bc = *has_dif_bc;
+      if (phase == 1) { q.beam_mode = 1; q.has_dif_bc = false; q.out_alb = side; q.out_src = side + ncg; }
+      if (phase == 2) { q.sfc_alb_dif = side; q.sfc_alb_dir = side + ncg; q.sfc_src_given = true; q.out_fd = side + 2 * ncg; q.out_dir = side + 3 * ncg; }
+      if (phase == 3) { q.beam_mode = 2; q.inc_flux_dir = side + 3 * ncg; q.inc_flux_dif = side + 2 * ncg; q.has_dif_bc = true; q.skip_first_level = true; }
+      const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + ((L == 9 || L >= 11) ? 1 : 2) * 8 * L + ((L <= 9 || L >= 11) ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
+      rte::ProfScope p("sw_2stream_seg_kernel");
+      const dim3 grid(col_tiles, ngroups), blk(64 * q.S);
+      if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, false, true>), grid, blk, lds_bytes, st0, q);
+      else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9, false, true>), grid, blk, lds_bytes, st0, q);
+      else if (L == 10) hipLaunchKernelGGL((sw_2stream_seg_kernel<10, false, true>), grid, blk, lds_bytes, st0, q);
+      else if (L == 11) hipLaunchKernelGGL((sw_2stream_seg_kernel<11, false, true>), grid, blk, lds_bytes, st0, q);
+      else hipLaunchKernelGGL((sw_2stream_seg_kernel<12, false, true>), grid, blk, lds_bytes, st0, q);
+    };
+    run(nT, nB, 1);
+    run(0, nT, 2);
+    run(nT, nB, 3);
+    rte::ProfScope p("sw_reduce_parts");
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, parts, d_bu, (Float)1, false);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, parts + nclv * ngroups, d_bd, (Float)1, false);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, parts + 2 * nclv * ngroups, d_bdir, (Float)1, false);
     return;
   }
   if (!do_broadband && nlay <= kSwMaxLay && !g_sw_force_generic && nclv < ((size_t)1 << 29)) {
