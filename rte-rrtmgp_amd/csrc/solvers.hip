@@ -1125,7 +1125,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     }
   }
   auto spec_store = [&](Float* __restrict__ arr, int i, Float v) {
-    if (active && (i < np || (last && i == np)))
+    if (active && (i < np || (last && i == np)) && !(WIN && a.skip_first_level && s == 0 && i == 0))
       rte::store_stream(reinterpret_cast<Float*>(reinterpret_cast<char*>(arr + nclv * gcur) + (olev0 + (unsigned)i * dlev)), v);
   };
   auto add_dir = [&](int i, Float v) {
@@ -2148,7 +2148,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_dir, d_bdir, (Float)1, false);
     return;
   }
-  if (do_broadband && nlay > kSwMaxLay && nlay <= 2 * kSwMaxLay && !g_sw_force_generic && nclv < ((size_t)1 << 29)) {
+  if (nlay > kSwMaxLay && nlay <= 2 * kSwMaxLay && !g_sw_force_generic && nclv < ((size_t)1 << 29)) {
     // ------------------------------------------------------------------ 97 ... 192 layers: the column as an upper part T and a
     // lower part B, each on the segmented kernel (WIN).  The adding method composes: (1) B alone gives the albedo and the source
     // (per unit of beam) it presents at its top; (2) T is solved with those as its "surface" and leaves the diffuse and the
@@ -2158,7 +2158,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
     const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
-    Float* parts = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * 3);
+    Float* parts = do_broadband ? (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * 3) : nullptr;
     Float* side = (Float*)rte::scratch(sizeof(Float) * ncg * 4);  // albedo / source at B's top, diffuse / direct flux at T's bottom
     const bool top = *top_at_1;
     auto run = [&](int lay0, int nl, int phase) {
@@ -2169,15 +2169,26 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
       const size_t off = (size_t)ncol * (top ? lay0 : nlay - lay0 - nl);
       q.tau = a.tau + off; q.ssa = a.ssa + off; q.g = a.g + off; q.mu0 = a.mu0 + off;
       q.plane_lay = ncl; q.plane_lev = nclv; q.plane_part = nclv;
-      q.part_up = parts + off; q.part_dn = q.part_up + nclv * ngroups; q.part_dir = q.part_dn + nclv * ngroups;
+      if (do_broadband) { q.part_up = parts + off; q.part_dn = q.part_up + nclv * ngroups; q.part_dir = q.part_dn + nclv * ngroups; }
+      else { q.spec_up = d_up + off; q.spec_dn = d_dn + off; q.spec_dir = d_dir + off; }  // (spectral: phase 1 writes B's levels too, phases 2 and 3 overwrite them)
       q.sfc_alb_dir = a.sfc_alb_dir; q.sfc_alb_dif = a.sfc_alb_dif; q.inc_flux_dir = a.inc_flux_dir; q.inc_flux_dif = a.inc_flux_dif;
       q.has_dif_bc = *has_dif_bc;
       if (phase == 1) { q.beam_mode = 1; q.has_dif_bc = false; q.out_alb = side; q.out_src = side + ncg; }
       if (phase == 2) { q.sfc_alb_dif = side; q.sfc_alb_dir = side + ncg; q.sfc_src_given = true; q.out_fd = side + 2 * ncg; q.out_dir = side + 3 * ncg; }
       if (phase == 3) { q.beam_mode = 2; q.inc_flux_dir = side + 3 * ncg; q.inc_flux_dif = side + 2 * ncg; q.has_dif_bc = true; q.skip_first_level = true; }
-      const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + ((L == 9 || L >= 11) ? 1 : 2) * 8 * L + ((L <= 9 || L >= 11) ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
-      rte::ProfScope p("sw_2stream_seg_kernel");
+      const size_t lds_bytes = do_broadband
+          ? sizeof(Float) * 64 * (8 * 8 + 2 * 8 + ((L == 9 || L >= 11) ? 1 : 2) * 8 * L + ((L <= 9 || L >= 11) ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0))
+          : sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 2 * 8 * L);
+      rte::ProfScope p(do_broadband ? "sw_2stream_seg_kernel" : "sw_2stream_seg_spectral_kernel");
       const dim3 grid(col_tiles, ngroups), blk(64 * q.S);
+      if (!do_broadband) {
+        if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, true, true>), grid, blk, lds_bytes, st0, q);
+        else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9, true, true>), grid, blk, lds_bytes, st0, q);
+        else if (L == 10) hipLaunchKernelGGL((sw_2stream_seg_kernel<10, true, true>), grid, blk, lds_bytes, st0, q);
+        else if (L == 11) hipLaunchKernelGGL((sw_2stream_seg_kernel<11, true, true>), grid, blk, lds_bytes, st0, q);
+        else hipLaunchKernelGGL((sw_2stream_seg_kernel<12, true, true>), grid, blk, lds_bytes, st0, q);
+        return;
+      }
       if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, false, true>), grid, blk, lds_bytes, st0, q);
       else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9, false, true>), grid, blk, lds_bytes, st0, q);
       else if (L == 10) hipLaunchKernelGGL((sw_2stream_seg_kernel<10, false, true>), grid, blk, lds_bytes, st0, q);
@@ -2187,6 +2198,7 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     run(nT, nB, 1);
     run(0, nT, 2);
     run(nT, nB, 3);
+    if (!do_broadband) return;
     rte::ProfScope p("sw_reduce_parts");
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, parts, d_bu, (Float)1, false);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, parts + nclv * ngroups, d_bd, (Float)1, false);
