@@ -63,13 +63,18 @@ def test_two_threads_on_two_contexts_reproduce_the_serial_results():
 
     def work(kind, reps=3):
         try:
-            ctx = create(-1, None)  # own non-blocking stream
+            torch.cuda.set_device(0)
+            # one stream per thread for BOTH the library's kernels and torch's own (fills, copies made by the array
+            # container): the frontend mirror assumes that the two are ordered, as bench.py arranges with rte_hip_set_stream
+            st = torch.cuda.Stream()
+            ctx = create(-1, ctypes.c_void_p(st.cuda_stream))
             assert ctx
             setc(ctx)
-            torch.cuda.set_device(0)
             try:
-                for _ in range(reps):
-                    results[kind] = _chain(hip, xp, kind, *cases[kind], ncol)
+                with torch.cuda.stream(st):
+                    for _ in range(reps):
+                        results[kind] = _chain(hip, xp, kind, *cases[kind], ncol)
+                    st.synchronize()
             finally:
                 setc(None)
                 assert destroy(ctx) == 0
