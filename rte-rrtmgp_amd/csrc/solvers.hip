@@ -1361,11 +1361,16 @@ struct Lw2SegArgs {
   bool top_at_1, lev_gpt1;
   const Float *tau, *ssa, *g, *lev_source, *sfc_emis, *sfc_src, *inc_flux;
   Float *flux_up, *flux_dn;  // (ncol, nlev, ngpt)
+  // WIN (more than 96 layers, solved as an upper and a lower part; see sw_2stream_seg_kernel): window of nlay layers inside
+  // arrays with these plane sizes; the "surface" given as albedo and source (in sfc_emis, sfc_src); side outputs
+  size_t plane_lay, plane_lev;
+  bool sfc_given, skip_first_level;
+  Float *out_alb, *out_src, *out_fd;  // (ncol, ngpt)
 };
 
-template <int L>
+template <int L, bool WIN = false>
 __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
-  constexpr bool PREF = L <= 10;  // input prefetch while it fits (see sw_2stream_seg_kernel); 11 and 12 layers per wave without
+  constexpr bool PREF = L <= 10 && !WIN;  // input prefetch while it fits (see sw_2stream_seg_kernel); 11 and 12 layers per wave without
   constexpr int SMAX = 8, NC1 = 7;
   extern __shared__ Float lds[];  // X1[NC1][SMAX][64] (m00, m02, m10, m11, m12, m20, m22), X2[2][SMAX][64] (A, B)
   Float* const X1 = lds;
@@ -1376,7 +1381,7 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
   const int icol = blockIdx.x * 64 + lane;
   const bool active = icol < ncol;
   const int c = active ? icol : ncol - 1;  // clamp: inactive lanes compute on a valid column, never store
-  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const size_t ncl = WIN ? a.plane_lay : (size_t)ncol * nlay, nclv = WIN ? a.plane_lev : (size_t)ncol * (nlay + 1);
   const int p0 = s * L;
   const int np = min(L, nlay - p0);  // layers in this segment (>= 1 by construction)
   const bool last = (s == S - 1);
@@ -1455,8 +1460,8 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
     X1[(6 * SMAX + s) * 64 + lane] = m22;
     __syncthreads();
     // ---- (2) adding chain from the surface up to this segment's lower edge, then the own layers
-    Float alb = (Float)1 - emis;        // :428
-    Float src = kPi * emis * ssrc;      // :965
+    Float alb = (WIN && a.sfc_given) ? emis : (Float)1 - emis;        // :428
+    Float src = (WIN && a.sfc_given) ? ssrc : kPi * emis * ssrc;      // :965
 #pragma unroll
     for (int q = SMAX - 1; q > 0; --q) {
       if (q < S && q > s) {  // wave-uniform
@@ -1482,6 +1487,9 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
       alb = alb_new; src = src_new;
       al[i] = alb; sr[i] = src;
     }
+    if constexpr (WIN) {
+      if (a.out_alb && s == 0 && active) { a.out_alb[icol + (size_t)ncol * igpt] = al[0]; a.out_src[icol + (size_t)ncol * igpt] = sr[0]; }
+    }
     Float A = 1, B = 0;
 #pragma unroll
     for (int i = 0; i < L; ++i) { B = fa[i] * B + fb[i]; A = fa[i] * A; }
@@ -1497,13 +1505,16 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
     Float* fdn = a.flux_dn + icol + nclv * igpt;
 #pragma unroll
     for (int i = 0; i <= L; ++i) {
-      if (active && (i < np || (last && i == np))) {
+      if (active && (i < np || (last && i == np)) && !(WIN && a.skip_first_level && s == 0 && i == 0)) {
         const int p = p0 + i;  // level position from the top
         const size_t ol = (size_t)ncol * (a.top_at_1 ? p : nlay - p);
         fup[ol] = fd * al[i] + sr[i];
         fdn[ol] = fd;
       }
       if (i < L) fd = fa[i] * fd + fb[i];
+    }
+    if constexpr (WIN) {
+      if (a.out_fd && last && active) a.out_fd[icol + (size_t)ncol * igpt] = fd;  // (neutral slots pass it on: the window's bottom)
     }
   };
 
@@ -2055,6 +2066,43 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     else if (L == 10) hipLaunchKernelGGL((lw_2stream_seg_kernel<10>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
     else if (L == 11) hipLaunchKernelGGL((lw_2stream_seg_kernel<11>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
     else hipLaunchKernelGGL((lw_2stream_seg_kernel<12>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
+    return;
+  }
+  if (nlay > 96 && nlay <= 192 && !g_lw_force_generic) {
+    // ------------------------------------------------------------------ 97 ... 192 layers: an upper part T and a lower part
+    // B on the segmented kernel, coupled through the adding method as in rte_sw_solver_2stream (B alone -> its albedo and
+    // source at its top; T with those as its surface -> the flux leaving its bottom; B again with that flux entering)
+    const int nT = nlay <= 88 + 96 ? 88 : 96, nB = nlay - nT;
+    const int col_tiles = cdiv(ncol, 64);
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    Float* side = (Float*)rte::scratch(sizeof(Float) * ncg * 3);
+    const bool top = *top_at_1;
+    auto run = [&](int lay0, int nl, int phase) {
+      Lw2SegArgs q{};
+      const int L = nl <= 64 ? 8 : (nl <= 72 ? 9 : nl <= 80 ? 10 : nl <= 88 ? 11 : 12);
+      q.ncol = ncol; q.nlay = nl; q.ngpt = ngpt; q.S = (nl + L - 1) / L; q.g_per_block = g_per_block; q.top_at_1 = top;
+      q.lev_gpt1 = a.lev_gpt1;
+      const size_t off = (size_t)ncol * (top ? lay0 : nlay - lay0 - nl);
+      q.tau = a.tau + off; q.ssa = a.ssa + off; q.g = a.g + off; q.lev_source = a.lev_source + off;
+      q.flux_up = a.flux_up + off; q.flux_dn = a.flux_dn + off;
+      q.plane_lay = ncl; q.plane_lev = nclv;
+      q.sfc_emis = a.sfc_emis; q.sfc_src = a.sfc_src; q.inc_flux = a.inc_flux;
+      if (phase == 1) { q.out_alb = side; q.out_src = side + ncg; }
+      if (phase == 2) { q.sfc_emis = side; q.sfc_src = side + ncg; q.sfc_given = true; q.out_fd = side + 2 * ncg; }
+      if (phase == 3) { q.inc_flux = side + 2 * ncg; q.skip_first_level = true; }
+      const size_t lds_bytes = sizeof(Float) * 64 * 8 * (7 + 2);
+      rte::ProfScope p("lw_2stream_seg_kernel");
+      const dim3 grid(col_tiles, ngroups), blk(64 * q.S);
+      if (L == 8) hipLaunchKernelGGL((lw_2stream_seg_kernel<8, true>), grid, blk, lds_bytes, rte::stream(), q);
+      else if (L == 9) hipLaunchKernelGGL((lw_2stream_seg_kernel<9, true>), grid, blk, lds_bytes, rte::stream(), q);
+      else if (L == 10) hipLaunchKernelGGL((lw_2stream_seg_kernel<10, true>), grid, blk, lds_bytes, rte::stream(), q);
+      else if (L == 11) hipLaunchKernelGGL((lw_2stream_seg_kernel<11, true>), grid, blk, lds_bytes, rte::stream(), q);
+      else hipLaunchKernelGGL((lw_2stream_seg_kernel<12, true>), grid, blk, lds_bytes, rte::stream(), q);
+    };
+    run(nT, nB, 1);
+    run(0, nT, 2);
+    run(nT, nB, 3);
     return;
   }
   const size_t gchunk = pick_gchunk(sizeof(Float) * ncl * 4, ngpt);
