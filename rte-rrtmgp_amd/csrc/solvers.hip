@@ -2211,7 +2211,8 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const bool top = *top_at_1;
     auto run = [&](int lay0, int nl, int phase) {
       Sw2SegArgs q{};
-      const int L = nl <= 64 ? 8 : (nl <= 72 ? 9 : nl <= 80 ? 10 : nl <= 88 ? 11 : 12);
+      // (a short lower part gets 4 layers per wave: all eight waves -- all four SIMDs -- work instead of two or three)
+      const int L = nl <= 32 ? 4 : nl <= 64 ? 8 : (nl <= 72 ? 9 : nl <= 80 ? 10 : nl <= 88 ? 11 : 12);
       q.ncol = ncol; q.nlay = nl; q.ngpt = ngpt; q.S = (nl + L - 1) / L; q.g_per_block = g_per_block; q.top_at_1 = top;
       // first row of the window: layer position lay0 from the top (layers), the same for levels
       const size_t off = (size_t)ncol * (top ? lay0 : nlay - lay0 - nl);
@@ -2230,14 +2231,16 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
       rte::ProfScope p(do_broadband ? "sw_2stream_seg_kernel" : "sw_2stream_seg_spectral_kernel");
       const dim3 grid(col_tiles, ngroups), blk(64 * q.S);
       if (!do_broadband) {
-        if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, true, true>), grid, blk, lds_bytes, st0, q);
+        if (L == 4) hipLaunchKernelGGL((sw_2stream_seg_kernel<4, true, true>), grid, blk, lds_bytes, st0, q);
+        else if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, true, true>), grid, blk, lds_bytes, st0, q);
         else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9, true, true>), grid, blk, lds_bytes, st0, q);
         else if (L == 10) hipLaunchKernelGGL((sw_2stream_seg_kernel<10, true, true>), grid, blk, lds_bytes, st0, q);
         else if (L == 11) hipLaunchKernelGGL((sw_2stream_seg_kernel<11, true, true>), grid, blk, lds_bytes, st0, q);
         else hipLaunchKernelGGL((sw_2stream_seg_kernel<12, true, true>), grid, blk, lds_bytes, st0, q);
         return;
       }
-      if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, false, true>), grid, blk, lds_bytes, st0, q);
+      if (L == 4) hipLaunchKernelGGL((sw_2stream_seg_kernel<4, false, true>), grid, blk, lds_bytes, st0, q);
+      else if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, false, true>), grid, blk, lds_bytes, st0, q);
       else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9, false, true>), grid, blk, lds_bytes, st0, q);
       else if (L == 10) hipLaunchKernelGGL((sw_2stream_seg_kernel<10, false, true>), grid, blk, lds_bytes, st0, q);
       else if (L == 11) hipLaunchKernelGGL((sw_2stream_seg_kernel<11, false, true>), grid, blk, lds_bytes, st0, q);
