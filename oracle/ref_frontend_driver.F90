@@ -23,7 +23,8 @@
 !         [, variant: 0 default; 1 LW optimal transport angles (k%compute_optimal_angles -> rte_lw(lw_Ds=)); 2 fluxes by band
 !         (ty_fluxes_byband: the solvers' spectral output + rte_sum_byband; the bands are summed for the output file);
 !         3 LW with two-stream clouds (needs the cloud stream): rte_lw's default for 2str properties, the Tang rescaling;
-!         4 the same through lw_solver_2stream (use_2stream=.true.)]  -- the configurations of tests/check_variants.F90
+!         4 the same through lw_solver_2stream (use_2stream=.true.); 5 a diffuse flux incident at the top (LW inc_flux, SW
+!         inc_flux_dif: 0.1 per g-point)]  -- the configurations of tests/check_variants.F90
 !   p_lay, p_lev, t_lay, t_lev (ncol, nlay[+1]); vmr(ncol, nlay, ngases) in the order of <gases>; col_dry(ncol, nlay);
 !   LW: t_sfc(ncol), sfc_emis(ncol);  SW: mu0(ncol), sfc_alb(ncol)
 ! Output (stream): flux_up, flux_dn (ncol, nlay+1) [, flux_dn_dir for SW], float64, column fastest.
@@ -199,7 +200,7 @@ contains
     type(ty_optical_props_2str) :: cld2
     type(ty_fluxes_byband) :: bfl
     real(wp), allocatable, target :: bbu(:,:,:), bbd(:,:,:), bbdir(:,:,:)
-    real(wp), allocatable :: ds(:,:)
+    real(wp), allocatable :: ds(:,:), incf(:,:)
     integer :: b, tid, nthr
     integer(8) :: tb, tc, td, tick_go, tick_rte
     character(len=128) :: e
@@ -217,6 +218,9 @@ contains
       call stop_on_err(op2%alloc_2str(bs, nlay, k))
     end if
     if (variant == 1) allocate(ds(bs, ngpt))
+    if (variant == 5) then
+      allocate(incf(bs, ngpt)); incf = 0.1_wp
+    end if
     if (variant == 2) then
       allocate(bbu(bs, nlay+1, nbnd), bbd(bs, nlay+1, nbnd))
       bfl%bnd_flux_up => bbu; bfl%bnd_flux_dn => bbd
@@ -224,7 +228,7 @@ contains
         allocate(bbdir(bs, nlay+1, nbnd)); bfl%bnd_flux_dn_dir => bbdir
       end if
     end if
-    if (variant >= 3) then
+    if (variant == 3 .or. variant == 4) then
       if (.not. (is_lw .and. with_clouds)) error stop 'ref_frontend_driver: variants 3 and 4 are longwave with clouds'
       call stop_on_err(op2%alloc_2str(bs, nlay, k)); call stop_on_err(cld2%alloc_2str(bs, nlay, cloud_spec))
     end if
@@ -262,6 +266,8 @@ contains
           call stop_on_err(cloud_spec%cloud_optics(blwp(:,:,b), biwp(:,:,b), brel(:,:,b), bdei(:,:,b), cld2))
           call stop_on_err(cld2%increment(op2))
           call stop_on_err(rte_lw(op2, src, bsfc(:,:,b), fluxes, n_gauss_angles=n_ang, use_2stream=(variant == 4)))
+        case (5)
+          call stop_on_err(rte_lw(op1, src, bsfc(:,:,b), fluxes, inc_flux=incf, n_gauss_angles=n_ang))
         case default
           call stop_on_err(rte_lw(op1, src, bsfc(:,:,b), fluxes, n_gauss_angles=n_ang))
         end select
@@ -283,6 +289,8 @@ contains
         if (variant == 2) then
           call stop_on_err(rte_sw(op2, bmu0(:,b), toa, bsfc(:,:,b), bsfc(:,:,b), bfl))
           bup(:, :, b) = sum(bbu, dim=3); bdn(:, :, b) = sum(bbd, dim=3); bdir(:, :, b) = sum(bbdir, dim=3)
+        else if (variant == 5) then
+          call stop_on_err(rte_sw(op2, bmu0(:,b), toa, bsfc(:,:,b), bsfc(:,:,b), fluxes, inc_flux_dif=incf))
         else
           call stop_on_err(rte_sw(op2, bmu0(:,b), toa, bsfc(:,:,b), bsfc(:,:,b), fluxes))
         end if

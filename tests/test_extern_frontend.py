@@ -318,6 +318,8 @@ VARIANTS = [
     ("sw", 2, 1, False, "fluxes by band"),
     ("lw", 3, 1, True, "two-stream clouds: Tang rescaling"),
     ("lw", 4, 1, True, "two-stream clouds: lw_solver_2stream"),
+    ("lw", 5, 1, False, "incident diffuse flux at the top"),
+    ("sw", 5, 1, False, "incident diffuse flux at the top"),
 ]
 
 
