@@ -31,8 +31,16 @@ __device__ __forceinline__ double fma_c(double p, double r, double c) {
 
 __device__ __forceinline__ double exp_nonpos(double x) {
   // x = k ln2 + r, |r| <= ln2/2; exp(r) by its Taylor polynomial of degree 13 (truncation 4e-18 relative)
-  x = x < -1100.0 ? -1100.0 : x;  // exp underflows to 0 long before; keeps k and r finite for any input; a NaN stays a NaN
-                                  // (fmax would turn it into -1100, i.e. a silent 0 where the reference's exp propagates it)
+  {
+    // exp underflows to 0 long before -1100; the clamp keeps k and r finite for any input and leaves a NaN a NaN (fmax would
+    // turn it into a silent 0 where the reference's exp propagates it).  Only the HIGH word is replaced (one v_cndmask
+    // instead of two): any low word under -1100's high word is a value in [-1100.001, -1100], as good a clamp as -1100
+    unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned hi = (unsigned)(b >> 32);
+    const unsigned hi_c = x < -1100.0 ? 0xC0913000u : hi;  // high word of -1100.0 (0xC091300000000000)
+    b = ((unsigned long long)hi_c << 32) | (unsigned)b;
+    x = __builtin_bit_cast(double, b);
+  }
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double r = __builtin_fma(k, -6.93147180369123816490e-01, x);  // ln2 high part: k * hi is exact
   r = __builtin_fma(k, -1.90821492927058770002e-10, r);         // ln2 low part

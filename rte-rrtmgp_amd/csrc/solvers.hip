@@ -1214,8 +1214,9 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         Rdir = fmax((Float)0, fmin(Rdir, ((Float)1 - Tnoscat)));
         Tdir = fmax((Float)0, fmin(Tdir, ((Float)1 - Tnoscat - Rdir)));
         const bool sun = imu > (Float)0;  // :1122-1125
-        su[i] = sun ? Rdir * P : (Float)0;
-        sd[i] = sun ? Tdir * P : (Float)0;
+        const Float Ps = sun ? P : (Float)0;  // (one select instead of two: Rdir, Tdir are finite)
+        su[i] = Rdir * Ps;
+        sd[i] = Tdir * Ps;
         Tn[i] = Tnoscat;
         P = Tnoscat * P;
       }
