@@ -773,3 +773,46 @@ def test_size_independent_properties(hip):
     upF, dnF = run(flip, tile, True)
     assert cases.rel_err(upF[:, ::-1], up1) <= 1e-13 and cases.rel_err(dnF[:, ::-1], dn1) <= 1e-13
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlay", [91, 137])
+def test_single_precision_solvers_at_host_model_layer_counts(oracle_c, nlay):
+    """The wide solver paths (eleven / twelve layers per wave, two sub-segments, the two-part two-stream solves) in the
+    -DRTE_USE_SP build: fluxes against the DOUBLE-precision oracle on the same inputs, within 2e-4 of the largest flux or three
+    times what the single-precision ORACLE loses on them (lw_two_stream's differences of nearly equal terms cost 1e-2 in float)."""
+    import numpy as np
+
+    hip_sp = hiplib.load("sp")
+    xs = frontend.TorchArrays("cuda:0", "sp")
+    xo = frontend.NumpyArrays()
+    rng = np.random.default_rng(7 + nlay)
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    ncol, ngpt, top = 70, 16, nlay == 91
+    tau, ssa, g = F(ncol, nlay, ngpt) * 0.5, F(ncol, nlay, ngpt) * 0.9, F(ncol, nlay, ngpt) * 0.8
+    lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
+    emis, sfc, inc = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10, F(ncol, ngpt)
+    mu0 = np.asfortranarray(np.repeat((rng.random(ncol) * 0.8 + 0.2)[:, None], nlay, axis=1))
+    adir, adif, idir = F(ncol, ngpt) * 0.5, F(ncol, ngpt) * 0.5, F(ncol, ngpt) * 100
+    S = xs.asarray
+    runs = {
+        "lw noscat": (lambda lib, x, c: frontend.rte_lw(lib, x, ncol, nlay, ngpt, top, c(tau), c(lay), c(lev), c(emis), c(sfc), inc_flux=c(inc)),
+                      ("flux_up", "flux_dn")),
+        "lw rescaled": (lambda lib, x, c: frontend.rte_lw(lib, x, ncol, nlay, ngpt, top, c(tau), c(lay), c(lev), c(emis), c(sfc), ssa=c(ssa),
+                                                          g=c(g), inc_flux=c(inc)), ("flux_up", "flux_dn")),
+        "lw 2-stream": (lambda lib, x, c: frontend.rte_lw(lib, x, ncol, nlay, ngpt, top, c(tau), c(lay), c(lev), c(emis), c(sfc), ssa=c(ssa),
+                                                          g=c(g), inc_flux=c(inc), use_2stream=True), ("gpt_flux_up", "gpt_flux_dn")),
+        "sw 2-stream": (lambda lib, x, c: frontend.rte_sw(lib, x, ncol, nlay, ngpt, top, c(tau), c(ssa), c(g), c(mu0), c(idir), c(adir), c(adif)),
+                        ("flux_up", "flux_dn", "flux_dir")),
+    }
+    from oracle import oracle as O
+
+    osp, xo_sp = O.load_c("sp"), frontend.NumpyArrays("sp")
+    for name, (fn, keys) in runs.items():
+        ref = fn(oracle_c, xo, lambda a: a)
+        ref_sp = fn(osp, xo_sp, xo_sp.asarray)  # what single precision costs on these inputs (lw_two_stream: 1e-2)
+        out = fn(hip_sp, xs, S)
+        for k in keys:
+            e_hip = cases.rel_err(xs.to_numpy(out[k]).astype(np.float64), ref[k])
+            e_sp = cases.rel_err(np.asarray(ref_sp[k], dtype=np.float64), ref[k])
+            assert e_hip <= max(2e-4, 3.0 * e_sp), (name, k, nlay, e_hip, e_sp)
