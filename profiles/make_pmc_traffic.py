@@ -15,12 +15,32 @@ GROUPS = {
                               "tau_setup_kernel", "tau_absorption_kernel"),
     "planck_source_kernel": ("planck_source_v9_kernel", "planck_source_worklist_kernel", "planck_flags_kernel",
                              "planck_source_kernel", "relayout_gfast_kernel"),
-    "lw_noscat_seg_kernel": ("lw_noscat_seg_kernel",),
+    "lw_noscat_seg_kernel": ("lw_noscat_seg_kernel", "reduce_parts_kernel"),
 }
+
+
+MAIN = {"interpolation_kernel": "interpolation_kernel", "tau_absorption_kernel": "tau_absorption_v9_kernel",
+        "planck_source_kernel": "planck_source_v9_kernel", "lw_noscat_seg_kernel": "lw_noscat_seg_kernel"}
+
+
+def rocprof_averages(tag):
+    """avg_us per launch of every kernel in profiles/<tag>_lw_kernel_stats.md (rocprofv3 --kernel-trace --stats of the bench command)."""
+    avg = {}
+    path = os.path.join(HERE, f"{tag}_lw_kernel_stats.md")
+    if not os.path.exists(path):
+        return avg
+    for line in open(path):
+        c = [x.strip() for x in line.split("|")]
+        if len(c) >= 6 and c[2].isdigit():
+            name = c[1].split("<")[0]
+            calls, total = avg.get(name, (0, 0.0))
+            avg[name] = (calls + int(c[2]), total + float(c[3]))
+    return avg
 
 
 def main(tag):
     rows = list(csv.DictReader(open(os.path.join(HERE, f"{tag}_pmc_summary.csv"))))
+    avg = rocprof_averages(tag)
     out = {}
     for group, names in GROUPS.items():
         rd = wr = 0.0
@@ -29,6 +49,10 @@ def main(tag):
                 rd += 2.0 * float(r["FETCH_SIZE"]) * 1024 / 1e9
                 wr += float(r["WRITE_SIZE"]) * 1024 / 1e9
         out[group] = {"hbm_GB_per_launch": round(rd + wr, 3), "read_GB": round(rd, 3), "write_GB": round(wr, 3)}
+        if MAIN[group] in avg:  # the call's main kernel, and its helper kernels beside it (rocprofv3 averages per launch)
+            calls, total = avg[MAIN[group]]
+            out[group]["rocprof_avg_us"] = round(total / calls, 1)
+            out[group]["rocprof_helpers_us"] = round(sum(avg[n][1] for n in names if n in avg and n != MAIN[group]) / calls, 1)
     doc = {
         "ncol": 100000, "round": tag,
         "source": f"profiles/{tag}_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "

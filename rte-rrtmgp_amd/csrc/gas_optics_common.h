@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
   __syncthreads();
   static_assert(TILE % 256 == 0, "the interpolation kernel leaves one mask record per 256 columns");
   const bool pre = a.imask != nullptr && *a.irregular == 0;
-  if (a.stat && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *a.stat = pre ? 1 : 2;
+  if (a.stat && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) { *a.stat = pre ? 1 : 2; if (!a.planck) a.stat[1] = 9; }  // (rte_hip_stat(3): which tau kernel ran)
   if (pre && tid >= 128) return;  // two waves do the rest (4 + 2 * nflav <= 68 words; finished waves no longer count at the barrier)
   if (pre) {
     const int W = 4 + 2 * nflav;

@@ -4,10 +4,12 @@
 
 // process-wide tuning switches (set from any thread: relaxed atomics)
 std::atomic<int> g_tau_force_direct{0};
-std::atomic<int> g_tau_variant{9};
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+std::atomic<int> g_tau_variant{env_int("RTE_HIP_TAU_VARIANT", 9)};
 std::atomic<int> g_planck_variant{9};  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
 std::atomic<int> g_geom_variant{2};  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
-std::atomic<int> g_share_geom_default{0};  // what a context starts with (the last rte_hip_share_geometry of any context)
+// (RTE_HIP_SHARE_GEOMETRY=1: the opt-in of rte_hip_share_geometry for an unchanged binary)
+std::atomic<int> g_share_geom_default{env_int("RTE_HIP_SHARE_GEOMETRY", 0)};  // what a context starts with (the last rte_hip_share_geometry of any context)
 
 extern "C" {
 

@@ -67,7 +67,8 @@ struct Context {
   hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
   // ---- deferred zero fill
   std::vector<PendingZero> pending;
-  bool defer_zero = false;
+  // (RTE_HIP_DEFER_ZERO=1: the opt-in for an unchanged device-pointer binary that cannot call rte_hip_defer_zero)
+  bool defer_zero = getenv("RTE_HIP_DEFER_ZERO") && atoi(getenv("RTE_HIP_DEFER_ZERO")) > 0;
   long seq = 0;
   // ---- host-mirror mode
   std::vector<Mirror> mirrors;

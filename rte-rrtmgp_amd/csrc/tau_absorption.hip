@@ -16,6 +16,7 @@
 //   * Planck: each thread owns one (column, band) and walks the layers sequentially so the
 //     geometric mean of adjacent layers' Planck fractions needs no second gather.
 #include "gas_optics_common.h"
+#include "tau_mx.h"
 
 // shape of the specialised-wave tau kernel (defaults: that of gas_optics_common.h; overridable for experiments)
 #ifndef TAU_NCW
@@ -205,6 +206,7 @@ struct TauArgs {
   const Float* kmajor;
   MinorTables lower, upper;
   const int* run_if;  // when non-null the kernel does nothing unless *run_if != 0
+  const int* run_if2 = nullptr;  // ... or *run_if2 != 0 (the matrix-core kernel also leaves irregular profiles to this one)
   bool overwrite;     // tau is known to be zero (deferred zero_array): do not read it
   const int* lim;
   const Bool* tropo;
@@ -389,7 +391,7 @@ __device__ __forceinline__ void tau_direct_column_g(const TauArgs& a, const Gfas
 
 // direct kernel over all (column tile, layer, band) triples, grid-stride
 __global__ void __launch_bounds__(256) tau_absorption_kernel(TauArgs a, int nbnd) {
-  if (a.run_if && *a.run_if == 0) return;
+  if (a.run_if && *a.run_if == 0 && !(a.run_if2 && *a.run_if2 != 0)) return;
   const unsigned tiles_x = (a.ncol + 255) / 256;
   const size_t total = (size_t)tiles_x * a.nlay * nbnd;
   for (size_t w = blockIdx.x; w < total; w += gridDim.x) {
@@ -1833,8 +1835,45 @@ static void tau_absorption_impl(
   constexpr int BS = V7_BS;
   v.worklist = worklist;
   hipStream_t aux = nullptr;
+  // ---- the matrix-core kernel (tau_mx.h; rte_hip_tau_variant(10)): double precision, 16-wide stages, no fused Rayleigh
+#ifndef RTE_USE_SP
+  const bool use_mx = g_tau_variant == 10 && cache.gw == 16 && rh == nullptr && ntemp < 64 && npres + 2 < 128 && neta < 32 &&
+                      2 * ntemp * (npres + 2) <= MX_NB && nflav <= MAXFLAV && nbnd <= MAXB;
+  if (use_mx) {
+    constexpr int NW = 8, TILE = NW * 64;
+    const unsigned tiles = cdiv(ncol, TILE);
+    unsigned short* sort_idx = (unsigned short*)rte::scratch(sizeof(unsigned short) * (size_t)tiles * nlay * nflav * TILE);
+    int* n_lo = (int*)rte::scratch(sizeof(int) * (size_t)tiles * nlay);
+    {
+      rte::ProfScope p("tau_absorption_setup");
+      hipLaunchKernelGGL((tau_mx_sort_kernel<TILE>), dim3(tiles, nlay), dim3(TILE), 0, st, ncol, nlay, nflav, neta, d_jtemp, d_jpress,
+                         d_tropo, d_jeta, (const int*)overlap, (const int*)irregular, sort_idx, n_lo);
+    }
+    MxArgs m{};
+    m.ncol = ncol; m.nlay = nlay; m.ngpt = ngpt; m.nbnd = nbnd; m.ntemp = ntemp; m.TE = TE; m.idx_h2o = *idx_h2o_;
+    m.nk_lo = nkl; m.nk_up = nku; m.nflav = nflav; m.bmeta = d_bm; m.kmaj = kmaj_g; m.klo = klo_g; m.kup = kup_g;
+    m.jeta = d_jeta; m.jtemp = d_jtemp; m.jpress = d_jpress; m.tropo = d_tropo; m.col_mix = d_col_mix; m.fmajor = d_fmajor;
+    m.fminor = d_fminor; m.play = d_play; m.tlay = d_tlay; m.col_gas = d_col_gas; m.tau = d_tau; m.add_bybnd = d_add;
+    m.skip_if = overlap; m.skip_if2 = irregular; m.sort_idx = sort_idx; m.n_lo = n_lo; m.stat = stats_dev() + 3;
+    const dim3 grid(tiles, nlay), blk(2 * TILE);
+    const size_t dyn = sizeof(BandMeta) * nbnd;
+    rte::ProfScope p("tau_absorption_kernel");
+    if (overwrite_ok) {
+      if (d_add) hipLaunchKernelGGL((tau_absorption_mx_kernel<NW, true, true>), grid, blk, dyn, st, m);
+      else hipLaunchKernelGGL((tau_absorption_mx_kernel<NW, true, false>), grid, blk, dyn, st, m);
+    } else {
+      if (d_add) hipLaunchKernelGGL((tau_absorption_mx_kernel<NW, false, true>), grid, blk, dyn, st, m);
+      else hipLaunchKernelGGL((tau_absorption_mx_kernel<NW, false, false>), grid, blk, dyn, st, m);
+    }
+    a.run_if2 = irregular;
+  }
+#else
+  const bool use_mx = false;
+#endif
   const bool use_v9 = g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr || rh != nullptr;  // the single-role kernel exists for 16-wide stages only
-  if (use_v9) {
+  if (use_mx) {
+    // (launched above)
+  } else if (use_v9) {
     constexpr int NCW = TAU_NCW, NLW = TAU_NLW, SLAB9 = TAU_SLAB;  // compute + loader waves, 2 x 68 KB slab: one block per CU
     const unsigned tiles = cdiv(ncol, NCW * 64);
     const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
@@ -1922,7 +1961,9 @@ static void tau_absorption_impl(
     const bool offsets_fit = (size_t)(npres + 1) * TE * ngpt < ((size_t)1 << 31) && (size_t)TE * nkl < ((size_t)1 << 31) &&
                              (size_t)TE * nku < ((size_t)1 << 31);
     if (!g_worklist_native && offsets_fit) { gft.kmaj = kmaj_g; gft.klo = klo_g; gft.kup = kup_g; gft.nkl = nkl; gft.nku = nku; }
-    if (gft.kmaj)
+    if (use_mx) {
+      // (no bounding boxes, no worklist)
+    } else if (gft.kmaj)
       hipLaunchKernelGGL(tau_absorption_worklist_kernel<true>, dim3(aux ? 16384 : 4096), dim3(aux ? 64 : 256), 0, st, aw, gft,
                          (const int*)v.worklist, use_v9 ? TAU_NCW * 64 : BS, stats_dev() + 0);
     else
@@ -1935,6 +1976,15 @@ static void tau_absorption_impl(
   RTE_CATCH(api_name)
 }
 
+#if defined(MX_TIMING) && !defined(RTE_USE_SP)
+extern "C" int rte_hip_mx_timing(unsigned long long* out /*[4]: column waves busy, waiting; matrix waves busy, waiting*/) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(mx_clk), sizeof(unsigned long long) * 4);
+  unsigned long long z[4] = {0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(mx_clk), z, sizeof(z));
+  return 0;
+}
+#endif
 extern "C" {
 void rrtmgp_compute_tau_absorption(
     const int* ncol_, const int* nlay_, const int* nbnd_, const int* ngpt_, const int* ngas_,

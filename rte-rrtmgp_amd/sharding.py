@@ -29,7 +29,12 @@ def allreduce_mean_profile(flux_up, flux_dn, ncol_global: int, group=None):
 
     prof = torch.stack([flux_up.sum(dim=1), flux_dn.sum(dim=1)])
     if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(prof, group=group)
+        if prof.is_cuda and dist.get_backend(group) == "gloo":  # (ranks sharing one device in the plumbing test: through the host)
+            host = prof.cpu()
+            dist.all_reduce(host, group=group)
+            prof = host.to(prof.device)
+        else:
+            dist.all_reduce(prof, group=group)
     return prof / float(ncol_global)
 
 
@@ -45,8 +50,9 @@ def allgather_fluxes(flux, ncol_global: int, group=None):
     nlev = flux.shape[0]
     widths = [shard_columns(ncol_global, r, world)[1] for r in range(world)]
     wmax = max(widths)
-    pad = torch.zeros(nlev, wmax, dtype=flux.dtype, device=flux.device)
+    via_host = flux.is_cuda and dist.get_backend(group) == "gloo"
+    pad = torch.zeros(nlev, wmax, dtype=flux.dtype, device=("cpu" if via_host else flux.device))
     pad[:, : flux.shape[1]] = flux
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:, :w] for p, w in zip(parts, widths)], dim=1)
+    return torch.cat([p[:, :w] for p, w in zip(parts, widths)], dim=1).to(flux.device)

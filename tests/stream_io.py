@@ -191,8 +191,15 @@ def measure_frontend_driver(kind="lw", ncol=98304, block=8192, modes=("mirror",)
             rep = [ln.strip() for ln in last_stderr.splitlines() if "staging report" in ln]
             detail = [ln.rstrip() for ln in last_stderr.splitlines() if ln.startswith("    ")]  # per-entry wall clock
             detail += [ln.rstrip() for ln in log.splitlines() if ln.startswith("  thread 0:")]     # REF_DRIVER_TIMING=1
+            passes = [ln.split(":", 1)[1].strip() for ln in log.splitlines() if ln.startswith("pass")]
+            rates = []
+            for p_ in passes:  # "0.0611 s,    1609088.3 columns/s (8 host threads)"
+                try:
+                    rates.append(float(p_.split(",")[1].split()[0]))
+                except (IndexError, ValueError):
+                    pass
             out[mode] = {"columns_per_s": best, "report": rep[0] if rep else None, "reports": rep, "detail": detail,
-                         "passes": [ln.split(":", 1)[1].strip() for ln in log.splitlines() if ln.startswith("pass")]}
+                         "passes": passes, "pass_rates": rates}
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out

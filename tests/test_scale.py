@@ -127,6 +127,39 @@ def test_mean_profile_allreduce_under_nccl():
             dist.destroy_process_group()
 
 
+def test_two_ranks_of_bench_share_one_device_over_gloo():
+    """The rank / seed / shard / collective plumbing of `bench.py --gpus N` on the HIP path: two ranks launched as the
+    driver launches them (torch.distributed.run, 127.0.0.1), both on this box's one GPU, gloo for the collective (RCCL
+    refuses two ranks on one device).  The JSON line must carry the whole-job rate, both ranks' step times and the
+    all-reduce time measured inside the step."""
+    import json
+    import socket
+    import subprocess
+
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ncol", "5000", "--steps", "2",
+           "--warmup", "1", "--dist-backend", "gloo", "--single-device", "--no-cpu-baseline", "--no-plain-abi"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak"
+    assert res["config"]["columns_per_gpu"] == 5000 and "10000 columns in all" in res["config"]["workload"]
+    assert res["config"]["rccl_world_size"] == 2 and res["config"]["dist_backend"] == "gloo"
+    pr = res["per_rank_ms_per_step"]
+    assert len(pr["ranks"]) == 2 and all(t > 0 for t in pr["ranks"]) and pr["min"] <= pr["median"] <= pr["max"]
+    assert abs(res["ms_per_step"] - pr["max"]) < 1e-3  # the job's step time is its slowest rank's
+    assert res["value"] == pytest.approx(10000 * 2 / (res["ms_per_step"] * 2 * 1e-3), rel=1e-3)
+    assert res["allreduce_ms_per_step"]["max_over_ranks"] > 0
+    assert res["step_ms"]["n"] == 2 and res["step_ms"]["min"] <= res["step_ms"]["median"]
+
+
 def test_32bit_offset_guard_falls_back():
     """The segmented solver addresses a g-point plane with 32-bit byte offsets (8 * ncol * (nlay+1) < 2^32).  A call
     beyond that must take the generic kernel, not abort or wrap: 2^24 columns x 32 layers x 1 g-point (13 GB of
