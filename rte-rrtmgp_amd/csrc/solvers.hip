@@ -1183,6 +1183,8 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         const Float tau_s = i < np ? x.tau[i] : (Float)0, w0_s = x.ssa[i], g_s = x.g[i];
         const Float gamma1 = ((Float)8 - w0_s * ((Float)5 + (Float)3 * g_s)) * (Float).25;
         const Float gamma2 = (Float)3 * (w0_s * ((Float)1 - g_s)) * (Float).25;
+        // (the reference's own operation order: gamma1 - gamma2 cancels for conservative scattering, and a differently rounded
+        //  pair moves the fluxes of cloudy columns by 1e-8 relative to the reference's -- measured, all-sky at 1e5 columns)
         const Float kk = rte::sqrt_nr(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
         const Float e1 = rte::exp_nonpos(-tau_s * kk);
         const Float e2 = e1 * e1;
@@ -1197,20 +1199,28 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         R[i] = RT * gamma2 * ((Float)1 - e2);
         T[i] = i < np ? RT * (Float)2 * kk * e1 : (Float)1;
         RT = w0_s * inv;
-        const Float gamma3 = ((Float)2 - (Float)3 * mu0_s * g_s) * (Float).25;
-        const Float gamma4 = (Float)1 - gamma3;
-        const Float alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
-        const Float alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
-        const Float k_gamma3 = kk * gamma3, k_gamma4 = kk * gamma4;
+        const Float gamma3 = (Float).5 - ((Float).75 * mu0_s) * g_s;  // (2 - 3 mu0 g) / 4
+        // alpha1 = gamma1 gamma4 + gamma2 gamma3, alpha2 = gamma1 gamma3 + gamma2 gamma4 with gamma4 = 1 - gamma3 (:1078-1081)
+        const Float dgam = gamma1 - gamma2;
+        const Float alpha1 = gamma1 - gamma3 * dgam;
+        const Float alpha2 = gamma2 + gamma3 * dgam;
+        const Float k_gamma3 = kk * gamma3, k_gamma4 = kk - k_gamma3;
         Float imu;
         if constexpr (ONEMU) { const Float r_ = rte::rcp_nr(mu0_s); imu = mu0s[i * 64] > (Float)0 ? r_ : -r_; }
         else imu = mu0i[i * 64];
         const Float Tnoscat = rte::exp_nonpos(-tau_s * fabs(imu));
-        Float Rdir = RT * (((Float)1 - k_mu) * (alpha2 + k_gamma3) - ((Float)1 + k_mu) * (alpha2 - k_gamma3) * e2 -
-                           (Float)2.0 * (k_gamma3 - alpha2 * k_mu) * e1 * Tnoscat);
-        Float Tdir = -RT * (((Float)1 + k_mu) * (alpha1 + k_gamma4) * Tnoscat -
-                            ((Float)1 - k_mu) * (alpha1 - k_gamma4) * e2 * Tnoscat -
-                            (Float)2.0 * (k_gamma4 + alpha1 * k_mu) * e1);
+        // Rdir, Tdir (:1097-1105, Meador & Weaver eq. 14-15 as the reference rearranges them), multiplied out in the
+        // products with (1 -+ k mu0) and collected by 1 - e2 and 1 + e2, which the diffuse part has formed already:
+        //   Rdir / RT  = (1 - k mu0)(alpha2 + k gamma3) - (1 + k mu0)(alpha2 - k gamma3) e2 - 2 (k gamma3 - alpha2 k mu0) e1 Tn
+        //              = u (1 - e2) + v (1 + e2 - 2 e1 Tn),        u = alpha2 - k mu0 k gamma3,  v = k gamma3 - k mu0 alpha2
+        //   Tdir / -RT = (1 + k mu0)(alpha1 + k gamma4) Tn - (1 - k mu0)(alpha1 - k gamma4) e2 Tn - 2 (k gamma4 + alpha1 k mu0) e1
+        //              = Tn (p (1 - e2) + q (1 + e2)) - 2 e1 q,   p = alpha1 + k mu0 k gamma4,  q = k gamma4 + k mu0 alpha1
+        // -- 15 fp64 operations for the pair instead of 32 (the kernel is bound by its fp64 issue)
+        const Float om2 = (Float)1 - e2, op2 = (Float)1 + e2;
+        const Float u_ = alpha2 - k_mu * k_gamma3, v_ = k_gamma3 - k_mu * alpha2;
+        const Float p_ = alpha1 + k_mu * k_gamma4, q_ = k_gamma4 + k_mu * alpha1;
+        Float Rdir = RT * (u_ * om2 + v_ * (op2 - (Float)2 * (e1 * Tnoscat)));
+        Float Tdir = -RT * (Tnoscat * (p_ * om2 + q_ * op2) - (Float)2 * (e1 * q_));
         Rdir = fmax((Float)0, fmin(Rdir, ((Float)1 - Tnoscat)));
         Tdir = fmax((Float)0, fmin(Tdir, ((Float)1 - Tnoscat - Rdir)));
         const bool sun = imu > (Float)0;  // :1122-1125

@@ -96,7 +96,8 @@ def load(precision: str = "dp", build_if_missing: bool = True) -> cabi.KernelLib
         return _loaded[precision]
     _one_hip_runtime()
     path = lib_path(precision)
-    if _stale(path):
+    # (an experiment build named by RTE_HIP_VARIANT is used as it is: rebuilding it here would drop its flags)
+    if _stale(path) and not (os.environ.get("RTE_HIP_VARIANT") and precision == "dp" and os.path.exists(path)):
         if not build_if_missing or not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
             if not os.path.exists(path):
                 raise RuntimeError(f"{path} is missing and cannot be built: the HIP extension is "
