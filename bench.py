@@ -123,6 +123,8 @@ def _cpu_chain(workload, seed, ncol_block, shm_dir=None):
     except Exception:
         lib = None
     if lib is None:
+        # the C restatement stands in only where the reference build is absent; a build that is present but does not load is an error
+        assert not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefkernels.so")), "oracle/_ref/librefkernels.so does not load"
         lib, kind = O.load_c(), "port"
     xp = frontend.NumpyArrays()
     nlay_b = 72 if workload == "allsky" else NLAY

@@ -74,6 +74,11 @@ $FC -o "$OUT/bin/ref_frontend_driver" ref_frontend_driver.o mo_raw_stream.o $FRO
 if [ -f "$OUT/librefkernels.so" ]; then
   $FC -o "$OUT/bin/ref_frontend_driver_cpuref" ref_frontend_driver.o mo_raw_stream.o $FRONT_OBJS shim.o \
       -L"$OUT" -lrefkernels -L"$HERE" -loracle -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../..'
+  # ... and with oracle/glue_recorder.c in front of three kernel symbols: records what the reference FRONTEND computed on
+  # its way to them (col_gas, tlev, secants, expanded emissivity) -> tests/golden/make_glue_golden.py
+  gcc -O1 -fPIC -c "$HERE/glue_recorder.c" -o glue_recorder.o
+  $FC -o "$OUT/bin/ref_frontend_driver_glue" ref_frontend_driver.o mo_raw_stream.o $FRONT_OBJS shim.o glue_recorder.o \
+      -L"$OUT" -lrefkernels -L"$HERE" -loracle -ldl -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../..'
 fi
 # the invariances of the reference's tests/check_equivalence.F90 on the synthetic streams (oracle/ref_equivalence_driver.F90, ours)
 $FC $FFLAGS -c "$HERE/ref_equivalence_driver.F90" 2> err.log || { cat err.log >&2; exit 1; }

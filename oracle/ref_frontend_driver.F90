@@ -57,7 +57,7 @@ program ref_frontend_driver
   logical :: is_lw
   integer, allocatable :: opts(:)
   integer :: ncol, nlay, bs, nblocks, nrep, n_ang, ngpt, nbnd, ngas
-  logical :: use_col_dry, use_tlev, checks, timing_lines
+  logical :: use_col_dry, use_tlev, checks, timing_lines, band_emis
   character(len=8) :: envv
   real(wp), allocatable :: p_lay(:,:), p_lev(:,:), t_lay(:,:), t_lev(:,:), vmr(:,:,:), col_dry(:,:), t_sfc(:), sfc_emis(:), &
                            mu0(:), sfc_alb(:)
@@ -108,6 +108,8 @@ program ref_frontend_driver
     call stop_on_err(cloud_spec%set_ice_roughness(irgh))
   end if
   if (mod(ncol, bs) /= 0) error stop 'ref_frontend_driver: ncol is not a multiple of the block size'
+  call get_environment_variable('REF_DRIVER_BAND_EMIS', envv)
+  band_emis = len_trim(envv) > 0 .and. envv(1:1) /= '0'
   nblocks = ncol / bs
   ! rte/frontend/mo_rte_config.F90:25-49 (the all-sky example switches the checks off after its first pass,
   ! examples/all-sky/rrtmgp_allsky.F90:334)
@@ -146,6 +148,9 @@ program ref_frontend_driver
     do ig = 1, nbnd
       if (is_lw) then
         bsfc(ig, :, b) = sfc_emis(c0:c1)
+        ! (REF_DRIVER_BAND_EMIS: an emissivity that depends on the band, so that what rte_lw's expand_and_transpose hands to the
+        !  solver is not a plain broadcast -- tests/golden/make_glue_golden.py)
+        if (band_emis) bsfc(ig, :, b) = sfc_emis(c0:c1) * (1._wp - 0.00390625_wp * real(ig, wp))   ! (2**-8: the factor is exact in binary)
       else
         bsfc(ig, :, b) = sfc_alb(c0:c1)
       end if

@@ -82,8 +82,14 @@ def _worker(workload, d, c0, c1, nlay):
             lib = O.load_ref()
         except Exception:
             lib = None
+        checker = "reference" if lib is not None else "port"
         if lib is None:
             lib = O.load_c()
+        # where the reference build exists (oracle/_ref/librefkernels.so travels to the GPU box) it MUST be the checker
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefkernels.so")):
+            assert checker == "reference", "oracle/_ref/librefkernels.so is present but could not be loaded"
+        with open(os.path.join(d, f"checker_{c0}.txt"), "w") as f:
+            f.write(checker)
         xp = frontend.NumpyArrays()
         atm = {k: np.load(os.path.join(d, k + ".npy"), mmap_mode="r") for k in ATM_FIELDS}
         clouds = None
@@ -105,6 +111,9 @@ def _worker(workload, d, c0, c1, nlay):
     t = threading.Thread(target=body)
     t.start()
     t.join()
+
+
+last_checker = None
 
 
 def run(workload, atm, nlay, clouds=None, cores=None):
@@ -130,6 +139,10 @@ def run(workload, atm, nlay, clouds=None, cores=None):
             so, se = p.communicate(timeout=3600)
             assert p.returncode == 0, (rg, so[-2000:], se[-2000:])
         parts = [np.load(os.path.join(d, f"out_{c0}.npz")) for c0, _ in ranges]
+        kinds = {open(os.path.join(d, f"checker_{c0}.txt")).read() for c0, _ in ranges}
+        assert len(kinds) == 1, kinds
+        global last_checker
+        last_checker = kinds.pop()   # "reference" (the reference's own Fortran kernels) or "port" (the C restatement)
         return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0].files}
     finally:
         shutil.rmtree(d, ignore_errors=True)

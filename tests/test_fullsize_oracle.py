@@ -85,6 +85,9 @@ def test_full_size_config_against_the_reference_kernels(workload):
     t0 = time.time()
     ref = ref_pool.run(workload, atm, nlay, clouds=clouds)
     t_ref = time.time() - t0
+    # which checker produced `ref`: the reference's own kernels wherever their build exists (it travels to the GPU box)
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefkernels.so")):
+        assert ref_pool.last_checker == "reference", ref_pool.last_checker
     a = {k: A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry")}
     a["top_at_1"] = atm.top_at_1
     out = {}
@@ -128,4 +131,4 @@ def test_full_size_config_against_the_reference_kernels(workload):
         worst = max(worst, e)
         assert e <= (TOL_ALLSKY if workload == "allsky" else TOL), (workload, k, e)
     print(f"full size {workload}: {NCOL} columns x {nlay} layers, {len(ref)} flux fields, worst elementwise relative error {worst:.2e} "
-          f"(CPU kernels on {ref_pool.usable_cores()} cores: {t_ref:.1f} s)")
+          f"(checker: {ref_pool.last_checker}; CPU kernels on {ref_pool.usable_cores()} cores: {t_ref:.1f} s)")

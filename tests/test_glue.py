@@ -168,6 +168,48 @@ def test_c_restatement_matches_reference_build():
     assert np.array_equal(got["layer_mass"], mass)
 
 
+# ---- the frontend's own glue loops, pinned against the reference (tests/golden/glue_frontend.npz: recorded by
+# oracle/glue_recorder.c from a run of the reference's Fortran frontend on its CPU kernels; generator beside the fixture)
+def _frontend_fixture():
+    f = np.load(os.path.join(ROOT, "tests", "golden", "glue_frontend.npz"))
+    return {k: np.asfortranarray(f[k]) for k in f.files}
+
+
+def _glue_on_fixture(lib, xp, fx):
+    """col_gas, tlev, optimal-angle secants and the expanded emissivity from the inputs the reference frontend was given."""
+    A = xp.asarray
+    E = lambda *a, **k: hiplib.ext_call(lib, *a, **k)  # noqa: E731
+    ncol, nlay, _, _, ngpt, nbnd, ngas = (int(v) for v in fx["meta"])
+    col_gas = xp.empty((ncol, nlay, ngas + 1)); E("rte_hip_col_gas_fill", "iiiaaa", ncol, nlay, ngas, A(fx["vmr"]), A(fx["col_dry"]), col_gas)
+    tlev = xp.empty((ncol, nlay + 1)); E("rte_hip_tlev_interp", "iiaaaa", ncol, nlay, A(fx["play"]), A(fx["plev"]), A(fx["tlay"]), tlev)
+    ang = xp.empty((ncol, ngpt))
+    E("rte_hip_compute_optimal_angles", "iiiiaaaa", ncol, nlay, ngpt, nbnd, A(fx["band_lims_gpt"]), A(fx["ref_tau"]), A(fx["optimal_angle_fit"]), ang)
+    ex = xp.empty((ncol, ngpt)); E("rte_hip_expand_and_transpose", "iiiaaa", ncol, nbnd, ngpt, A(fx["band_lims_gpt"]), A(fx["sfc_emis_bnd"]), ex)
+    xp.sync()
+    return {k: np.array(xp.to_numpy(v)) for k, v in (("col_gas", col_gas), ("tlev", tlev), ("Ds", ang), ("sfc_emis_gpt", ex))}
+
+
+def _check_against_frontend(got, fx, label):
+    # products, sums and one division per element, no transcendental function: the same bits as the Fortran frontend's
+    assert np.array_equal(got["col_gas"], fx["ref_col_gas"]), label
+    assert np.array_equal(got["sfc_emis_gpt"], fx["ref_sfc_emis_gpt"]), label
+    assert float(np.max(np.abs(got["tlev"] - fx["ref_tlev"]) / fx["ref_tlev"])) <= 4e-16, label
+    # D = fit1 exp(-sum tau) + fit2: libm / device exp
+    assert float(np.max(np.abs(got["Ds"] - fx["ref_Ds"][:, :, 0]) / fx["ref_Ds"][:, :, 0])) <= 1e-14, label
+    assert fx["ref_Ds"].min() >= 1.0 and np.ptp(fx["ref_Ds"]) > 0.01 and np.ptp(fx["ref_sfc_emis_gpt"], axis=1).min() > 0  # a real test
+
+
+def test_c_restatement_matches_the_reference_frontend():
+    fx = _frontend_fixture()
+    _check_against_frontend(_glue_on_fixture(O.load_c(), frontend.NumpyArrays(), fx), fx, "glue_oracle.c vs the reference frontend")
+
+
+@pytest.mark.gpu
+def test_hip_glue_matches_the_reference_frontend():
+    fx = _frontend_fixture()
+    _check_against_frontend(_glue_on_fixture(hiplib.load(), frontend.TorchArrays("cuda:0"), fx), fx, "csrc/glue.hip vs the reference frontend")
+
+
 @pytest.mark.gpu
 def test_hip_glue_matches_oracle():
     import torch
