@@ -59,6 +59,8 @@ program ref_frontend_driver
   integer :: ncol, nlay, bs, nblocks, nrep, n_ang, ngpt, nbnd, ngas
   logical :: use_col_dry, use_tlev, checks, timing_lines, band_emis
   character(len=8) :: envv
+  character(len=16) :: envpad
+  integer :: pad_mb, ios
   real(wp), allocatable :: p_lay(:,:), p_lev(:,:), t_lay(:,:), t_lev(:,:), vmr(:,:,:), col_dry(:,:), t_sfc(:), sfc_emis(:), &
                            mu0(:), sfc_alb(:)
   real(wp), allocatable, target :: flux_up(:,:), flux_dn(:,:), flux_dir(:,:)
@@ -77,7 +79,15 @@ program ref_frontend_driver
   if (with_clouds) call get_command_argument(5, fcld)
   call split_names(gases_arg, gases)
   ngas = size(gases)
-  call load_kdist_stream(fk, gases, k, is_lw)
+  ! REF_DRIVER_DEEP_SETUP_MB (the OpenMP-offload build, oracle/build_extern_offload.sh): run the set-up calls that many
+  ! megabytes further down the stack.  flang maps 40-byte descriptor temporaries of the classes' allocatable components with
+  ! `target enter data` and never unmaps them (rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:956,1171;
+  ! gas-optics-template/mo_gas_concentrations.F90:89,269); left where the block loop's automatic arrays come to lie, the next
+  ! `map` of such an array overlaps a stale entry and libomptarget stops ("explicit extension not allowed").
+  pad_mb = 0
+  call get_environment_variable('REF_DRIVER_DEEP_SETUP_MB', envpad)
+  if (len_trim(envpad) > 0) read(envpad, *, iostat=ios) pad_mb
+  call with_stack_pad(pad_mb, 1)
   ngpt = k%get_ngpt(); nbnd = k%get_nband()
 
   open(newunit=u, file=trim(fatm), access='stream', form='unformatted', status='old')
@@ -117,13 +127,7 @@ program ref_frontend_driver
 
   ! gas concentrations per block (examples/rfmip-clear-sky: read_and_block_gases_ty)
   allocate(concs(nblocks))
-  do b = 1, nblocks
-    c0 = (b - 1) * bs + 1; c1 = b * bs
-    call stop_on_err(concs(b)%init(gases))
-    do ig = 1, ngas
-      call stop_on_err(concs(b)%set_vmr(trim(gases(ig)), vmr(c0:c1, :, ig)))
-    end do
-  end do
+  call with_stack_pad(pad_mb, 2)
 
   allocate(flux_up(ncol, nlay+1), flux_dn(ncol, nlay+1))
   if (.not. is_lw) allocate(flux_dir(ncol, nlay+1))
@@ -306,6 +310,28 @@ contains
     ! where a thread's time went (wall clock of the frontend calls, the library's share of them is in its own report)
     if (tid == 0 .and. timing_lines) print '(a,f9.4,a,f9.4,a)', '  thread 0: gas_optics ', real(tick_go, 8) / real(rate, 8), &
       ' s, rte ', real(tick_rte, 8) / real(rate, 8), ' s'
+  end subroutine
+  subroutine setup_k()
+    call load_kdist_stream(fk, gases, k, is_lw)
+  end subroutine
+  subroutine setup_concs()
+    integer :: b, ig, c0, c1
+    do b = 1, nblocks
+      c0 = (b - 1) * bs + 1; c1 = b * bs
+      call stop_on_err(concs(b)%init(gases))
+      do ig = 1, ngas
+        call stop_on_err(concs(b)%set_vmr(trim(gases(ig)), vmr(c0:c1, :, ig)))
+      end do
+    end do
+  end subroutine
+  ! runs `proc` with mb megabytes of stack pushed first (an automatic array that is touched at both ends)
+  subroutine with_stack_pad(mb, which)
+    integer, intent(in) :: mb, which
+    character(len=1) :: pad(int(max(1, mb), 8) * 1048576_8)
+    pad(1) = 'a'; pad(size(pad, kind=8)) = 'z'
+    if (which == 1) call setup_k()
+    if (which == 2) call setup_concs()
+    if (pad(1) /= 'a' .or. pad(size(pad, kind=8)) /= 'z') error stop 'ref_frontend_driver: stack pad overwritten'
   end subroutine
   subroutine stop_on_err(msg)
     character(len=*), intent(in) :: msg

@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <dlfcn.h>
 #include <chrono>
 #include <exception>
 #include <mutex>
@@ -280,6 +281,28 @@ void* persistent(int slot, size_t bytes, bool* fresh) {
 // 0: ordinary host memory (staged through the arena), 1: device memory (launch in place, asynchronously),
 // 2: host-VISIBLE memory a kernel can address (pinned / registered host memory, managed memory): launched in place
 //    through `dev`, but the host may read it as soon as the call returns, so the call must drain the stream.
+// OpenMP target offload in the CALLER (the reference frontend built with `flang -fopenmp --offload-arch=gfx950` keeps its
+// arrays on the device with its own `!$omp target data` regions, rte/frontend/mo_rte_lw.F90:327-365,
+// rrtmgp/frontend/mo_gas_optics_rrtmgp.F90:594-609): such a caller passes the HOST address of a MAPPED array.  If the
+// process has an OpenMP offload runtime (omp_get_mapped_ptr, OpenMP 5.1, resolved at run time: the library does not link
+// libomptarget), the array's device address is used in place -- no staging, no mirror.  RTE_HIP_OMP_MAPPED=0 switches
+// the look-up off.
+static void* omp_mapped(const void* p) {
+  typedef void* (*get_mapped_t)(const void*, int);
+  typedef int (*get_dev_t)(void);
+  static const get_mapped_t get_mapped = (get_mapped_t)dlsym(RTLD_DEFAULT, "omp_get_mapped_ptr");
+  static const get_dev_t get_dev = (get_dev_t)dlsym(RTLD_DEFAULT, "omp_get_default_device");
+  static const bool on = get_mapped && get_dev && !(getenv("RTE_HIP_OMP_MAPPED") && atoi(getenv("RTE_HIP_OMP_MAPPED")) == 0);
+  static const bool verbose = getenv("RTE_HIP_OMP_MAPPED") && atoi(getenv("RTE_HIP_OMP_MAPPED")) == 2;
+  if (verbose) {
+    static bool said = false;
+    if (!said) { said = true; fprintf(stderr, "rte_rrtmgp_hip: omp_get_mapped_ptr %p, omp_get_default_device %p, look-up %s\n", (void*)get_mapped, (void*)get_dev, on ? "on" : "off"); }
+  }
+  if (!on) return nullptr;
+  void* d = get_mapped(p, get_dev());
+  if (verbose) fprintf(stderr, "rte_rrtmgp_hip: omp_get_mapped_ptr(%p) = %p\n", p, d);
+  return (d && d != p) ? d : nullptr;
+}
 static int classify(const void* p, void** dev) {
   *dev = const_cast<void*>(p);
   if (!p) return 1;
@@ -287,10 +310,14 @@ static int classify(const void* p, void** dev) {
   hipError_t e = hipPointerGetAttributes(&a, p);
   if (e != hipSuccess) {
     (void)hipGetLastError();  // plain malloc'ed host memory: "invalid value"
+    // ... unless the caller's OpenMP runtime has it mapped: launched in place on the device copy, and (like host-visible
+    // memory) the call drains the stream before it returns -- the caller's next target region runs on a queue of its own
+    if (void* d = omp_mapped(p)) { *dev = d; return 2; }
     return 0;
   }
   if (a.type == hipMemoryTypeDevice) return 1;
   if (a.type == hipMemoryTypeManaged) return 2;
+  if (void* d = omp_mapped(p)) { *dev = d; return 2; }  // (an array the caller's OpenMP runtime has mapped may also be page-locked by it)
   if (a.type == hipMemoryTypeHost && a.devicePointer != nullptr) { *dev = a.devicePointer; return 2; }
   return 0;
 }
@@ -532,7 +559,18 @@ static void mirror_drop(size_t i) {
 static void mirror_age_out() {
   Context& c = C;
   for (size_t i = c.mirrors.size(); i-- > 0;)
-    if (c.seq - c.mirrors[i].last_use > c.mirror_max_age) { mirror_drop(i); ++c.mstat[6]; }
+    if (c.seq - c.mirrors[i].last_use > c.mirror_max_age) {
+      // An aged-out array whose canaries are still in place was never written back: its host copy holds the canaries and
+      // whatever was there before.  Usually the array is simply gone (freed); if the program hands it to the library again
+      // it is staged as it is -- say so once (rte_hip_writeback(ptr) or a larger RTE_HIP_MIRROR_MAX_AGE are the remedies).
+      static std::atomic<bool> warned{false};
+      if (canaries_intact(c.mirrors[i]) && !warned.exchange(true))
+        fprintf(stderr, "rte_rrtmgp_hip: host-mirror mode dropped the device copy of a %zu-byte host array at %p unused for %ld calls "
+                        "(RTE_HIP_MIRROR_MAX_AGE); its host memory was not written back (rte_hip_writeback); further cases are "
+                        "counted only (rte_hip_mirror_stat(6))\n", c.mirrors[i].bytes, (void*)c.mirrors[i].host, c.mirror_max_age);
+      mirror_drop(i);
+      ++c.mstat[6];
+    }
 }
 static void mirror_drop_all() {
   Context& c = C;
@@ -541,14 +579,26 @@ static void mirror_drop_all() {
 }
 // the mirror that CONTAINS [p, p+bytes) with its canaries intact (index), or -1; mirrors that merely overlap the range, or
 // whose host memory was changed, are dropped on the way (the host reused the memory)
-static long mirror_find(const char* p, size_t bytes) {
+static long mirror_find(const char* p, size_t bytes, bool declared = false /* the host program names the array itself (rte_hip_writeback) */) {
   Context& c = C;
   long hit = -1;
   for (size_t i = c.mirrors.size(); i-- > 0;) {
     Mirror& m = c.mirrors[i];
     if (p + bytes <= m.host || m.host + m.bytes <= p) continue;
     const bool contained = m.host <= p && p + bytes <= m.host + m.bytes;
-    if (contained && hit < 0 && canaries_intact(m)) { hit = (long)i; continue; }
+    // A PART of a mirrored array is only served from the device copy if the part itself holds one of the array's canaries:
+    // a smaller host array allocated later inside a freed mirrored one, between two canaries, would otherwise be a hit with
+    // every canary intact and the kernel would get the stale device copy instead of the host's data.  (Whole arrays --
+    // what the frontend hands from one kernel to the next -- always hold all of them.)
+    bool guarded = contained && ((bytes == m.bytes && p == m.host) || declared);
+    if (contained && !guarded) {
+      const size_t lo = (size_t)(p - m.host), hi = lo + bytes;
+      for (int k = 0; k < kCanaries && !guarded; ++k) {
+        const size_t o = canary_offset(m.bytes, k);
+        guarded = o >= lo && o + 16 <= hi;
+      }
+    }
+    if (contained && guarded && hit < 0 && canaries_intact(m)) { hit = (long)i; continue; }
     ++c.mstat[contained ? 4 : 5];
     mirror_drop(i);
     if (hit > (long)i) --hit;
@@ -1039,7 +1089,7 @@ int rte_hip_writeback(const void* p) {
   RTE_TRY
   LOCK_CTX;
   rte::Context& c = rte::ctx();
-  const long hit = rte::mirror_find((const char*)p, 1);
+  const long hit = rte::mirror_find((const char*)p, 1, true);
   if (hit < 0) return 0;
   rte::Mirror m = c.mirrors[(size_t)hit];
   if (m.zero_pending) HIP_CHECK(hipMemsetAsync(m.dev, 0, m.bytes, c.stream));

@@ -5,6 +5,8 @@
 //        (reference rte/kernels/mo_fluxes_broadband_kernels.F90:32-128).
 // Extension symbols (rte_hip_*): device versions of frontend glue loops that are not behind the
 // reference's C API but must run on the device in a device-resident driver.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -17,7 +19,13 @@ __global__ void __launch_bounds__(256) fill_kernel(Float* __restrict__ a, size_t
   for (; i < n; i += stride) a[i] = v;
 }
 
-void fill(const char* name, Float* a, size_t n, Float v) {
+// rank: of the array as the caller declared it.  Host arrays (what the unchanged Fortran frontend passes): a zero fill of
+// a 1-D or 2-D array is done where the array lives, on the host -- callers read such arrays there right away (the RFMIP
+// driver accumulates into def_tsi, rrtmgp_rfmip_sw.F90:274-283; the simple spectral model fills part of vmr,
+// ssm/mo_optics_ssm.F90:606-612) -- and so is every fill outside host-mirror mode.  Only the 3-D / 4-D arrays of the
+// tau / ssa / g path are recorded on a device copy in host-mirror mode (the frontend hands them straight to the next kernel:
+// mo_gas_optics_rrtmgp.F90:637,679; the mode's contract).
+void fill(const char* name, Float* a, size_t n, Float v, int rank) {
   if (n == 0) return;
   if (v == (Float)0 && rte::defer_zero_enabled() && rte::is_device_memory(a)) {
     rte::defer_zero(a, n * sizeof(Float));  // materialised by the next library call unless consumed
@@ -25,7 +33,11 @@ void fill(const char* name, Float* a, size_t n, Float v) {
   }
   RTE_TRY
   rte::Call c(name);
-  if (v == (Float)0 && c.lazy_zero(a, n * sizeof(Float))) return;  // host-mirror mode: recorded on the device copy
+  if (v == (Float)0 && rank >= 3 && c.lazy_zero(a, n * sizeof(Float))) return;  // host-mirror mode: recorded on the device copy
+  if (v == (Float)0 && !rte::is_device_pointer(a)) {  // pageable host array: zeroed in place (a mirror of it, if any, loses its canaries)
+    memset(a, 0, n * sizeof(Float));
+    return;
+  }
   Float* d = v == (Float)0 ? c.out_lazy(a, n) : c.out(a, n);
   rte::ProfScope p("fill_kernel");
   if (v == (Float)0) {
@@ -123,23 +135,23 @@ broadcast_gpt_kernel(int ncol, int ngpt, const Float* __restrict__ per_gpt, Floa
 }  // namespace
 
 extern "C" {
-void zero_array_1D(const int* ni, Float* a) { fill("zero_array_1D", a, (size_t)*ni, 0); }
-void zero_array_2D(const int* ni, const int* nj, Float* a) { fill("zero_array_2D", a, (size_t)*ni * *nj, 0); }
+void zero_array_1D(const int* ni, Float* a) { fill("zero_array_1D", a, (size_t)*ni, 0, 1); }
+void zero_array_2D(const int* ni, const int* nj, Float* a) { fill("zero_array_2D", a, (size_t)*ni * *nj, 0, 2); }
 void zero_array_3D(const int* ni, const int* nj, const int* nk, Float* a) {
-  fill("zero_array_3D", a, (size_t)*ni * *nj * *nk, 0);
+  fill("zero_array_3D", a, (size_t)*ni * *nj * *nk, 0, 3);
 }
 void zero_array_4D(const int* ni, const int* nj, const int* nk, const int* nl, Float* a) {
-  fill("zero_array_4D", a, (size_t)*ni * *nj * *nk * *nl, 0);
+  fill("zero_array_4D", a, (size_t)*ni * *nj * *nk * *nl, 0, 4);
 }
-void set_to_scalar_1D(const int* ni, Float* a, const Float* v) { fill("set_to_scalar_1D", a, (size_t)*ni, *v); }
+void set_to_scalar_1D(const int* ni, Float* a, const Float* v) { fill("set_to_scalar_1D", a, (size_t)*ni, *v, 1); }
 void set_to_scalar_2D(const int* ni, const int* nj, Float* a, const Float* v) {
-  fill("set_to_scalar_2D", a, (size_t)*ni * *nj, *v);
+  fill("set_to_scalar_2D", a, (size_t)*ni * *nj, *v, 2);
 }
 void set_to_scalar_3D(const int* ni, const int* nj, const int* nk, Float* a, const Float* v) {
-  fill("set_to_scalar_3D", a, (size_t)*ni * *nj * *nk, *v);
+  fill("set_to_scalar_3D", a, (size_t)*ni * *nj * *nk, *v, 3);
 }
 void set_to_scalar_4D(const int* ni, const int* nj, const int* nk, const int* nl, Float* a, const Float* v) {
-  fill("set_to_scalar_4D", a, (size_t)*ni * *nj * *nk * *nl, *v);
+  fill("set_to_scalar_4D", a, (size_t)*ni * *nj * *nk * *nl, *v, 4);
 }
 
 void rte_sum_broadband(const int* ncol, const int* nlev, const int* ngpt, const Float* spectral_flux,

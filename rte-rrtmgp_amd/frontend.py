@@ -626,8 +626,10 @@ def rte_lw_byband(lib, xp, ncol, nlay, ngpt, nbnd, band_lims_gpt, top_at_1, tau,
         rc = hiplib.ext_call(lib, "rte_hip_lw_solver_noscat_byband", "iiiiiiaaaaaaaaaaa", ncol, nlay, ngpt, nbnd, int(top_at_1), nmus,
                              b[("secants", nmus)], weights, band_lims_gpt, tau, lay_src, lev_src, sfc_emis_gpt, sfc_src, inc_flux,
                              b["bb_up"], b["bb_dn"])
-        assert rc == 0, rc
-        return b
+        assert rc in (0, -2), rc
+        if rc == 0:
+            return b
+        # (-2: a shape the extension does not take, e.g. ncol * (nlay + 1) >= 2^29 -- the reference's route below)
     r = rte_lw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, lay_src, lev_src, sfc_emis_gpt, sfc_src, n_gauss_angles=n_gauss_angles,
                inc_flux=inc_flux, do_broadband=False, buffers=b)
     lib.rte_sum_byband(ncol, nlay + 1, ngpt, nbnd, band_lims_gpt, r["gpt_flux_up"], b["bb_up"])
@@ -649,8 +651,10 @@ def rte_sw_byband(lib, xp, ncol, nlay, ngpt, nbnd, band_lims_gpt, top_at_1, tau,
         rc = hiplib.ext_call(lib, "rte_hip_sw_solver_2stream_byband", "iiiiiaaaaaaaaiaaaa", ncol, nlay, ngpt, nbnd, int(top_at_1),
                              band_lims_gpt, tau, ssa, g, mu0, sfc_alb_dir_gpt, sfc_alb_dif_gpt, inc_flux_dir,
                              1 if inc_flux_dif is not None else 0, dif, b["bb_up"], b["bb_dn"], b["bb_dir"])
-        assert rc == 0, rc
-        return b
+        assert rc in (0, -2), rc
+        if rc == 0:
+            return b
+        # (-2: a shape the extension does not take -- the spectral arrays + rte_sum_byband below)
     r = rte_sw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, inc_flux_dir, sfc_alb_dir_gpt, sfc_alb_dif_gpt,
                inc_flux_dif=inc_flux_dif, do_broadband=False, buffers=b)
     for k_in, k_out in (("gpt_flux_up", "bb_up"), ("gpt_flux_dn", "bb_dn"), ("gpt_flux_dir", "bb_dir")):

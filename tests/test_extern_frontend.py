@@ -412,3 +412,18 @@ def test_reference_gas_optics_frontend_in_single_precision(kind, top_at_1, block
         e_hip, e_cpu = float(np.max(np.abs(out[k] - truth[k]))), float(np.max(np.abs(cpu_sp[k] - truth[k])))
         assert e_hip <= 3.5e-1, (k, e_hip)
         assert e_hip <= 3.0 * e_cpu + 1e-3, (k, e_hip, e_cpu)
+
+
+@pytest.mark.gpu
+def test_host_addresses_of_openmp_mapped_arrays_are_resolved():
+    """A host program with OpenMP target offload (what the reference frontend is when built with -fopenmp
+    --offload-arch=gfx950) keeps its arrays on the device in `target data` regions and calls the kernel symbols with the HOST
+    addresses of the mapped arrays.  The library resolves them with omp_get_mapped_ptr and works on the device copies in
+    place: oracle/omp_mapped_check.c (ours) verifies the result ON the device before anything is copied back, that no byte
+    was staged for the mapped call, and that the staged call on unmapped arrays gives the same bits."""
+    path = os.path.join(BIN, "omp_mapped_check")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/bin/omp_mapped_check absent (oracle/build_extern_offload.sh needs the build container)")
+    r = subprocess.run([path], capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(os.environ, OMP_TARGET_OFFLOAD="MANDATORY"))
+    assert r.returncode == 0 and "omp_mapped_check ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    assert "mapped call: 0 bytes staged to the device, 0 back" in r.stdout
