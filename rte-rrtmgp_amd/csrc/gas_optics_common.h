@@ -198,6 +198,12 @@ struct TauV5 {
   const int* skip_if;  // device flag: some column has overlapping regimes -> the fallback kernel does the call
   int* worklist;       // [0] = count, then (tile, layer, band) triples for tau_absorption_worklist_kernel
   bool overwrite;      // tau is known to be zero (deferred zero_array): do not read it
+  // Plain-ABI calls (no deferred zero fill): tau is intent(inout), but the frontend has just zeroed it
+  // (mo_gas_optics_rrtmgp.F90:637,679).  tau_is_zero_kernel reads the array once (12 GB at the load ceiling: 2 ms) and leaves
+  // "some element is not zero" in *nonzero; the OVERWRITE instance of the kernel then runs if it is 0, the accumulating one
+  // (fp64 atomics in L2, 9.8 ms against 4.9) only if it is not.  run_when: 0 always, 1 if *nonzero == 0, 2 if *nonzero != 0.
+  const int* nonzero;
+  int run_when;
   bool atomic_ok;      // tau is device memory proper: hardware floating-point atomics are defined on it (not on host-visible memory)
   const Float* add_bybnd;  // (ncol, nlay, nbnd) or nullptr: see TauArgs
   RaylFuse rf;             // used by the RAYL instantiations only
@@ -410,6 +416,20 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
   }
 }
 
+// "is any element of a[0 .. n) not zero" (NaNs count as not zero): sets *flag, never clears it
+__global__ void __launch_bounds__(256) tau_is_zero_kernel(const Float* __restrict__ a, size_t n, int* __restrict__ flag) {
+  typedef Float vec2 __attribute__((ext_vector_type(2)));
+  const size_t n2 = n / 2;
+  const vec2* a2 = reinterpret_cast<const vec2*>(a);  // (16-byte aligned: checked by the host)
+  bool nz = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) {
+    const vec2 v = __builtin_nontemporal_load(a2 + i);
+    nz = nz || !(v.x == (Float)0) || !(v.y == (Float)0);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) nz = nz || !(a[n - 1] == (Float)0);
+  if (__ballot(nz) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 // the few flag / counter words a call needs zeroed, in ONE launch (each hipMemsetAsync is a launch of its own)
 __global__ void __launch_bounds__(256) zero_words_kernel(int* a, unsigned na, int* b, unsigned nb, int* c, unsigned nc) {
   for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < na + nb + nc; i += gridDim.x * 256) {
@@ -428,6 +448,7 @@ __global__ void __launch_bounds__(256) zero_words_kernel(int* a, unsigned na, in
 // process-wide tuning switches (set from any thread: relaxed atomics; defined in plans.hip)
 extern std::atomic<int> g_tau_force_direct;
 extern std::atomic<int> g_tau_variant;
+extern std::atomic<int> g_tau_no_zero_check;
 extern std::atomic<int> g_planck_variant;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
 extern std::atomic<int> g_geom_variant;  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
 // Every piece of mutable host-side state of this file lives in the calling thread's current CONTEXT (runtime.hip):

@@ -776,6 +776,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   __shared__ TileGeom tg;
   extern __shared__ BandMeta bm[];  // [nbnd]
   if (*a.skip_if) return;
+  if (a.run_when != 0 && (*a.nonzero != 0) != (a.run_when == 2)) return;  // (plain-ABI calls: see TauV5::nonzero)
   const int tid = threadIdx.x;
   const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
   const unsigned ncl = ncol * nlay;  // host guarantees < 2^31
@@ -1571,8 +1572,9 @@ static void tau_absorption_impl(
   hipStream_t st = rte::stream();
   if (!rh && !c.any_host() && rte::is_device_memory(d_tau)) rte::fork_point(d_tau, sizeof(Float) * ncl * ngpt);
   // layer limits of the two regimes per column (:274-285) + "regimes overlap somewhere" flag
-  int* lim = (int*)rte::scratch(sizeof(int) * (4 * (size_t)ncol + 2));
+  int* lim = (int*)rte::scratch(sizeof(int) * (4 * (size_t)ncol + 3));
   int* overlap = lim + 4 * (size_t)ncol;
+  int* nonzero = overlap + 2;    // some element of the incoming tau is not zero (tau_is_zero_kernel, plain-ABI calls)
   int* irregular = overlap + 1;  // some column's layer ranges are not those of its tropo flags (see tropo_limits_kernel)
   const size_t wl_cap = (size_t)cdiv(ncol, 256) * nlay * nbnd;  // tiles are at least 256 columns wide
   int* const worklist = (int*)rte::scratch(sizeof(int) * (1 + 3 * wl_cap));
@@ -1581,7 +1583,7 @@ static void tau_absorption_impl(
     rte::ProfScope p("tau_absorption_setup");
     // (the validity word of a geometry shared with compute_Planck_source is cleared here too: it is set again only if this
     //  call's geometry kernel runs)
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, overlap, 2u, worklist, 1u, valid_word, valid_word ? 1u : 0u);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, overlap, 3u, worklist, 1u, valid_word, valid_word ? 1u : 0u);
   }  // (layer limits: tropo_limits_kernel below, or a role of tau_setup_kernel on the production path)
   int* d_stale = stale_flag();
   stale_poll();
@@ -1821,6 +1823,14 @@ static void tau_absorption_impl(
   v.col_mix = d_col_mix; v.fmajor = d_fmajor; v.fminor = d_fminor; v.play = d_play; v.tlay = d_tlay;
   v.col_gas = d_col_gas; v.tau = d_tau; v.skip_if = overlap; v.overwrite = overwrite_ok; v.add_bybnd = d_add;
   v.atomic_ok = rte::is_device_memory(d_tau);
+  v.nonzero = nonzero; v.run_when = 0;
+  // plain-ABI accumulate onto device memory: find out first whether tau is (still) the zero array the frontend made of it
+  const bool zero_check = !overwrite_ok && v.atomic_ok && !g_tau_no_zero_check && al(d_tau, 16) && cache.gw != 0 &&
+                          (g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr);
+  if (zero_check) {
+    rte::ProfScope p("tau_is_zero_kernel");
+    hipLaunchKernelGGL(tau_is_zero_kernel, dim3(256 * 16), dim3(256), 0, st, (const Float*)d_tau, ncl * (size_t)ngpt, nonzero);
+  }
   v.rf = RaylFuse{};
   if (rh) {
     v.rf.krayl_g[0] = kray_g; v.rf.krayl_g[1] = kray_g + tn * ngpt; v.rf.col_dry = d_col_dry;
@@ -1919,6 +1929,13 @@ static void tau_absorption_impl(
 #define RTE_LAUNCH_TAU9_(GW, AB)                                                                                  \
   do {                                                                                                            \
     if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
+    else if (zero_check) {                                                                                        \
+      TauV5 vz = v;                                                                                               \
+      vz.run_when = 1; vz.overwrite = true;  /* tau is all zero: the overwriting instance */                      \
+      hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4, AB>), grid, blk, dyn, st, vz, cg); \
+      vz.run_when = 2; vz.overwrite = false;  /* it is not: accumulate */                                         \
+      hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4, AB>), grid, blk, dyn, st, vz, cg); \
+    }                                                                                                             \
     else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
   } while (0)
 #define RTE_LAUNCH_TAU9(GW)                                                                                       \

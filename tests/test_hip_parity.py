@@ -561,6 +561,44 @@ def test_tau_accumulates_onto_device_and_pinned_buffers(hip):
     assert np.array_equal(xp.to_numpy(dev), expect)
 
 
+def test_plain_abi_accumulate_looks_whether_tau_is_zero(hip):
+    """Without the deferred zero fill compute_tau_absorption must accumulate, but the frontend has just zeroed tau
+    (mo_gas_optics_rrtmgp.F90:637,679): the call reads the array once and runs the overwriting kernel when every element is
+    zero, the accumulating one otherwise (TauV5::nonzero).  Same bits as the accumulating kernel alone on a zero array; one
+    non-zero element anywhere -- or a NaN -- and the whole call accumulates."""
+    import torch
+    from rte_rrtmgp_amd import synth
+
+    kd = synth.make_kdist("lw", ngpt=64, nbnd=4)
+    ncol, nlay = 1100, 24
+    atm = synth.make_atmosphere(ncol, nlay, seed=23, kdist=kd)
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    go = frontend.GasOptics(hip, kd, xp)
+    play, tlay, col_gas = A(atm.play), A(atm.tlay), A(atm.col_gas)
+    st = go.interpolation(ncol, nlay, play, tlay, col_gas)
+
+    def run(start, check):
+        hiplib.ext_call(hip, "rte_hip_tau_zero_check", ["i"], 1 if check else 0)
+        try:
+            tau = A(start)
+            go.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau)
+            return xp.to_numpy(tau).copy()
+        finally:
+            hiplib.ext_call(hip, "rte_hip_tau_zero_check", ["i"], 1)
+
+    zero = np.zeros((ncol, nlay, kd.ngpt), order="F")
+    base = run(zero, False)
+    assert base.max() > 0 and np.array_equal(run(zero, True), base)
+    one = zero.copy(order="F"); one[ncol - 1, nlay - 1, kd.ngpt - 1] = 2.5; one[0, 0, 0] = -0.0
+    got = run(one, True)
+    assert np.array_equal(got, run(one, False)) and got[ncol - 1, nlay - 1, kd.ngpt - 1] == 2.5 + base[ncol - 1, nlay - 1, kd.ngpt - 1]
+    bad = zero.copy(order="F"); bad[5, 3, 7] = np.nan
+    got = run(bad, True)
+    assert np.isnan(got[5, 3, 7]) and np.array_equal(np.nan_to_num(got), np.nan_to_num(run(bad, False)))
+    torch.cuda.synchronize()
+
+
 def test_fused_rayleigh_combine_matches_unfused(hip, oracle_c):
     """rte_hip_tau_rayleigh_combine_2str (compute_tau_rayleigh + the 2-stream branch of combine_abs_and_rayleigh in one
     pass, in place on the absorption optical depth) against the unfused ABI calls -- bit-identical -- and the oracle;
