@@ -427,3 +427,47 @@ def test_host_addresses_of_openmp_mapped_arrays_are_resolved():
     r = subprocess.run([path], capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(os.environ, OMP_TARGET_OFFLOAD="MANDATORY"))
     assert r.returncode == 0 and "omp_mapped_check ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
     assert "mapped call: 0 bytes staged to the device, 0 back" in r.stdout
+
+
+@pytest.mark.gpu
+def test_environment_opt_ins_of_an_unchanged_binary(tmp_path):
+    """RTE_HIP_DEFER_ZERO / RTE_HIP_SHARE_GEOMETRY: the opt-in modes for a device-pointer program that cannot call an
+    extension.  A child process that only uses the reference ABI (device arrays, zero_array -> compute_tau_absorption ->
+    compute_Planck_source -> rte_lw) runs with and without the variables: same fluxes bit for bit; with them no fill kernel is
+    launched (the zero fill is folded into the tau kernel) and the tau geometry comes from the interpolation call's masks."""
+    import json
+    import sys
+
+    script = tmp_path / "child.py"
+    script.write_text('''
+import ctypes, json, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import rte_rrtmgp_amd
+from rte_rrtmgp_amd import frontend, hiplib, synth
+lib = hiplib.load(); xp = frontend.TorchArrays("cuda:0"); A = xp.asarray
+kd = synth.make_kdist("lw"); ncol, nlay = 2048, 60
+atm = synth.make_atmosphere(ncol, nlay, seed=12, kdist=kd)
+go = frontend.GasOptics(lib, kd, xp)
+args = [A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tsfc", "col_gas", "tlev")]
+hiplib.ext_call(lib, "rte_hip_profile_reset", []); hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
+b = go.gas_optics_lw(ncol, nlay, *args, atm.top_at_1)
+r = frontend.rte_lw(lib, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"], xp.full((ncol, kd.ngpt), 0.98), b["sfc_src"])
+torch.cuda.synchronize(); hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 0)
+names = []
+for i in range(hiplib.ext_call(lib, "rte_hip_profile_count", [])):
+    buf = ctypes.create_string_buffer(128); cnt, ms = ctypes.c_longlong(0), ctypes.c_double(0)
+    lib.raw("rte_hip_profile_get")(ctypes.c_int(i), buf, ctypes.c_int(128), ctypes.byref(cnt), ctypes.byref(ms))
+    names.append(buf.value.decode())
+up = xp.to_numpy(r["flux_up"])
+print(json.dumps({"kernels": names, "geom_source": hiplib.ext_call(lib, "rte_hip_stat", ["i"], 2), "sum": float(up.sum()), "hex": up.tobytes().hex()[:4096]}))
+''' % ROOT)
+    out = {}
+    for label, env in (("plain", {}), ("opt-in", {"RTE_HIP_DEFER_ZERO": "1", "RTE_HIP_SHARE_GEOMETRY": "1"})):
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[label] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["plain"]["hex"] == out["opt-in"]["hex"] and out["plain"]["sum"] == out["opt-in"]["sum"]
+    assert "fill_kernel" in out["plain"]["kernels"] and "fill_kernel" not in out["opt-in"]["kernels"]
+    assert "tau_is_zero_kernel" in out["plain"]["kernels"] and "tau_is_zero_kernel" not in out["opt-in"]["kernels"]
+    assert out["plain"]["geom_source"] == 2 and out["opt-in"]["geom_source"] == 1   # derived by the geometry kernel / taken from the interpolation call
