@@ -104,7 +104,8 @@ struct Context {
   ProfEntry* cur = nullptr;
   hipEvent_t cur_start = nullptr;
   // ---- error channel
-  bool sticky_errors = false;    // rte_hip_error_mode(1): record and return instead of abort()
+  // rte_hip_error_mode(1) / RTE_HIP_ERROR_MODE=1: record and return instead of abort() (a host model polls rte_hip_last_error)
+  bool sticky_errors = getenv("RTE_HIP_ERROR_MODE") && atoi(getenv("RTE_HIP_ERROR_MODE")) > 0;
   int last_error = 0;            // hipError_t of the first failure since rte_hip_clear_error()
   std::string last_error_msg;
   // ---- state of other translation units (plan caches of the gas-optics kernels), created on demand
