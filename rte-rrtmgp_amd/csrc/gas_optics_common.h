@@ -455,6 +455,15 @@ extern std::atomic<int> g_geom_variant;  // 2: bit-mask pre-pass (tile_geom2_ker
 // plan caches, the geometry shared between consecutive calls, the guards' flag words.  Tuning switches (rte_hip_*_variant)
 // are process-wide.
 namespace {
+// one stage of the matrix-core tau kernel (tau_mx.h): 16 g-points of a band, at most 4 minor intervals per regime; built with
+// the plan on the host, read by the kernel's matrix waves with scalar loads
+struct MxStageRec {
+  int b, g0, k0, flags;   // band, first g-point (0-based), first minor interval of this sub-stage, 1: first sub-stage | 2: last
+  int flav[2];            // the band's flavor per regime
+  unsigned act[2];        // per regime, bit j: interval k0 + j exists and covers these g-points
+  unsigned koff[2][4];    // per regime and interval: offset of these g-points in the regime's minor table row
+};
+constexpr int MX_MAXSTAGE = 128;
 struct TauPlanCache {
   const void* key[14] = {};
   int dims[7] = {};
@@ -464,6 +473,7 @@ struct TauPlanCache {
   bool uploads_pending = false;  // bands changed since the last upload to the device
   unsigned guard = 0;            // checksum of the index tables the plan was built from (tables_guard_kernel)
   std::vector<BandMeta> bands;
+  std::vector<MxStageRec> mx_stages;  // empty: the table is not eligible for the matrix-core kernel
   bool matches(const void* const* k, const int* d, int e) const {
     if (e != epoch) return false;
     for (int i = 0; i < 14; ++i)

@@ -1702,6 +1702,32 @@ static void tau_absorption_impl(
     cache.fast_ok = ok;
     cache.gw = ok ? gw : 0;
     cache.uploads_pending = true;
+    // stage list of the matrix-core kernel: bands in order, 16 g-points at a time, 4 minor intervals per sub-stage
+    cache.mx_stages.clear();
+    if (ok && gw == 16) {
+      for (int b = 0; b < nbnd; ++b) {
+        const BandMeta& bmh = cache.bands[b];
+        const int nmax = bmh.cnt[0] > bmh.cnt[1] ? bmh.cnt[0] : bmh.cnt[1];
+        const int nsub = nmax <= 4 ? 1 : (nmax + 3) / 4;
+        for (int g0 = bmh.gS; g0 <= bmh.gE; g0 += 16)
+          for (int sub = 0; sub < nsub; ++sub) {
+            MxStageRec r{};
+            r.b = b; r.g0 = g0; r.k0 = 4 * sub; r.flags = (sub == 0 ? 1 : 0) | (sub == nsub - 1 ? 2 : 0);
+            for (int q = 0; q < 2; ++q) {
+              r.flav[q] = bmh.flav[q];
+              for (int j = 0; j < 4; ++j) {
+                const int k = r.k0 + j;
+                if (k < bmh.cnt[q] && bmh.m[q][k].mS <= g0 && bmh.m[q][k].mE >= g0) {
+                  r.act[q] |= 1u << j;
+                  r.koff[q][j] = (unsigned)(bmh.m[q][k].kstart + (g0 - bmh.m[q][k].mS));
+                }
+              }
+            }
+            cache.mx_stages.push_back(r);
+          }
+      }
+      if ((int)cache.mx_stages.size() > MX_MAXSTAGE) cache.mx_stages.clear();
+    }
   }
   // A deferred zero fill turns the accumulate into an overwrite of the g-points the bands cover; if the bands do not
   // tile 1..ngpt the fill is executed after all (zero_array would have zeroed the uncovered g-points too)
@@ -1770,10 +1796,13 @@ static void tau_absorption_impl(
   // band metadata lives in a persistent device buffer and is uploaded only when the host plan was rebuilt
   // (a per-call copy from pageable host memory stalls the submitting thread)
   bool bm_fresh = false;
-  BandMeta* d_bm = (BandMeta*)rte::persistent(plan_slot, sizeof(BandMeta) * MAXB, &bm_fresh);
+  BandMeta* d_bm = (BandMeta*)rte::persistent(plan_slot, sizeof(BandMeta) * MAXB + sizeof(MxStageRec) * MX_MAXSTAGE, &bm_fresh);
+  MxStageRec* d_mx_stages = (MxStageRec*)(d_bm + MAXB);
   {
     rte::ProfScope p("relayout_gfast_kernel");
     if (bm_fresh || cache.uploads_pending) {
+      if (!cache.mx_stages.empty())
+        HIP_CHECK(hipMemcpyAsync(d_mx_stages, cache.mx_stages.data(), sizeof(MxStageRec) * cache.mx_stages.size(), hipMemcpyHostToDevice, st));
       HIP_CHECK(hipMemcpyAsync(d_bm, cache.bands.data(), sizeof(BandMeta) * nbnd, hipMemcpyHostToDevice, st));
       HIP_CHECK(hipStreamSynchronize(st));  // cache.bands is host memory that the next rebuild overwrites
       cache.uploads_pending = false;
@@ -1847,24 +1876,25 @@ static void tau_absorption_impl(
   hipStream_t aux = nullptr;
   // ---- the matrix-core kernel (tau_mx.h; rte_hip_tau_variant(10)): double precision, 16-wide stages, no fused Rayleigh
 #ifndef RTE_USE_SP
-  const bool use_mx = g_tau_variant == 10 && cache.gw == 16 && rh == nullptr && ntemp < 64 && npres + 2 < 128 && neta < 32 &&
-                      2 * ntemp * (npres + 2) <= MX_NB && nflav <= MAXFLAV && nbnd <= MAXB;
+  const bool use_mx = g_tau_variant == 10 && cache.gw == 16 && rh == nullptr && ntemp < 32 && npres + 2 < 64 && neta <= 16 &&
+                      2 * ntemp * (npres + 2) <= MX_NB && nflav <= MAXFLAV && nbnd <= MAXB && !cache.mx_stages.empty();
   if (use_mx) {
     constexpr int NW = 8, TILE = NW * 64;
     const unsigned tiles = cdiv(ncol, TILE);
-    unsigned short* sort_idx = (unsigned short*)rte::scratch(sizeof(unsigned short) * (size_t)tiles * nlay * nflav * TILE);
+    unsigned* sort_pk = (unsigned*)rte::scratch(sizeof(unsigned) * (size_t)tiles * nlay * nflav * TILE);
     int* n_lo = (int*)rte::scratch(sizeof(int) * (size_t)tiles * nlay);
     {
       rte::ProfScope p("tau_absorption_setup");
       hipLaunchKernelGGL((tau_mx_sort_kernel<TILE>), dim3(tiles, nlay), dim3(TILE), 0, st, ncol, nlay, nflav, neta, d_jtemp, d_jpress,
-                         d_tropo, d_jeta, (const int*)overlap, (const int*)irregular, sort_idx, n_lo);
+                         d_tropo, d_jeta, (const int*)overlap, (const int*)irregular, sort_pk, n_lo);
     }
     MxArgs m{};
     m.ncol = ncol; m.nlay = nlay; m.ngpt = ngpt; m.nbnd = nbnd; m.ntemp = ntemp; m.TE = TE; m.idx_h2o = *idx_h2o_;
     m.nk_lo = nkl; m.nk_up = nku; m.nflav = nflav; m.bmeta = d_bm; m.kmaj = kmaj_g; m.klo = klo_g; m.kup = kup_g;
     m.jeta = d_jeta; m.jtemp = d_jtemp; m.jpress = d_jpress; m.tropo = d_tropo; m.col_mix = d_col_mix; m.fmajor = d_fmajor;
     m.fminor = d_fminor; m.play = d_play; m.tlay = d_tlay; m.col_gas = d_col_gas; m.tau = d_tau; m.add_bybnd = d_add;
-    m.skip_if = overlap; m.skip_if2 = irregular; m.sort_idx = sort_idx; m.n_lo = n_lo; m.stat = stats_dev() + 3;
+    m.skip_if = overlap; m.skip_if2 = irregular; m.sort_pk = sort_pk; m.n_lo = n_lo; m.stat = stats_dev() + 3;
+    m.stages = d_mx_stages; m.nstage = (int)cache.mx_stages.size();
     const dim3 grid(tiles, nlay), blk(2 * TILE);
     const size_t dyn = sizeof(BandMeta) * nbnd;
     rte::ProfScope p("tau_absorption_kernel");

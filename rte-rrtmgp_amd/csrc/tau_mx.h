@@ -48,9 +48,9 @@ constexpr int MX_MINOR = 4;   // minor intervals per sub-stage
 // (consecutive rows, same logical granule) and the 16 rows an MFMA operand gathers spread over the banks
 __device__ __forceinline__ int mx_elem(int row, int e) { return row * 16 + ((((e >> 1) ^ (row & 7)) << 1) | (e & 1)); }
 
-// key of a column: jT < 64, jp < 128, eta indices < 32 (checked by the host)
+// key of a column, 20 bits: jT < 32, jp = jpress + itropo + 1 < 64, eta indices < 16 (checked by the host)
 __device__ __forceinline__ unsigned mx_key(int jT, int jp, int itropo, int e1, int e2) {
-  return (unsigned)jT | ((unsigned)jp << 6) | ((unsigned)itropo << 13) | ((unsigned)e1 << 14) | ((unsigned)e2 << 19);
+  return (unsigned)jT | ((unsigned)jp << 5) | ((unsigned)itropo << 11) | ((unsigned)e1 << 12) | ((unsigned)e2 << 16);
 }
 
 // inclusive scan over the block of one value per thread (TILE threads); returns the exclusive prefix, *total = block sum.
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(TILE)
 tau_mx_sort_kernel(int ncol, int nlay, int nflav, int neta, const int* __restrict__ jtemp, const int* __restrict__ jpress,
                    const Bool* __restrict__ tropo, const int* __restrict__ jeta, const int* __restrict__ skip_if,
                    const int* __restrict__ skip_if2,
-                   unsigned short* __restrict__ sort_idx /*[tile][lay][flav][TILE]*/, int* __restrict__ n_lo_out /*[tile][lay]*/) {
+                   unsigned* __restrict__ sort_pk /*[tile][lay][flav][TILE]: column | key << 9*/, int* __restrict__ n_lo_out /*[tile][lay]*/) {
   constexpr int NW = TILE / 64, BPT = MX_NB / TILE;
   static_assert(MX_NB % TILE == 0, "bins per thread");
   __shared__ int bins[2][MX_NB];
@@ -134,7 +134,8 @@ tau_mx_sort_kernel(int ncol, int nlay, int nflav, int neta, const int* __restric
   }
   const int NE = neta;  // eta indices are 1 .. neta - 1
   const int nbins = nbase * NE * NE;
-  unsigned short* const out = sort_idx + (size_t)(blockIdx.x + gridDim.x * ilay) * nflav * TILE;
+  unsigned* const out = sort_pk + (size_t)(blockIdx.x + gridDim.x * ilay) * nflav * TILE;
+  static_assert(TILE <= 512, "9 bits for the column");
   int it = 0;
   for (int f = 0; f < nflav; ++f) {
     const int2 je_next = *reinterpret_cast<const int2*>(jeta + 2 * (cl + ncl * (size_t)min(f + 1, nflav - 1)));
@@ -155,7 +156,7 @@ tau_mx_sort_kernel(int ncol, int nlay, int nflav, int neta, const int* __restric
 #pragma unroll
       for (int j = 0; j < BPT; ++j) B[BPT * tid + j] = base + ex + loc[j];
       __syncthreads();
-      if (in) out[(size_t)f * TILE + B[code - win] + r] = (unsigned short)tid;
+      if (in) out[(size_t)f * TILE + B[code - win] + r] = (unsigned)tid | (mx_key(jT, jp + 1, itropo, je.x, je.y) << 9);
       base += total;
     }
     je = je_next;
@@ -187,7 +188,9 @@ struct MxArgs {
   Float* tau;
   const Float* add_bybnd;
   const int *skip_if, *skip_if2;  // overlapping regimes / a stale plan; layer ranges that are not those of the tropo flags
-  const unsigned short* sort_idx;
+  const unsigned* sort_pk;      // per (tile, layer, flavor): the tile's columns sorted by key, column | key << 9
+  const MxStageRec* stages;     // the stage list (plan)
+  int nstage;
   const int* n_lo;
   int* stat;  // rte_hip_stat(3) = 10: this kernel did the call
 };
@@ -223,7 +226,6 @@ template <int NW /* column waves = matrix waves */, bool OVERWRITE, bool ADDB>
 __global__ void __launch_bounds__(NW * 128) tau_absorption_mx_kernel(MxArgs a) {
   constexpr int TILE = NW * 64;
   __shared__ __align__(16) double buf[2][TILE * 16];
-  __shared__ unsigned kbase[TILE];  // (jtemp, jpress + itropo + 1, itropo) of the tile's columns: the flavor-independent part of the key
   extern __shared__ BandMeta bm[];  // [nbnd]
   if (*a.skip_if || *a.skip_if2) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -248,10 +250,14 @@ __global__ void __launch_bounds__(NW * 128) tau_absorption_mx_kernel(MxArgs a) {
   const int rtid = tid & (TILE - 1);  // thread index within the role
   if (is_matrix) {
     // ================================ matrix waves ================================
-    // Per stage and wave: 64 sorted positions = 4 groups of 16.  Everything a stage's MFMAs need except the weight rows is
-    // known BEFORE the stage's barrier: the sorted column list (requested two stages ahead), the columns' eta indices
-    // (gathered one stage ahead -> their keys -> the runs of equal keys among the 64 positions) and hence the K rows of the
-    // first MX_PRE runs, whose loads are in flight while the wave waits at the barrier.
+    // Per stage and wave: 64 sorted positions = 4 groups of 16, in RUNS of equal keys.  Everything a stage's MFMAs need except
+    // the weight rows is known BEFORE the stage's barrier: the sorted (column, key) list of the band's flavor comes from the
+    // pre-pass (requested three stages ahead: under the column waves' stores a request takes about a stage to come back),
+    // hence the runs and the K rows of the first MX_PRE runs, whose loads are in flight while the wave waits at the barrier;
+    // the stage's plan (band, g-points, active minor intervals, offsets) comes from the plan's stage list by scalar loads.
+    // (A ring of K sets reloaded a whole stage ahead -- statically unrolled run sections, counted waits -- was built and
+    //  measured as well: no faster.  What the K rows cost is their VOLUME, 12-18 GB per launch through L2 and the fabric,
+    //  not their latency: DESIGN.md section 4.2b.)
     constexpr int MX_PRE = 3;
 #ifdef MX_PRIO
     __builtin_amdgcn_s_setprio(MX_PRIO);
@@ -260,43 +266,26 @@ __global__ void __launch_bounds__(NW * 128) tau_absorption_mx_kernel(MxArgs a) {
     const int kk = lane >> 4, gl = lane & 15;
     const size_t tl = blockIdx.x + (size_t)gridDim.x * ilay;
     const int n_lo = a.n_lo[tl];
-    const int rl = p < n_lo ? 0 : 1;  // the regime of the column at this position (lower columns sort first)
-    const unsigned short* const sidx = a.sort_idx + tl * a.nflav * TILE + p;
-    const unsigned col0 = blockIdx.x * TILE;
-    auto je_of = [&](int c, int flav) -> int2 {
-      const unsigned clc = min(col0 + (unsigned)c, ncol - 1) + ncol * ilay;
-      return *reinterpret_cast<const int2*>(a.jeta + 2 * ((size_t)clc + (size_t)ncl * flav));
+    const bool up = p >= n_lo;  // the regime of the column at this position (lower columns sort first)
+    const unsigned* const spk = a.sort_pk + tl * a.nflav * TILE + p;
+    const MxStageRec* const ST = a.stages;
+    const int nst = a.nstage;
+    auto pk_of = [&](int j) -> unsigned {
+      const MxStageRec& r = ST[min(j, nst - 1)];
+      return spk[(size_t)(up ? r.flav[1] : r.flav[0]) * TILE];
     };
     struct KRun { double K0, K1, Km[MX_MINOR]; };
-    MxStage sA = s0;            // stage i
-    mx_stage_uniform(sA);
-    MxStage sB = sA;            // stage i + 1
-    mx_stage_next(bm, nbnd, sB); mx_stage_uniform(sB);
-    int idxA = sidx[(size_t)bm[sA.b].flav[rl] * TILE];
-    int idxB = sidx[(size_t)bm[sB.b].flav[rl] * TILE];
-    int2 jeA = je_of(idxA, bm[sA.b].flav[rl]);
-    __syncthreads();  // kbase is written
+    unsigned pkA = pk_of(0), pkB = pk_of(1), pkC = pk_of(2);
+    __syncthreads();  // (the column waves' prologue barrier)
     MX_T0();
 #pragma unroll 1
     for (int i = 0; i <= nstage; ++i) {
-      const MxStage sc = sA;
-      const int g0 = sc.g0;
-      // ---- the stage's minor-interval plan per regime (band table in LDS -> scalars)
-      unsigned actm[2] = {0, 0};
-      unsigned koff[2][MX_MINOR];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int cnt = __builtin_amdgcn_readfirstlane(bm[sc.b].cnt[r]);
-#pragma unroll
-        for (int j = 0; j < MX_MINOR; ++j) {
-          const MinorMeta& m = bm[sc.b].m[r][min(sc.k0 + j, MAXM - 1)];
-          const int mS = __builtin_amdgcn_readfirstlane(m.mS), mE = __builtin_amdgcn_readfirstlane(m.mE);
-          koff[r][j] = (unsigned)__builtin_amdgcn_readfirstlane(m.kstart) + (unsigned)(g0 - mS);
-          if (sc.k0 + j < cnt && mS <= g0 && mE >= g0) actm[r] |= 1u << j;
-        }
-      }
+      const MxStageRec st = ST[min(i, nst - 1)];
+      const int g0 = st.g0;
+      const bool first = (st.flags & 1) != 0;
       // ---- keys of my 64 positions, runs of equal keys
-      const unsigned key_l = kbase[idxA] | ((unsigned)jeA.x << 14) | ((unsigned)jeA.y << 19);
+      const unsigned key_l = pkA >> 9;
+      const int idxA = (int)(pkA & 511u);
       const unsigned key_p = (unsigned)__shfl_up((int)key_l, 1);
       const unsigned long long starts = __ballot(lane == 0 || key_l != key_p);
       auto load_run = [&](unsigned kc, KRun& k) {
@@ -304,7 +293,10 @@ __global__ void __launch_bounds__(NW * 128) tau_absorption_mx_kernel(MxArgs a) {
         k.K0 = 1.0; k.K1 = 2.0; k.Km[0] = k.Km[1] = k.Km[2] = k.Km[3] = 0.5;
         return;
 #endif
-        const int jT = kc & 63, jp = (kc >> 6) & 127, itr = (kc >> 13) & 1, e1 = (kc >> 14) & 31, e2 = (kc >> 19) & 31;
+#ifdef MX_X_KFIXED   // experiment: every request goes to the same rows (what do the requests cost when they hit the nearest cache?)
+        kc = 2u | (3u << 5) | (1u << 12) | (1u << 16);
+#endif
+        const int jT = kc & 31, jp = (kc >> 5) & 63, itr = (kc >> 11) & 1, e1 = (kc >> 12) & 15, e2 = (kc >> 16) & 15;
         // major: corner kk = eta offset + 2 x pressure offset, of temperature jT (K0, eta index e1) and jT + 1 (K1, e2)
         const unsigned rp = (unsigned)(jp - 2 + (kk >> 1)) * (unsigned)TE;
         k.K0 = a.kmaj[(size_t)(rp + (unsigned)(e1 - 1 + (kk & 1)) * ntemp + (unsigned)(jT - 1)) * ngpt + g0 + gl];
@@ -313,11 +305,11 @@ __global__ void __launch_bounds__(NW * 128) tau_absorption_mx_kernel(MxArgs a) {
         const Float* const kt = itr ? a.kup : a.klo;
         const unsigned nk = itr ? a.nk_up : a.nk_lo;
         const unsigned rm = (unsigned)(((kk >> 1) ? e2 : e1) - 1 + (kk & 1)) * ntemp + (unsigned)(jT - 1 + (kk >> 1));
-        const unsigned am = itr ? actm[1] : actm[0];
+        const unsigned am = itr ? st.act[1] : st.act[0];
 #pragma unroll
         for (int j = 0; j < MX_MINOR; ++j) {
           k.Km[j] = 0;
-          if (am & (1u << j)) k.Km[j] = kt[(size_t)rm * nk + (itr ? koff[1][j] : koff[0][j]) + gl];
+          if (am & (1u << j)) k.Km[j] = kt[(size_t)rm * nk + (itr ? st.koff[1][j] : st.koff[0][j]) + gl];
         }
       };
       KRun kp[MX_PRE];
@@ -334,88 +326,74 @@ __global__ void __launch_bounds__(NW * 128) tau_absorption_mx_kernel(MxArgs a) {
           }
         }
       }
-      // ---- requests for the next stages
-      mx_stage_next(bm, nbnd, sA); mx_stage_uniform(sA);  // -> stage i + 1 (= sB)
-      MxStage sC = sA;
-      mx_stage_next(bm, nbnd, sC); mx_stage_uniform(sC);  // stage i + 2
-      const int2 jeB = je_of(idxB, bm[sA.b].flav[rl]);
-      const int idxC = sidx[(size_t)bm[sC.b].flav[rl] * TILE];
+      const unsigned pkD = pk_of(i + 3);  // (three stages ahead)
       MX_ARRIVE();
       __syncthreads();  // B(i): the weight rows of stage i are in buf[i & 1]; the column waves have tau of stage i - 1
       MX_LEAVE();
       if (i == nstage) break;
 #ifdef MX_X_NOMAT
-      idxA = idxB; idxB = idxC; jeA = jeB;
+      pkA = pkB; pkB = pkC; pkC = pkD;
       continue;
 #endif
       double* const rows = buf[i & 1];
-      int rcur = -1;
+      // ---- state of the group being worked on (a group may span runs: its accumulator lives across the run sections)
+      int pos = 0, qcur = -1, rcur = -1;
+      unsigned ka = 0, actc = 0;
+      int cd[4] = {0, 0, 0, 0};
+      double w0 = 0, w1 = 0, wm[MX_MINOR] = {0, 0, 0, 0};
+      mx_v4d D = {0, 0, 0, 0};
       KRun kc_;  // the run being worked on
       kc_.K0 = 0; kc_.K1 = 0;
 #pragma unroll
       for (int j = 0; j < MX_MINOR; ++j) kc_.Km[j] = 0;
-      unsigned actc = 0;
 #pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        // weights and result rows of two groups in one LDS round trip
-        int ca[2], cd[2][4];
-        unsigned ka[2];
-        double w0[2], w1[2], wm[2][MX_MINOR];
+      while (pos < 64) {
+        const int q = pos >> 4;
+        if (q != qcur) {  // weights and result rows of the group
+          qcur = q;
+          const int ca = __shfl(idxA, 16 * q + gl);
+          ka = (unsigned)__shfl((int)key_l, 16 * q + gl);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int q = 2 * h + g;
-          ca[g] = __shfl(idxA, 16 * q + gl);
-          ka[g] = (unsigned)__shfl((int)key_l, 16 * q + gl);
+          for (int r = 0; r < 4; ++r) cd[r] = __shfl(idxA, 16 * q + kk + 4 * r);
+          w0 = rows[mx_elem(ca, kk)]; w1 = rows[mx_elem(ca, 4 + kk)];
+          const double wf = rows[mx_elem(ca, 8 + kk)];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) cd[g][r] = __shfl(idxA, 16 * q + kk + 4 * r);
+          for (int j = 0; j < MX_MINOR; ++j) wm[j] = wf * rows[mx_elem(ca, 12 + j)];
+          D = mx_v4d{0, 0, 0, 0};
         }
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          w0[g] = rows[mx_elem(ca[g], kk)]; w1[g] = rows[mx_elem(ca[g], 4 + kk)];
-          const double wf = rows[mx_elem(ca[g], 8 + kk)];
-#pragma unroll
-          for (int j = 0; j < MX_MINOR; ++j) wm[g][j] = wf * rows[mx_elem(ca[g], 12 + j)];
+        // the run that holds position `pos`: its index among the wave's runs, its key, where the next one starts
+        const int r = __popcll(starts & ((2ull << pos) - 1ull)) - 1;
+        const unsigned kc = (unsigned)__builtin_amdgcn_readlane((int)key_l, pos);
+        const unsigned long long later = pos < 63 ? (starts >> (pos + 1)) : 0ull;
+        const int end = later ? pos + 1 + __builtin_ctzll(later) : 64;
+        if (r != rcur) {
+          rcur = r;
+          actc = ((kc >> 11) & 1) ? st.act[1] : st.act[0];
+          if (r == 0) kc_ = kp[0];
+          else if (r == 1) kc_ = kp[1];
+          else if (r == 2) kc_ = kp[2];
+          else load_run(kc, kc_);
         }
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int q = 2 * h + g;
-          mx_v4d D = {0, 0, 0, 0};
-          int pos = 16 * q;
-#pragma unroll 1
-          while (pos < 16 * q + 16) {
-            // the run that holds position `pos`: its index among the wave's runs, its key, where the next one starts
-            const int r = __popcll(starts & ((2ull << pos) - 1ull)) - 1;
-            const unsigned kc = (unsigned)__builtin_amdgcn_readlane((int)key_l, pos);
-            const unsigned long long later = pos < 63 ? (starts >> (pos + 1)) : 0ull;
-            const int next = later ? pos + 1 + __builtin_ctzll(later) : 64;
-            if (r != rcur) {
-              rcur = r;
-              actc = ((kc >> 13) & 1) ? actm[1] : actm[0];
-              if (r == 0) kc_ = kp[0];
-              else if (r == 1) kc_ = kp[1];
-              else if (r == 2) kc_ = kp[2];
-              else load_run(kc, kc_);
-            }
-            const bool mine = ka[g] == kc;
+        const bool mine = ka == kc;
 #ifndef MX_X_NOMFMA
-            if (sc.first) {
-              D = __builtin_amdgcn_mfma_f64_16x16x4f64(mine ? w0[g] : 0.0, kc_.K0, D, 0, 0, 0);
-              D = __builtin_amdgcn_mfma_f64_16x16x4f64(mine ? w1[g] : 0.0, kc_.K1, D, 0, 0, 0);
-            }
+        if (first) {
+          D = __builtin_amdgcn_mfma_f64_16x16x4f64(mine ? w0 : 0.0, kc_.K0, D, 0, 0, 0);
+          D = __builtin_amdgcn_mfma_f64_16x16x4f64(mine ? w1 : 0.0, kc_.K1, D, 0, 0, 0);
+        }
 #pragma unroll
-            for (int j = 0; j < MX_MINOR; ++j)
-              if (actc & (1u << j)) D = __builtin_amdgcn_mfma_f64_16x16x4f64(mine ? wm[g][j] : 0.0, kc_.Km[j], D, 0, 0, 0);
+        for (int j = 0; j < MX_MINOR; ++j)
+          if (actc & (1u << j)) D = __builtin_amdgcn_mfma_f64_16x16x4f64(mine ? wm[j] : 0.0, kc_.Km[j], D, 0, 0, 0);
 #else
-            D[0] += (mine ? w0[g] + w1[g] + wm[g][0] + wm[g][1] + wm[g][2] + wm[g][3] : 0.0) + kc_.K0 + kc_.K1 + kc_.Km[0] + kc_.Km[1] + kc_.Km[2] + kc_.Km[3];
+        D[0] += (mine ? w0 + w1 + wm[0] + wm[1] + wm[2] + wm[3] : 0.0) + kc_.K0 + kc_.K1 + kc_.Km[0] + kc_.Km[1] + kc_.Km[2] + kc_.Km[3];
 #endif
-            pos = next;
-          }
-          // result rows (lane >> 4) + 4 r of the group, g-point gl: back into the columns' rows, in place
+        const int gend = 16 * q + 16;
+        pos = end < gend ? end : gend;
+        if (pos == gend) {  // the group is complete: result rows (lane >> 4) + 4 r, g-point gl, back into the columns' rows, in place
 #pragma unroll
-          for (int r = 0; r < 4; ++r) rows[mx_elem(cd[g][r], gl)] = D[r];
+          for (int r2 = 0; r2 < 4; ++r2) rows[mx_elem(cd[r2], gl)] = D[r2];
         }
       }
-      idxA = idxB; idxB = idxC; jeA = jeB;
+      pkA = pkB; pkB = pkC; pkC = pkD;
     }
     MX_TEND(1);
     return;
@@ -427,15 +405,12 @@ __global__ void __launch_bounds__(NW * 128) tau_absorption_mx_kernel(MxArgs a) {
   const unsigned cl = ic + ncol * ilay;
   const unsigned cl8 = cl * (unsigned)sizeof(Float);
   const int itropo = a.tropo[cl] ? 0 : 1;
-  const int jT = a.jtemp[cl];
-  const int jp = a.jpress[cl] + itropo + 1;  // levels jp - 1, jp (1-based)
   const Float P = a.play[cl], T = a.tlay[cl];
   const Float dens = (Float)0.01 * P / T;                                                             // :469
   const Float vmr_fact = (Float)1 / a.col_gas[cl];                                                    // :471
   const Float dry_fact = (Float)1 / ((Float)1 + a.col_gas[cl + (size_t)ncl * a.idx_h2o] * vmr_fact);  // :472
   const Float sfact = vmr_fact * dry_fact;
-  kbase[rtid] = (unsigned)jT | ((unsigned)jp << 6) | ((unsigned)itropo << 13);
-  __syncthreads();  // (the matrix waves read it before the first stage barrier)
+  __syncthreads();  // (prologue barrier, paired with the matrix waves')
   struct In { Float2 fm[4], cm, fn[2]; Float cg[MX_MINOR], cgs[MX_MINOR], addv; };
   auto load_in = [&](const MxStage& s, In& x) {
     const BandMeta& B = bm[s.b];
