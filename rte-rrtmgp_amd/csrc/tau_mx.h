@@ -17,11 +17,11 @@
 //
 //   * tau_mx_sort_kernel (pre-pass): per (512-column tile, layer, FLAVOR) the tile's columns sorted by key (counting
 //     sort on a dense code; regime is the leading key part, so the sort of the band's lower flavor serves the lower
-//     columns and that of its upper flavor the upper ones).  Output: 2 bytes per (column, layer, flavor).
+//     columns and that of its upper flavor the upper ones).  Output: 4 bytes per (column, layer, flavor): column | key << 9.
 //   * tau_absorption_mx_kernel: block = (512-column tile, layer) = 8 COLUMN waves + 8 MATRIX waves, one barrier per
 //     stage (16 g-points of a band), a double-buffered LDS tile of one 128-byte row per column:
 //       column waves (lanes = columns; all global traffic is coalesced as before): write the stage's weight row
-//         [8 major (col_mix folded in) | 4 fminor | 4 minor scalings] + the column's key; a stage later read the row
+//         [8 major (col_mix folded in) | 4 fminor | 4 minor scalings]; a stage later read the row
 //         back -- now holding tau of the stage's 16 g-points -- and store it (non-temporal, 512 B per wave and plane);
 //       matrix waves: 16 sorted positions at a time, per distinct key among them: K rows from the g-fastest tables
 //         (L2 / Infinity Cache; one 8-byte load per lane and 4 rows), A = the columns' weights gathered from their
