@@ -5,7 +5,7 @@
 // selects), a/b 12, sqrt ~12.  The replacements below are written for the argument ranges these kernels
 // actually have and stay within ~1-2 ulp of the correctly rounded result (the tests assert 1e-10 on fluxes
 // against the reference kernels, whose libm is itself only faithful to ~1 ulp):
-//   exp_nonpos(x)  x <= 0 (optical depths): no overflow path, underflow through v_ldexp          19 instr
+//   exp_nonpos(x)  x <= 0 (optical depths): no overflow path, underflow through v_ldexp          18 instr
 //   rcp_nr(d), div_nr(n, d)  d normal and away from the exponent range limits                       6 / 8
 //   sqrt_nr(x), rsqrt_nr(x)  x >= 0 normal or zero                                                   8
 // Single-precision builds (RTE_USE_SP) map to the plain functions.
@@ -21,6 +21,7 @@ __device__ __forceinline__ float exp_nonpos(float x) { return expf(x); }
 __device__ __forceinline__ float rcp_nr(float d) { return 1.0f / d; }
 __device__ __forceinline__ float div_nr(float n, float d) { return n / d; }
 __device__ __forceinline__ float sqrt_nr(float x) { return sqrtf(x); }
+__device__ __forceinline__ float sqrt_pos(float x) { return sqrtf(x); }
 #else
 // Horner step with the coefficient as the addend; the constant sits in a register pair of its own (VGPRs: these kernels have no scalar registers to spare),
 // so a step is ONE v_fma_f64 instead of the v_mov_b64 + v_fmac_f64 pair the generic code gets
@@ -30,7 +31,7 @@ __device__ __forceinline__ double fma_c(double p, double r, double c) {
 }
 
 __device__ __forceinline__ double exp_nonpos(double x) {
-  // x = k ln2 + r, |r| <= ln2/2; exp(r) by its Taylor polynomial of degree 13 (truncation 4e-18 relative)
+  // x = k ln2 + r, |r| <= ln2/2; exp(r) by a polynomial of degree 11 (below)
   {
     // exp underflows to 0 long before -1100; the clamp keeps k and r finite for any input and leaves a NaN a NaN (fmax would
     // turn it into a silent 0 where the reference's exp propagates it).  Only the HIGH word is replaced (one v_cndmask
@@ -41,24 +42,42 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     b = ((unsigned long long)hi_c << 32) | (unsigned)b;
     x = __builtin_bit_cast(double, b);
   }
-  const double k = __builtin_rint(x * 1.4426950408889634074);
+  // k = nearest integer to x / ln2 through the 1.5 * 2^52 shift: the sum's low word IS k as a 32-bit integer (|k| < 2^31), and
+  // subtracting the shift again gives k as a double -- fma + add instead of mul + rndne + cvt
+  const double shift = 6755399441055744.0;
+  const double t = __builtin_fma(x, 1.4426950408889634074, shift);
+  const double k = t - shift;
+  const int ki = (int)(unsigned)__builtin_bit_cast(unsigned long long, t);
   double r = __builtin_fma(k, -6.93147180369123816490e-01, x);  // ln2 high part: k * hi is exact
   r = __builtin_fma(k, -1.90821492927058770002e-10, r);         // ln2 low part
-  double p = 1.0 / 6227020800.0;
-  p = fma_c(p, r, 1.0 / 479001600.0);
-  p = fma_c(p, r, 1.0 / 39916800.0);
-  p = fma_c(p, r, 1.0 / 3628800.0);
-  p = fma_c(p, r, 1.0 / 362880.0);
-  p = fma_c(p, r, 1.0 / 40320.0);
-  p = fma_c(p, r, 1.0 / 5040.0);
-  p = fma_c(p, r, 1.0 / 720.0);
-  p = fma_c(p, r, 1.0 / 120.0);
-  p = fma_c(p, r, 1.0 / 24.0);
-  p = fma_c(p, r, 1.0 / 6.0);
-  p = __builtin_fma(p, r, 0.5);
+  // exp(r) = 1 + r + r^2 q(r), q of degree 9: the minimax coefficients of tools/exp_minimax.py (relative truncation error
+  // 3.6e-18 on |r| <= ln2 / 2; the double-precision evaluation is as close to exp as that of the degree-13 Taylor polynomial
+  // it replaces, 1.12e-16 against 1.11e-16 worst case, in two steps less)
+  double p = 0x1.ad7f6c51b1da1p-26;
+  p = fma_c(p, r, 0x1.28ad72cedc06bp-22);
+  p = fma_c(p, r, 0x1.71df2553d8691p-19);
+  p = fma_c(p, r, 0x1.a0199a0c64c3ep-16);
+  p = fma_c(p, r, 0x1.a01a012a57075p-13);
+  p = fma_c(p, r, 0x1.6c16c1842a12ap-10);
+  p = fma_c(p, r, 0x1.1111111127be7p-7);
+  p = fma_c(p, r, 0x1.555555555087cp-5);
+  p = fma_c(p, r, 0x1.55555555554fap-3);
+  p = fma_c(p, r, 0x1.000000000000ap-1);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  return __builtin_amdgcn_ldexp(p, (int)k);  // gradual underflow / 0 for large |x|
+  return __builtin_amdgcn_ldexp(p, ki);  // gradual underflow / 0 for large |x|
+}
+
+// sqrt(x) for x > 0 and normal (the caller has clamped it from below): sqrt_nr without the select that guards x = 0
+__device__ __forceinline__ double sqrt_pos(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double s = x * y;
+  double h = 0.5 * y;
+  double e = __builtin_fma(-h, s, 0.5);
+  s = __builtin_fma(s, e, s);
+  h = __builtin_fma(h, e, h);
+  e = __builtin_fma(-s, s, x);
+  return __builtin_fma(e, h, s);
 }
 
 // 1/d: hardware estimate + two Newton steps (quadratic: 2^-26 -> 2^-52 -> rounding level).  Deviation from IEEE division:

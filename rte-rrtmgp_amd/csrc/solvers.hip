@@ -1039,6 +1039,16 @@ struct Sw2SegArgs {
 
 // SPEC: spectral output (rte_sw with a ty_fluxes other than ty_fluxes_broadband, rte/frontend/mo_rte_sw.F90): every wave
 // stores the three fluxes of the levels it owns per g-point instead of accumulating them
+
+#ifdef SW_TIMING
+// experiment builds only (tools/fastbuild.py swt:solvers.hip=-DSW_TIMING): s_memtime ticks the waves of sw_2stream_seg_kernel spend
+// in each phase of a g-point, summed per segment number: [wave][0] pass 1 + composite, [1] waiting at the first barrier,
+// [2] beam + adding chain, [3] own layers + downward composite, [4] waiting at the second barrier, [5] final sweep
+__device__ unsigned long long sw_clk[8][6];
+#define SW_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define SW_T(k) do { } while (0)
+#endif
 template <int L, bool SPEC = false, bool WIN = false>
 __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 #pragma clang fp contract(fast)  // VALU-bound: fuse a*b+c (the segment composites already differ from the reference's rounding)
@@ -1155,19 +1165,28 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   unsigned ocg = (unsigned)c * (unsigned)sizeof(Float);
   asm volatile("" : "+v"(ocg));
   auto at = [](const Float* plane, unsigned off) {  // plane is wave-uniform
-    asm volatile("" : "+v"(off));  // opaque inside the g-point loop: its 64-bit extension cannot be hoisted
     return *reinterpret_cast<const Float*>(reinterpret_cast<const char*>(plane) + off);
   };
   auto load = [&](In& x, int igpt_) {
     const int igpt = min(igpt_, g_end - 1);
     const Float *ptau = a.tau + ncl * igpt, *pssa = a.ssa + ncl * igpt, *pg = a.g + ncl * igpt;
+    // the row offsets are made opaque IN PLACE once per g-point (their 64-bit extension cannot be hoisted out of the loop into
+    // registers of its own); as a by-value copy per load the compiler moved every offset into a scratch register first: 27
+    // v_mov per g-point and wave
 #pragma unroll
-    for (int i = 0; i < L; ++i) { x.tau[i] = at(ptau, orow[i]); x.ssa[i] = at(pssa, orow[i]); x.g[i] = at(pg, orow[i]); }
+    for (int i = 0; i < L; ++i) {
+      asm volatile("" : "+v"(orow[i]));
+      x.tau[i] = at(ptau, orow[i]); x.ssa[i] = at(pssa, orow[i]); x.g[i] = at(pg, orow[i]);
+    }
+    asm volatile("" : "+v"(ocg));
     const size_t cg = (size_t)ncol * igpt;
     x.inc_dir = at(a.inc_flux_dir + cg, ocg); x.alb_dir = at(a.sfc_alb_dir + cg, ocg); x.alb_dif = at(a.sfc_alb_dif + cg, ocg);
     x.inc_dif = a.has_dif_bc ? at(a.inc_flux_dif + cg, ocg) : (Float)0;  // :579-583
   };
 
+#ifdef SW_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
   auto process = [&](In& x, int igpt_next) {
 #pragma clang fp contract(fast)
     Float R[L], T[L], su[L], sd[L];  // Rdif, Tdif, source up / down (relative to the beam entering the segment)
@@ -1185,7 +1204,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         const Float gamma2 = (Float)3 * (w0_s * ((Float)1 - g_s)) * (Float).25;
         // (the reference's own operation order: gamma1 - gamma2 cancels for conservative scattering, and a differently rounded
         //  pair moves the fluxes of cloudy columns by 1e-8 relative to the reference's -- measured, all-sky at 1e5 columns)
-        const Float kk = rte::sqrt_nr(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
+        const Float kk = rte::sqrt_pos(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
         const Float e1 = rte::exp_nonpos(-tau_s * kk);
         const Float e2 = e1 * e1;
         // RT = 1 / x (:1031) and w0 RT / om (:1054) from ONE reciprocal, of x om
@@ -1231,10 +1250,22 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         P = Tnoscat * P;
       }
     }
+    // the layer inputs are dead: request the next g-point's into the same registers (in flight during (2), (3);
+    // spreading the requests over pass (1), layer by layer, was tried: the register allocator spills)
+    const Float inc_dir = x.inc_dir, alb_dir = x.alb_dir, alb_dif = x.alb_dif, inc_dif = x.inc_dif;
+    if constexpr (PREF) load(x, igpt_next);
     // ---- segment composite of the adding recurrence (bottom -> top product of the per-layer maps)
-    Float m00 = 1, m02 = 0, m10 = 0, m11 = 1, m12 = 0, m20 = 0, m22 = 1;
+    // the sources of the adding chain are carried RELATIVE to the beam entering the segment below (sigma = src / beam): with
+    // beam(q + 1) = beam(q) P(q) the step reads  sigma' = (c10 alb + (c11 P) sigma + c12) w  -- the wave publishes m11 P and the
+    // chain needs no beam per segment (was: a prefix product over all segments in every wave, two more products per step).
+    // (Skipping the top segment's composite, which nobody reads, was measured: no gain -- that wave waits at the barrier anyway.)
+    X1[(0 * SMAX + s) * 64 + lane] = P;
+    // (the product starts FROM the lowest layer's map instead of multiplying it into the identity: the compiler may not drop
+    //  x * 0 and x + 0, and kept all 17 operations of that step)
+    Float m00 = T[L - 1] * T[L - 1] - R[L - 1] * R[L - 1], m02 = R[L - 1], m10 = T[L - 1] * sd[L - 1] - su[L - 1] * R[L - 1],
+          m11 = T[L - 1], m12 = su[L - 1], m20 = -R[L - 1], m22 = 1;
 #pragma unroll
-    for (int i = L - 1; i >= 0; --i) {
+    for (int i = L - 2; i >= 0; --i) {
       const Float q00 = T[i] * T[i] - R[i] * R[i], q02 = R[i], q10 = T[i] * sd[i] - su[i] * R[i], q11 = T[i], q12 = su[i],
                   q20 = -R[i];  // q22 = 1, q01 = q21 = 0
       const Float n00 = q00 * m00 + q02 * m20, n02 = q00 * m02 + q02 * m22;
@@ -1242,45 +1273,49 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
       const Float n20 = q20 * m00 + m20, n22 = q20 * m02 + m22;
       m00 = n00; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m22 = n22;
     }
-    // the layer inputs are dead: request the next g-point's into the same registers (in flight during (2), (3);
-    // spreading the requests over pass (1), layer by layer, was tried: the register allocator spills)
-    const Float inc_dir = x.inc_dir, alb_dir = x.alb_dir, alb_dif = x.alb_dif, inc_dif = x.inc_dif;
-    if constexpr (PREF) load(x, igpt_next);
-    X1[(0 * SMAX + s) * 64 + lane] = P;
     X1[(1 * SMAX + s) * 64 + lane] = m00;
     X1[(2 * SMAX + s) * 64 + lane] = m02;
     X1[(3 * SMAX + s) * 64 + lane] = m10;
-    X1[(4 * SMAX + s) * 64 + lane] = m11;
+    X1[(4 * SMAX + s) * 64 + lane] = m11 * P;
     X1[(5 * SMAX + s) * 64 + lane] = m12;
     X1[(6 * SMAX + s) * 64 + lane] = m20;
     X1[(7 * SMAX + s) * 64 + lane] = m22;
+    SW_T(0);
     __syncthreads();
-    // ---- (2) beam entering every segment; adding chain from the surface up to this segment's lower edge
+    SW_T(1);
+    // comparisons with the wave's segment number stay scalar instructions inside the loop: hoisted out of it they became 64-bit
+    // masks in spilled scalar registers (two v_readlane in front of every branch)
+    int s_u = s, S_u = S;
+    asm volatile("" : "+s"(s_u), "+s"(S_u));
+    // ---- (2) beam entering this segment (all transmissions are requested at once: one wait, not one per segment)
     const Float dir_toa = !WIN || a.beam_mode == 0 ? inc_dir * mu0_top : (a.beam_mode == 1 ? (Float)1 : inc_dir);  // :575
-    Float dir_in = dir_toa, dir_q = dir_toa;    // dir_q: beam entering segment q
-    Float dq[SMAX];
+    Float pq[SMAX - 1];
 #pragma unroll
-    for (int q = 0; q < SMAX; ++q) {
-      dq[q] = dir_q;
-      if (q == s) dir_in = dir_q;
-      if (q < S) dir_q = dir_q * X1[(0 * SMAX + q) * 64 + lane];
-    }
-    const Float dir_sfc = dir_q;
+    for (int q = 0; q < SMAX - 1; ++q) pq[q] = X1[(0 * SMAX + q) * 64 + lane];
+    const Float P_own = X1[(0 * SMAX + s) * 64 + lane];
+    Float dir_in = dir_toa;
+#pragma unroll
+    for (int q = 0; q < SMAX - 1; ++q)
+      if (q < s_u) dir_in = dir_in * pq[q];
+    // ---- adding chain from the surface up to this segment's lower edge
     Float alb = alb_dif;                                                  // :1121
-    Float src = (mu0_sfc > (Float)0 || (WIN && a.sfc_src_given)) ? dir_sfc * alb_dir : (Float)0;     // :1120
+    Float sig = (mu0_sfc > (Float)0 || (WIN && a.sfc_src_given)) ? alb_dir : (Float)0;     // :1120, per unit of beam at the surface
 #pragma unroll
     for (int q = SMAX - 1; q > 0; --q) {
-      if (q < S && q > s) {  // wave-uniform
+      if (q < S_u && q > s_u) {  // wave-uniform
         const Float c00 = X1[(1 * SMAX + q) * 64 + lane], c02 = X1[(2 * SMAX + q) * 64 + lane];
-        const Float c10 = X1[(3 * SMAX + q) * 64 + lane] * dq[q], c11 = X1[(4 * SMAX + q) * 64 + lane];
-        const Float c12 = X1[(5 * SMAX + q) * 64 + lane] * dq[q];
+        const Float c10 = X1[(3 * SMAX + q) * 64 + lane], c11 = X1[(4 * SMAX + q) * 64 + lane];
+        const Float c12 = X1[(5 * SMAX + q) * 64 + lane];
         const Float c20 = X1[(6 * SMAX + q) * 64 + lane], c22 = X1[(7 * SMAX + q) * 64 + lane];
         const Float w = rte::rcp_nr(c20 * alb + c22);
         const Float a_new = (c00 * alb + c02) * w;
-        const Float s_new = (c10 * alb + c11 * src + c12) * w;
-        alb = a_new; src = s_new;
+        sig = (c10 * alb + c11 * sig + c12) * w;
+        alb = a_new;
       }
     }
+    Float src = sig * (dir_in * P_own);  // the beam leaving this segment
+    asm volatile("" : "+v"(src), "+v"(alb));
+    SW_T(2);
     // ---- own layers, bottom -> top, the reference's expressions (:1174-1186 / :1214-1226); the beam at the
     // levels is accumulated on the way (direct flux, and the direct part of flux_dn, :603,:606)
     Float al[L + 1], sr[L + 1];  // albedo and source at the levels of the segment (slot i = top of layer i)
@@ -1308,12 +1343,19 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     for (int i = 0; i < L; ++i) { B = fa[i] * B + fb[i]; A = fa[i] * A; }
     X2[(0 * SMAX + s) * 64 + lane] = A;
     X2[(1 * SMAX + s) * 64 + lane] = B;
+    SW_T(3);
     __syncthreads();
+    SW_T(4);
     // ---- (3) diffuse flux entering the segment from above, final sweep (:1188-1202 / :1228-1243)
     Float fd = inc_dif;
+    {
+      Float qa[SMAX - 1], qb[SMAX - 1];  // requested at once, whatever the segment
 #pragma unroll
-    for (int q = 0; q < SMAX - 1; ++q)
-      if (q < s) fd = X2[(0 * SMAX + q) * 64 + lane] * fd + X2[(1 * SMAX + q) * 64 + lane];
+      for (int q = 0; q < SMAX - 1; ++q) { qa[q] = X2[(0 * SMAX + q) * 64 + lane]; qb[q] = X2[(1 * SMAX + q) * 64 + lane]; }
+#pragma unroll
+      for (int q = 0; q < SMAX - 1; ++q)
+        if (q < s_u) fd = qa[q] * fd + qb[q];
+    }
     Float dirl = dir_in;  // beam at the segment's levels
 #pragma unroll
     for (int i = 0; i < L; ++i) {
@@ -1340,7 +1382,12 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     gcur = igpt;
     if constexpr (!PREF) load(cur, igpt);
     process(cur, igpt + 1);
+    SW_T(5);
   }
+#ifdef SW_TIMING
+  if (lane == 0)
+    for (int k = 0; k < 6; ++k) atomicAdd(&sw_clk[s][k], tacc[k]);
+#endif
   if constexpr (SPEC) return;
   if (active) {
     const size_t base = icol + nclp * blockIdx.y;
@@ -1429,7 +1476,7 @@ __global__ void __launch_bounds__(64 * 8) lw_2stream_seg_kernel(Lw2SegArgs a) {
         const Float t = x.tau[i], w0 = x.ssa[i], g = x.g[i];
         const Float gamma1 = LW_diff_sec * ((Float)1 - (Float)0.5 * w0 * ((Float)1 + g));
         const Float gamma2 = LW_diff_sec * (Float)0.5 * w0 * ((Float)1 - g);
-        const Float kk = rte::sqrt_nr(fmax((gamma1 - gamma2) * (gamma1 + gamma2), (Float)1.e-12));
+        const Float kk = rte::sqrt_pos(fmax((gamma1 - gamma2) * (gamma1 + gamma2), (Float)1.e-12));
         const Float e1 = rte::exp_nonpos(-t * kk);
         const Float e2 = e1 * e1;
         const Float RT = rte::rcp_nr(kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2));
@@ -2392,3 +2439,13 @@ int rte_hip_sw_solver_2stream_byband(int ncol, int nlay, int ngpt, int nbnd, int
 
 }  // extern "C"
 
+
+#ifdef SW_TIMING
+extern "C" int rte_hip_sw_timing(unsigned long long* out /*[8][6]*/) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_clk), sizeof(unsigned long long) * 48);
+  unsigned long long z[48] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(sw_clk), z, sizeof(z));
+  return 0;
+}
+#endif
