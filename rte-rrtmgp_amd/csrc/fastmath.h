@@ -22,6 +22,7 @@ __device__ __forceinline__ float rcp_nr(float d) { return 1.0f / d; }
 __device__ __forceinline__ float div_nr(float n, float d) { return n / d; }
 __device__ __forceinline__ float sqrt_nr(float x) { return sqrtf(x); }
 __device__ __forceinline__ float sqrt_pos(float x) { return sqrtf(x); }
+__device__ __forceinline__ float sqrt_cr0(float x) { return sqrtf(x); }
 #else
 // Horner step with the coefficient as the addend; the constant sits in a register pair of its own (VGPRs: these kernels have no scalar registers to spare),
 // so a step is ONE v_fma_f64 instead of the v_mov_b64 + v_fmac_f64 pair the generic code gets
@@ -108,6 +109,28 @@ __device__ __forceinline__ double sqrt_nr(double x) {
   h = __builtin_fma(h, e, h);
   e = __builtin_fma(-s, s, x);    // residual
   return __builtin_fma(e, h, s);
+}
+// sqrt(x), correctly rounded, for x = 0 or x >= 2^-767 and finite: the sequence the compiler emits for sqrt() without its range
+// scaling (which only acts below 2^-767) and without its inf / NaN / zero selects -- the same bits as sqrt() on that domain,
+// 12 instructions instead of 19.  A zero argument zeroes the estimate (rsq(0) = +inf has a zero low word: only the high word
+// is replaced), and the sequence then returns 0.
+__device__ __forceinline__ double sqrt_cr0(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  {
+    unsigned long long b = __builtin_bit_cast(unsigned long long, y);
+    const unsigned hi = x == 0.0 ? 0u : (unsigned)(b >> 32);
+    b = ((unsigned long long)hi << 32) | (unsigned)b;
+    y = __builtin_bit_cast(double, b);
+  }
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
 }
 #endif
 

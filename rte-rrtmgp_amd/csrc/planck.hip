@@ -27,6 +27,10 @@ struct PlanckArgs {
   const Float* totplnk;
   const int* gpoint_flavor;
   Float *sfc_src, *lay_src, *lev_src, *sfc_source_Jac;
+  // factored output (rte_hip_compute_Planck_source_factored): lay_src receives the Planck fraction itself, lev_src is not written,
+  // and the band's Planck function at the layer / level temperatures goes to plk_lay (ncol, nlay, nbnd) / plk_lev (ncol, nlay+1, nbnd)
+  int factored;
+  Float *plk_lay, *plk_lev;
 };
 
 // one column, one band, native table layout: always applicable
@@ -67,6 +71,10 @@ __device__ __forceinline__ void planck_direct_column(const PlanckArgs& q, const 
       const size_t b0 = (size_t)jT + (size_t)ntemp * (je2 - 1) + tn * (size_t)(jp - 2);
       const Float pl_lay = planck_1d(tlay[cl], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
       const Float pl_lev = planck_1d(tlev[icol + (size_t)ncol * ilay], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
+      if (q.factored && g0 == gptS) {
+        q.plk_lay[cl + ncl * (size_t)ibnd] = pl_lay;
+        q.plk_lev[icol + (size_t)ncol * ilay + nclv * (size_t)ibnd] = pl_lev;
+      }
 #pragma unroll
       for (int j = 0; j < GC; ++j) {
         const int g = g0 + j;
@@ -77,9 +85,13 @@ __device__ __forceinline__ void planck_direct_column(const PlanckArgs& q, const 
           const Float pf =
               (Float)1 * (fm[0] * ka[0] + fm[1] * ka[ntemp] + fm[2] * ka[tn] + fm[3] * ka[tn + ntemp]) +
               (Float)1 * (fm[4] * kb[0] + fm[5] * kb[ntemp] + fm[6] * kb[tn] + fm[7] * kb[tn + ntemp]);
-          lay_src[cl + ncl * (size_t)g] = pf * pl_lay;                                   // :674
-          const Float lv = (ilay == 0) ? pf : sqrt(pf_prev[j] * pf);                      // :695,:699
-          lev_src[icol + (size_t)ncol * ilay + nclv * (size_t)g] = lv * pl_lev;
+          if (q.factored) {
+            lay_src[cl + ncl * (size_t)g] = pf;
+          } else {
+            lay_src[cl + ncl * (size_t)g] = pf * pl_lay;                                   // :674
+            const Float lv = (ilay == 0) ? pf : sqrt(pf_prev[j] * pf);                      // :695,:699
+            lev_src[icol + (size_t)ncol * ilay + nclv * (size_t)g] = lv * pl_lev;
+          }
           if (ilay == sfc_lay - 1) {                                                      // :651-653
             sfc_src[icol + (size_t)ncol * g] = pf * pl_sfc;
             sfc_source_Jac[icol + (size_t)ncol * g] = pf * (pl_sfc1 - pl_sfc);
@@ -89,6 +101,10 @@ __device__ __forceinline__ void planck_direct_column(const PlanckArgs& q, const 
       }
     }
     const Float pl_top = planck_1d(tlev[icol + (size_t)ncol * nlay], temp_ref_min, totplnk_delta_r, tp, nPlanckTemp);
+    if (q.factored) {
+      if (g0 == gptS) q.plk_lev[icol + (size_t)ncol * nlay + nclv * (size_t)ibnd] = pl_top;
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < GC; ++j)
       if (g0 + j <= gptE) lev_src[icol + (size_t)ncol * nlay + nclv * (size_t)(g0 + j)] = pf_prev[j] * pl_top;  // :705
@@ -128,6 +144,7 @@ struct PlanckV7 {
   const Bool* tropo;
   const Float *pf_g, *totplnk, *fmajor, *tlay, *tlev, *tsfc;
   Float *sfc_src, *lay_src, *lev_src, *sfc_jac;
+  Float *plk_lay, *plk_lev;  // factored output (planck_source_v9_kernel<..., FACT>; see PlanckArgs)
   int* worklist;  // [0] = count, then (tile, band) pairs for planck_source_worklist_kernel
   const int* skip_if;  // plan guard raised: the direct kernel does the call
 };
@@ -385,7 +402,9 @@ planck_flags_kernel(const TileGeom* __restrict__ geom, int tiles, int nlay, int 
   }
 }
 
-template <int NCW, int NLW, int SLAB, int G>
+// FACT: factored output -- the Planck fraction goes to lay_src as it is (16 stores per stage instead of 32), the band's Planck
+// function at the layer and level temperatures to plk_lay / plk_lev (once per band), nothing to lev_src.
+template <int NCW, int NLW, int SLAB, int G, bool FACT = false>
 __global__ void __launch_bounds__((NCW + NLW) * 64, (NCW + NLW + 3) / 4)
 planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* __restrict__ geom,
                         const int* __restrict__ flags) {
@@ -536,6 +555,12 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
       char* const play_ = reinterpret_cast<char*>(a.lay_src + (size_t)ncl * g0);
       char* const plev_ = reinterpret_cast<char*>(a.lev_src + (size_t)nclv * g0);
       const size_t slay = (size_t)ncl * sizeof(Float), slev = (size_t)nclv * sizeof(Float);
+      if constexpr (FACT) {
+        if (g0 == gptS) {  // (block-uniform; unconditional across lanes like the other stores)
+          store_stream(reinterpret_cast<Float*>(reinterpret_cast<char*>(a.plk_lay + (size_t)ncl * ibnd) + olay), pl_lay);
+          store_stream(reinterpret_cast<Float*>(reinterpret_cast<char*>(a.plk_lev + (size_t)nclv * ibnd) + olay), pl_lev);
+        }
+      }
 #pragma unroll
       for (int jj = 0; jj < G; jj += 2) {
         // interpolate3D_byflav with scaling (1,1), :791-801; one 16-byte read feeds two g-points
@@ -554,13 +579,17 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
         for (int u = 0; u < 2; ++u) {
           const int j = jj + u;
           const Float pf = pfv[u] + pgv[u];
-          const Float vlay = pf * pl_lay;                                      // :674
-          const Float vlev = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;      // :695,:699
           // lanes past the last column repeat it (ic is clamped) and store the same values to the same
           // addresses: unconditional stores keep the number of outstanding memory operations static, so the
           // wait for the next layer's weights is a counted one instead of a drain of these stores
-          store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), vlay);
-          store_stream(reinterpret_cast<Float*>(plev_ + slev * j + olay), vlev);  // level l of (ncol, nlay+1): same column offset
+          if constexpr (FACT) {
+            store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), pf);
+          } else {
+            const Float vlay = pf * pl_lay;                                      // :674
+            const Float vlev = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;      // :695,:699
+            store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), vlay);
+            store_stream(reinterpret_cast<Float*>(plev_ + slev * j + olay), vlev);  // level l of (ncol, nlay+1): same column offset
+          }
           prev[j] = pf;
         }
         asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));  // keep the pair's arithmetic here
@@ -569,8 +598,12 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
     }
     if (valid) {
       const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
+      if constexpr (FACT) {
+        if (g0 == gptS) a.plk_lev[ic + ncol * nlay + (size_t)nclv * ibnd] = pl_top;
+      } else {
 #pragma unroll
-      for (int j = 0; j < G; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
+        for (int j = 0; j < G; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
+      }
     }
     // ---- surface source (:651-653) from the Planck fractions of the surface layer
     if (lsfc != (int)nlay - 1) {
@@ -608,26 +641,41 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
 }
 
 
+
+// factored -> lay_source / lev_source (one thread per (column, level, band), the band's g-points in a loop)
+__global__ void __launch_bounds__(256)
+expand_factored_sources_kernel(int ncol, int nlay, const int* __restrict__ band_lims, const Float* __restrict__ pfrac,
+                               const Float* __restrict__ plk_lay, const Float* __restrict__ plk_lev, Float* __restrict__ lay_src,
+                               Float* __restrict__ lev_src) {
+  const int icol = blockIdx.x * blockDim.x + threadIdx.x, ilev = blockIdx.y, ibnd = blockIdx.z;
+  if (icol >= ncol) return;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const int gS = band_lims[2 * ibnd] - 1, gE = band_lims[2 * ibnd + 1] - 1;
+  const Float pl_lev = plk_lev[icol + (size_t)ncol * ilev + nclv * ibnd];
+  const Float pl_lay = ilev < nlay ? plk_lay[icol + (size_t)ncol * ilev + ncl * ibnd] : (Float)0;
+  for (int g = gS; g <= gE; ++g) {
+    const Float* pf = pfrac + ncl * (size_t)g + icol;
+    const Float below = pf[(size_t)ncol * min(ilev, nlay - 1)];
+    if (ilev < nlay) lay_src[icol + (size_t)ncol * ilev + ncl * g] = below * pl_lay;                       // :674
+    const Float f = (ilev == 0 || ilev == nlay) ? below : sqrt(pf[(size_t)ncol * (ilev - 1)] * below);   // :695, :699, :705
+    lev_src[icol + (size_t)ncol * ilev + nclv * g] = f * pl_lev;
+  }
+}
+
 }  // namespace
 
-extern "C" {
-void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int* nbnd_,
-                                  const int* ngpt_, const int* nflav_, const int* neta_,
-                                  const int* npres_, const int* ntemp_, const int* nPlanckTemp_,
-                                  const Float* tlay, const Float* tlev, const Float* tsfc,
-                                  const int* sfc_lay_, const Float* fmajor, const int* jeta,
-                                  const Bool* tropo, const int* jtemp, const int* jpress,
-                                  const int* gpoint_bands, const int* band_lims_gpt,
-                                  const Float* pfracin, const Float* temp_ref_min,
-                                  const Float* totplnk_delta, const Float* totplnk,
-                                  const int* gpoint_flavor, Float* sfc_src, Float* lay_src,
-                                  Float* lev_src, Float* sfc_source_Jac) {
-  const int ncol = *ncol_, nlay = *nlay_, nbnd = *nbnd_, ngpt = *ngpt_, nflav = *nflav_, neta = *neta_,
-            npres = *npres_, ntemp = *ntemp_, nPlanckTemp = *nPlanckTemp_;
-  (void)gpoint_bands;
+// the body of rrtmgp_compute_Planck_source and of its factored form (plk_lay != nullptr: see PlanckArgs)
+static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, int ngpt, int nflav, int neta, int npres, int ntemp,
+                               int nPlanckTemp, const Float* tlay, const Float* tlev, const Float* tsfc, int sfc_lay,
+                               const Float* fmajor, const int* jeta, const Bool* tropo, const int* jtemp, const int* jpress,
+                               const int* band_lims_gpt, const Float* pfracin, Float temp_ref_min_v, Float totplnk_delta_v,
+                               const Float* totplnk, const int* gpoint_flavor, Float* sfc_src, Float* lay_src, Float* lev_src,
+                               Float* sfc_source_Jac, Float* plk_lay, Float* plk_lev) {
+  const bool factored = plk_lay != nullptr;
+  const int* sfc_lay_ = &sfc_lay;
+  const Float *temp_ref_min = &temp_ref_min_v, *totplnk_delta = &totplnk_delta_v;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
-  RTE_TRY
-  rte::Call c("rrtmgp_compute_Planck_source");
+  rte::Call c(name);
   const size_t ncl = (size_t)ncol * nlay;
   const Float* d_tlay = c.in(tlay, ncl);
   const Float* d_tlev = c.in(tlev, (size_t)ncol * (nlay + 1));
@@ -643,14 +691,16 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   const int* d_gpoint_flavor = c.in(gpoint_flavor, (size_t)2 * ngpt);
   Float* d_sfc_src = c.out_lazy(sfc_src, (size_t)ncol * ngpt);  // (lazy: host-mirror mode keeps the sources on the device)
   Float* d_lay_src = c.out_lazy(lay_src, ncl * ngpt);
-  Float* d_lev_src = c.out_lazy(lev_src, (size_t)ncol * (nlay + 1) * ngpt);
+  Float* d_lev_src = factored ? nullptr : c.out_lazy(lev_src, (size_t)ncol * (nlay + 1) * ngpt);
   Float* d_sfc_jac = c.out_lazy(sfc_source_Jac, (size_t)ncol * ngpt);
+  Float* d_plk_lay = factored ? c.out_lazy(plk_lay, ncl * nbnd) : nullptr;
+  Float* d_plk_lev = factored ? c.out_lazy(plk_lev, (size_t)ncol * (nlay + 1) * nbnd) : nullptr;
   const Float totplnk_delta_r = (Float)1 / *totplnk_delta;  // :636
   {
     const void* outs[4] = {d_sfc_src, d_lay_src, d_lev_src, d_sfc_jac};
     const size_t ob[4] = {sizeof(Float) * (size_t)ncol * ngpt, sizeof(Float) * ncl * ngpt,
                           sizeof(Float) * (size_t)ncol * (nlay + 1) * ngpt, sizeof(Float) * (size_t)ncol * ngpt};
-    c.try_fork(outs, ob, 4);  // opt-in: concurrently with the compute_tau_absorption call this one follows
+    if (!factored) c.try_fork(outs, ob, 4);  // opt-in: concurrently with the compute_tau_absorption call this one follows
   }
   hipStream_t st = rte::stream();
   int* d_stale = stale_flag();
@@ -687,6 +737,7 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   q.temp_ref_min = *temp_ref_min; q.totplnk_delta_r = totplnk_delta_r; q.totplnk = d_totplnk;
   q.gpoint_flavor = d_gpoint_flavor; q.sfc_src = d_sfc_src; q.lay_src = d_lay_src; q.lev_src = d_lev_src;
   q.sfc_source_Jac = d_sfc_jac;
+  q.factored = factored ? 1 : 0; q.plk_lay = d_plk_lay; q.plk_lev = d_plk_lev;
   if (!fast) {
     rte::ProfScope p("planck_source_kernel");
     hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)nullptr);
@@ -714,12 +765,13 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   v.jpress = d_jpress; v.tropo = d_tropo; v.pf_g = pf_g; v.totplnk = d_totplnk; v.fmajor = d_fmajor;
   v.tlay = d_tlay; v.tlev = d_tlev; v.tsfc = d_tsfc;
   v.sfc_src = d_sfc_src; v.lay_src = d_lay_src; v.lev_src = d_lev_src; v.sfc_jac = d_sfc_jac;
+  v.plk_lay = d_plk_lay; v.plk_lev = d_plk_lev;
   v.skip_if = guard;
   v.worklist = worklist;
   int wl_tile = BS;
   const bool planck9 = (g_planck_variant == 9 || bl_gw != 16) && nlay <= 256 && nbnd <= MAXB &&
                        (size_t)ncol * (nlay + 1) < ((size_t)1 << 29);
-  if (!planck9 && bl_gw != 16) {  // 8-wide stages exist only in the specialised-wave kernel
+  if (!planck9 && (bl_gw != 16 || factored)) {  // 8-wide stages and the factored output exist only in the specialised-wave kernel
     rte::ProfScope p("planck_source_kernel");
     hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)nullptr);
     return;
@@ -754,7 +806,12 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
       else hipLaunchKernelGGL((planck_geom_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, \
                               d_flags, SLAB9);                                                                    \
     }                                                                                                             \
-    rte::ProfScope p("planck_source_kernel");                                                                     \
+    rte::ProfScope p(factored ? "planck_source_factored_kernel" : "planck_source_kernel");                        \
+    if (factored)                                                                                                 \
+      hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW, true>), dim3(nbnd * 8 * cdiv(tiles, 8)),  \
+                         dim3((NCW + NLW) * 64), sizeof(Float) * nPlanckTemp, st, v, nbnd, tiles,                 \
+                         (const TileGeom*)d_geom, (const int*)d_flags);                                           \
+    else                                                                                                          \
     hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW>), dim3(nbnd * 8 * cdiv(tiles, 8)),          \
                        dim3((NCW + NLW) * 64), sizeof(Float) * nPlanckTemp, st, v, nbnd, tiles,                   \
                        (const TileGeom*)d_geom, (const int*)d_flags);                                             \
@@ -774,7 +831,67 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
     // the whole call on the direct kernel if the guard fired
     hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)guard);
   }
+}
+
+extern "C" {
+void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int* nbnd_,
+                                  const int* ngpt_, const int* nflav_, const int* neta_,
+                                  const int* npres_, const int* ntemp_, const int* nPlanckTemp_,
+                                  const Float* tlay, const Float* tlev, const Float* tsfc,
+                                  const int* sfc_lay_, const Float* fmajor, const int* jeta,
+                                  const Bool* tropo, const int* jtemp, const int* jpress,
+                                  const int* gpoint_bands, const int* band_lims_gpt,
+                                  const Float* pfracin, const Float* temp_ref_min,
+                                  const Float* totplnk_delta, const Float* totplnk,
+                                  const int* gpoint_flavor, Float* sfc_src, Float* lay_src,
+                                  Float* lev_src, Float* sfc_source_Jac) {
+  (void)gpoint_bands;
+  RTE_TRY
+  planck_source_impl("rrtmgp_compute_Planck_source", *ncol_, *nlay_, *nbnd_, *ngpt_, *nflav_, *neta_, *npres_, *ntemp_, *nPlanckTemp_,
+                     tlay, tlev, tsfc, *sfc_lay_, fmajor, jeta, tropo, jtemp, jpress, band_lims_gpt, pfracin, *temp_ref_min,
+                     *totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_source_Jac, nullptr, nullptr);
   RTE_CATCH("rrtmgp_compute_Planck_source")
+}
+
+// compute_Planck_source with FACTORED output (extension): the source is the product of the Planck fraction of the g-point and the
+// Planck function of its band (:674), and the level source the geometric mean of the neighbouring layers' fractions times the band's
+// function at the level temperature (:695-705) -- this entry stores the factors: pfrac (ncol, nlay, ngpt), planck_lay (ncol, nlay, nbnd),
+// planck_lev (ncol, nlay+1, nbnd); sfc_src and sfc_source_Jac as in the ABI call.  rte_hip_lw_solver_noscat_factored forms the same
+// products per g-point; rte_hip_expand_factored_sources writes lay_source / lev_source from the factors for any other consumer.
+// 12.9 + 1.5 GB instead of 26 GB written at 1e5 x 60 x 256.
+int rte_hip_compute_Planck_source_factored(int ncol, int nlay, int nbnd, int ngpt, int nflav, int neta, int npres, int ntemp,
+                                           int nPlanckTemp, const Float* tlay, const Float* tlev, const Float* tsfc, int sfc_lay,
+                                           const Float* fmajor, const int* jeta, const Bool* tropo, const int* jtemp,
+                                           const int* jpress, const int* band_lims_gpt, const Float* pfracin, double temp_ref_min,
+                                           double totplnk_delta, const Float* totplnk, const int* gpoint_flavor, Float* sfc_src,
+                                           Float* pfrac, Float* planck_lay, Float* planck_lev, Float* sfc_source_Jac) {
+  if (!planck_lay || !planck_lev || !pfrac) return -1;
+  RTE_TRY
+  planck_source_impl("rte_hip_compute_Planck_source_factored", ncol, nlay, nbnd, ngpt, nflav, neta, npres, ntemp, nPlanckTemp, tlay, tlev,
+                     tsfc, sfc_lay, fmajor, jeta, tropo, jtemp, jpress, band_lims_gpt, pfracin, (Float)temp_ref_min, (Float)totplnk_delta, totplnk,
+                     gpoint_flavor, sfc_src, pfrac, nullptr, sfc_source_Jac, planck_lay, planck_lev);
+  return 0;
+  RTE_CATCH("rte_hip_compute_Planck_source_factored")
+  return -1;
+}
+
+// lay_source (ncol, nlay, ngpt) and lev_source (ncol, nlay+1, ngpt) from the factored form, with the operations of
+// compute_Planck_source (bit-identical to its output)
+int rte_hip_expand_factored_sources(int ncol, int nlay, int nbnd, int ngpt, const int* band_lims_gpt, const Float* pfrac,
+                                    const Float* planck_lay, const Float* planck_lev, Float* lay_source, Float* lev_source) {
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return 0;
+  RTE_TRY
+  rte::Call c("rte_hip_expand_factored_sources");
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const int* d_bl = c.in(band_lims_gpt, (size_t)2 * nbnd);
+  const Float *d_pf = c.in(pfrac, ncl * ngpt), *d_ply = c.in(planck_lay, ncl * nbnd), *d_plv = c.in(planck_lev, nclv * nbnd);
+  Float *d_lay = c.out(lay_source, ncl * ngpt), *d_lev = c.out(lev_source, nclv * ngpt);
+  rte::ProfScope p("expand_factored_sources_kernel");
+  hipLaunchKernelGGL(expand_factored_sources_kernel, dim3(cdiv(ncol, 256), nlay + 1, nbnd), dim3(256), 0, rte::stream(), ncol, nlay,
+                     d_bl, d_pf, d_ply, d_plv, d_lay, d_lev);
+  return 0;
+  RTE_CATCH("rte_hip_expand_factored_sources")
+  return -1;
 }
 
 }  // extern "C"

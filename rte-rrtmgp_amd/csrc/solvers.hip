@@ -237,6 +237,16 @@ __global__ void __launch_bounds__(256) lw_noscat_generic_kernel(LwArgs a) {
 // formed from composites (same mathematics, different rounding: ~1e-16 relative).
 // After the block's g-points: acc * pi * weight -> partial broadband slab for this g-group.
 // ---------------------------------------------------------------------------------------------
+#ifdef LW_TIMING
+// experiment builds only (tools/fastbuild.py lwt:solvers.hip=-DLW_TIMING): s_memtime ticks the waves of lw_noscat_seg_kernel spend per
+// g-point, summed per segment number: [0] issuing the next g-point's loads, [1] pass 1 up to the LDS writes (includes the wait for
+// this g-point's inputs), [2] waiting at the barrier, [3] chains across segments, [4] pass 2
+__device__ unsigned long long lw_clk[8][5];
+#define LW_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define LW_T(k) do { } while (0)
+#endif
+
 template <int L>
 struct SegTile {  // one g-point's inputs for one thread's segment
   Float tau[L], lay[L], lev[L + 1], D, emis, ssrc, inc, sjac;
@@ -250,8 +260,16 @@ struct SegOffsets {
   unsigned lay[L], lev[L + 1], cg;
 };
 
-template <int L>
+template <int L, bool FACT = false>
 __device__ __forceinline__ void seg_offsets(SegOffsets<L>& o, int c, int ncol, int nlay, int p0, int np, bool top_at_1) {
+  if constexpr (FACT) {
+    // factored sources (see lw_noscat_seg_kernel): lev[0], lev[1] are the LAYER rows just above and just below the segment
+    // (clamped to the column), whose Planck fractions enter the geometric means at the segment's outer levels
+    const int pa = max(p0 - 1, 0), pb = min(p0 + L, nlay - 1);
+    o.lev[0] = ((unsigned)c + (unsigned)ncol * (unsigned)(top_at_1 ? pa : nlay - 1 - pa)) * (unsigned)sizeof(Float);
+    o.lev[1] = ((unsigned)c + (unsigned)ncol * (unsigned)(top_at_1 ? pb : nlay - 1 - pb)) * (unsigned)sizeof(Float);
+    asm volatile("" : "+v"(o.lev[0]), "+v"(o.lev[1]));
+  }
 #pragma unroll
   for (int i = 0; i < L; ++i) {
     // out-of-segment slots (only the last segment can have them) re-read a valid layer and are then
@@ -261,26 +279,39 @@ __device__ __forceinline__ void seg_offsets(SegOffsets<L>& o, int c, int ncol, i
     o.lay[i] = ((unsigned)c + (unsigned)ncol * (unsigned)ilay) * (unsigned)sizeof(Float);
     asm volatile("" : "+v"(o.lay[i]));  // keep it a 32-bit VGPR value (not re-derived per load in 64 bits)
   }
+  if constexpr (!FACT) {
 #pragma unroll
-  for (int i = 0; i <= L; ++i) {
-    const int p = p0 + min(i, np);
-    o.lev[i] = ((unsigned)c + (unsigned)ncol * (unsigned)(top_at_1 ? p : nlay - p)) * (unsigned)sizeof(Float);
-    asm volatile("" : "+v"(o.lev[i]));
+    for (int i = 0; i <= L; ++i) {
+      const int p = p0 + min(i, np);
+      o.lev[i] = ((unsigned)c + (unsigned)ncol * (unsigned)(top_at_1 ? p : nlay - p)) * (unsigned)sizeof(Float);
+      asm volatile("" : "+v"(o.lev[i]));
+    }
   }
   o.cg = (unsigned)c * (unsigned)sizeof(Float);
   asm volatile("" : "+v"(o.cg));
 }
 
-template <int L, bool do_jac, bool SFC = true>
-__device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, int igpt, int ncol, int nlay, int np,
+template <int L, bool do_jac, bool SFC = true, bool FACT = false>
+__device__ __forceinline__ void seg_load(SegTile<L>& t, SegOffsets<L>& o, int igpt, int ncol, int nlay, int np,
                                          const Float* __restrict__ Dsec,
                                          const Float* __restrict__ tau_, const Float* __restrict__ lay_source_,
                                          const Float* __restrict__ lev_source_, const Float* __restrict__ sfc_emis,
                                          const Float* __restrict__ sfc_src, const Float* __restrict__ inc_flux,
-                                         const Float* __restrict__ sfc_srcJac) {
+                                         const Float* __restrict__ sfc_srcJac, const int i0 = 0, const int i1 = L) {
+  // [i0, i1): the layer slots whose rows this call requests (the whole tile by default; lw_noscat_seg_kernel spreads a g-point's
+  // requests over pass 1 of the previous one, two slots at a time); the level row below the last slot (FACT: the layer row below the
+  // segment) goes with the last group, the per-(column, g-point) arrays (FACT: and the layer row above the segment) with the first
   const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1), ncg = (size_t)ncol * igpt;
+  // the row offsets are made opaque IN PLACE, once per g-point: their 64-bit extension cannot be hoisted out of the g-point loop
+  // (as a by-value copy per load every offset was first moved into a scratch register: 25 v_mov per g-point and wave)
+#pragma unroll
+  for (int i = 0; i < L; ++i)
+    if (i >= i0 && i < i1) asm volatile("" : "+v"(o.lay[i]));
+#pragma unroll
+  for (int i = 0; i <= (FACT ? 1 : L); ++i)
+    if (FACT ? (i == 0 ? i0 == 0 : i1 == L) : (i >= i0 && (i < i1 || i1 == L))) asm volatile("" : "+v"(o.lev[i]));
+  if (SFC && i0 == 0) asm volatile("" : "+v"(o.cg));
   auto at = [](const Float* plane, unsigned off) {  // plane is wave-uniform
-    asm volatile("" : "+v"(off));  // opaque here, inside the g-point loop: its 64-bit extension cannot be hoisted
     // every byte of tau / lay_source / lev_source is read exactly once: non-temporal loads (6.92 -> 6.87 ms in one
     // process, within the noise of that comparison but never slower)
 #ifdef RTE_NO_NT_LOADS
@@ -289,11 +320,17 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, 
     return __builtin_nontemporal_load(reinterpret_cast<const Float*>(reinterpret_cast<const char*>(plane) + off));
 #endif
   };
-  const Float* tau = tau_ + ncl * igpt;
-  const Float* lay = lay_source_ + ncl * igpt;
-  const Float* lev = lev_source_ + nclv * igpt;
+#ifdef LW_X_SAMEPLANE  // timing experiment: every g-point reads the first g-point's planes (cache hits; wrong results)
+  const int igp = 0;
+#else
+  const int igp = igpt;
+#endif
+  const Float* tau = tau_ + ncl * igp;
+  const Float* lay = lay_source_ + ncl * igp;
+  const Float* lev = lev_source_ + nclv * igp;
 #pragma unroll
   for (int i = 0; i < L; ++i) {
+    if (i < i0 || i >= i1) continue;
     // tau = 0 alone makes an out-of-segment slot NEUTRAL whatever finite sources it carries: trans = 1,
     // 1 - trans = 0, fact = 0 -> layer sources = 0, so the sweeps need no predication and the slot after
     // the last real layer naturally receives the surface values
@@ -301,9 +338,15 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, 
     t.tau[i] = i < np ? tv : (Float)0;
     t.lay[i] = at(lay, o.lay[i]);
   }
+  if constexpr (FACT) {  // lay_source_ is the Planck fraction (ncol, nlay, ngpt): t.lay = the segment's, t.lev[0 / 1] = the rows above / below
+    if (i0 == 0) t.lev[0] = at(lay, o.lev[0]);  // (the row above is consumed first, the row below last: refreshed in place)
+    if (i1 == L) t.lev[1] = at(lay, o.lev[1]);
+  } else {
 #pragma unroll
-  for (int i = 0; i <= L; ++i) t.lev[i] = at(lev, o.lev[i]);
-  if (SFC) {
+    for (int i = 0; i <= L; ++i)
+      if (i >= i0 && (i < i1 || i1 == L)) t.lev[i] = at(lev, o.lev[i]);
+  }
+  if (SFC && i0 == 0) {
     t.D = at(Dsec + ncg, o.cg);
     t.emis = at(sfc_emis + ncg, o.cg);
     t.ssrc = at(sfc_src + ncg, o.cg);
@@ -323,7 +366,13 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, const SegOffsets<L>& o, 
 // BYBAND (extension rte_hip_lw_solver_noscat_byband): one block per (column tile, BAND) -- grid.y = band, the g-point range
 // comes from band_lims_gpt -- and the block's sums leave as the by-band fluxes themselves, pi * weight applied (what
 // rte_sum_byband of the spectral arrays gives, rte/extensions/mo_fluxes_byband.F90:46-137, without the spectral arrays).
-template <int L, bool do_jac, bool SFCLDS, bool SPEC = false, bool BYBAND = false>
+// FACT (extension rte_hip_lw_solver_noscat_factored): the sources arrive FACTORED, as rte_hip_compute_Planck_source_factored
+// leaves them -- the Planck fraction (ncol, nlay, ngpt) in lay_source_, the band's Planck function at the layer and level
+// temperatures (ncol, nlay, nbnd) in plk_lay and (ncol, nlay + 1, nbnd) in lev_source_ -- and the kernel forms
+// lay_source = pfrac * planck_lay (:674) and lev_source = sqrt(pfrac(above) * pfrac(below)) * planck_lev (:695-705, the fraction
+// itself at the column's two ends) with the operations of compute_Planck_source: the same bits, a third less to read
+// (8 + 10 instead of 8 + 8 + 9 rows per g-point and wave) and 26 GB the gas optics no longer write at 1e5 x 60 x 256.
+template <int L, bool do_jac, bool SFCLDS, bool SPEC = false, bool BYBAND = false, bool FACT = false>
 __global__ void __launch_bounds__(64 * 8)
 lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
                      const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
@@ -332,7 +381,7 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
                      const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
                      Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac,
                      Float* __restrict__ spec_up = nullptr, Float* __restrict__ spec_dn = nullptr, bool spec_add = false,
-                     const int* __restrict__ band_lims = nullptr) {
+                     const int* __restrict__ band_lims = nullptr, const Float* __restrict__ plk_lay = nullptr) {
 #pragma clang fp contract(fast)  // this kernel is fp64-issue bound: fuse the recurrences' a*b+c
   extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][MAXS][64]
   const int lane = threadIdx.x & 63;
@@ -364,7 +413,28 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 #pragma unroll
   for (int i = 0; i <= L; ++i) { if (!SPEC) { acc_dn[i] = 0; acc_up[i] = 0; } if (do_jac) acc_j[i] = 0; }
   SegOffsets<L> offs;
-  seg_offsets<L>(offs, c, ncol, nlay, p0, np, top_at_1);
+  seg_offsets<L, FACT>(offs, c, ncol, nlay, p0, np, top_at_1);
+  // FACT: the band's Planck function at this wave's layers and levels (reloaded when the g-point loop enters the next band)
+  // and, per level slot, whether the rows above and below it are the same row (the column's ends, and the repeated bottom
+  // level of a partial last segment): the source there is the fraction itself, :695 / :705
+  // (parked in the thread's own LDS slots, 2 L + 1 values: in registers they cost the kernel its input prefetch -- 31 spilled)
+  Float* const PLK = SFCB + (SFCLDS ? 2 * CH * NA * 64 : 0) + (size_t)s * (2 * L + 1) * 64 + lane;  // ply[i] at [i * 64], plv[i] at [(L + i) * 64]
+  int band = 0, band_end = 0;  // FACT: current band (0-based) and the first g-point after it
+  auto load_band = [&](int igpt) {
+    while (band_lims[2 * band + 1] <= igpt) ++band;  // (1-based inclusive limits)
+    band_end = band_lims[2 * band + 1];
+    // rows of the (ncol, nlay) / (ncol, nlay + 1) band planes: the layer offsets of the g-point loads; a level row is its layer's
+    // row or the one after it, by orientation (slot i = top of layer i) and past the last layer
+    const char* pl = reinterpret_cast<const char*>(plk_lay + (size_t)ncol * nlay * band);
+    const char* pv = reinterpret_cast<const char*>(lev_source_ + nclv * band);
+#pragma unroll
+    for (int i = 0; i < L; ++i) PLK[i * 64] = *reinterpret_cast<const Float*>(pl + offs.lay[i]);
+#pragma unroll
+    for (int i = 0; i <= L; ++i) {
+      const unsigned step = ((i < np) != top_at_1) ? (unsigned)ncol * (unsigned)sizeof(Float) : 0u;  // wave-uniform
+      PLK[(L + i) * 64] = *reinterpret_cast<const Float*>(pv + (offs.lay[i < L ? i : L - 1] + step));
+    }
+  };
   // level slot i of this wave: accumulate (broadband) or store the flux of g-point `ig` (spectral; owned levels only)
   auto put = [&](Float* acc, Float* __restrict__ spec, int i, Float v, int ig) {
     if constexpr (SPEC) {
@@ -378,8 +448,15 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     }
   };
 
+#ifdef LW_TIMING
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
   // One g-point of work on tile `cur` (padded slots are neutral, see seg_load: no predication)
-  auto process = [&](const SegTile<L>& cur_, int buf, int gl, int cbuf, int ig) {
+  // `request(i0, i1)`: the next g-point's rows of slots [i0, i1), issued BETWEEN the layer pairs of pass 1 (fenced on both sides).
+  // Issued in one burst at the top of the g-point, the block's 200-264 row requests kept every wave stalled at its load
+  // instructions for 2400-4400 cycles of the 8400 a g-point took (tools/time_lw_phases.py: the CU's memory pipeline takes
+  // ~24 cycles per 512-byte row, whether the rows come from HBM or from the caches), with only the SIMD's other wave computing.
+  auto process = [&](SegTile<L>& cur_, int buf, int gl, int cbuf, int ig, auto&& request) {
 #pragma clang fp contract(fast)
     struct Sfc { Float D, emis, ssrc, inc, sjac; } cur;
     if (SFCLDS) {
@@ -389,6 +466,24 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       cur.D = cur_.D; cur.emis = cur_.emis; cur.ssrc = cur_.ssrc; cur.inc = cur_.inc; cur.sjac = cur_.sjac;
     }
     Float t[L], sd[L], su[L];
+    // FACT: the level source at slot i of this g-point, :695 / :699 / :705 (a rounded product, as the array element it replaces:
+    // no contraction into its users)
+    auto level_src = [&](int i) {
+      const Float pa = i == 0 ? cur_.lev[0] : cur_.lay[i - 1], pb = i == L ? cur_.lev[1] : cur_.lay[i];
+      // at the column's ends (and on the repeated bottom level of a partial last segment) both rows are the same row, and the
+      // correctly rounded root of the rounded square is the fraction itself (:695 / :705) for every value whose square neither
+      // underflows nor overflows -- no select (measured: 18 v_cndmask per g-point and wave in a kernel bound by its issue)
+#ifdef FACT_X_NOSQRT  // timing experiment: what the kernel costs without the nine roots (wrong results)
+      const Float gm = pa * pb;
+#else
+      const Float gm = rte::sqrt_cr0(pa * pb);
+#endif
+      Float v = gm * PLK[(L + i) * 64];
+      asm volatile("" : "+v"(v));
+      return v;
+    };
+    Float lv_hi = 0;
+    if constexpr (FACT) lv_hi = level_src(0);
     // ---- pass 1: layer transmissivities and sources (:180-190), segment composites
     Float Td = 1, Sd = 0;
 #pragma unroll
@@ -397,11 +492,26 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       const Float tr = rte::exp_nonpos(-tau_loc);
       // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo): "toward bottom" uses the
       // bottom level source, "toward top" the top level source
+      if constexpr (FACT) {
+        Float ls = cur_.lay[i] * PLK[i * 64];  // :674
+        asm volatile("" : "+v"(ls));
+        const Float lv_lo = level_src(i + 1);
+        lw_source_layer_fast(tau_loc, tr, ls, lv_hi, lv_lo, sd[i], su[i]);
+        lv_hi = lv_lo;
+      } else
       lw_source_layer_fast(tau_loc, tr, cur_.lay[i], cur_.lev[i], cur_.lev[i + 1], sd[i], su[i]);
       t[i] = tr;
       Sd = tr * Sd + sd[i];
       Td = Td * tr;
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (register pressure) to 2 layers
+      if (i & 1) {
+        __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (register pressure) to 2 layers
+        request(i - 1, i + 1 == L ? L : i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr ((L & 1) != 0) {
+      request(L - 1, L);
+      __builtin_amdgcn_sched_barrier(0);
     }
     Float Su = 0;
 #pragma unroll
@@ -413,7 +523,9 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     X[(0 * MAXS + s) * 64 + lane] = Td;
     X[(1 * MAXS + s) * 64 + lane] = Sd;
     X[(2 * MAXS + s) * 64 + lane] = Su;
+    LW_T(1);
     __syncthreads();
+    LW_T(2);
     Float r = cur.inc * inv_piw;  // radiance entering segment 0 from above (:144)
     Float r_in = r;
     Float u, jv;
@@ -447,6 +559,8 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       }
     }
     // the level below the segment's last slot (used only by a FULL last segment: the surface)
+    asm volatile("" : "+v"(u), "+v"(r_in));
+    LW_T(3);
     put(acc_up, spec_up, L, u, ig);
     if (do_jac) acc_j[L] += jv;
     // ---- pass 2: down; slot i is the level at the top of layer i.  In a partial last segment the
@@ -467,9 +581,9 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       if (do_jac) { jv = t[i] * jv; acc_j[i] += jv; }
     }
   };
-  auto load = [&](SegTile<L>& tile, int igpt) {
-    seg_load<L, do_jac, !SFCLDS>(tile, offs, min(igpt, g_end - 1), ncol, nlay, np, Dsec, tau_, lay_source_, lev_source_,
-                                 sfc_emis, sfc_src, inc_flux, sfc_srcJac);
+  auto load = [&](SegTile<L>& tile, int igpt, int i0 = 0, int i1 = L) {
+    seg_load<L, do_jac, !SFCLDS, FACT>(tile, offs, min(igpt, g_end - 1), ncol, nlay, np, Dsec, tau_, lay_source_, lev_source_,
+                                       sfc_emis, sfc_src, inc_flux, sfc_srcJac, i0, i1);
   };
   // surface-array chunks: wave s fetches g-points 2s, 2s+1 of a chunk (row i: array i % NA of g-point 2s + i / NA)
   Float sfcpf[RPW];
@@ -496,18 +610,32 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   // unrolled so that no tile is copied measures the same and needs 45 more registers; two g-points ahead spill.)
   // (round 3: without this prefetch the kernel needs 179 instead of 230 registers and is 1-4 % slower, 7.5-7.7 against
   // 7.4 ms at 1e5 x 60 x 256 -- the two waves of a SIMD cover most of each other's waits; kept, it fits)
+  // ONE tile, refreshed in place: the rows of slots (i - 1, i) are requested for the next g-point right after pass 1 has consumed
+  // them for this one (`request` in process), into the same registers.  (Round 1-3 kept a second tile, filled by a burst of requests
+  // at the top of the g-point and copied at its end: 50 registers more, and the burst stalled the waves -- see process.)
   SegTile<L> cur;
   load(cur, g_begin);
   int buf = 0, gl = 0, chunk = 0;
-  for (int igpt = g_begin; igpt < g_end; ++igpt, buf ^= 1) {
-    SegTile<L> nxt;
-    if (SFCLDS && gl == 0) sfc_fetch(chunk + 1);           // a chunk ahead, behind this g-point's barrier ...
-    load(nxt, igpt + 1);
-    if (SFCLDS && gl == 1) sfc_publish((chunk + 1) & 1);   // ... written an iteration later, read 14 barriers later
-    process(cur, buf, gl, chunk & 1, igpt);
-    cur = nxt;
-    if (++gl == CH) { gl = 0; ++chunk; }
+  for (int igpt = g_begin; igpt < g_end;) {
+    int g_stop = g_end;
+    if constexpr (FACT) {  // band by band: the band's Planck functions are loaded between the g-point loops, not inside them
+      load_band(igpt);
+      g_stop = min(g_end, band_end);
+    }
+#pragma unroll 1
+    for (; igpt < g_stop; ++igpt, buf ^= 1) {
+      if (SFCLDS && gl == 0) sfc_fetch(chunk + 1);           // a chunk ahead, behind this g-point's barrier ...
+      if (SFCLDS && gl == 1) sfc_publish((chunk + 1) & 1);   // ... written an iteration later, read 14 barriers later
+      LW_T(0);
+      process(cur, buf, gl, chunk & 1, igpt, [&](int i0, int i1) { load(cur, igpt + 1, i0, i1); });
+      LW_T(4);
+      if (++gl == CH) { gl = 0; ++chunk; }
+    }
   }
+#ifdef LW_TIMING
+  if (lane == 0)
+    for (int k = 0; k < 5; ++k) atomicAdd(&lw_clk[s][k], tacc[k]);
+#endif
   // ---- partial broadband for this g-group: (ncol, nlev, ngroups)
   if (active && (!SPEC || do_jac)) {
     const size_t base = icol + nclv * blockIdx.y;
@@ -2403,6 +2531,72 @@ int rte_hip_lw_solver_noscat_byband(int ncol, int nlay, int ngpt, int nbnd, int 
   return -1;
 }
 
+// ---- rte_lw_solver_noscat on FACTORED sources (extension): what rte_hip_compute_Planck_source_factored leaves -- the Planck
+//      fraction per g-point and the Planck function per band -- instead of lay_source / lev_source (ncol, nlay[+1], ngpt).  Broadband
+//      output, no rescaling, [Jacobian], nlay <= 80: lw_noscat_seg_kernel<..., FACT> forms the sources per g-point with the operations
+//      of compute_Planck_source (results bit-identical to the two ABI calls; 26 GB less written and 13 GB less read at 1e5 x 60 x 256).
+//      Returns -2 for what it does not cover: the caller expands the sources (rte_hip_expand_factored_sources) and calls the ABI.
+int rte_hip_lw_solver_noscat_factored(int ncol, int nlay, int ngpt, int nbnd, int top_at_1, int nmus, const Float* Ds,
+                                      const Float* weights, const int* band_lims_gpt, const Float* tau, const Float* pfrac,
+                                      const Float* planck_lay, const Float* planck_lev, const Float* sfc_emis, const Float* sfc_src,
+                                      const Float* inc_flux, Float* broadband_up, Float* broadband_dn, int do_jac,
+                                      const Float* sfc_srcJac, Float* flux_upJac) {
+  if (ncol <= 0 || nlay <= 0 || ngpt <= 0 || nbnd <= 0 || nmus <= 0) return 0;
+  const int nlev = nlay + 1;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev, ncg = (size_t)ncol * ngpt;
+  if (nlay > 80 || nclv >= ((size_t)1 << 29) || g_lw_force_generic) return -2;
+  RTE_TRY
+  rte::Call c("rte_hip_lw_solver_noscat_factored");
+  const Float* w_h = c.host(weights, (size_t)nmus);
+  const Float* d_Ds = c.in(Ds, ncg * nmus);
+  const int* d_bl = c.in(band_lims_gpt, (size_t)2 * nbnd);
+  const Float *d_tau = c.in(tau, ncl * ngpt), *d_pf = c.in(pfrac, ncl * ngpt);
+  const Float *d_ply = c.in(planck_lay, ncl * nbnd), *d_plv = c.in(planck_lev, nclv * nbnd);
+  const Float *d_emis = c.in(sfc_emis, ncg), *d_sfc = c.in(sfc_src, ncg), *d_inc = c.in(inc_flux, ncg);
+  const Float* d_srcJac = do_jac ? c.in(sfc_srcJac, ncg) : nullptr;
+  Float *d_bb_up = c.out(broadband_up, nclv), *d_bb_dn = c.out(broadband_dn, nclv);
+  Float* d_jac = do_jac ? c.out(flux_upJac, nclv) : nullptr;
+  hipStream_t st = rte::stream();
+  const int L = nlay <= 64 ? 8 : nlay <= 72 ? 9 : 10;
+  const int S = (nlay + L - 1) / L;
+  const int col_tiles = cdiv(ncol, 64);
+  const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+  const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
+  Float* part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
+  Float* part_dn = part_up + nclv * ngroups;
+  Float* part_jac = do_jac ? part_dn + nclv * ngroups : nullptr;
+  // (the band's Planck functions are parked in LDS beside the composites; the shared surface arrays only where both fit in 160 KB)
+  const size_t lds_plk = 8 * (2 * L + 1) * 64, lds_sfc = 2 * 16 * (do_jac ? 5 : 4) * 64;
+  const bool sfclds = g_lw_sfc_lds && S == 8 && (L == 8 || !do_jac) && sizeof(Float) * (2 * 3 * 8 * 64 + lds_sfc + lds_plk) <= 160 * 1024;
+  const size_t lds_bytes = sizeof(Float) * (2 * 3 * 8 * 64 + (sfclds ? lds_sfc : 0) + lds_plk);
+  for (int imu = 0; imu < nmus; ++imu) {
+    {
+      rte::ProfScope p("lw_noscat_seg_factored_kernel");
+#define RTE_LAUNCH_SEGF(LL, JJ, SS)                                                                                       \
+  hipLaunchKernelGGL((lw_noscat_seg_kernel<LL, JJ, SS, false, false, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st, \
+                     ncol, nlay, ngpt, S, g_per_block, top_at_1 != 0, w_h[imu], d_Ds + ncg * imu, d_tau, d_pf, d_plv, d_emis, \
+                     d_sfc, d_inc, d_srcJac, part_up, part_dn, part_jac, (Float*)nullptr, (Float*)nullptr, false, d_bl, d_ply)
+#define RTE_LAUNCH_SEGF_(LL)                                                                     \
+  do {                                                                                           \
+    if (sfclds) { if (do_jac) RTE_LAUNCH_SEGF(LL, true, true); else RTE_LAUNCH_SEGF(LL, false, true); } \
+    else        { if (do_jac) RTE_LAUNCH_SEGF(LL, true, false); else RTE_LAUNCH_SEGF(LL, false, false); } \
+  } while (0)
+      if (L == 8) RTE_LAUNCH_SEGF_(8); else if (L == 9) RTE_LAUNCH_SEGF_(9); else RTE_LAUNCH_SEGF_(10);
+#undef RTE_LAUNCH_SEGF_
+#undef RTE_LAUNCH_SEGF
+    }
+    rte::ProfScope p("lw_reduce_parts");
+    const Float piw = (Float)3.14159265358979323846264338327950288 * w_h[imu];
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_up, d_bb_up, piw, imu > 0);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_dn, d_bb_dn, piw, imu > 0);
+    if (do_jac)
+      hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_jac, d_jac, piw, imu > 0);
+  }
+  return 0;
+  RTE_CATCH("rte_hip_lw_solver_noscat_factored")
+  return -1;
+}
+
 int rte_hip_sw_solver_2stream_byband(int ncol, int nlay, int ngpt, int nbnd, int top_at_1, const int* band_lims_gpt,
                                      const Float* tau, const Float* ssa, const Float* g, const Float* mu0,
                                      const Float* sfc_alb_dir, const Float* sfc_alb_dif, const Float* inc_flux_dir,
@@ -2440,6 +2634,15 @@ int rte_hip_sw_solver_2stream_byband(int ncol, int nlay, int ngpt, int nbnd, int
 }  // extern "C"
 
 
+#ifdef LW_TIMING
+extern "C" int rte_hip_lw_timing(unsigned long long* out /*[8][5]*/) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lw_clk), sizeof(unsigned long long) * 40);
+  unsigned long long z[40] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(lw_clk), z, sizeof(z));
+  return 0;
+}
+#endif
 #ifdef SW_TIMING
 extern "C" int rte_hip_sw_timing(unsigned long long* out /*[8][6]*/) {
   (void)hipDeviceSynchronize();

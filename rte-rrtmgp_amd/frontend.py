@@ -231,9 +231,33 @@ class GasOptics:
             st.jpress, t["gpoint_bands"], t["band_lims_gpt"], t["planck_frac"], kd.temp_ref_min,
             kd.totplnk_delta, t["totplnk"], t["gpoint_flavor"], sfc_src, lay_src, lev_src, sfc_src_jac)
 
+    def source_factored(self, ncol, nlay, st: InterpState, tlay, tlev, tsfc, top_at_1, sfc_src, pfrac, planck_lay, planck_lev,
+                        sfc_src_jac):
+        """``source`` with FACTORED output (library extension ``rte_hip_compute_Planck_source_factored``): the Planck fraction
+        ``pfrac`` (ncol, nlay, ngpt) and the band's Planck function at the layer / level temperatures, ``planck_lay`` (ncol, nlay,
+        nbnd) / ``planck_lev`` (ncol, nlay+1, nbnd), instead of their products lay_source / lev_source (:674, :695-705).
+        ``rte_lw_factored`` consumes them; ``expand_factored_sources`` turns them into the reference's arrays."""
+        from .hiplib import ext_call
+
+        t, kd = self.t, self.kd
+        sfc_lay = nlay if top_at_1 else 1  # :920
+        rc = ext_call(self.lib, "rte_hip_compute_Planck_source_factored", "iiiiiiiiiaaaiaaaaaaaddaaaaaaa", ncol, nlay, self.nbnd,
+                      self.ngpt, self.nflav, self.neta, self.npres, self.ntemp, int(kd.nPlanckTemp), tlay, tlev, tsfc, sfc_lay,
+                      st.fmajor, st.jeta, st.tropo, st.jtemp, st.jpress, t["band_lims_gpt"], t["planck_frac"],
+                      float(kd.temp_ref_min), float(kd.totplnk_delta), t["totplnk"], t["gpoint_flavor"], sfc_src, pfrac,
+                      planck_lay, planck_lev, sfc_src_jac)
+        assert rc == 0, rc
+
+    def expand_factored_sources(self, ncol, nlay, pfrac, planck_lay, planck_lev, lay_src, lev_src):
+        from .hiplib import ext_call
+
+        rc = ext_call(self.lib, "rte_hip_expand_factored_sources", "iiiiaaaaaa", ncol, nlay, self.nbnd, self.ngpt,
+                      self.t["band_lims_gpt"], pfrac, planck_lay, planck_lev, lay_src, lev_src)
+        assert rc == 0, rc
+
     # -- gas_optics_int: LW, returns 1scl optical props + sources
     def gas_optics_lw(self, ncol, nlay, play, plev, tlay, tsfc, col_gas, tlev, top_at_1,
-                      buffers: Optional[Dict[str, object]] = None, tau_bybnd=None):
+                      buffers: Optional[Dict[str, object]] = None, tau_bybnd=None, factored_sources: bool = False):
         xp = self.xp
         b = buffers if buffers is not None else {}
 
@@ -247,10 +271,15 @@ class GasOptics:
         tau = buf("tau", (ncol, nlay, self.ngpt))
         self.lib.zero_array_3D(ncol, nlay, self.ngpt, tau)  # :679
         self.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau, tau_bybnd=tau_bybnd)
-        lay_src = buf("lay_src", (ncol, nlay, self.ngpt))
-        lev_src = buf("lev_src", (ncol, nlay + 1, self.ngpt))
         sfc_src = buf("sfc_src", (ncol, self.ngpt))
         sfc_src_jac = buf("sfc_src_jac", (ncol, self.ngpt))
+        if factored_sources:  # library extension: the sources stay factored (see source_factored / rte_lw_factored)
+            self.source_factored(ncol, nlay, st, tlay, tlev, tsfc, top_at_1, sfc_src, buf("pfrac", (ncol, nlay, self.ngpt)),
+                                 buf("planck_lay", (ncol, nlay, self.nbnd)), buf("planck_lev", (ncol, nlay + 1, self.nbnd)),
+                                 sfc_src_jac)
+            return b
+        lay_src = buf("lay_src", (ncol, nlay, self.ngpt))
+        lev_src = buf("lev_src", (ncol, nlay + 1, self.ngpt))
         self.source(ncol, nlay, st, tlay, tlev, tsfc, top_at_1, sfc_src, lay_src, lev_src, sfc_src_jac)
         return b
 
@@ -559,6 +588,50 @@ def rte_lw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, lay_src, lev_src, sfc_emis_
         lev_src, sfc_emis_gpt, sfc_src, inc_flux, gfu, gfd, do_broadband, fu, fd, do_jacobians,
         sfc_src_jac if do_jacobians else sfc_src, jac, do_rescaling, ssa if do_rescaling else tau,
         g if do_rescaling else tau)
+    return b
+
+
+def rte_lw_factored(lib, xp, ncol, nlay, ngpt, nbnd, band_lims_gpt, top_at_1, tau, pfrac, planck_lay, planck_lev, sfc_emis_gpt,
+                    sfc_src, n_gauss_angles: int = 1, inc_flux=None, sfc_src_jac=None, do_jacobians=False,
+                    buffers: Optional[Dict[str, object]] = None):
+    """``rte_lw`` (broadband fluxes, no scattering) on FACTORED sources -- what ``GasOptics.gas_optics_lw(factored_sources=True)``
+    leaves: the library extension ``rte_hip_lw_solver_noscat_factored`` forms lay_source / lev_source per g-point inside the
+    solver with the operations of compute_Planck_source (bit-identical fluxes), so the two (ncol, nlay[+1], ngpt) source arrays are
+    neither written nor read.  Shapes the extension does not take (-2) are expanded and go through ``rte_lw``."""
+    from . import hiplib
+
+    b = buffers if buffers is not None else {}
+
+    def buf(name, shape, kind="f"):
+        if name not in b:
+            b[name] = xp.empty(shape, kind)
+        return b[name]
+
+    if inc_flux is None:
+        if "inc_flux_zero" not in b:
+            b["inc_flux_zero"] = xp.zeros((ncol, ngpt))
+        inc_flux = b["inc_flux_zero"]
+    nmus = n_gauss_angles
+    key = ("secants", nmus, id(None))
+    if key not in b:
+        sec = np.empty((ncol, ngpt, nmus), order="F")
+        for imu in range(nmus):
+            sec[:, :, imu] = GAUSS_DS[nmus - 1][imu]
+        b[key] = xp.asarray(sec)
+        b[("weights", nmus)] = np.array(GAUSS_WTS[nmus - 1], dtype=xp.ftype)
+    fu, fd = buf("flux_up", (ncol, nlay + 1)), buf("flux_dn", (ncol, nlay + 1))
+    jac = buf("flux_up_jac", (ncol, nlay + 1)) if do_jacobians else buf("decoy2D", (ncol, nlay + 1))
+    rc = hiplib.ext_call(lib, "rte_hip_lw_solver_noscat_factored", "iiiiiiaaaaaaaaaaaaiaa", ncol, nlay, ngpt, nbnd, int(top_at_1), nmus,
+                         b[key], b[("weights", nmus)], band_lims_gpt, tau, pfrac, planck_lay, planck_lev, sfc_emis_gpt, sfc_src,
+                         inc_flux, fu, fd, int(bool(do_jacobians)), sfc_src_jac if do_jacobians else sfc_src, jac)
+    assert rc in (0, -2), rc
+    if rc == -2:
+        lay_src, lev_src = buf("lay_src", (ncol, nlay, ngpt)), buf("lev_src", (ncol, nlay + 1, ngpt))
+        rc = hiplib.ext_call(lib, "rte_hip_expand_factored_sources", "iiiiaaaaaa", ncol, nlay, nbnd, ngpt, band_lims_gpt, pfrac,
+                             planck_lay, planck_lev, lay_src, lev_src)
+        assert rc == 0, rc
+        return rte_lw(lib, xp, ncol, nlay, ngpt, top_at_1, tau, lay_src, lev_src, sfc_emis_gpt, sfc_src, n_gauss_angles=nmus,
+                      inc_flux=inc_flux, sfc_src_jac=sfc_src_jac, do_jacobians=do_jacobians, buffers=b)
     return b
 
 

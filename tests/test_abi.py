@@ -39,7 +39,8 @@ def test_library_builds_and_exports_every_header_symbol():
                 "rte_hip_rfmip_sw_mu0", "rte_hip_broadcast_cols", "rte_hip_mask_columns",
                 "rte_hip_tau_rayleigh_combine_2str", "rte_hip_compute_tau_absorption_inc_bybnd",
                 "rte_hip_cloud_optics_fused", "rte_hip_lw_sfc_lds", "rte_hip_stat", "rte_hip_overlap_planck", "rte_hip_share_geometry", "rte_hip_gas_optics_sw_2str",
-                "rte_hip_aux_stream", "rte_hip_profile_only", "rte_hip_lw_solver_noscat_byband", "rte_hip_sw_solver_2stream_byband"):
+                "rte_hip_aux_stream", "rte_hip_profile_only", "rte_hip_lw_solver_noscat_byband", "rte_hip_sw_solver_2stream_byband",
+                "rte_hip_compute_Planck_source_factored", "rte_hip_lw_solver_noscat_factored", "rte_hip_expand_factored_sources"):
         assert hasattr(dll, ext)
     # the public extension header: contexts, error channel, host-mirror mode, opt-in modes, timing
     ext_h = open(os.path.join(ROOT, "include", "rte_hip_ext.h")).read()

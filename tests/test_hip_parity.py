@@ -854,3 +854,48 @@ def test_single_precision_solvers_at_host_model_layer_counts(oracle_c, nlay):
             e_hip = cases.rel_err(xs.to_numpy(out[k]).astype(np.float64), ref[k])
             e_sp = cases.rel_err(np.asarray(ref_sp[k], dtype=np.float64), ref[k])
             assert e_hip <= max(2e-4, 3.0 * e_sp), (name, k, nlay, e_hip, e_sp)
+
+
+@pytest.mark.parametrize("nlay,top_at_1,nmus,do_jac", [(60, True, 1, False), (60, False, 2, True), (19, True, 1, True),
+                                                        (64, False, 1, False), (72, True, 3, False), (77, False, 1, True),
+                                                        (100, True, 1, False)])
+def test_factored_lw_sources_give_the_same_bits(hip, nlay, top_at_1, nmus, do_jac):
+    """The factored LW path (extensions rte_hip_compute_Planck_source_factored -> rte_hip_lw_solver_noscat_factored): the Planck
+    fraction per g-point and the Planck function per band instead of lay_source / lev_source.  The factors, expanded with
+    rte_hip_expand_factored_sources, are the ABI call's arrays bit for bit (production and direct Planck kernels); the solver on
+    the factors returns the fluxes [and the Jacobian] of the ABI solver on the arrays bit for bit -- both orientations, full and
+    partial last segments (60 / 19 / 77 layers), 8 / 9 / 10 layers per wave, several angles, a ragged last column tile; 100
+    layers take the expand-and-call-the-ABI route (-2)."""
+    from rte_rrtmgp_amd import synth
+    import torch
+
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    ncol = 700
+    kd = synth.make_kdist("lw", ngpt=64, nbnd=4)
+    atm = synth.make_atmosphere(ncol, nlay, seed=11, kdist=kd, top_at_1=top_at_1)
+    go = frontend.GasOptics(hip, kd, xp)
+    args = (ncol, nlay, A(atm.play), A(atm.plev), A(atm.tlay), A(atm.tsfc), A(atm.col_gas), A(atm.tlev), atm.top_at_1)
+    rng = np.random.default_rng(5)
+    emis = A(np.asfortranarray(rng.uniform(0.9, 1.0, (ncol, kd.ngpt))))
+    inc = A(np.asfortranarray(rng.uniform(0.0, 5.0, (ncol, kd.ngpt))))
+    for direct in (0, 1):
+        hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], direct)
+        try:
+            ref = go.gas_optics_lw(*args, buffers={})
+            fac = go.gas_optics_lw(*args, buffers={}, factored_sources=True)
+            lay, lev = xp.empty((ncol, nlay, kd.ngpt)), xp.empty((ncol, nlay + 1, kd.ngpt))
+            go.expand_factored_sources(ncol, nlay, fac["pfrac"], fac["planck_lay"], fac["planck_lev"], lay, lev)
+        finally:
+            hiplib.ext_call(hip, "rte_hip_force_direct_gather", ["i"], 0)
+        for k, v in (("lay_src", lay), ("lev_src", lev), ("sfc_src", fac["sfc_src"]), ("sfc_src_jac", fac["sfc_src_jac"]), ("tau", fac["tau"])):
+            assert torch.equal(v, ref[k]), (k, direct)
+        assert float(ref["lev_src"].min()) > 0
+    r0 = frontend.rte_lw(hip, xp, ncol, nlay, kd.ngpt, atm.top_at_1, ref["tau"], ref["lay_src"], ref["lev_src"], emis, ref["sfc_src"],
+                         n_gauss_angles=nmus, inc_flux=inc, sfc_src_jac=ref["sfc_src_jac"], do_jacobians=do_jac, buffers={})
+    r1 = frontend.rte_lw_factored(hip, xp, ncol, nlay, kd.ngpt, kd.nbnd, go.t["band_lims_gpt"], atm.top_at_1, fac["tau"], fac["pfrac"],
+                                  fac["planck_lay"], fac["planck_lev"], emis, fac["sfc_src"], n_gauss_angles=nmus, inc_flux=inc,
+                                  sfc_src_jac=fac["sfc_src_jac"], do_jacobians=do_jac, buffers={})
+    for k in ("flux_up", "flux_dn") + (("flux_up_jac",) if do_jac else ()):
+        assert torch.equal(r0[k], r1[k]), (k, float((r0[k] - r1[k]).abs().max()))
+    assert float(r0["flux_up"].min()) > 0
