@@ -376,6 +376,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plain-abi", action="store_true",
                     help="skip the untimed plain-ABI steps (for rocprofv3 passes: their kernel variants would mix into the per-kernel averages)")
+    ap.add_argument("--no-factored", action="store_true", help="skip the extra measurement of the LW step with factored sources")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
     ap.add_argument("--seg-groups", type=int, default=0, help="experiment: g-point groups per column tile of the segmented solvers (0 = automatic)")
     ap.add_argument("--no-aux-stream", action="store_true",
@@ -639,6 +640,41 @@ def main():
     hiplib.ext_call(lib, "rte_hip_defer_zero", ["i"], 0 if args.no_defer_zero else 1)
     hiplib.ext_call(lib, "rte_hip_share_geometry", ["i"], (args.share_geometry_mode if share_geom else 0))
     hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1 if overlap else 0)
+    # the LW step with the sources FACTORED between gas optics and solver (library extensions; the headline stays the chain of
+    # reference-ABI kernels): 5 steps outside the timed region + 3 instrumented ones, fluxes compared bit for bit
+    factored = None
+    if args.workload == "lw" and not args.no_factored:
+        try:
+            rb_f = {}
+
+            def step_factored():
+                go.gas_optics_lw(ncol, NLAY, play, plev, tlay, tsfc, col_gas, tlev, atm.top_at_1, buffers=bufs, factored_sources=True)
+                frontend.rte_lw_factored(lib, xp, ncol, NLAY, kd.ngpt, kd.nbnd, go.t["band_lims_gpt"], atm.top_at_1, bufs["tau"],
+                                         bufs["pfrac"], bufs["planck_lay"], bufs["planck_lev"], emis, bufs["sfc_src"], buffers=rb_f)
+
+            f_ms = timed_ms(step_factored, reps=5)
+            hiplib.ext_call(lib, "rte_hip_profile_reset", [])
+            hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
+            for _ in range(3):
+                step_factored()
+            fence()
+            hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 0)
+            fk = read_profile(3)
+            step()  # the ABI chain again: its fluxes for the comparison (and its buffers as the timed region left them)
+            fence()
+            factored = {"ms_per_step": round(f_ms, 4), "columns_per_s": round(ncol * world / (f_ms * 1e-3), 1),
+                        "fluxes_bit_identical_to_abi_chain": bool(torch.equal(rb["flux_up"], rb_f["flux_up"]) and
+                                                                  torch.equal(rb["flux_dn"], rb_f["flux_dn"])),
+                        "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(fk.items(), key=lambda kv: -kv[1]["avg_ms"]) if v["avg_ms"] >= 0.02},
+                        "note": "rte_hip_compute_Planck_source_factored -> rte_hip_lw_solver_noscat_factored: Planck fraction per g-point + "
+                                "Planck function per band instead of lay_source / lev_source (26 GB less written, 13 GB less read); "
+                                "outside the timed region, never `value`"}
+            rb_f.clear()
+            for k in ("pfrac", "planck_lay", "planck_lev"):
+                bufs.pop(k, None)
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            factored = f"failed: {e}"
     # assembling the global broadband field on every rank (all-gather of the per-rank slabs), outside the timed region
     allgather_ms = None
     if dist is not None:
@@ -798,6 +834,7 @@ def main():
                        "plain_abi_ms_per_step": (round(plain_abi_ms, 4) if isinstance(plain_abi_ms, float) else plain_abi_ms),
                        "plain_abi_columns_per_s": (round(ncol * world / (plain_abi_ms * 1e-3), 1) if isinstance(plain_abi_ms, float) else None),
                        "plain_abi_note": "the same step through the reference ABI only, no rte_hip_* opt-ins (3 steps outside the timed region)",
+                       "factored_sources": factored,
                        "glue_ms_per_step_outside_timed_region": (round(glue_ms, 4) if glue_ms is not None else None),
                        "allgather_global_fluxes_ms_outside_timed_region": (round(allgather_ms, 4) if allgather_ms is not None else None),
                        "dist_backend": (args.dist_backend if dist is not None else None),

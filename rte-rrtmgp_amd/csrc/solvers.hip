@@ -334,8 +334,9 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, SegOffsets<L>& o, int ig
     // tau = 0 alone makes an out-of-segment slot NEUTRAL whatever finite sources it carries: trans = 1,
     // 1 - trans = 0, fact = 0 -> layer sources = 0, so the sweeps need no predication and the slot after
     // the last real layer naturally receives the surface values
-    const Float tv = at(tau, o.lay[i]);
-    t.tau[i] = i < np ? tv : (Float)0;
+    // (the consumer applies `i < np ? tau : 0`, where the value is used: selected here, at the request, the selects -- and the
+    //  waits for the rows -- were scheduled at the END of the g-point that requested them, a few hundred cycles after the request)
+    t.tau[i] = at(tau, o.lay[i]);
     t.lay[i] = at(lay, o.lay[i]);
   }
   if constexpr (FACT) {  // lay_source_ is the Planck fraction (ncol, nlay, ngpt): t.lay = the segment's, t.lev[0 / 1] = the rows above / below
@@ -488,7 +489,7 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     Float Td = 1, Sd = 0;
 #pragma unroll
     for (int i = 0; i < L; ++i) {
-      const Float tau_loc = cur_.tau[i] * cur.D;
+      const Float tau_loc = (i < np ? cur_.tau[i] : (Float)0) * cur.D;  // neutral slot (see seg_load)
       const Float tr = rte::exp_nonpos(-tau_loc);
       // lw_source_layer(lo, hi) returns (inc: uses hi, dec: uses lo): "toward bottom" uses the
       // bottom level source, "toward top" the top level source
@@ -503,6 +504,12 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       t[i] = tr;
       Sd = tr * Sd + sd[i];
       Td = Td * tr;
+#ifdef LW_X_FINE  // experiment: one slot's rows after every layer (the in-place refresh cannot move above the slot's last use)
+      if (i >= 1) request(i - 1, i);
+      if (i == L - 1) request(L - 1, L);
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+#else
       if (i & 1) {
         __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (register pressure) to 2 layers
         request(i - 1, i + 1 == L ? L : i + 1);
@@ -513,6 +520,7 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       request(L - 1, L);
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     Float Su = 0;
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) Su = t[i] * Su + su[i];
@@ -627,7 +635,11 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       if (SFCLDS && gl == 0) sfc_fetch(chunk + 1);           // a chunk ahead, behind this g-point's barrier ...
       if (SFCLDS && gl == 1) sfc_publish((chunk + 1) & 1);   // ... written an iteration later, read 14 barriers later
       LW_T(0);
+#ifdef LW_X_NOLOAD  // timing experiment: no requests after the first g-point's (compute and synchronisation alone; wrong results)
+      process(cur, buf, gl, chunk & 1, igpt, [&](int, int) {});
+#else
       process(cur, buf, gl, chunk & 1, igpt, [&](int i0, int i1) { load(cur, igpt + 1, i0, i1); });
+#endif
       LW_T(4);
       if (++gl == CH) { gl = 0; ++chunk; }
     }
