@@ -376,7 +376,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plain-abi", action="store_true",
                     help="skip the untimed plain-ABI steps (for rocprofv3 passes: their kernel variants would mix into the per-kernel averages)")
-    ap.add_argument("--no-factored", action="store_true", help="skip the extra measurement of the LW step with factored sources")
+    ap.add_argument("--no-factored", action="store_true", help="skip the extra measurements outside the timed region: the LW step with factored sources, the SW step with implicit g")
     ap.add_argument("--no-defer-zero", action="store_true", help="execute zero_array as its own memset")
     ap.add_argument("--seg-groups", type=int, default=0, help="experiment: g-point groups per column tile of the segmented solvers (0 = automatic)")
     ap.add_argument("--no-aux-stream", action="store_true",
@@ -675,6 +675,36 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
             factored = f"failed: {e}"
+    # the clear-sky SW step without the array of zeros that is g (library extension: g == NULL): outside the timed region
+    implicit_g = None
+    if args.workload == "sw" and not args.no_factored:
+        try:
+            bufs_g, rb_g = {"interp": bufs["interp"]}, {}
+
+            def step_sw_g():
+                go.gas_optics_sw(ncol, NLAY, play, plev, tlay, col_gas, col_dry, buffers=bufs_g, fuse_rayleigh="all", implicit_g=True)
+                frontend.rte_sw(lib, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, bufs_g["tau"], bufs_g["ssa"], None, mu0, bufs_g["toa_src"],
+                                alb, alb, buffers=rb_g)
+
+            g_ms = timed_ms(step_sw_g, reps=5)
+            hiplib.ext_call(lib, "rte_hip_profile_reset", [])
+            hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
+            for _ in range(3):
+                step_sw_g()
+            fence()
+            hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 0)
+            gk = read_profile(3)
+            step()
+            fence()
+            implicit_g = {"ms_per_step": round(g_ms, 4), "columns_per_s": round(ncol * world / (g_ms * 1e-3), 1),
+                          "fluxes_bit_identical": bool(all(torch.equal(rb[k], rb_g[k]) for k in ("flux_up", "flux_dn", "flux_dir"))),
+                          "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(gk.items(), key=lambda kv: -kv[1]["avg_ms"]) if v["avg_ms"] >= 0.02},
+                          "note": "clear-sky g = 0 neither stored by rte_hip_gas_optics_sw_2str nor read by rte_sw_solver_2stream (g == NULL); "
+                                  "outside the timed region, never `value`"}
+            bufs_g.clear(); rb_g.clear()
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            implicit_g = f"failed: {e}"
     # assembling the global broadband field on every rank (all-gather of the per-rank slabs), outside the timed region
     allgather_ms = None
     if dist is not None:
@@ -835,6 +865,7 @@ def main():
                        "plain_abi_columns_per_s": (round(ncol * world / (plain_abi_ms * 1e-3), 1) if isinstance(plain_abi_ms, float) else None),
                        "plain_abi_note": "the same step through the reference ABI only, no rte_hip_* opt-ins (3 steps outside the timed region)",
                        "factored_sources": factored,
+                       "implicit_g": implicit_g,
                        "glue_ms_per_step_outside_timed_region": (round(glue_ms, 4) if glue_ms is not None else None),
                        "allgather_global_fluxes_ms_outside_timed_region": (round(allgather_ms, 4) if allgather_ms is not None else None),
                        "dist_backend": (args.dist_backend if dist is not None else None),

@@ -1189,7 +1189,10 @@ __device__ unsigned long long sw_clk[8][6];
 #else
 #define SW_T(k) do { } while (0)
 #endif
-template <int L, bool SPEC = false, bool WIN = false>
+// G0: the asymmetry parameter is zero everywhere and its array does not exist (g == NULL in rte_sw_solver_2stream: clear-sky optical
+// properties as rte_hip_gas_optics_sw_2str leaves them without a g array) -- nothing is read for it and the terms it multiplies are
+// dropped as written (5 + 3 * 0, 1 - 0, 0.75 mu0 * 0): the same bits as with an array of zeros.
+template <int L, bool SPEC = false, bool WIN = false, bool G0 = false>
 __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 #pragma clang fp contract(fast)  // VALU-bound: fuse a*b+c (the segment composites already differ from the reference's rounding)
   constexpr int SMAX = 8, NC1 = 8, NC2 = 2;
@@ -1309,14 +1312,15 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   };
   auto load = [&](In& x, int igpt_) {
     const int igpt = min(igpt_, g_end - 1);
-    const Float *ptau = a.tau + ncl * igpt, *pssa = a.ssa + ncl * igpt, *pg = a.g + ncl * igpt;
+    const Float *ptau = a.tau + ncl * igpt, *pssa = a.ssa + ncl * igpt, *pg = G0 ? nullptr : a.g + ncl * igpt;
     // the row offsets are made opaque IN PLACE once per g-point (their 64-bit extension cannot be hoisted out of the loop into
     // registers of its own); as a by-value copy per load the compiler moved every offset into a scratch register first: 27
     // v_mov per g-point and wave
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       asm volatile("" : "+v"(orow[i]));
-      x.tau[i] = at(ptau, orow[i]); x.ssa[i] = at(pssa, orow[i]); x.g[i] = at(pg, orow[i]);
+      x.tau[i] = at(ptau, orow[i]); x.ssa[i] = at(pssa, orow[i]);
+      if constexpr (!G0) x.g[i] = at(pg, orow[i]);
     }
     asm volatile("" : "+v"(ocg));
     const size_t cg = (size_t)ncol * igpt;
@@ -1339,9 +1343,9 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         // a slot past the segment's last layer (partial last segment only) is made NEUTRAL by tau = 0: e1 = e2 =
         // Tnoscat = 1, so Rdif = 0, the clamps give Rdir = Tdir = 0 exactly, and Tdif (1 up to rounding) is set to 1
         // -- the identity in every recurrence, without a branch around the layer
-        const Float tau_s = i < np ? x.tau[i] : (Float)0, w0_s = x.ssa[i], g_s = x.g[i];
-        const Float gamma1 = ((Float)8 - w0_s * ((Float)5 + (Float)3 * g_s)) * (Float).25;
-        const Float gamma2 = (Float)3 * (w0_s * ((Float)1 - g_s)) * (Float).25;
+        const Float tau_s = i < np ? x.tau[i] : (Float)0, w0_s = x.ssa[i], g_s = G0 ? (Float)0 : x.g[i];
+        const Float gamma1 = G0 ? ((Float)8 - w0_s * (Float)5) * (Float).25 : ((Float)8 - w0_s * ((Float)5 + (Float)3 * g_s)) * (Float).25;
+        const Float gamma2 = G0 ? (Float)3 * w0_s * (Float).25 : (Float)3 * (w0_s * ((Float)1 - g_s)) * (Float).25;
         // (the reference's own operation order: gamma1 - gamma2 cancels for conservative scattering, and a differently rounded
         //  pair moves the fluxes of cloudy columns by 1e-8 relative to the reference's -- measured, all-sky at 1e5 columns)
         const Float kk = rte::sqrt_pos(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
@@ -1358,7 +1362,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
         R[i] = RT * gamma2 * ((Float)1 - e2);
         T[i] = i < np ? RT * (Float)2 * kk * e1 : (Float)1;
         RT = w0_s * inv;
-        const Float gamma3 = (Float).5 - ((Float).75 * mu0_s) * g_s;  // (2 - 3 mu0 g) / 4
+        const Float gamma3 = G0 ? (Float).5 : (Float).5 - ((Float).75 * mu0_s) * g_s;  // (2 - 3 mu0 g) / 4
         // alpha1 = gamma1 gamma4 + gamma2 gamma3, alpha2 = gamma1 gamma3 + gamma2 gamma4 with gamma4 = 1 - gamma3 (:1078-1081)
         const Float dgam = gamma1 - gamma2;
         const Float alpha1 = gamma1 - gamma3 * dgam;
@@ -2348,7 +2352,17 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
   Sw2Args a;
   a.ncol = ncol; a.nlay = nlay; a.ngpt = ngpt; a.top_at_1 = *top_at_1; a.has_dif_bc = *has_dif_bc;
   a.add_dir_to_dn = true;
-  a.tau = c.in(tau, ncl * ngpt); a.ssa = c.in(ssa, ncl * ngpt); a.g = c.in(g, ncl * ngpt);
+  a.tau = c.in(tau, ncl * ngpt); a.ssa = c.in(ssa, ncl * ngpt);
+  // extension: g == NULL means "g = 0 everywhere" (what rte_hip_gas_optics_sw_2str leaves when it is given no g array).  The
+  // broadband segmented kernel at 8 / 9 layers per wave has an instance that reads nothing for it; every other path gets zeros.
+  const bool g0_kernel = !g && do_broadband && nlay <= 72 && !g_sw_force_generic && ncl < ((size_t)1 << 29);
+  if (g) a.g = c.in(g, ncl * ngpt);
+  else if (g0_kernel) a.g = nullptr;
+  else {
+    Float* z = (Float*)rte::scratch(sizeof(Float) * ncl * ngpt);
+    HIP_CHECK(hipMemsetAsync(z, 0, sizeof(Float) * ncl * ngpt, rte::stream()));
+    a.g = z;
+  }
   a.mu0 = c.in(mu0, ncl);
   a.sfc_alb_dir = c.in(sfc_alb_dir, ncg); a.sfc_alb_dif = c.in(sfc_alb_dif, ncg);
   a.inc_flux_dir = c.in(inc_flux_dir, ncg);
@@ -2382,7 +2396,9 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + ((L == 9 || L >= 11) ? 1 : 2) * 8 * L + ((L <= 9 || L >= 11) ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
     {
       rte::ProfScope p("sw_2stream_seg_kernel");
-      if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+      if (g0_kernel && L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, false, false, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+      else if (g0_kernel) hipLaunchKernelGGL((sw_2stream_seg_kernel<9, false, false, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
+      else if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
       else if (L == 9) hipLaunchKernelGGL((sw_2stream_seg_kernel<9>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
       else if (L == 10) hipLaunchKernelGGL((sw_2stream_seg_kernel<10>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
       else if (L == 11) hipLaunchKernelGGL((sw_2stream_seg_kernel<11>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);

@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __res
 // test: a conditional load changes the number of outstanding memory operations from path to path, and the compiler
 // then waits for (nearly) all of them, i.e. for the previous stage's stores, at the top of every stage.
 // RAYL: fused with compute_tau_rayleigh + combine_abs_and_rayleigh (2-stream) [+ by-band 2-stream increment]: see RaylFuse
-template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G, int MM, bool ADDB, int RAYL = 0 /* 1: fused, 2: + by-band clouds */>
+template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G, int MM, bool ADDB, int RAYL = 0 /* 1: fused, 2: + by-band clouds, 3: fused, g (all zero) not stored */>
 __global__ void __launch_bounds__((NCW + NLW) * 64, TAU_MINW)
 tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
@@ -1261,7 +1261,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       const Float* R1 = sl + (rowsMaj + rowsLo + rowsUp_ + ((itropo * nT + (jT_r - Tmin)) * nE + (je1 - emin))) * RS;
       const Float* R2 = sl + (rowsMaj + rowsLo + rowsUp_ + ((itropo * nT + (jT_r + 1 - Tmin)) * nE + (je2 - emin))) * RS;
       char* const splane = reinterpret_cast<char*>(a.rf.ssa + (size_t)ncl * g0);
-      char* const gplane = reinterpret_cast<char*>(a.rf.g + (size_t)ncl * g0);
+      char* const gplane = RAYL == 3 ? nullptr : reinterpret_cast<char*>(a.rf.g + (size_t)ncl * g0);
 #pragma unroll
       for (int j = 0; j < G; j += 2) {
         const Float2 a0 = ld2(R1 + j), a1 = ld2(R1 + RS + j), b0 = ld2(R2 + j), b1 = ld2(R2 + RS + j);
@@ -1273,7 +1273,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
           rayl_finish(acc[j + u], (u == 0 ? ka : kb) * wray_s, RAYL == 2, cld_t, cld_s, cld_g, t_, s_, g_);
           store_stream(tau_at(j + u), t_);
           store_stream(reinterpret_cast<Float*>(splane + gstride * (j + u) + toff), s_);
-          store_stream(reinterpret_cast<Float*>(gplane + gstride * (j + u) + toff), g_);
+          if constexpr (RAYL != 3) store_stream(reinterpret_cast<Float*>(gplane + gstride * (j + u) + toff), g_);
         }
       }
     } else if constexpr (ROT) {
@@ -1333,7 +1333,7 @@ __device__ __forceinline__ void rayl_store(const RaylCombine& cb, Float* tau_ray
               cld ? cb.cld_g[idx_bnd] : (Float)0, t, s_, g_);
   cb.ssa[idx] = s_;
   cb.tau[idx] = t;
-  cb.g[idx] = g_;
+  if (cb.g) cb.g[idx] = g_;  // (nullptr: clear sky, the caller keeps "g = 0" implicit)
 }
 
 // direct kernel: work items (column tile, layer, band) in grid stride (a small grid when it only stands by for the plan guard)
@@ -1493,7 +1493,7 @@ __global__ void __launch_bounds__(BS) tau_rayleigh_slab_kernel(RaylArgs a) {
           if (icol < ncol) {  // tau may alias tau_abs: the clamped lanes past the last column must not update it again
             *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.ssa) + po) = s_;
             *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.tau) + po) = t;
-            *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.g) + po) = g_;
+            if (a.cb.g) *reinterpret_cast<Float*>(reinterpret_cast<char*>(a.cb.g) + po) = g_;
           }
         }
       }
@@ -1567,7 +1567,7 @@ static void tau_absorption_impl(
     if (rh->cld_tau) { cb.cld_tau = c.in(rh->cld_tau, ncl * nbnd); cb.cld_ssa = c.in(rh->cld_ssa, ncl * nbnd); cb.cld_g = c.in(rh->cld_g, ncl * nbnd); }
     cb.tau_abs = d_tau; cb.tau = d_tau;  // the direct kernels combine in place
     cb.ssa = c.out_lazy(rh->ssa, ncl * ngpt);
-    cb.g = c.out_lazy(rh->g, ncl * ngpt);
+    cb.g = rh->g ? c.out_lazy(rh->g, ncl * ngpt) : nullptr;  // (nullptr without clouds: g = 0 is not stored)
   }
   hipStream_t st = rte::stream();
   if (!rh && !c.any_host() && rte::is_device_memory(d_tau)) rte::fork_point(d_tau, sizeof(Float) * ncl * ngpt);
@@ -1979,7 +1979,8 @@ static void tau_absorption_impl(
     rte::ProfScope p("tau_absorption_kernel");                                                                    \
     if (rh) {                                                                                                     \
       if (cb.cld_tau) RTE_LAUNCH_TAU9R_(GW, 4, 2);                                                                \
-      else            RTE_LAUNCH_TAU9R_(GW, 4, 1);                                                                \
+      else if (cb.g)  RTE_LAUNCH_TAU9R_(GW, 4, 1);                                                                \
+      else            RTE_LAUNCH_TAU9R_(GW, 4, 3);                                                                \
     } else if (d_add) RTE_LAUNCH_TAU9_(GW, true); else RTE_LAUNCH_TAU9_(GW, false);                               \
   } while (0)
     if (cache.gw == 16) RTE_LAUNCH_TAU9(16); else RTE_LAUNCH_TAU9(8);
@@ -2084,6 +2085,8 @@ int rte_hip_compute_tau_absorption_inc_bybnd(
 // increment by 2-stream cloud properties -- in ONE pass over (column, layer, g-point): the absorption optical depth
 // never goes to memory (-21.5 GB per step at 1e5 x 60 x 224).  Same operations in the same order on the same doubles
 // as the chain compute_tau_absorption -> rte_hip_tau_rayleigh_combine_2str: bit-identical tau, ssa, g.
+// g == NULL (clear sky only): combine_abs_and_rayleigh's g = 0 is NOT stored -- 10.75 GB less to write at 1e5 x 60 x 224, and
+// rte_sw_solver_2stream takes g == NULL as "g = 0" (same bits as with the array of zeros, nothing to read).
 int rte_hip_gas_optics_sw_2str(
     int ncol, int nlay, int nbnd, int ngpt, int ngas, int nflav, int neta, int npres, int ntemp, int nminorlower,
     int nminorklower, int nminorupper, int nminorkupper, int idx_h2o, const int* gpoint_flavor,
@@ -2097,6 +2100,7 @@ int rte_hip_gas_optics_sw_2str(
     const Float* play, const Float* tlay, const Float* col_gas, const int* jeta, const int* jtemp,
     const int* jpress, const Float* krayl, const Float* col_dry, Float* tau, Float* ssa, Float* g,
     const Float* cld_tau, const Float* cld_ssa, const Float* cld_g) {
+  if (!g && cld_tau) return -1;  // g may be omitted (g = 0 stays implicit) only without clouds
   RaylHost rh{krayl, col_dry, cld_tau, cld_ssa, cld_g, ssa, g};
   tau_absorption_impl("rte_hip_gas_optics_sw_2str", ncol, nlay, nbnd, ngpt, ngas, nflav, neta, npres, ntemp,
                       nminorlower, nminorklower, nminorupper, nminorkupper, idx_h2o, gpoint_flavor, band_lims_gpt, kmajor,

@@ -285,7 +285,10 @@ class GasOptics:
 
     # -- gas_optics_ext: SW, returns 2str optical props + toa source
     def gas_optics_sw(self, ncol, nlay, play, plev, tlay, col_gas, col_dry,
-                      buffers: Optional[Dict[str, object]] = None, glue=None, fuse_rayleigh: bool = False, clouds_bybnd=None):
+                      buffers: Optional[Dict[str, object]] = None, glue=None, fuse_rayleigh: bool = False, clouds_bybnd=None,
+                      implicit_g: bool = False):
+        """``implicit_g`` (with ``fuse_rayleigh="all"``, no clouds): combine_abs_and_rayleigh's ``g = 0`` (:1983-2002) is not stored --
+        ``b["g"]`` is None and ``rte_sw`` / the library's ``rte_sw_solver_2stream`` take a missing ``g`` as zero (library extension)."""
         xp = self.xp
         b = buffers if buffers is not None else {}
 
@@ -301,7 +304,11 @@ class GasOptics:
         assert clouds_bybnd is None or fused, "the by-band cloud increment is part of the fused kernel"
         if fused and fuse_rayleigh == "all" and hasattr(gl, "gas_optics_sw_2str"):
             # absorption, Rayleigh, combine (and the by-band cloud increment) in ONE pass: tau_abs never goes to memory
-            tau, ssa, g = (buf(n, (ncol, nlay, self.ngpt)) for n in ("tau", "ssa", "g"))
+            tau, ssa = (buf(n, (ncol, nlay, self.ngpt)) for n in ("tau", "ssa"))
+            if implicit_g and clouds_bybnd is None:
+                b["g"] = g = None
+            else:
+                g = buf("g", (ncol, nlay, self.ngpt))
             gl.gas_optics_sw_2str(self, ncol, nlay, st, play, tlay, col_gas, col_dry, tau, ssa, g, clouds_bybnd)
             toa = buf("toa_src", (ncol, self.ngpt))
             gl.broadcast_gpt(ncol, self.ngpt, self.t["solar_source"], toa)

@@ -899,3 +899,39 @@ def test_factored_lw_sources_give_the_same_bits(hip, nlay, top_at_1, nmus, do_ja
     for k in ("flux_up", "flux_dn") + (("flux_up_jac",) if do_jac else ()):
         assert torch.equal(r0[k], r1[k]), (k, float((r0[k] - r1[k]).abs().max()))
     assert float(r0["flux_up"].min()) > 0
+
+
+@pytest.mark.parametrize("nlay,top_at_1,do_broadband", [(60, True, True), (72, False, True), (37, True, True), (100, True, True),
+                                                         (60, False, False)])
+def test_implicit_asymmetry_parameter_of_clear_sky_sw(hip, nlay, top_at_1, do_broadband):
+    """Clear-sky SW optical properties have g = 0 (combine_abs_and_rayleigh, mo_gas_optics_rrtmgp.F90:1983-2002).  With
+    ``implicit_g`` the one-pass SW gas optics does not store that array and rte_sw_solver_2stream is called with g == NULL: tau and
+    ssa are the same bits, and so are the fluxes -- on the instance of the segmented kernel that reads nothing for g (8 and 9 layers
+    per wave, broadband) and on the paths that get an array of zeros from the library (more layers, spectral output)."""
+    from rte_rrtmgp_amd import synth
+    import torch
+
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    ncol = 700
+    kd = synth.make_kdist("sw", ngpt=64, nbnd=4)
+    atm = synth.make_atmosphere(ncol, nlay, seed=13, kdist=kd, top_at_1=top_at_1)
+    go = frontend.GasOptics(hip, kd, xp)
+    args = (ncol, nlay, A(atm.play), A(atm.plev), A(atm.tlay), A(atm.col_gas), A(atm.col_dry))
+    ref = go.gas_optics_sw(*args, buffers={}, fuse_rayleigh="all")
+    imp = go.gas_optics_sw(*args, buffers={}, fuse_rayleigh="all", implicit_g=True)
+    assert imp["g"] is None and float(ref["g"].abs().max()) == 0.0
+    for k in ("tau", "ssa", "toa_src"):
+        assert torch.equal(ref[k], imp[k]), k
+    rng = np.random.default_rng(3)
+    mu0 = np.repeat(rng.uniform(-0.2, 1.0, (ncol, 1)), nlay, axis=1)  # night columns among them
+    alb = A(np.asfortranarray(rng.uniform(0.05, 0.4, (ncol, kd.ngpt))))
+    out = []
+    for b in (ref, imp):
+        r = frontend.rte_sw(hip, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["ssa"], b["g"], A(np.asfortranarray(mu0)),
+                            b["toa_src"], alb, alb, do_broadband=do_broadband, buffers={})
+        out.append(r)
+    keys = ("flux_up", "flux_dn", "flux_dir") if do_broadband else ("gpt_flux_up", "gpt_flux_dn", "gpt_flux_dir")
+    for k in keys:
+        assert torch.equal(out[0][k], out[1][k]), (k, float((out[0][k] - out[1][k]).abs().max()))
+    assert float(out[0][keys[0]].max()) > 0
