@@ -490,21 +490,26 @@ class CloudOptics:
 
 
 def allsky_lw(lib, xp, go: "GasOptics", co: CloudOptics, ncol, nlay, atm, clouds, sfc_emis_gpt, gb=None, cb=None, rb=None,
-              fuse: bool = True):
+              fuse: bool = True, factored_sources: bool = False):
     """LW half of examples/all-sky/rrtmgp_allsky.F90:362-380: clouds as absorbers (1scl) added to the gas optical
     depth band by band, then rte_lw without scattering.  ``fuse`` (device containers only): the library's fused
     extension kernels -- cloud optics in one pass, and the band-wise increment applied inside compute_tau_absorption;
     same values, each 3-D array written once."""
     fuse = fuse and not isinstance(xp, NumpyArrays)
+    factored_sources = factored_sources and fuse  # (library extensions: the sources stay factored, see rte_lw_factored)
     if fuse:
         cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], False, buffers=cb, fused=True)
         gb = go.gas_optics_lw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["tsfc"], atm["col_gas"], atm["tlev"],
-                              atm["top_at_1"], buffers=gb, tau_bybnd=cb["cld_tau"])                                 # :374 fused in
+                              atm["top_at_1"], buffers=gb, tau_bybnd=cb["cld_tau"], factored_sources=factored_sources)  # :374 fused in
     else:
         gb = go.gas_optics_lw(ncol, nlay, atm["play"], atm["plev"], atm["tlay"], atm["tsfc"], atm["col_gas"], atm["tlev"],
                               atm["top_at_1"], buffers=gb)
         cb = co.cloud_optics(ncol, nlay, clouds["lwp"], clouds["iwp"], clouds["rel"], clouds["dei"], False, buffers=cb)
         lib.rte_inc_1scalar_by_1scalar_bybnd(ncol, nlay, go.ngpt, gb["tau"], cb["cld_tau"], go.nbnd, go.t["band_lims_gpt"])  # :374
+    if factored_sources:
+        rb = rte_lw_factored(lib, xp, ncol, nlay, go.ngpt, go.nbnd, go.t["band_lims_gpt"], atm["top_at_1"], gb["tau"], gb["pfrac"],
+                             gb["planck_lay"], gb["planck_lev"], sfc_emis_gpt, gb["sfc_src"], buffers=rb)
+        return gb, cb, rb
     rb = rte_lw(lib, xp, ncol, nlay, go.ngpt, atm["top_at_1"], gb["tau"], gb["lay_src"], gb["lev_src"], sfc_emis_gpt,
                 gb["sfc_src"], buffers=rb)
     return gb, cb, rb
