@@ -9,6 +9,8 @@ from rte_rrtmgp_amd import frontend, hiplib, synth
 lib = hiplib.load(); xp = frontend.TorchArrays("cuda:0")
 hiplib.set_stream(lib, torch.cuda.current_stream().cuda_stream)
 hiplib.ext_call(lib, "rte_hip_defer_zero", ["i"], 1); hiplib.ext_call(lib, "rte_hip_share_geometry", ["i"], 1)
+import os
+if os.environ.get("LW_SFC_LDS"): hiplib.ext_call(lib, "rte_hip_lw_sfc_lds", ["i"], int(os.environ["LW_SFC_LDS"]))
 ncol, nlay = int(sys.argv[1]) if len(sys.argv) > 1 else 100000, 60
 kd = synth.make_kdist("lw"); atm = synth.make_atmosphere(ncol, nlay, seed=42, kdist=kd)
 go = frontend.GasOptics(lib, kd, xp); A = xp.asarray
