@@ -766,6 +766,16 @@ __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __res
 // ADDB: a band-wise operand is added (rte_hip_compute_tau_absorption_inc_bybnd) -- a template parameter, not a run-time
 // test: a conditional load changes the number of outstanding memory operations from path to path, and the compiler
 // then waits for (nearly) all of them, i.e. for the previous stage's stores, at the top of every stage.
+#ifdef TAU_TIMING
+// experiment builds only (tools/fastbuild.py taut:tau_absorption.hip=-DTAU_TIMING): s_memtime ticks of the waves of tau_absorption_v9_kernel
+// per role and phase of a stage.  Compute waves: [0] waiting at the stage's barrier, [1] the previous stage's stores (ROT) + set-up,
+// [2] major gather + FMAs, [3] minor species, rest of the stage.  Loader waves: [4] requesting + waiting for the table pieces,
+// [5] writing them to LDS, [6] waiting at the barrier.
+__device__ unsigned long long tau_clk[8];
+#define TAU_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define TAU_T(k) do { } while (0)
+#endif
 // RAYL: fused with compute_tau_rayleigh + combine_abs_and_rayleigh (2-stream) [+ by-band 2-stream increment]: see RaylFuse
 template <int NCW, int NLW, int SLAB, bool OVERWRITE, int G, int MM, bool ADDB, int RAYL = 0 /* 1: fused, 2: + by-band clouds, 3: fused, g (all zero) not stored */>
 __global__ void __launch_bounds__((NCW + NLW) * 64, TAU_MINW)
@@ -805,6 +815,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const float inv_nT = 1.0f / (float)nT;
     constexpr int SB = V9_SB;  // 16-byte pieces per lane requested back to back
     int ibnd = 0;
+#ifdef TAU_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
     for (int s = 0; s < nstage; ++s) {
       const int g0 = s * G;
@@ -850,15 +863,25 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
           Float2 v[SB];
 #pragma unroll
           for (int u = 0; u < SB; ++u) v[u] = piece(min(base + u * NLT, nAll - 1));
+#ifdef TAU_TIMING
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the pieces have arrived
+          TAU_T(4);
+#endif
 #pragma unroll
           for (int u = 0; u < SB; ++u) {
             const int idx = base + u * NLT;
             if (idx < nAll) *reinterpret_cast<Float2*>(sl + (idx >> PSH) * RS + 2 * (idx & (PPR - 1))) = v[u];
           }
+          TAU_T(5);
         }
       }
       __syncthreads();  // B(s): slab(s) complete; the compute waves are done with the other buffer
+      TAU_T(6);
     }
+#ifdef TAU_TIMING
+    if ((tid & 63) == 0)
+      for (int k = 4; k < 7; ++k) atomicAdd(&tau_clk[k], tacc[k]);
+#endif
     return;
   }
 
@@ -1048,6 +1071,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // wait for all but three of the previous stage's stores.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   int ibnd = 0;
+#ifdef TAU_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
   for (int s = 0; s < nstage; ++s) {
     const int g0 = s * G;
@@ -1080,7 +1106,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const Float w0 = mj.cm.x * mj.fm[0].x, w1 = mj.cm.x * mj.fm[0].y, w2 = mj.cm.x * mj.fm[1].x, w3 = mj.cm.x * mj.fm[1].y,
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
     const int je1 = mj.je.x, je2 = mj.je.y;
+    TAU_T(3);
     __syncthreads();  // B(s): slab(s) is complete
+    TAU_T(0);
     if constexpr (ROT) {
       if (ALLRUN ? s > 0 : have_prev) flush(g0_prev, addv_prev);
       have_prev = false;
@@ -1107,6 +1135,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     auto tau_at = [&](int j) { return reinterpret_cast<Float*>(tplane + gstride * j + toff); };
 #pragma unroll
     for (int j = 0; j < G; ++j) acc[j] = 0;
+    TAU_T(1);
     if constexpr (ROLL) {
       // rolling: the next four rows are requested BEFORE the FMAs on the four that arrived (at most 8 row reads in flight
       // per wave; the LDS serves the other waves' and this wave's next rows while the SIMD works on these)
@@ -1160,6 +1189,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       if ((j & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads (64 VGPRs) in flight
     }
     }
+    TAU_T(2);
     // next stage's major weights: their registers are free now, and the request is a minor pass ahead of its use
     // (requested with the minor weights at the end of the stage, their latency is exposed: 5.5 -> 5.9 ms)
     load_major(nq.flav_major, mj);
@@ -1285,6 +1315,11 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   if constexpr (ROT) {
     if (ALLRUN ? nstage > 0 : have_prev) flush(g0_prev, addv_prev);
   }
+#ifdef TAU_TIMING
+  TAU_T(3);
+  if ((tid & 63) == 0)
+    for (int k = 0; k < 4; ++k) atomicAdd(&tau_clk[k], tacc[k]);
+#endif
   };
   // (round 3: 5.30 -> 5.19 ms at 1e5 x 60 x 256; -DTAU_NO_ROT for the A/B.  The fused variants end a stage with LDS
   // reads of their own slab and stay as they were.)
@@ -2024,6 +2059,15 @@ static void tau_absorption_impl(
   RTE_CATCH(api_name)
 }
 
+#ifdef TAU_TIMING
+extern "C" int rte_hip_tau_timing(unsigned long long* out /*[8]*/) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(tau_clk), sizeof(unsigned long long) * 8);
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(tau_clk), z, sizeof(z));
+  return 0;
+}
+#endif
 #if defined(MX_TIMING) && !defined(RTE_USE_SP)
 extern "C" int rte_hip_mx_timing(unsigned long long* out /*[4]: column waves busy, waiting; matrix waves busy, waiting*/) {
   (void)hipDeviceSynchronize();
