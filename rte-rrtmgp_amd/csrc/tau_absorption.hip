@@ -812,7 +812,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     // in one process, no change for Planck)
     __builtin_amdgcn_s_setprio(1);
     const int lt = tid - TILE;
-    const float inv_nT = 1.0f / (float)nT;
+    const float inv_nT = 1.0f / (float)nT, inv_nP = 1.0f / (float)nP;
     constexpr int SB = V9_SB;  // 16-byte pieces per lane requested back to back
     int ibnd = 0;
 #ifdef TAU_TIMING
@@ -834,8 +834,16 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         auto piece = [&](int idx) -> Float2 {
           const int j = idx & (PPR - 1), r = idx >> PSH;
           if (r < rowsMaj) {
+#ifdef TAU_ROWS_PTE  // the rounds 1-3 order of the major rows, [p][t][eta] (A/B)
             const int rest = (int)(((float)r + 0.5f) * inv_nE), e = r - rest * nE;  // rows < 2^12: exact
             const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
+#else
+            // major rows ordered [t][eta][p], the pressure level innermost: the rows of a 16-lane group of a gather then fall into
+            // different 4-bank windows far more often (tools/lds_conflict_sim.py: 1.15 instead of 1.70 LDS cycles per group access;
+            // with [p][t][eta] the p and p + 1 rows of neighbouring columns were often 16 rows apart = the same window)
+            const int rest = (int)(((float)r + 0.5f) * inv_nP), p_l = r - rest * nP;  // rows < 2^12: exact
+            const int t_l = (int)(((float)rest + 0.5f) * inv_nE), e = rest - t_l * nE;
+#endif
             return *reinterpret_cast<const Float2*>(
                 a.kmaj + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
           }
@@ -1124,9 +1132,17 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const int rowsMaj = nP * nT * nE;
     const int rowsLo = (has_lo ? bm[ibnd].cnt[0] : 0) * nT * nE;
     const int jT_s = RTE_PARKED_I(0, jT), jp_s = RTE_PARKED_I(1, jp);
+#ifdef TAU_ROWS_PTE
     const Float* A0 = sl + (((jp_s - 1 - Pmin) * nT + (jT_s - Tmin)) * nE + (je1 - emin)) * RS;
     const Float* B0 = sl + (((jp_s - 1 - Pmin) * nT + (jT_s + 1 - Tmin)) * nE + (je2 - emin)) * RS;
-    const int sP = nT * nE * RS;
+    const int sP = nT * nE * RS;  // to the row of the next pressure level
+    constexpr int sE = RS;        // to the row of the next eta
+#else
+    const Float* A0 = sl + (((jT_s - Tmin) * nE + (je1 - emin)) * nP + (jp_s - 1 - Pmin)) * RS;
+    const Float* B0 = sl + (((jT_s + 1 - Tmin) * nE + (je2 - emin)) * nP + (jp_s - 1 - Pmin)) * RS;
+    constexpr int sP = RS;   // to the row of the next pressure level (innermost, see the loader)
+    const int sE = nP * RS;  // to the row of the next eta
+#endif
     const Float* M0 = sl + (rowsMaj + (regime == 2 ? rowsLo : 0)) * RS;
     // (RAYL: the stage's stores are issued here, see below)
     char* const tplane = reinterpret_cast<char*>(a.tau + (size_t)ncl * g0);
@@ -1142,7 +1158,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       Float2 kb[2][4];
       auto rd = [&](Float2 (&k)[4], int h) {  // h: half-step index, (pair, lower / upper temperature)
         const Float* base = ((h & 1) ? B0 : A0) + 2 * (h >> 1);
-        k[0] = ld2(base); k[1] = ld2(base + RS); k[2] = ld2(base + sP); k[3] = ld2(base + sP + RS);
+        k[0] = ld2(base); k[1] = ld2(base + sE); k[2] = ld2(base + sP); k[3] = ld2(base + sP + sE);
       };
       rd(kb[0], 0);
       Float m = 0, n = 0;
@@ -1172,8 +1188,8 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
     for (int j = 0; j < G; j += 2) {
       // :791-801 with col_mix folded into the weights; one 16-byte LDS read feeds two g-points
-      const Float2 k0 = ld2(A0 + j), k1 = ld2(A0 + RS + j), k2 = ld2(A0 + sP + j), k3 = ld2(A0 + sP + RS + j),
-                   k4 = ld2(B0 + j), k5 = ld2(B0 + RS + j), k6 = ld2(B0 + sP + j), k7 = ld2(B0 + sP + RS + j);
+      const Float2 k0 = ld2(A0 + j), k1 = ld2(A0 + sE + j), k2 = ld2(A0 + sP + j), k3 = ld2(A0 + sP + sE + j),
+                   k4 = ld2(B0 + j), k5 = ld2(B0 + sE + j), k6 = ld2(B0 + sP + j), k7 = ld2(B0 + sP + sE + j);
       Float m = w0 * k0.x, n = w0 * k0.y;
       m = fma(w1, k1.x, m); n = fma(w1, k1.y, n);
       m = fma(w2, k2.x, m); n = fma(w2, k2.y, n);

@@ -79,7 +79,22 @@ def mscore(fn, S):
         tot+=np.bincount(fn(row,p,t,e)%16,minlength=16).max()
     return tot/len(S)
 print("minor: distinct rows per group %.2f"%np.mean([len(k) for k,_,_ in msamples]))
-for name,fn in (("current",lambda r,p,t,e:9*r),("xor t&1",lambda r,p,t,e:9*r+(t&1)),("xor e&1",lambda r,p,t,e:9*r+(e&1)),("xor (t&1)|(e&1)<<1 (2 bit)",lambda r,p,t,e:9*r+((t&1)|((e&1)<<1))),("xor r>>4 &1",lambda r,p,t,e:9*r+((r>>4)&1)),("xor r>>4 &7",lambda r,p,t,e:9*r+((r>>4)&7))):
+for name,fn in [] and (("current",lambda r,p,t,e:9*r),("xor t&1",lambda r,p,t,e:9*r+(t&1)),("xor e&1",lambda r,p,t,e:9*r+(e&1)),("xor (t&1)|(e&1)<<1 (2 bit)",lambda r,p,t,e:9*r+((t&1)|((e&1)<<1))),("xor r>>4 &1",lambda r,p,t,e:9*r+((r>>4)&1)),("xor r>>4 &7",lambda r,p,t,e:9*r+((r>>4)&7))):
     print("  minor %-28s %.3f"%(name,mscore(fn,msamples)))
 for name,fn in (("current",lambda r,p,t,e:9*r),("xor p&1",lambda r,p,t,e:9*r+(p&1)),("xor (p&1)|(t&1)<<1",lambda r,p,t,e:9*r+((p&1)|((t&1)<<1))),("xor (p&1)|(e&1)<<1",lambda r,p,t,e:9*r+((p&1)|((e&1)<<1)))):
     print("  major %-28s %.3f"%(name,mscore(fn,samples)))
+
+# ---- pure reorderings of the major box (no rotation): which dimension is innermost?  nP = 2 in nearly every box
+def oscore(order):
+    tot=0
+    for key,nT,nE in samples:
+        p,t,e=key[:,0],key[:,1],key[:,2]
+        nP=int(p.max())+1 if False else 3   # boxes hold up to 3 pressure levels; the stride must be the box's own nP: use max seen
+        dims={"p":(p,3),"t":(t,nT),"e":(e,nE)}
+        row=0
+        for d in order:
+            v,n=dims[d]; row=row*n+v
+        tot+=np.bincount((9*row)%16,minlength=16).max()
+    return tot/len(samples)
+for order in ("pte","tep","etp","tpe","ept","pet"):
+    print("  major rows ordered [%s] (last = innermost): %.3f"%("][".join(order),oscore(order)))
