@@ -99,12 +99,26 @@ def test_full_size_config_against_the_reference_kernels(workload):
             r = frontend.rte_lw(hip, xp, NCOL, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"],
                                 xp.full((NCOL, kd.ngpt), 0.98), b["sfc_src"])
             out = {"up": r["flux_up"], "dn": r["flux_dn"]}
+            # the same step with the sources factored between gas optics and solver (library extensions): the same bits at full size
+            bf = go.gas_optics_lw(NCOL, nlay, a["play"], a["plev"], a["tlay"], a["tsfc"], a["col_gas"], a["tlev"], atm.top_at_1,
+                                  buffers={"interp": b["interp"], "tau": b["tau"]}, factored_sources=True)
+            rf = frontend.rte_lw_factored(hip, xp, NCOL, nlay, kd.ngpt, kd.nbnd, go.t["band_lims_gpt"], atm.top_at_1, bf["tau"], bf["pfrac"],
+                                          bf["planck_lay"], bf["planck_lev"], xp.full((NCOL, kd.ngpt), 0.98), bf["sfc_src"])
+            assert torch.equal(rf["flux_up"], r["flux_up"]) and torch.equal(rf["flux_dn"], r["flux_dn"])
+            del bf, rf
         elif workload == "sw":
             go = frontend.GasOptics(hip, kd, xp)
             b = go.gas_optics_sw(NCOL, nlay, a["play"], a["plev"], a["tlay"], a["col_gas"], a["col_dry"], fuse_rayleigh="all")
             r = frontend.rte_sw(hip, xp, NCOL, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["ssa"], b["g"], xp.full((NCOL, nlay), 0.86),
                                 b["toa_src"], xp.full((NCOL, kd.ngpt), 0.06), xp.full((NCOL, kd.ngpt), 0.06))
             out = {"up": r["flux_up"], "dn": r["flux_dn"], "dir": r["flux_dir"]}
+            # clear-sky g = 0 left implicit (library extension): the same bits at full size
+            bg = go.gas_optics_sw(NCOL, nlay, a["play"], a["plev"], a["tlay"], a["col_gas"], a["col_dry"], fuse_rayleigh="all",
+                                  buffers={"interp": b["interp"]}, implicit_g=True)
+            rg = frontend.rte_sw(hip, xp, NCOL, nlay, kd.ngpt, atm.top_at_1, bg["tau"], bg["ssa"], None, xp.full((NCOL, nlay), 0.86),
+                                 bg["toa_src"], xp.full((NCOL, kd.ngpt), 0.06), xp.full((NCOL, kd.ngpt), 0.06))
+            assert all(torch.equal(rg[k], r[k]) for k in ("flux_up", "flux_dn", "flux_dir"))
+            del bg, rg
         else:
             kds = synth.make_kdist("sw")
             gol, gos = frontend.GasOptics(hip, kd, xp), frontend.GasOptics(hip, kds, xp)
