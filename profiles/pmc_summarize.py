@@ -10,7 +10,7 @@ from collections import defaultdict
 
 def short(name):
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return n.split("(")[0][:48].replace(",", ";").replace(" ", "")
+    return n.split("(")[0][:72].replace(",", ";").replace(" ", "")
 
 
 def main(dirs):
