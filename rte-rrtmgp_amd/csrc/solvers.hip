@@ -418,8 +418,16 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   // FACT: the band's Planck function at this wave's layers and levels (reloaded when the g-point loop enters the next band)
   // and, per level slot, whether the rows above and below it are the same row (the column's ends, and the repeated bottom
   // level of a partial last segment): the source there is the fraction itself, :695 / :705
-  // (parked in the thread's own LDS slots, 2 L + 1 values: in registers they cost the kernel its input prefetch -- 31 spilled)
-  Float* const PLK = SFCB + (SFCLDS ? 2 * CH * NA * 64 : 0) + (size_t)s * (2 * L + 1) * 64 + lane;  // ply[i] at [i * 64], plv[i] at [(L + i) * 64]
+  // ... in registers where they fit beside the single in-place tile (6.45 -> 6.12 ms against the thread's own LDS slots, which the
+  // 10-layer variant with Jacobians keeps: it would spill)
+  constexpr bool PLKREG = L <= 9 || !do_jac;
+  Float plk_r[FACT && PLKREG ? 2 * L + 1 : 1];
+  Float* const plk_l = SFCB + (SFCLDS ? 2 * CH * NA * 64 : 0) + (size_t)s * (2 * L + 1) * 64 + lane;
+  struct PlkRef {  // element i * 64 as the LDS layout has it: ply[i] at [i * 64], plv[i] at [(L + i) * 64]
+    Float *r, *l;
+    __device__ __forceinline__ Float& operator[](int i) const { return PLKREG ? r[i / 64] : l[i]; }
+  };
+  const PlkRef PLK{plk_r, plk_l};
   int band = 0, band_end = 0;  // FACT: current band (0-based) and the first g-point after it
   auto load_band = [&](int igpt) {
     while (band_lims[2 * band + 1] <= igpt) ++band;  // (1-based inclusive limits)
@@ -2593,8 +2601,8 @@ int rte_hip_lw_solver_noscat_factored(int ncol, int nlay, int ngpt, int nbnd, in
   Float* part_up = (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * (do_jac ? 3 : 2));
   Float* part_dn = part_up + nclv * ngroups;
   Float* part_jac = do_jac ? part_dn + nclv * ngroups : nullptr;
-  // (the band's Planck functions are parked in LDS beside the composites; the shared surface arrays only where both fit in 160 KB)
-  const size_t lds_plk = 8 * (2 * L + 1) * 64, lds_sfc = 2 * 16 * (do_jac ? 5 : 4) * 64;
+  // (the 10-layer Jacobian variant parks the band's Planck functions in LDS beside the composites; the shared surface arrays only where both fit in 160 KB)
+  const size_t lds_plk = (L <= 9 || !do_jac) ? 0 : 8 * (2 * L + 1) * 64, lds_sfc = 2 * 16 * (do_jac ? 5 : 4) * 64;  // (PLKREG in the kernel)
   const bool sfclds = g_lw_sfc_lds && S == 8 && (L == 8 || !do_jac) && sizeof(Float) * (2 * 3 * 8 * 64 + lds_sfc + lds_plk) <= 160 * 1024;
   const size_t lds_bytes = sizeof(Float) * (2 * 3 * 8 * 64 + (sfclds ? lds_sfc : 0) + lds_plk);
   for (int imu = 0; imu < nmus; ++imu) {
