@@ -21,7 +21,11 @@
 // shape of the specialised-wave tau kernel (defaults: that of gas_optics_common.h; overridable for experiments)
 #ifndef TAU_NCW
 #define TAU_NCW V9_NCW
-#define TAU_NLW V9_NLW
+#ifdef RTE_USE_SP
+#define TAU_NLW V9_NLW  // (single precision: rows of floats are not whole 16-byte pieces with the 8-byte pad; loader waves)
+#else
+#define TAU_NLW 0       // no loader waves: the compute waves stage the slab by LDS-DMA (tau_absorption_v9_kernel, DMA)
+#endif
 #endif
 #ifndef TAU_SLAB
 #define TAU_SLAB V9_SLAB
@@ -782,7 +786,18 @@ __global__ void __launch_bounds__((NCW + NLW) * 64, TAU_MINW)
 tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr int TILE = NCW * 64, NLT = NLW * 64, NT = TILE + NLT;
   constexpr int RS = G + 2, PPR = G / 2, PSH = G == 16 ? 3 : 2;  // row stride, 16-byte pieces per row, log2(PPR)
+  // DMA (NLW == 0): no loader waves.  The compute waves stage slab s+1 themselves with LDS-DMA (global_load_lds_dwordx4:
+  // 64 lanes x 16 bytes land LINEARLY in LDS at a wave-uniform base, the source address is per lane), issued right after
+  // the barrier of stage s.  The padded row image (RS = G + 2 doubles = PPR + 1 pieces of 16 bytes) is kept -- lane l of
+  // DMA instruction i carries padded piece 64 i + l, the pad piece re-fetches the row's last one -- so the gathers are
+  // the loader-wave kernel's, immediate offsets and conflict pattern included.  A block is then 8 waves = two per SIMD:
+  // 256 registers per lane instead of the 168 that ten waves allowed.
+  constexpr bool DMA = NLW == 0;
+  static_assert(!DMA || sizeof(Float) == 8, "the DMA staging moves 16-byte pieces of rows of doubles");
+  constexpr int PPRP = PPR + 1;             // 16-byte pieces per padded row
+  constexpr int NROW = SLAB / RS;           // rows a slab buffer holds
   __shared__ __align__(16) Float slab[2][SLAB];
+  __shared__ unsigned s_rowoff[DMA ? 2 : 1][DMA ? NROW : 1];  // where each row's first g-point is: 16-byte units from a.kmaj (the g-fastest tables are one allocation)
   __shared__ TileGeom tg;
   extern __shared__ BandMeta bm[];  // [nbnd]
   if (*a.skip_if) return;
@@ -805,7 +820,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   const bool has_lo = tg.has_lo != 0, has_up = tg.has_up != 0;
   const int nstage = ngpt / G;  // host guarantees whole, G-aligned chunks per band
 
-  if (tid >= TILE) {
+  if constexpr (!DMA) if (tid >= TILE) {
     // ================================ loader waves ================================
     // the loaders issue little and mostly wait for memory: a raised issue priority lets their requests and LDS writes go
     // out ahead of the eight compute waves' FMAs, so that the next slab is complete a little earlier (tau 5.34 -> 5.28 ms
@@ -920,7 +935,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // `s_waitcnt vmcnt(0)` -- in the middle of the minor pass that drains the previous stage's 48 stores (vector memory
   // retires in order).  These three per-column factors are used a few times per stage only: park them in the thread's
   // own LDS slots instead (a `ds_read` waits on lgkmcnt).  The unfused variants keep them in registers.
-  constexpr bool PARK = RAYL != 0;  // (the variants that would otherwise spill)
+  constexpr bool PARK = RAYL != 0 && NLW != 0;  // (the variants that would otherwise spill; with two waves per SIMD -- no loader waves -- none does)
   constexpr int NPARK = PARK ? 3 : 0;
   __shared__ Float s_park[NPARK ? NPARK : 1][NPARK ? TILE : 1];
   // ... and the two row indices (temperature, pressure), packed into one int: the compiler kept address terms derived from
@@ -1011,6 +1026,89 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // second instance of the loop (ALLRUN = false) that pays the drains.
   bool all_run = true;
   for (int b = 0; b < nbnd; ++b) all_run = all_run && tg.eg[b].y > 0;
+  // ---- DMA staging (NLW == 0).  Rows of a stage's slab, as the loader waves ordered them: major [t][eta][p], then one
+  // [t][eta] plane per minor interval of the lower, then of the upper regime (+ RAYL: the two Rayleigh planes).
+  // plan_rows(s2, b2): thread r leaves the source of row r of stage s2 (band b2) in s_rowoff[s2 & 1] -- called two
+  // stages ahead of the gathers, one barrier ahead of issue_dma(s2), which reads it.
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  auto stage_rows = [&](int b, int& rowsMaj, int& rowsLo, int& rowsUp) -> int {  // block-uniform
+    const int nE = tg.eg[b].y;
+    if (nE <= 0) { rowsMaj = rowsLo = rowsUp = 0; return 0; }
+    const int n_lo = has_lo ? bm[b].cnt[0] : 0, n_up = has_up ? bm[b].cnt[1] : 0;
+    rowsMaj = nP * nT * nE; rowsLo = n_lo * nT * nE; rowsUp = n_up * nT * nE;
+    return rowsMaj + rowsLo + rowsUp + (RAYL ? 2 * nT * nE : 0);
+  };
+  auto plan_rows = [&](int s2, int b2) {
+    if constexpr (DMA) {
+      if (s2 >= nstage) return;
+      int rowsMaj, rowsLo, rowsUp;
+      const int rowsAll = stage_rows(b2, rowsMaj, rowsLo, rowsUp);
+      const int g0 = s2 * G;
+      const int emin = tg.eg[b2].x, nE = tg.eg[b2].y;
+      const float inv_nT = 1.0f / (float)nT, inv_nP = 1.0f / (float)nP, inv_nE = 1.0f / (float)(nE > 0 ? nE : 1);
+      for (int r = tid; r < rowsAll; r += TILE) {
+        const Float* src;
+        if (r < rowsMaj) {
+#ifdef TAU_ROWS_PTE
+          const int rest = (int)(((float)r + 0.5f) * inv_nE), e = r - rest * nE;  // rows < 2^12: exact
+          const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
+#else
+          const int rest = (int)(((float)r + 0.5f) * inv_nP), p_l = r - rest * nP;
+          const int t_l = (int)(((float)rest + 0.5f) * inv_nE), e = rest - t_l * nE;
+#endif
+          src = a.kmaj + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0);
+        } else {
+          const int rm = r - rowsMaj;
+          if (RAYL && rm >= rowsLo + rowsUp) {
+            const int rr = rm - rowsLo - rowsUp;
+            const int rest = (int)(((float)rr + 0.5f) * inv_nE), e = rr - rest * nE;
+            const int k = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - k * nT;  // k: regime
+            src = a.rf.krayl_g[k] + ((size_t)((emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0);
+          } else {
+            const bool up = rm >= rowsLo;
+            const int rr = up ? rm - rowsLo : rm;
+            const int rest = (int)(((float)rr + 0.5f) * inv_nE), e = rr - rest * nE;
+            const int k = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - k * nT;
+            const MinorMeta& m = bm[b2].m[up ? 1 : 0][k];
+            const bool on = m.mS <= g0 && m.mE >= g0;  // off: any valid address, the row is never read
+            const Float* kg = up ? a.kup : a.klo;
+            const unsigned nk = up ? a.nk_up : a.nk_lo;
+            src = kg + ((size_t)((emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * nk + (unsigned)m.kstart + (on ? g0 - m.mS : 0));
+          }
+        }
+        s_rowoff[s2 & 1][r] = (unsigned)((size_t)(src - a.kmaj) >> 1);  // (rows start on 16-byte boundaries: even g0, kstart, nk)
+      }
+    }
+  };
+  // issue_dma(s1, b1): this wave's share of the DMA instructions that fill slab[s1 & 1]: instruction i carries the padded
+  // pieces 64 i ... 64 i + 63 to LDS bytes 1024 i ... of the buffer.  Hidden from the compiler (inline assembly: it neither
+  // counts them in its s_waitcnt bookkeeping nor orders LDS reads behind them); their completion is waited for explicitly
+  // before the barrier that opens stage s1 (dma_wait).
+  const unsigned slab_lds = (unsigned)(uintptr_t)&slab[0][0];
+  auto issue_dma = [&](int s1, int b1) {
+    if constexpr (DMA) {
+      if (s1 >= nstage) return;
+      int rowsMaj, rowsLo, rowsUp;
+      const int rowsAll = stage_rows(b1, rowsMaj, rowsLo, rowsUp);
+      const int nD = (rowsAll * PPRP + 63) >> 6;  // (0 when the band does not run here)
+      const unsigned* tab = s_rowoff[s1 & 1];
+      const unsigned dst0 = slab_lds + (unsigned)((s1 & 1) * SLAB * sizeof(Float));
+      constexpr int MAGIC = PPRP == 9 ? 7282 : 13108;  // (P * MAGIC) >> 16 == P / PPRP for P < 2^13
+      static_assert(PPRP == 9 || PPRP == 5, "stage widths of 16 and 8 g-points");
+#pragma unroll 1
+      for (int i = wv; i < nD; i += NCW) {
+        const int P = 64 * i + lane;
+        int r = (P * MAGIC) >> 16;
+        int q = P - r * PPRP;
+        r = min(r, rowsAll - 1); q = min(q, PPR - 1);
+        const char* src = reinterpret_cast<const char*>(a.kmaj) + 16 * ((size_t)tab[r] + (unsigned)q);
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(dst0 + 1024u * (unsigned)i));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+      }
+    }
+  };
   auto run_stages = [&](auto allrun_tag, auto rot_tag) {
   constexpr bool ALLRUN = decltype(allrun_tag)::value;
   // ROT: this wave issues a stage's tau stores AFTER the next stage's barrier (while the other half of the compute
@@ -1070,6 +1168,21 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   Minor mn;
   MinorIdx nq;
   Minor mw;  // (only fn0, fn1, em are used: the next stage's)
+  if constexpr (DMA) {  // slab 0 on its way, the row addresses of stage 1 in place
+    int b1 = 0;
+    if (nstage > 1) while (b1 + 1 < nbnd && bm[b1].gE < G) ++b1;
+    plan_rows(0, 0);
+    plan_rows(1, b1);
+    __syncthreads();
+    issue_dma(0, 0);
+  }
+  // what of this wave's memory operations may still be outstanding once its DMA pieces of the next slab have landed: the
+  // stage's stores, which are the last thing a wave that stores at the end of the stage issues (everything it requests for
+  // the next stage goes out before them); a rotated wave has nothing younger than its requests.  Vector memory operations
+  // of a wave retire in order, so vmcnt(that many) means "my pieces are in LDS".
+  constexpr int NST = RAYL == 0 ? G : (RAYL == 3 ? 2 * G : 3 * G);
+  constexpr int DMA_LEAVE = (ALLRUN && OVERWRITE && !ROT) ? NST : 0;
+  static_assert(DMA_LEAVE < 64, "vmcnt has six bits");
   peek_minor(0, n_minor(0), nq);
   load_major(nq.flav_major, mj);
   load_minor(0, nq, mn);
@@ -1115,8 +1228,16 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
     const int je1 = mj.je.x, je2 = mj.je.y;
     TAU_T(3);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_LEAVE) : "memory");  // this wave's pieces of slab(s) have landed
     __syncthreads();  // B(s): slab(s) is complete
     TAU_T(0);
+    if constexpr (DMA) {
+      // slab(s+1) into the buffer every wave has just finished reading; the row addresses of stage s+2 for the next round
+      issue_dma(s + 1, ibnd_n);
+      int ibnd_nn = ibnd_n;
+      if (s + 2 < nstage) while (ibnd_nn + 1 < nbnd && bm[ibnd_nn].gE < g0 + 2 * G) ++ibnd_nn;
+      plan_rows(s + 2, ibnd_nn);
+    }
     if constexpr (ROT) {
       if (ALLRUN ? s > 0 : have_prev) flush(g0_prev, addv_prev);
       have_prev = false;
@@ -1795,6 +1916,7 @@ static void tau_absorption_impl(
   // (accumulating onto a host-visible -- pinned / managed -- tau: hardware floating-point atomics are not defined there,
   //  the direct kernels' plain read - add - write is)
   const bool fast = cache.fast_ok && ncol >= 512 && !g_tau_force_direct && ncl < ((size_t)1 << 29) &&
+                    sizeof(Float) * (tn * (npres + 1) * ngpt + tn * ((size_t)nkl_ + nku_ + 2 * (size_t)ngpt + 4)) < ((size_t)1 << 35) &&  // (32-bit row offsets in 16-byte units)
                     al(d_fmajor, 16) && al(d_fminor, 16) && al(d_col_mix, 16) && al(d_jeta, 8) &&
                     (overwrite_ok || rte::is_device_memory(d_tau)) &&
                     (!rh || (overwrite_ok && g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 &&
@@ -1840,10 +1962,15 @@ static void tau_absorption_impl(
   }
   // ---- production path: g-fastest copies of the three tables (scratch, this call only)
   const int TE = ntemp * neta, nkl = *nminorklower_, nku = *nminorkupper_;
-  Float* kmaj_g = (Float*)rte::scratch(sizeof(Float) * tn * (npres + 1) * ngpt);
-  Float* klo_g = (Float*)rte::scratch(sizeof(Float) * tn * (nkl > 0 ? nkl : 1));
-  Float* kup_g = (Float*)rte::scratch(sizeof(Float) * tn * (nku > 0 ? nku : 1));
-  Float* kray_g = nullptr;
+  // (ONE allocation: the DMA staging of tau_absorption_v9_kernel addresses every table row as a 32-bit count of 16-byte
+  //  units from kmaj_g)
+  auto even = [](size_t n) { return (n + 1) & ~(size_t)1; };
+  const size_t n_maj = even(tn * (npres + 1) * ngpt), n_klo = even(tn * (nkl > 0 ? nkl : 1)), n_kup = even(tn * (nku > 0 ? nku : 1));
+  const size_t n_ray = rh ? even(tn * ngpt * 2) : 0;
+  Float* kmaj_g = (Float*)rte::scratch(sizeof(Float) * (n_maj + n_klo + n_kup + n_ray));
+  Float* klo_g = kmaj_g + n_maj;
+  Float* kup_g = klo_g + n_klo;
+  Float* kray_g = rh ? kup_g + n_kup : nullptr;
   // band metadata lives in a persistent device buffer and is uploaded only when the host plan was rebuilt
   // (a per-call copy from pageable host memory stalls the submitting thread)
   bool bm_fresh = false;
@@ -1877,7 +2004,6 @@ static void tau_absorption_impl(
     table(lo.kminor, klo_g, 1, nkl);
     table(up.kminor, kup_g, 1, nku);
     if (rh) {  // the Rayleigh table (ntemp, neta, ngpt, 2): one g-fastest copy per regime
-      kray_g = (Float*)rte::scratch(sizeof(Float) * tn * ngpt * 2);
       for (int r = 0; r < 2; ++r) table(d_krayl + tn * ngpt * r, kray_g + tn * ngpt * r, 1, ngpt);
     }
     sa.first_block[sa.ntab] = (int)nb;
