@@ -285,6 +285,7 @@ struct Geom2Args {
   const int* skip_if2;       // Planck: the geometry left by the compute_tau_absorption call before is valid (shared)
   int* valid_out;            // tau: set to 1 once this geometry is (being) written, for a Planck call that shares it
   int extra_planes;          // tau: more (T, eta) planes staged per stage (2 with the fused Rayleigh rows)
+  int row_stride;            // tau: values between slab rows (0: G + 2; the DMA-staged slab pads rows by 16 bytes: G + 4 floats)
   int* worklist;             // tau: (tile, layer, band) triples; Planck: (tile, band) pairs
   int* flags;                // Planck: one worklist entry per (tile, band)
   const unsigned* imask;     // tau: masks per (256-column block, layer) left by the interpolation call (InterpMasks), or nullptr
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(TILE) tile_geom2_kernel(Geom2Args a, TileGeom*
     const int emin = me ? __ffs(me) - 1 : 1, nE = me ? (32 - __clz(me)) - emin : 0;
     const int n_lo = has_lo ? cnt[tid][0] : 0, n_up = has_up ? cnt[tid][1] : 0;
     const int rows = (nP + n_lo + n_up + (a.planck ? 0 : a.extra_planes)) * nT * nE;
-    const bool fits = rows * RS <= a.slab_floats;
+    const bool fits = rows * (a.row_stride > 0 ? a.row_stride : RS) <= a.slab_floats;
     if (a.planck) {
       if (!fits && atomicCAS(&a.flags[blockIdx.x * nbnd + tid], 0, 1) == 0) {  // once per (tile, band)
         const int w = atomicAdd(&a.worklist[0], 1);

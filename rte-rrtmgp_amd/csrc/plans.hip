@@ -5,7 +5,7 @@
 // process-wide tuning switches (set from any thread: relaxed atomics)
 std::atomic<int> g_tau_force_direct{0};
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-std::atomic<int> g_tau_variant{env_int("RTE_HIP_TAU_VARIANT", 9)};
+std::atomic<int> g_tau_variant{env_int("RTE_HIP_TAU_VARIANT", 11)};
 std::atomic<int> g_tau_no_zero_check{env_int("RTE_HIP_NO_ZERO_CHECK", 0)};  // A/B: accumulate without looking whether tau is zero
 std::atomic<int> g_planck_variant{9};  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
 std::atomic<int> g_geom_variant{2};  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)

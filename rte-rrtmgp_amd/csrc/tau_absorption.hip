@@ -17,18 +17,24 @@
 //     geometric mean of adjacent layers' Planck fractions needs no second gather.
 #include "gas_optics_common.h"
 #include "tau_mx.h"
+#include "tau_slab.h"
 
 // shape of the specialised-wave tau kernel (defaults: that of gas_optics_common.h; overridable for experiments)
 #ifndef TAU_NCW
 #define TAU_NCW V9_NCW
-#ifdef RTE_USE_SP
-#define TAU_NLW V9_NLW  // (single precision: rows of floats are not whole 16-byte pieces with the 8-byte pad; loader waves)
-#else
-#define TAU_NLW 0       // no loader waves: the compute waves stage the slab by LDS-DMA (tau_absorption_v9_kernel, DMA)
-#endif
+#define TAU_NLW V9_NLW
 #endif
 #ifndef TAU_SLAB
 #define TAU_SLAB V9_SLAB
+#endif
+#ifndef TAU_DMA_WAVES  // experiments: which waves issue the DMA pieces (0: all, 1: the rotated half, 2: the other half) ...
+#define TAU_DMA_WAVES 0
+#endif
+#ifndef TAU_DMA_LATE   // ... and when the waves that have just stored do (0: behind the barrier, 1: after the major pass)
+#define TAU_DMA_LATE 0
+#endif
+#ifndef TAU_DEPTH
+#define TAU_DEPTH 4  // steps (4 LDS row reads each) in flight per wave in the DMA form of tau_absorption_v9_kernel; 0: the rounds 3-4 gathers
 #endif
 #ifndef TAU_MINW
 #define TAU_MINW ((TAU_NCW + TAU_NLW + 3) / 4)
@@ -775,7 +781,7 @@ __global__ void __launch_bounds__(TILE) tau_geom_kernel(TauV5 a, TileGeom* __res
 // per role and phase of a stage.  Compute waves: [0] waiting at the stage's barrier, [1] the previous stage's stores (ROT) + set-up,
 // [2] major gather + FMAs, [3] minor species, rest of the stage.  Loader waves: [4] requesting + waiting for the table pieces,
 // [5] writing them to LDS, [6] waiting at the barrier.
-__device__ unsigned long long tau_clk[8];
+// (tau_clk: tau_slab.h)
 #define TAU_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define TAU_T(k) do { } while (0)
@@ -1045,7 +1051,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       const int rowsAll = stage_rows(b2, rowsMaj, rowsLo, rowsUp);
       const int g0 = s2 * G;
       const int emin = tg.eg[b2].x, nE = tg.eg[b2].y;
-      const float inv_nT = 1.0f / (float)nT, inv_nP = 1.0f / (float)nP, inv_nE = 1.0f / (float)(nE > 0 ? nE : 1);
+      // (v_rcp_f32 is good to 1 ulp: (r + 0.5) / n truncates to r / n exactly for r < 2^12)
+      const float inv_nT = __builtin_amdgcn_rcpf((float)nT), inv_nP = __builtin_amdgcn_rcpf((float)nP),
+                  inv_nE = __builtin_amdgcn_rcpf((float)(nE > 0 ? nE : 1));
       for (int r = tid; r < rowsAll; r += TILE) {
         const Float* src;
         if (r < rowsMaj) {
@@ -1095,8 +1103,11 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       const unsigned dst0 = slab_lds + (unsigned)((s1 & 1) * SLAB * sizeof(Float));
       constexpr int MAGIC = PPRP == 9 ? 7282 : 13108;  // (P * MAGIC) >> 16 == P / PPRP for P < 2^13
       static_assert(PPRP == 9 || PPRP == 5, "stage widths of 16 and 8 g-points");
+      int first = wv, stride = NCW;
+      if constexpr (TAU_DMA_WAVES == 1) { if (wv < NCW / 2) return; first = wv - NCW / 2; stride = NCW / 2; }  // the rotated waves only
+      if constexpr (TAU_DMA_WAVES == 2) { if (wv >= NCW / 2) return; stride = NCW / 2; }                       // the others only
 #pragma unroll 1
-      for (int i = wv; i < nD; i += NCW) {
+      for (int i = first; i < nD; i += stride) {
         const int P = 64 * i + lane;
         int r = (P * MAGIC) >> 16;
         int q = P - r * PPRP;
@@ -1124,6 +1135,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   constexpr bool ROLL = RAYL == 0 && !ADDB;
 #endif
   static_assert(!ROT || RAYL == 0, "the fused variants finish a stage from its own slab");
+  constexpr bool DEEP = DMA && TAU_DEPTH > 0;  // one rolling read pipeline through the stage (below); needs the registers of the 8-wave block
   Float acc[G];
   bool have_prev = false;
   int g0_prev = 0;
@@ -1227,16 +1239,18 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const Float w0 = mj.cm.x * mj.fm[0].x, w1 = mj.cm.x * mj.fm[0].y, w2 = mj.cm.x * mj.fm[1].x, w3 = mj.cm.x * mj.fm[1].y,
                 w4 = mj.cm.y * mj.fm[2].x, w5 = mj.cm.y * mj.fm[2].y, w6 = mj.cm.y * mj.fm[3].x, w7 = mj.cm.y * mj.fm[3].y;
     const int je1 = mj.je.x, je2 = mj.je.y;
-    TAU_T(3);
+    TAU_T(DMA ? 6 : 3);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_LEAVE) : "memory");  // this wave's pieces of slab(s) have landed
+    TAU_T(4);
     __syncthreads();  // B(s): slab(s) is complete
     TAU_T(0);
     if constexpr (DMA) {
       // slab(s+1) into the buffer every wave has just finished reading; the row addresses of stage s+2 for the next round
-      issue_dma(s + 1, ibnd_n);
+      if constexpr (!(TAU_DMA_LATE && !ROT)) issue_dma(s + 1, ibnd_n);
       int ibnd_nn = ibnd_n;
       if (s + 2 < nstage) while (ibnd_nn + 1 < nbnd && bm[ibnd_nn].gE < g0 + 2 * G) ++ibnd_nn;
       plan_rows(s + 2, ibnd_nn);
+      TAU_T(5);
     }
     if constexpr (ROT) {
       if (ALLRUN ? s > 0 : have_prev) flush(g0_prev, addv_prev);
@@ -1244,6 +1258,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     }
     peek_minor(ibnd_n, n_minor(ibnd_n), nq);
     if (!ALLRUN && !run) {
+      if constexpr (DMA && TAU_DMA_LATE && !ROT) issue_dma(s + 1, ibnd_n);
       load_major(nq.flav_major, mj);
       load_minor_w(nq, mw);
       load_minor(ibnd_n, nq, mn);
@@ -1273,6 +1288,7 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
     for (int j = 0; j < G; ++j) acc[j] = 0;
     TAU_T(1);
+    if constexpr (!DEEP) {
     if constexpr (ROLL) {
       // rolling: the next four rows are requested BEFORE the FMAs on the four that arrived (at most 8 row reads in flight
       // per wave; the LDS serves the other waves' and this wave's next rows while the SIMD works on these)
@@ -1416,6 +1432,161 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         minor_rows(k, scaling);
       }
     }
+    } else {
+      // ================= DEEP: ONE rolling pipeline of LDS row reads through the whole stage =================
+      // A step = 4 row reads (16 bytes each: two g-points of four corner rows) + the FMAs on them.  The major species are 2 G / 2
+      // steps (lower / upper temperature of each g-point pair), every minor interval G / 2.  DEPTH steps are in flight all the
+      // time: a step's registers are refilled with the step DEPTH ahead as soon as its FMAs are issued -- through the end of
+      // the major pass into the first minor interval and from one interval into the next (the rolling form of rounds 3-4 kept 8
+      // reads in flight, restarted at every interval, and had 168 registers).  Same operations per g-point in the
+      // same order as before: bit-identical.
+      constexpr int DEPTH = TAU_DEPTH;
+      static_assert(DEPTH == 2 || DEPTH == 4 || DEPTH == 8, "the buffers rotate through G and G / 2 steps");
+      static_assert(G % DEPTH == 0 && (G / 2) % DEPTH == 0 || DEPTH > G / 2, "whole rotations");
+      // ---- the minor intervals of this lane: scalings (:461-480), 0 for a slot that is not this lane's or not this stage's
+      const int n_reg = n_my < MM ? n_my : MM;
+      Float scl[MM];
+      unsigned act = 0;
+#pragma unroll
+      for (int k = 0; k < MM; ++k) {
+        scl[k] = 0;
+        if (k < n_reg) {
+          const MinorMeta& m = bm[ibnd].m[rsel][k];
+          if (!(m.mE < g0 || m.mS > g0)) {  // intervals are whole G-aligned chunks inside the band
+            Float v = sc[k];
+            if (m.flags & 1) {
+              v = v * dens;  // :469
+              if (m.idx_scaling > 0) {  // :470-478
+                if (m.flags & 2) v = v * ((Float)1 - cgs[k] * vmr_fact * dry_fact);
+                else v = v * (cgs[k] * vmr_fact * dry_fact);
+              }
+            }
+            scl[k] = v;
+            act |= 1u << k;
+          }
+        }
+      }
+      // slots the wave walks: up to the last one any of its lanes uses (wave-uniform; lanes without that slot add 0 x a row they may read)
+      int nslot = 0;
+#pragma unroll
+      for (int k = 0; k < MM; ++k)
+        if (__builtin_amdgcn_ballot_w64((act >> k) & 1u) != 0) nslot = k + 1;
+      const Float f0 = fn0.x, f1 = fn0.y, f2 = fn1.x, f3 = fn1.y;
+      const Float* A1 = A0 + sE;
+      const Float* B1 = B0 + sE;
+      const Float* r1_0 = M0 + ((jT_s - Tmin) * nE + (em.x - emin)) * RS;
+      const Float* r2_0 = M0 + ((jT_s + 1 - Tmin) * nE + (em.y - emin)) * RS;
+      const int plane = nT * nE * RS;
+      // rows of slot q for this lane; a lane that does not use the slot reads its major rows instead (always inside the slab)
+      auto slot_rows = [&](int q, const Float*& p1, const Float*& p2) {
+        const bool on = ((act >> q) & 1u) != 0;
+        p1 = on ? r1_0 + q * plane : A0;
+        p2 = on ? r2_0 + q * plane : A0;
+      };
+      Float2 kb[DEPTH][4];
+      auto rd_major = [&](Float2 (&k)[4], int h) {  // h: (g-point pair, lower / upper temperature)
+        const Float* b0 = ((h & 1) ? B0 : A0) + 2 * (h >> 1);
+        const Float* b1 = ((h & 1) ? B1 : A1) + 2 * (h >> 1);
+        k[0] = ld2(b0); k[1] = ld2(b1); k[2] = ld2(b0 + sP); k[3] = ld2(b1 + sP);
+      };
+      auto rd_minor = [&](Float2 (&k)[4], const Float* p1, const Float* p2, int j) {  // j: g-point pair
+        k[0] = ld2(p1 + 2 * j); k[1] = ld2(p1 + RS + 2 * j); k[2] = ld2(p2 + 2 * j); k[3] = ld2(p2 + RS + 2 * j);
+      };
+      const Float* c1;
+      const Float* c2;
+      slot_rows(0, c1, c2);
+#pragma unroll
+      for (int h = 0; h < DEPTH; ++h) rd_major(kb[h], h);
+      {
+        Float m = 0, n = 0;
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+          Float2 (&k)[4] = kb[h % DEPTH];
+          if ((h & 1) == 0) {
+            m = w0 * k[0].x; n = w0 * k[0].y;
+            m = fma(w1, k[1].x, m); n = fma(w1, k[1].y, n);
+            m = fma(w2, k[2].x, m); n = fma(w2, k[2].y, n);
+            m = fma(w3, k[3].x, m); n = fma(w3, k[3].y, n);
+            asm volatile("" : "+v"(m), "+v"(n));
+          } else {
+            m = fma(w4, k[0].x, m); n = fma(w4, k[0].y, n);
+            m = fma(w5, k[1].x, m); n = fma(w5, k[1].y, n);
+            m = fma(w6, k[2].x, m); n = fma(w6, k[2].y, n);
+            m = fma(w7, k[3].x, m); n = fma(w7, k[3].y, n);
+            const int j = h & ~1;
+            acc[j] = acc[j] + m;
+            acc[j + 1] = acc[j + 1] + n;
+            asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
+          }
+          if (h + DEPTH < G) rd_major(k, h + DEPTH);
+          else if (nslot > 0) rd_minor(k, c1, c2, h + DEPTH - G);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      TAU_T(2);
+      if constexpr (TAU_DMA_LATE && !ROT) issue_dma(s + 1, ibnd_n);
+      // next stage's major weights: their registers are free now, and the request is a minor pass ahead of its use
+      load_major(nq.flav_major, mj);
+      load_minor_w(nq, mw);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+      for (int q = 0; q < nslot; ++q) {
+        Float scaling = scl[0];
+#pragma unroll
+        for (int u = 1; u < MM; ++u) scaling = (q == u) ? scl[u] : scaling;
+        const bool more = q + 1 < nslot;  // (wave-uniform)
+        const Float* n1;
+        const Float* n2;
+        slot_rows(q + 1, n1, n2);
+#pragma unroll
+        for (int j = 0; j < G / 2; ++j) {
+          Float2 (&k)[4] = kb[j % DEPTH];
+          Float s_ = f0 * k[0].x, t_ = f0 * k[0].y;
+          s_ = fma(f1, k[1].x, s_); t_ = fma(f1, k[1].y, t_);
+          s_ = fma(f2, k[2].x, s_); t_ = fma(f2, k[2].y, t_);
+          s_ = fma(f3, k[3].x, s_); t_ = fma(f3, k[3].y, t_);
+          acc[2 * j] = fma(scaling, s_, acc[2 * j]);
+          acc[2 * j + 1] = fma(scaling, t_, acc[2 * j + 1]);
+          asm volatile("" : "+v"(acc[2 * j]), "+v"(acc[2 * j + 1]));
+          if (j + DEPTH < G / 2) rd_minor(k, c1, c2, j + DEPTH);
+          else if (more) rd_minor(k, n1, n2, j + DEPTH - G / 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        c1 = n1; c2 = n2;
+      }
+      TAU_T(3);
+      if (n_my > MM) {
+        // the band's intervals beyond the MM held in registers: amounts requested here, same expressions (:461-480)
+#pragma unroll 1
+        for (int k = MM; k < n_my; ++k) {
+          const MinorMeta& mm = bm[ibnd].m[rsel][k];
+          if (mm.mE < g0 || mm.mS > g0) continue;
+          Float scaling = a.col_gas[cl + (size_t)ncl * mm.idx_minor];
+          if (mm.flags & 1) {
+            scaling = scaling * dens;  // :469
+            if (mm.idx_scaling > 0) {  // :470-478
+              const Float cg = a.col_gas[cl + (size_t)ncl * mm.idx_scaling];
+              if (mm.flags & 2) scaling = scaling * ((Float)1 - cg * vmr_fact * dry_fact);
+              else scaling = scaling * (cg * vmr_fact * dry_fact);
+            }
+          }
+          const Float* p1 = r1_0 + k * plane;
+          const Float* p2 = r2_0 + k * plane;
+#pragma unroll
+          for (int j = 0; j < G; j += 2) {
+            const Float2 q0 = ld2(p1 + j), q1 = ld2(p1 + RS + j), q2 = ld2(p2 + j), q3 = ld2(p2 + RS + j);
+            Float s_ = f0 * q0.x, t_ = f0 * q0.y;
+            s_ = fma(f1, q1.x, s_); t_ = fma(f1, q1.y, t_);
+            s_ = fma(f2, q2.x, s_); t_ = fma(f2, q2.y, t_);
+            s_ = fma(f3, q3.x, s_); t_ = fma(f3, q3.y, t_);
+            acc[j] = fma(scaling, s_, acc[j]);
+            acc[j + 1] = fma(scaling, t_, acc[j + 1]);
+            asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
+            if ((j & 6) == 6) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
     load_minor(ibnd_n, nq, mn);
     __builtin_amdgcn_sched_barrier(0);  // keep these requests ahead of the stores that follow
     if constexpr (RAYL != 0) {
@@ -1453,9 +1624,9 @@ tau_absorption_v9_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     if (ALLRUN ? nstage > 0 : have_prev) flush(g0_prev, addv_prev);
   }
 #ifdef TAU_TIMING
-  TAU_T(3);
+  TAU_T(DMA ? 6 : 3);
   if ((tid & 63) == 0)
-    for (int k = 0; k < 4; ++k) atomicAdd(&tau_clk[k], tacc[k]);
+    for (int k = 0; k < (DMA ? 7 : 4); ++k) atomicAdd(&tau_clk[k + (DMA && ROT ? 8 : 0)], tacc[k]);
 #endif
   };
   // (round 3: 5.30 -> 5.19 ms at 1e5 x 60 x 256; -DTAU_NO_ROT for the A/B.  The fused variants end a stage with LDS
@@ -1838,9 +2009,10 @@ static void tau_absorption_impl(
       }
     }
     for (int r = 0; r < 2 && ok; ++r) {
-      ok = ok && (nn[r] == 0 || nk2[r] % 2 == 0);
+      constexpr int PIECE = 16 / (int)sizeof(Float);  // table rows are staged in 16-byte pieces: row starts must be whole pieces
+      ok = ok && (nn[r] == 0 || nk2[r] % PIECE == 0);
       for (int i = 0; i < nn[r] && ok; ++i) {
-        ok = ok && (ks[r][i] - 1) % 2 == 0;
+        ok = ok && (ks[r][i] - 1) % PIECE == 0;
         int band = -1;
         for (int b = 0; b < nbnd; ++b)
           if (ml[r][2 * i] >= bl[2 * b] && ml[r][2 * i + 1] <= bl[2 * b + 1]) band = b;
@@ -1964,7 +2136,7 @@ static void tau_absorption_impl(
   const int TE = ntemp * neta, nkl = *nminorklower_, nku = *nminorkupper_;
   // (ONE allocation: the DMA staging of tau_absorption_v9_kernel addresses every table row as a 32-bit count of 16-byte
   //  units from kmaj_g)
-  auto even = [](size_t n) { return (n + 1) & ~(size_t)1; };
+  auto even = [](size_t n) { return (n + 3) & ~(size_t)3; };  // (whole 16-byte pieces in either precision)
   const size_t n_maj = even(tn * (npres + 1) * ngpt), n_klo = even(tn * (nkl > 0 ? nkl : 1)), n_kup = even(tn * (nku > 0 ? nku : 1));
   const size_t n_ray = rh ? even(tn * ngpt * 2) : 0;
   Float* kmaj_g = (Float*)rte::scratch(sizeof(Float) * (n_maj + n_klo + n_kup + n_ray));
@@ -2032,7 +2204,7 @@ static void tau_absorption_impl(
   v.nonzero = nonzero; v.run_when = 0;
   // plain-ABI accumulate onto device memory: find out first whether tau is (still) the zero array the frontend made of it
   const bool zero_check = !overwrite_ok && v.atomic_ok && !g_tau_no_zero_check && al(d_tau, 16) && cache.gw != 0 &&
-                          (g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr);
+                          (g_tau_variant == 9 || g_tau_variant == 11 || cache.gw != 16 || d_add != nullptr);
   if (zero_check) {
     rte::ProfScope p("tau_is_zero_kernel");
     hipLaunchKernelGGL(tau_is_zero_kernel, dim3(256 * 16), dim3(256), 0, st, (const Float*)d_tau, ncl * (size_t)ngpt, nonzero);
@@ -2087,7 +2259,9 @@ static void tau_absorption_impl(
 #else
   const bool use_mx = false;
 #endif
-  const bool use_v9 = g_tau_variant == 9 || cache.gw != 16 || d_add != nullptr || rh != nullptr;  // the single-role kernel exists for 16-wide stages only
+  const bool use_v9 = g_tau_variant == 9 || g_tau_variant == 11 || cache.gw != 16 || d_add != nullptr || rh != nullptr;  // the single-role kernel exists for 16-wide stages only
+  // the slab kernel of tau_slab.h (8 waves, LDS-DMA staging): the default; rte_hip_tau_variant(9) = the rounds 1-4 form with loader waves
+  const bool use_slab = g_tau_variant != 9 && g_tau_variant != 7 && ngpt / cache.gw <= SLAB_MAXSTAGE;
   if (use_mx) {
     // (launched above)
   } else if (use_v9) {
@@ -2115,7 +2289,7 @@ static void tau_absorption_impl(
     } else {
       d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
     }
-    const dim3 grid(tiles, nlay), blk((NCW + NLW) * 64);
+    const dim3 grid(tiles, nlay);
     const size_t dyn = sizeof(BandMeta) * nbnd;
     const TileGeom* cg = d_geom;
     Geom2Args ga{};
@@ -2123,6 +2297,7 @@ static void tau_absorption_impl(
     ga.lim = lim; ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.bmeta = d_bm;
     ga.skip_if = overlap; ga.worklist = v.worklist; ga.valid_out = share ? gs().shared.valid : nullptr;
     ga.extra_planes = rh ? 2 : 0;
+    ga.row_stride = use_slab ? cache.gw + 16 / (int)sizeof(Float) : 0;
     ga.irregular = irregular;
     ga.stat = stats_dev() + 2;
     if (share_masks() && gs().imask.seq >= 0 && gs().imask.seq + 1 == rte::call_seq() && gs().imask.jeta == jeta && gs().imask.jtemp == jtemp &&
@@ -2131,19 +2306,24 @@ static void tau_absorption_impl(
       ga.imask = gs().imask.buf;
       ga.imask_nblk = cdiv(ncol, 256);
     }
+#define RTE_TAU_K(OW, GW, AB, RV)                                                                                \
+  do {                                                                                                            \
+    if (use_slab) hipLaunchKernelGGL((tau_slab_kernel<NCW, SLAB9, OW, GW, 4, AB, RV, ((RV != 0 || AB) ? 2 : TAU_DEPTH)>), grid, dim3(NCW * 64), dyn, st, vk, cg); \
+    else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, V9_NLW, SLAB9, OW, GW, 4, AB, RV>), grid, dim3((NCW + V9_NLW) * 64), dyn, st, vk, cg); \
+  } while (0)
 #define RTE_LAUNCH_TAU9R_(GW, MMV, RV) \
-  hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, MMV, false, RV>), grid, blk, dyn, st, v, cg)
+  do { const TauV5& vk = v; RTE_TAU_K(true, GW, false, RV); } while (0)
 #define RTE_LAUNCH_TAU9_(GW, AB)                                                                                  \
   do {                                                                                                            \
-    if (overwrite_ok) hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
+    if (overwrite_ok) { const TauV5& vk = v; RTE_TAU_K(true, GW, AB, 0); }                                        \
     else if (zero_check) {                                                                                        \
-      TauV5 vz = v;                                                                                               \
-      vz.run_when = 1; vz.overwrite = true;  /* tau is all zero: the overwriting instance */                      \
-      hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, true, GW, 4, AB>), grid, blk, dyn, st, vz, cg); \
-      vz.run_when = 2; vz.overwrite = false;  /* it is not: accumulate */                                         \
-      hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4, AB>), grid, blk, dyn, st, vz, cg); \
+      TauV5 vk = v;                                                                                               \
+      vk.run_when = 1; vk.overwrite = true;  /* tau is all zero: the overwriting instance */                      \
+      RTE_TAU_K(true, GW, AB, 0);                                                                                 \
+      vk.run_when = 2; vk.overwrite = false;  /* it is not: accumulate */                                         \
+      RTE_TAU_K(false, GW, AB, 0);                                                                                \
     }                                                                                                             \
-    else hipLaunchKernelGGL((tau_absorption_v9_kernel<NCW, NLW, SLAB9, false, GW, 4, AB>), grid, blk, dyn, st, v, cg); \
+    else { const TauV5& vk = v; RTE_TAU_K(false, GW, AB, 0); }                                                    \
   } while (0)
 #define RTE_LAUNCH_TAU9(GW)                                                                                       \
   do {                                                                                                            \
@@ -2164,6 +2344,7 @@ static void tau_absorption_impl(
 #undef RTE_LAUNCH_TAU9
 #undef RTE_LAUNCH_TAU9_
 #undef RTE_LAUNCH_TAU9R_
+#undef RTE_TAU_K
   } else {
     rte::ProfScope p("tau_absorption_kernel");
     // <min waves per SIMD, g-points per register chunk>: measured best of {2,3} x {4,8,16} on MI355X
@@ -2202,10 +2383,10 @@ static void tau_absorption_impl(
 }
 
 #ifdef TAU_TIMING
-extern "C" int rte_hip_tau_timing(unsigned long long* out /*[8]*/) {
+extern "C" int rte_hip_tau_timing(unsigned long long* out /*[16]*/) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(tau_clk), sizeof(unsigned long long) * 8);
-  unsigned long long z[8] = {0};
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(tau_clk), sizeof(unsigned long long) * 16);
+  unsigned long long z[16] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(tau_clk), z, sizeof(z));
   return 0;
 }

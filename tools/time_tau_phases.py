@@ -18,15 +18,24 @@ def run():
     lib.zero_array_3D(ncol, nlay, kd.ngpt, tau)
     go.compute_tau_absorption(ncol, nlay, st, play, tlay, col_gas, tau)
 run(); run(); torch.cuda.synchronize()
-out = np.zeros(8, dtype=np.uint64); tm = lib.raw("rte_hip_tau_timing")
+out = np.zeros(16, dtype=np.uint64); tm = lib.raw("rte_hip_tau_timing")
 tm(out.ctypes.data_as(ctypes.c_void_p))
 t0 = time.perf_counter(); run(); torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3
 tm(out.ctypes.data_as(ctypes.c_void_p))
 nstage = -(-ncol // 512) * nlay * (kd.ngpt // 16)
 o = out.astype(np.float64)
 print("one call %.2f ms, %d stages; ticks per stage and wave:" % (ms, nstage))
-names = ["compute: waiting at the barrier", "compute: previous stage's stores + set-up", "compute: major gather + FMAs",
-         "compute: minor species, rest", "loader: requesting + waiting for table pieces", "loader: LDS writes", "loader: waiting at the barrier"]
-for k, n in enumerate(names):
-    print("  %-48s %9.1f" % (n, o[k] / (nstage * (8 if k < 4 else 2))))
-print("  compute sum %.1f, loader sum %.1f" % (o[:4].sum() / (nstage * 8), o[4:7].sum() / (nstage * 2)))
+if o[8:].sum() > 0:  # the DMA form (no loader waves): waves 0-3 store at the end of the stage, waves 4-7 after the next barrier
+    names = ["waiting at the barrier", "previous stage's stores (rotated waves) + set-up", "major gather + FMAs", "minor species",
+             "waiting for its own DMA pieces / weights", "DMA issue + row plan", "requests for the next stage + stores"]
+    for half, off in (("waves 0-3", 0), ("waves 4-7 (rotated)", 8)):
+        print(" ", half)
+        for k, n in enumerate(names):
+            print("    %-48s %9.1f" % (n, o[off + k] / (nstage * 4)))
+        print("    sum %.1f" % (o[off:off + 7].sum() / (nstage * 4)))
+else:
+    names = ["compute: waiting at the barrier", "compute: previous stage's stores + set-up", "compute: major gather + FMAs",
+             "compute: minor species, rest", "loader: requesting + waiting for table pieces", "loader: LDS writes", "loader: waiting at the barrier"]
+    for k, n in enumerate(names):
+        print("  %-48s %9.1f" % (n, o[k] / (nstage * (8 if k < 4 else 2))))
+    print("  compute sum %.1f, loader sum %.1f" % (o[:4].sum() / (nstage * 8), o[4:7].sum() / (nstage * 2)))
