@@ -112,26 +112,22 @@ relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, 
 }
 
 // -------------------------------------------------------------------------------------------
-// compute_tau_absorption, production kernels (LDS slab).
+// compute_tau_absorption / compute_Planck_source / compute_tau_rayleigh, production kernels (LDS slab): shared metadata.
 //
-// What the measurements on MI355X said (tools/membench.hip): kernels that gather
-// LUT values straight from global memory with lanes = columns run at ~20 ms per 1e5 columns whatever the
-// table layout, because each lane pulls its own cache line and the vector L1 retires about one distinct
-// line per clock.  Both kernels below therefore
-//   * copy the tables to a g-point-fastest layout per call (relayout_gfast_kernel), so that the 16 g-points
-//     of a stage are one 128-byte row piece;
-//   * stage, per (column tile, layer, band), the BOUNDING BOX of the rows the tile's columns need --
-//     pressure x temperature x eta ranges for kmajor, temperature x eta per minor interval -- into an LDS
-//     slab with a row stride of 18 doubles;
-//   * keep lanes = columns: every thread gathers its 8 major + 4-per-interval minor corner rows with
-//     16-byte LDS reads (two g-points per read) and writes tau with coalesced 512-byte wave stores.
-// tau_absorption_v7_kernel does all of it with one kind of wave and two barriers per band;
-// tau_absorption_v9_kernel (default) splits the roles: loader waves stage the next stage's slab into the
-// other half of a double-buffered slab while compute waves gather, one barrier per stage.
-// Tiles whose box does not fit the slab go to a worklist for the direct-gather kernel.
-// Arithmetic: the same products and sums as the reference (:791-801, :757-760) evaluated with
-// fused multiply-adds and col_mix folded into the major weights; differences from the reference
-// association are a few ulp (tests: 1e-12 relative).
+// What the measurements on MI355X said (tools/membench.hip): kernels that gather LUT values
+// straight from global memory with lanes = columns run at ~20 ms per 1e5 columns whatever the table layout, because
+// each lane pulls its own cache line and the vector L1 retires about one distinct line per clock.  The production
+// kernels therefore
+//   * copy the tables to a g-point-fastest layout per call (relayout_gfast_kernel), so that the 16 (or 8) g-points of a
+//     stage are one contiguous row piece;
+//   * stage, per (column tile, layer, band), the BOUNDING BOX of the rows the tile's columns need -- pressure x
+//     temperature x eta ranges for kmajor / pfrac, temperature x eta per minor interval -- into an LDS slab with an
+//     odd row stride in 16-byte pieces (tile_geom2_kernel below derives the boxes);
+//   * keep lanes = columns: every thread gathers its corner rows with 16-byte LDS reads (two g-points per read) and
+//     writes its outputs with coalesced 512-byte wave stores.
+// Tiles whose box does not fit the slab go to a worklist for the direct-gather kernels.  Arithmetic: the same products
+// and sums as the reference (:791-801, :757-760) evaluated with fused multiply-adds and col_mix folded into the major
+// weights; differences from the reference association are a few ulp (tests: 1e-12 relative).
 // -------------------------------------------------------------------------------------------
 constexpr int MAXM = 12;   // minor intervals per (band, regime) handled by the production kernels; more -> native kernel
 constexpr int MAXB = 32;   // bands
@@ -227,36 +223,11 @@ __device__ __forceinline__ int wave_max(int v) {
 // distinct banks (MI355X_MICROARCH.md, LDS), and b128 reaches the LDS peak with one wave per SIMD where
 // 8-byte reads need four.
 constexpr int RS = GC + 2;
-constexpr int SLAB_FLOATS = 8704;  // 68 KB of LUT slab per block (2 blocks per CU); tiles that need more go to the direct kernel
+constexpr int SLAB_FLOATS = 8704;  // values per slab buffer (68 KB in double precision; two buffers per block): boxes that need more go to the direct kernels
 
-#ifndef V9_NCW  // shape of the specialised-wave kernel (overridable for experiments: tools/variants.py)
-#define V9_NCW 8
-#define V9_NLW 2
-#endif
 #ifndef V9_SB
-#define V9_SB 8
+#define V9_SB 8  // 16-byte pieces a loader lane of planck_source_v9_kernel requests back to back
 #endif
-#ifndef V9_SLAB
-#define V9_SLAB 8704   // floats per slab buffer (two buffers per block)
-#endif
-#ifndef V9_MINW
-#define V9_MINW ((V9_NCW + V9_NLW + 3) / 4)  // waves per SIMD the register budget must allow
-#endif
-// -------------------------------------------------------------------------------------------
-// compute_tau_absorption, specialised-wave kernel ("v9").
-//
-// Measured on the slab kernel above (tools/variants.py, per-phase cycle counters): staging, compute and
-// the tau stores of a stage run back to back -- vector-memory operations of a wave retire in order, so a
-// staging load issued after the previous stage's stores waits for them, and the range reductions, the
-// dependent index loads and two barriers per stage sit on the same critical path.  Here the work is split:
-//   * tau_geom_kernel (tiny pre-pass) computes, per (column tile, layer), the bounding box of LUT rows
-//     every band needs, and sends oversized (tile, layer, band) triples to the direct-gather worklist;
-//   * the main kernel runs one block per CU with NCW compute waves (lanes = columns) and NLW loader
-//     waves.  The loaders know the whole schedule from the geometry table: they stage the slab of stage
-//     s+1 into the other half of a double-buffered LDS slab while the compute waves work on stage s, with
-//     ONE barrier per stage.  The loaders' memory queue holds only table reads; the compute waves' queue
-//     holds weights (requested one stage ahead) and tau stores, so neither waits for the other's traffic.
-// -------------------------------------------------------------------------------------------
 struct TileGeom {   // one per (column tile, layer)
   int Tmin, nT, Pmin, nP, has_lo, has_up, pad0, pad1;
   int2 eg[MAXB];    // per band: (emin, nE); nE = 0 -> band handled by the direct kernel (or no work)
@@ -448,23 +419,11 @@ __global__ void __launch_bounds__(256) zero_words_kernel(int* a, unsigned na, in
 
 // process-wide tuning switches (set from any thread: relaxed atomics; defined in plans.hip)
 extern std::atomic<int> g_tau_force_direct;
-extern std::atomic<int> g_tau_variant;
 extern std::atomic<int> g_tau_no_zero_check;
-extern std::atomic<int> g_planck_variant;  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
-extern std::atomic<int> g_geom_variant;  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
 // Every piece of mutable host-side state of this file lives in the calling thread's current CONTEXT (runtime.hip):
 // plan caches, the geometry shared between consecutive calls, the guards' flag words.  Tuning switches (rte_hip_*_variant)
 // are process-wide.
 namespace {
-// one stage of the matrix-core tau kernel (tau_mx.h): 16 g-points of a band, at most 4 minor intervals per regime; built with
-// the plan on the host, read by the kernel's matrix waves with scalar loads
-struct MxStageRec {
-  int b, g0, k0, flags;   // band, first g-point (0-based), first minor interval of this sub-stage, 1: first sub-stage | 2: last
-  int flav[2];            // the band's flavor per regime
-  unsigned act[2];        // per regime, bit j: interval k0 + j exists and covers these g-points
-  unsigned koff[2][4];    // per regime and interval: offset of these g-points in the regime's minor table row
-};
-constexpr int MX_MAXSTAGE = 128;
 struct TauPlanCache {
   const void* key[14] = {};
   int dims[7] = {};
@@ -474,7 +433,6 @@ struct TauPlanCache {
   bool uploads_pending = false;  // bands changed since the last upload to the device
   unsigned guard = 0;            // checksum of the index tables the plan was built from (tables_guard_kernel)
   std::vector<BandMeta> bands;
-  std::vector<MxStageRec> mx_stages;  // empty: the table is not eligible for the matrix-core kernel
   bool matches(const void* const* k, const int* d, int e) const {
     if (e != epoch) return false;
     for (int i = 0; i < 14; ++i)

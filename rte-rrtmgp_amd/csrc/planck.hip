@@ -130,12 +130,13 @@ planck_source_worklist_kernel(PlanckArgs q, const int* __restrict__ worklist, in
 }
 
 // -------------------------------------------------------------------------------------------
-// compute_Planck_source, production kernel: same scheme as tau_absorption_v7_kernel.
-// block = (256 columns, one band) and walks the LAYERS, so the previous layer's Planck fractions
-// stay in registers for the geometric mean at the interface (:699).  Per layer the tile's
-// bounding box of pfrac rows is staged in LDS from the g-fastest table; the band's totplnk column
-// sits in LDS for the whole block.  Interpolation state of layer l+1 is requested while layer l
-// is computed (two-deep: indices two layers ahead, flavor-dependent weights one layer ahead).
+// compute_Planck_source, production kernel (planck_source_v9_kernel below).
+// Block = (512 columns, one band): 8 compute waves (lanes = columns) walk the LAYERS, so the previous layer's Planck
+// fractions stay in registers for the geometric mean at the interface (:699); 2 loader waves stage the bounding box of
+// pfrac rows of layer l+1 (from the g-point-fastest table copy) into the other half of a double-buffered LDS slab while
+// layer l is computed; one barrier per layer; the band's totplnk column sits in LDS for the whole block.
+// tile_geom2_kernel (gas_optics_common.h) provides the boxes and sends (tile, band) pairs that do not fit the slab at
+// some layer to the direct kernel.
 // -------------------------------------------------------------------------------------------
 struct PlanckV7 {
   int ncol, nlay, ngpt, ntemp, TE, nPlanckTemp, sfc_lay;
@@ -148,237 +149,6 @@ struct PlanckV7 {
   int* worklist;  // [0] = count, then (tile, band) pairs for planck_source_worklist_kernel
   const int* skip_if;  // plan guard raised: the direct kernel does the call
 };
-
-template <int BS>
-__global__ void __launch_bounds__(BS, 2) planck_source_v7_kernel(PlanckV7 a) {
-  __shared__ int rng[2][6];  // per layer (ping-pong): Tmin, Tmax, Pmin, Pmax, emin, emax
-  constexpr int PSLAB = 8704;  // 68 KB: no minor tables here and 2 blocks per CU, so the slab can be larger
-  __shared__ __align__(16) Float slab[PSLAB];
-  extern __shared__ Float tpl[];  // totplnk(:, ibnd)
-  if (*a.skip_if) return;
-  const int tid = threadIdx.x;
-  const int ibnd = blockIdx.y;
-  const unsigned ncol = a.ncol, nlay = a.nlay;
-  const unsigned ncl = ncol * nlay, nclv = ncol * (nlay + 1);  // host guarantees < 2^31
-  const int ntemp = a.ntemp, TE = a.TE, ngpt = a.ngpt, nPT = a.nPlanckTemp;
-  const int gptS = a.band_lims[2 * ibnd] - 1, gptE = a.band_lims[2 * ibnd + 1] - 1;
-  for (int i = tid; i < nPT; i += BS) tpl[i] = a.totplnk[(size_t)nPT * ibnd + i];
-  if (tid < 12) rng[tid / 6][tid % 6] = (tid % 2 == 0) ? (1 << 30) : -1;
-  __syncthreads();
-  const unsigned icol = blockIdx.x * BS + tid;
-  const bool valid = icol < ncol;
-  const unsigned ic = min(icol, ncol - 1);
-  auto planck = [&](Float t) {  // interpolate1D :715-737 on the LDS copy of the band's column
-    const Float val0 = (t - a.temp_ref_min) * a.totplnk_delta_r;
-    const Float frac = val0 - trunc(val0);
-    const int index = min(nPT - 1, max(1, (int)val0 + 1));
-    const Float t0 = tpl[index - 1], t1 = tpl[index];
-    return t0 + frac * (t1 - t0);
-  };
-  const Float pl_sfc = planck(a.tsfc[ic]);
-  const Float pl_sfc1 = planck(a.tsfc[ic] + (Float)1);
-
-  struct Idx { int itropo, jT, jp; Float tlay, tlev; };
-  struct Wts { Float2 fm[4]; int je1, je2; };
-  auto load_idx = [&](unsigned l, Idx& x) {
-    const unsigned cl = ic + ncol * l;
-    x.itropo = a.tropo[cl] ? 0 : 1;
-    x.jT = a.jtemp[cl];
-    x.jp = a.jpress[cl] + x.itropo + 1;
-    x.tlay = a.tlay[cl];
-    x.tlev = a.tlev[cl];
-  };
-  auto load_wts = [&](unsigned l, const Idx& x, Wts& w) {
-    const unsigned cl = ic + ncol * l;
-    const int iflav = a.gpoint_flavor[x.itropo + 2 * gptS] - 1;
-    const size_t clf = cl + (size_t)ncl * iflav;
-    const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w.fm[i] = fmp[i];
-    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
-    w.je1 = je.x; w.je2 = je.y;
-  };
-  Idx x0, x1;   // layers l and l+1
-  Wts w0;       // layer l
-  load_idx(0, x0);
-  load_idx(min(1u, nlay - 1), x1);
-  load_wts(0, x0, w0);
-
-  for (int g0 = gptS; g0 <= gptE; g0 += GC) {  // host guarantees whole, 16-aligned chunks (one pass per 16 g)
-    if (g0 != gptS) {  // restart the layer walk for the next chunk of a wide band
-      load_idx(0, x0); load_idx(min(1u, nlay - 1), x1); load_wts(0, x0, w0);
-    }
-    Float prev[GC];
-#pragma unroll
-    for (int j = 0; j < GC; ++j) prev[j] = 0;
-    for (unsigned l = 0; l < nlay; ++l) {
-      int* r = rng[l & 1];
-      {
-        const int big = 1 << 30;
-        const int a0 = wave_min(valid ? x0.jT : big), a1 = wave_max(valid ? x0.jT + 1 : -1);
-        const int a2 = wave_min(valid ? x0.jp - 1 : big), a3 = wave_max(valid ? x0.jp : -1);
-        const int a4 = wave_min(valid ? min(w0.je1, w0.je2) : big), a5 = wave_max(valid ? max(w0.je1, w0.je2) + 1 : -1);
-        if ((tid & 63) == 0) {
-          atomicMin(&r[0], a0); atomicMax(&r[1], a1); atomicMin(&r[2], a2); atomicMax(&r[3], a3);
-          atomicMin(&r[4], a4); atomicMax(&r[5], a5);
-        }
-      }
-      __syncthreads();  // ranges complete; previous layer's compute finished (slab is free)
-      const int Tmin = r[0], nT = r[1] - r[0] + 1, Pmin = r[2], nP = r[3] - r[2] + 1, emin = r[4], nE = r[5] - r[4] + 1;
-      const int rows = nP * nT * nE;
-      if (rows * RS > PSLAB) {  // block-uniform: this (tile, band) goes to the direct kernel as a whole
-        if (tid == 0) {
-          const int w = atomicAdd(&a.worklist[0], 1);
-          a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = ibnd;
-        }
-        return;
-      }
-      constexpr bool use_lds = true;
-      if (tid < 6) rng[(l + 1) & 1][tid] = (tid % 2 == 0) ? (1 << 30) : -1;
-      if (use_lds) {
-        // 16-byte pieces of the bounding box, SB per thread requested back to back (index clamped, so the
-        // count is fixed): the tile pays the L2 latency once per batch
-        constexpr int SB = 4;
-        const int nAll = rows * (GC / 2);
-        const float inv_nE = 1.0f / (float)nE, inv_nT = 1.0f / (float)nT;
-        auto piece = [&](int idx) -> Float2 {
-          const int j = idx & 7, rr = idx >> 3;
-          const int rest = (int)(((float)rr + 0.5f) * inv_nE), e = rr - rest * nE;  // rows < 2^12: exact
-          const int p_l = (int)(((float)rest + 0.5f) * inv_nT), t_l = rest - p_l * nT;
-          return *reinterpret_cast<const Float2*>(
-              a.pf_g + ((size_t)((Pmin - 1 + p_l) * TE + (emin - 1 + e) * ntemp + (Tmin - 1 + t_l)) * ngpt + g0 + 2 * j));
-        };
-#pragma unroll 1
-        for (int base = tid; base < nAll; base += SB * BS) {
-          Float2 v[SB];
-#pragma unroll
-          for (int u = 0; u < SB; ++u) v[u] = piece(min(base + u * BS, nAll - 1));
-#pragma unroll
-          for (int u = 0; u < SB; ++u) {
-            const int idx = base + u * BS;
-            if (idx < nAll) *reinterpret_cast<Float2*>(slab + (idx >> 3) * RS + 2 * (idx & 7)) = v[u];
-          }
-        }
-      }
-      // this layer's values into locals, then request the following layers' inputs
-      const Float f0 = w0.fm[0].x, f1 = w0.fm[0].y, f2 = w0.fm[1].x, f3 = w0.fm[1].y, f4 = w0.fm[2].x, f5 = w0.fm[2].y,
-                  f6 = w0.fm[3].x, f7 = w0.fm[3].y;
-      const int je1 = w0.je1, je2 = w0.je2, jT = x0.jT, jp = x0.jp;
-      const Float tl = x0.tlay, tv = x0.tlev;
-      x0 = x1;
-      if (l + 1 < nlay) load_wts(l + 1, x0, w0);
-      if (l + 2 < nlay) load_idx(l + 2, x1);
-      __syncthreads();
-      if (!valid) continue;
-      const Float pl_lay = planck(tl), pl_lev = planck(tv);
-      const unsigned cl = ic + ncol * l;
-      Float* lay = a.lay_src + cl + (size_t)ncl * g0;
-      Float* lev = a.lev_src + (ic + ncol * l) + (size_t)nclv * g0;
-      const bool sfc = (int)l == a.sfc_lay - 1;
-      // one body, instantiated separately for LDS and for global rows (a merged pointer would be a
-      // generic one and every gather a slow flat load)
-      auto body = [&](const Float* __restrict__ A0, const Float* __restrict__ B0, const int sE, const int sP) {
-#pragma unroll
-        for (int jj = 0; jj < GC; jj += 2) {
-          // interpolate3D_byflav with scaling (1,1), :791-801; one 16-byte read feeds two g-points
-          const Float2 k0 = ld2(A0 + jj), k1 = ld2(A0 + sE + jj), k2 = ld2(A0 + sP + jj), k3 = ld2(A0 + sP + sE + jj),
-                       k4 = ld2(B0 + jj), k5 = ld2(B0 + sE + jj), k6 = ld2(B0 + sP + jj), k7 = ld2(B0 + sP + sE + jj);
-          Float pfv[2], pgv[2];
-          pfv[0] = f0 * k0.x; pfv[1] = f0 * k0.y;
-          pfv[0] = fma(f1, k1.x, pfv[0]); pfv[1] = fma(f1, k1.y, pfv[1]);
-          pfv[0] = fma(f2, k2.x, pfv[0]); pfv[1] = fma(f2, k2.y, pfv[1]);
-          pfv[0] = fma(f3, k3.x, pfv[0]); pfv[1] = fma(f3, k3.y, pfv[1]);
-          pgv[0] = f4 * k4.x; pgv[1] = f4 * k4.y;
-          pgv[0] = fma(f5, k5.x, pgv[0]); pgv[1] = fma(f5, k5.y, pgv[1]);
-          pgv[0] = fma(f6, k6.x, pgv[0]); pgv[1] = fma(f6, k6.y, pgv[1]);
-          pgv[0] = fma(f7, k7.x, pgv[0]); pgv[1] = fma(f7, k7.y, pgv[1]);
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int j = jj + u;
-            const Float pf = pfv[u] + pgv[u];
-            lay[(size_t)ncl * j] = pf * pl_lay;                                  // :674
-            lev[(size_t)nclv * j] = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;  // :695,:699
-            if (sfc) {                                                           // :651-653
-              a.sfc_src[ic + (size_t)ncol * (g0 + j)] = pf * pl_sfc;
-              a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = pf * (pl_sfc1 - pl_sfc);
-            }
-            prev[j] = pf;
-          }
-          asm volatile("" : "+v"(prev[jj]), "+v"(prev[jj + 1]));  // keep the pair's arithmetic here (see tau kernel)
-          if ((jj & 2) != 0) __builtin_amdgcn_sched_barrier(0);  // at most 16 row reads (64 VGPRs) in flight
-        }
-      };
-      body(slab + (((jp - 1 - Pmin) * nT + (jT - Tmin)) * nE + (je1 - emin)) * RS,
-           slab + (((jp - 1 - Pmin) * nT + (jT + 1 - Tmin)) * nE + (je2 - emin)) * RS, RS, nT * nE * RS);
-    }
-    if (valid) {
-      const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
-#pragma unroll
-      for (int j = 0; j < GC; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
-    }
-    __syncthreads();
-  }
-}
-
-
-// -------------------------------------------------------------------------------------------
-// compute_Planck_source, specialised-wave kernel: the loader / compute split of tau_absorption_v9_kernel.
-// Block = (NCW*64 columns, one band): NCW compute waves (lanes = columns) walk the LAYERS, so the previous
-// layer's Planck fractions stay in registers for the geometric mean at the interface (:699); NLW loader
-// waves stage the bounding box of pfrac rows of layer l+1 into the other half of a double-buffered LDS slab
-// while layer l is computed; one barrier per layer.  planck_geom_kernel provides the boxes and sends
-// (tile, band) pairs that do not fit the slab at some layer to the direct kernel.
-// -------------------------------------------------------------------------------------------
-template <int TILE, int G>
-__global__ void __launch_bounds__(TILE) planck_geom_kernel(PlanckV7 a, int nbnd, TileGeom* __restrict__ geom,
-                                                           int* __restrict__ flags, int slab_floats) {
-  constexpr int RS = G + 2;
-  __shared__ int rng[4];
-  __shared__ int erng[MAXB][2];
-  __shared__ int flav[MAXB][2];  // flavor (0-based) of band b per tropo regime
-  if (*a.skip_if) return;
-  const int tid = threadIdx.x;
-  const unsigned ncol = a.ncol, nlay = a.nlay, ilay = blockIdx.y;
-  const unsigned ncl = ncol * nlay;
-  if (tid == 0) { rng[0] = 1 << 30; rng[1] = -1; rng[2] = 1 << 30; rng[3] = -1; }
-  if (tid < MAXB) { erng[tid][0] = 1 << 30; erng[tid][1] = -1; }
-  if (tid < 2 * nbnd) flav[tid >> 1][tid & 1] = a.gpoint_flavor[(tid & 1) + 2 * (a.band_lims[2 * (tid >> 1)] - 1)] - 1;
-  __syncthreads();
-  const unsigned icol = blockIdx.x * TILE + tid;
-  const bool valid = icol < ncol;
-  const unsigned ic = min(icol, ncol - 1);
-  const unsigned cl = ic + ncol * ilay;
-  const int itropo = a.tropo[cl] ? 0 : 1;
-  const int jT = a.jtemp[cl];
-  const int jp = a.jpress[cl] + itropo + 1;
-  const int big = 1 << 30;
-  {
-    const int a0 = wave_min(valid ? jT : big), a1 = wave_max(valid ? jT + 1 : -1);
-    const int a2 = wave_min(valid ? jp - 1 : big), a3 = wave_max(valid ? jp : -1);
-    if ((tid & 63) == 0) { atomicMin(&rng[0], a0); atomicMax(&rng[1], a1); atomicMin(&rng[2], a2); atomicMax(&rng[3], a3); }
-  }
-  for (int b = 0; b < nbnd; ++b) {
-    const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * (cl + (size_t)ncl * flav[b][itropo]));
-    const int e0 = wave_min(valid ? min(je.x, je.y) : big), e1 = wave_max(valid ? max(je.x, je.y) + 1 : -1);
-    if ((tid & 63) == 0) { atomicMin(&erng[b][0], e0); atomicMax(&erng[b][1], e1); }
-  }
-  __syncthreads();
-  TileGeom* out = geom + (blockIdx.x + (size_t)gridDim.x * ilay);
-  const int nT = rng[1] - rng[0] + 1, nP = rng[3] - rng[2] + 1;
-  if (tid == 0) {
-    out->Tmin = rng[0]; out->nT = nT; out->Pmin = rng[2]; out->nP = nP; out->has_lo = 0; out->has_up = 0;
-    out->pad0 = 0; out->pad1 = 0;
-  }
-  if (tid < nbnd) {
-    const int emin = erng[tid][0], nE = erng[tid][1] - erng[tid][0] + 1;
-    const bool fits = nP * nT * nE * RS <= slab_floats;
-    if (!fits && atomicCAS(&flags[blockIdx.x * nbnd + tid], 0, 1) == 0) {  // once per (tile, band)
-      const int w = atomicAdd(&a.worklist[0], 1);
-      a.worklist[1 + 2 * w] = blockIdx.x; a.worklist[2 + 2 * w] = tid;
-    }
-    out->eg[tid] = make_int2(emin, nE);
-  }
-}
 
 // Planck on a geometry left by compute_tau_absorption (rte_hip_share_geometry): which (tile, band) pairs do not fit
 // the slab at some layer.  One wave per pair, lanes = layers (one thread walking the layers was 60 dependent latencies).
@@ -769,14 +539,16 @@ static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, i
   v.skip_if = guard;
   v.worklist = worklist;
   int wl_tile = BS;
-  const bool planck9 = (g_planck_variant == 9 || bl_gw != 16) && nlay <= 256 && nbnd <= MAXB &&
-                       (size_t)ncol * (nlay + 1) < ((size_t)1 << 29);
-  if (!planck9 && (bl_gw != 16 || factored)) {  // 8-wide stages and the factored output exist only in the specialised-wave kernel
+  // the production kernel: at most 256 layers (per-layer flags in LDS), the bit-mask geometry pre-pass (table dimensions
+  // within its mask words), 32-bit byte offsets into a g-point plane; otherwise the direct kernel
+  const bool planck9 = nlay <= 256 && nbnd <= MAXB && (size_t)ncol * (nlay + 1) < ((size_t)1 << 29) && nflav <= MAXFLAV &&
+                       neta < 31 && ntemp < 31 && npres + 1 < 63;
+  if (!planck9) {
     rte::ProfScope p("planck_source_kernel");
     hipLaunchKernelGGL(planck_source_kernel, dim3(cdiv(ncol, 256), nbnd), dim3(256), 0, st, q, (const int*)nullptr);
     return;
   }
-  if (planck9) {
+  {
     constexpr int NCW = 8, NLW = 2, SLAB9 = 8704;  // 8 compute + 2 loader waves, 2 x 68 KB slab: one block per CU
     wl_tile = NCW * 64;
     const unsigned tiles = cdiv(ncol, NCW * 64);
@@ -789,7 +561,6 @@ static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, i
     gs().shared.seq = -1;
     TileGeom* d_geom = shared ? gs().shared.geom : (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
     static_assert(NCW * 64 == 512, "d_flags is sized for 512-column tiles");
-    const bool geom2 = g_geom_variant == 2 && nflav <= MAXFLAV && neta < 31 && ntemp < 31 && npres + 1 < 63;
     Geom2Args ga{};
     ga.ncol = ncol; ga.nlay = nlay; ga.nbnd = nbnd; ga.nflav = nflav; ga.slab_floats = SLAB9; ga.planck = true;
     ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.band_lims = d_band_lims;
@@ -802,9 +573,7 @@ static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, i
       if (shared) hipLaunchKernelGGL(planck_flags_kernel, dim3(cdiv(tiles * nbnd, 4)), dim3(256), 0, st, (const TileGeom*)d_geom, \
                                      (int)tiles, nlay, nbnd, SLAB9, GW + 2, d_flags, v.worklist, (const int*)gs().shared.valid, \
                                      (const int*)guard);                                                          \
-      if (geom2) hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, ga, d_geom); \
-      else hipLaunchKernelGGL((planck_geom_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, v, nbnd, d_geom, \
-                              d_flags, SLAB9);                                                                    \
+      hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, ga, d_geom); \
     }                                                                                                             \
     rte::ProfScope p(factored ? "planck_source_factored_kernel" : "planck_source_kernel");                        \
     if (factored)                                                                                                 \
@@ -818,10 +587,6 @@ static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, i
   } while (0)
     if (bl_gw == 16) RTE_LAUNCH_PLANCK9(16); else RTE_LAUNCH_PLANCK9(8);
 #undef RTE_LAUNCH_PLANCK9
-  } else {
-    rte::ProfScope p("planck_source_kernel");
-    hipLaunchKernelGGL((planck_source_v7_kernel<BS>), dim3(cdiv(ncol, BS), nbnd), dim3(BS), sizeof(Float) * nPlanckTemp, st,
-                       v);
   }
   {
     // (tile, band) pairs whose pfrac bounding box exceeded the LDS slab at some layer

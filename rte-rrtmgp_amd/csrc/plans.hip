@@ -5,10 +5,7 @@
 // process-wide tuning switches (set from any thread: relaxed atomics)
 std::atomic<int> g_tau_force_direct{0};
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-std::atomic<int> g_tau_variant{env_int("RTE_HIP_TAU_VARIANT", 11)};
 std::atomic<int> g_tau_no_zero_check{env_int("RTE_HIP_NO_ZERO_CHECK", 0)};  // A/B: accumulate without looking whether tau is zero
-std::atomic<int> g_planck_variant{9};  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_planck_variant)  // 9: specialised-wave kernel, 7: single-role slab kernel (rte_hip_tau_variant)
-std::atomic<int> g_geom_variant{2};  // 2: bit-mask pre-pass (tile_geom2_kernel), 1: the band-walking pre-passes (rte_hip_geom_variant)
 // (RTE_HIP_SHARE_GEOMETRY=1: the opt-in of rte_hip_share_geometry for an unchanged binary)
 std::atomic<int> g_share_geom_default{env_int("RTE_HIP_SHARE_GEOMETRY", 0)};  // what a context starts with (the last rte_hip_share_geometry of any context)
 
@@ -20,9 +17,10 @@ int rte_hip_share_geometry(int on) {
   return 0;
 }
 int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
-int rte_hip_tau_variant(int v) { g_tau_variant = v; return 0; }
+// (rounds 1-4 had several generations of the tau / Planck / geometry kernels selectable at run time; one of each is left)
+int rte_hip_tau_variant(int) { return 0; }
 int rte_hip_tau_zero_check(int on) { g_tau_no_zero_check = on ? 0 : 1; return 0; }
-int rte_hip_planck_variant(int v) { g_planck_variant = v; return 0; }
+int rte_hip_planck_variant(int) { return 0; }
 int rte_hip_invalidate_plans(void) {
   RTE_TRY
   rte::CtxLock l;
@@ -31,7 +29,7 @@ int rte_hip_invalidate_plans(void) {
   RTE_CATCH("rte_hip_invalidate_plans")
   return 0;
 }
-int rte_hip_geom_variant(int v) { g_geom_variant = v; return 0; }
+int rte_hip_geom_variant(int) { return 0; }
 // diagnostics (synchronises): 0 = (column tile, layer, band) triples the last compute_tau_absorption call handed to the
 // direct-gather worklist, 1 = (column tile, band) pairs of the last compute_Planck_source call
 int rte_hip_stat(int which) {

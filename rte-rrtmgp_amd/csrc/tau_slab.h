@@ -236,11 +236,15 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // (one vector value, not an array of pieces: under this kernel's register pressure the compiler leaves an array in scratch)
   using PVec = SlabVec;
   const char* const kbase = reinterpret_cast<const char*>(a.kmaj);
+  // UP0 pieces per thread cover the usual box (the benchmark atmosphere's average is 4.1 per thread at G = 16); the pieces of
+  // a larger one are requested AND written in stage_rest, right away (block-uniform, rare; everything it requests it also
+  // waits for, so the counts of outstanding operations behind it are those of the common path)
+  constexpr int UP0 = (5 * UP + 7) / 8;
   auto stage_load = [&](int s1, int rowsAll, PVec& v) {
     const int nAll = rowsAll * PPR;
     const unsigned* tab = s_rowoff[s1 & 1];
 #pragma unroll
-    for (int u = 0; u < UP; ++u) {
+    for (int u = 0; u < UP0; ++u) {
       const int idx = max(min(tid + u * TILE, nAll - 1), 0);
       // (no special case for an empty stage: its one "piece" is row 0 of the table in use, or of a table planned earlier
       //  -- s_rowoff[.][0] starts as 0 -- a valid address either way)
@@ -249,11 +253,24 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       slab_put(v, u, t);
     }
   };
+  auto stage_rest = [&](int s1, int rowsAll) {
+    const int nAll = rowsAll * PPR;
+    if (nAll <= UP0 * TILE) return;  // (block-uniform)
+    const unsigned* tab = s_rowoff[s1 & 1];
+    Float* sl = slab[s1 & 1];
+#pragma unroll
+    for (int u = UP0; u < UP; ++u) {
+      const int idx = min(tid + u * TILE, nAll - 1);
+      const unsigned off = tab[idx / PPR] + (unsigned)(idx % PPR);
+      const Piece t = *reinterpret_cast<const Piece*>(kbase + 16 * (size_t)off);
+      *reinterpret_cast<Piece*>(sl + (idx / PPR) * RS + (idx % PPR) * FP) = t;  // (pieces past the image rewrite its last one)
+    }
+  };
   auto stage_write = [&](int s1, int rowsAll, const PVec& v) {
     const int nAll = rowsAll * PPR;
     Float* sl = slab[s1 & 1];
 #pragma unroll
-    for (int u = 0; u < UP; ++u) {
+    for (int u = 0; u < UP0; ++u) {
       const int idx = tid + u * TILE;
       Piece t;
       slab_get(v, u, t);
@@ -334,12 +351,8 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     if (OVERWRITE) {
       // lanes past the last column repeat it (ic is clamped): same values to the same addresses.  Unconditional
       // stores keep the count of outstanding memory operations static (counted waits instead of drains).
-#ifdef TAU_X_NOSTORE
-      { Float t_ = 0; for (int j = 0; j < G; ++j) t_ += acc[j]; if (t_ == (Float)-1.2345) store_stream(tau_at(0), t_); }
-#else
 #pragma unroll
       for (int j = 0; j < G; ++j) store_stream(tau_at(j), acc[j]);
-#endif
     } else if (valid) {
       // tau is inout (the reference accumulates onto it, :637,:679): the stage's sum is added to the incoming value as a
       // hardware floating-point atomic add performed in L2 (no return value) -- the same single addition tau_in + sum,
@@ -362,6 +375,7 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     PVec v0;
     const int rows0 = get_stage(0).rowsAll;
     stage_load(0, rows0, v0);
+    stage_rest(0, rows0);
     stage_write(0, rows0, v0);
   }
   peek_minor(0, nq);
@@ -401,6 +415,7 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const int rows_next = __builtin_amdgcn_readfirstlane(s_stage[s + 1].rowsAll);
     PVec pv;
     stage_load(s + 1, rows_next, pv);  // slab(s+1), for the buffer just released
+    stage_rest(s + 1, rows_next);
     TAU_T(5);
     if constexpr (ROT) {
       if (ALLRUN ? s > 0 : have_prev) flush(g0_prev, addv_prev);
@@ -458,18 +473,10 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     auto rd_major = [&](Float2 (&k)[4], int h) {  // h: (g-point pair, lower / upper temperature); :791-801
       const Float* b0 = ((h & 1) ? B0 : A0) + 2 * (h >> 1);
       const Float* b1 = ((h & 1) ? B1 : A1) + 2 * (h >> 1);
-#ifdef TAU_X_NOLDS
-      k[0] = Float2{w0, w1}; k[1] = k[0]; k[2] = k[0]; k[3] = k[0]; (void)b0; (void)b1;
-#else
       k[0] = ld2(b0); k[1] = ld2(b1); k[2] = ld2(b0 + sP); k[3] = ld2(b1 + sP);
-#endif
     };
     auto rd_minor = [&](Float2 (&k)[4], const Float* p1, const Float* p2, int j) {  // j: g-point pair; :757-760
-#ifdef TAU_X_NOLDS
-      k[0] = Float2{w0, w1}; k[1] = k[0]; k[2] = k[0]; k[3] = k[0]; (void)p1; (void)p2;
-#else
       k[0] = ld2(p1 + 2 * j); k[1] = ld2(p1 + RS + 2 * j); k[2] = ld2(p2 + 2 * j); k[3] = ld2(p2 + RS + 2 * j);
-#endif
     };
     const Float* c1;
     const Float* c2;
@@ -507,7 +514,6 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       }
     }
     TAU_T(2);
-    stage_write(s + 1, rows_next, pv);  // (the pieces requested behind the barrier have had the major pass to arrive)
     // the minor intervals of this lane: scalings (:461-480), 0 for a slot that is not this lane's or not this stage's
     Float scl[MM];
 #pragma unroll
@@ -526,11 +532,9 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     // everything the next stage needs of this column: its registers are free now, and the requests are a minor pass
     // ahead of their use (requested at the end of the stage their latency is exposed at the barrier; behind the
     // stage's stores they arrive a store drain late)
-#ifndef TAU_X_NOREQ
     load_major(nq.flav_major, mj);
     load_minor_w(nq, mw);
     load_minor(b_next, nq, mn);
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int q = 0; q < nslot; ++q) {
@@ -558,6 +562,9 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       c1 = n1; c2 = n2;
     }
     TAU_T(3);
+    // the next slab's pieces, requested behind the barrier, have had the stage to arrive (written after the major pass --
+    // 32 registers fewer through the minor pass -- the wave waits here for pieces that queue behind the previous stage's stores)
+    stage_write(s + 1, rows_next, pv);
     if (cq_n > MM) {
       // the band's intervals beyond the MM held in registers: amounts requested here, same expressions (:461-480)
 #pragma unroll 1
