@@ -397,34 +397,43 @@ def test_ragged_minor_intervals_on_production_kernels(hip, oracle_c, top_at_1):
                 assert cases.rel_err(outs["onepass"][k], outs["oracle"][k]) <= RTOL_GAS, (kind, k, "one-pass")
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("top_at_1", [False, True])
-def test_tile_geometry_prepasses_agree(hip, top_at_1):
-    """The bit-mask tile geometry pre-pass (DPP OR-reductions, rte_hip_geom_variant(2), default) and the
-    band-walking pre-passes (variant 1) give the production tau / Planck kernels the same LUT boxes: results
-    are bit-identical, including ragged last tiles, tropopause layers (both regimes in one tile) and tiles
-    that overflow to the direct-gather worklist."""
+@pytest.mark.parametrize("kind,top_at_1", [("lw", False), ("lw", True), ("sw", False), ("sw", True)])
+def test_production_kernels_at_the_real_table_shape_against_the_oracle(hip, oracle_c, kind, top_at_1):
+    """The production (slab) kernels at the REAL table shapes -- g256: 16 bands of 16 g-points, 10 flavors, 64 + 36 minor
+    intervals; g224: 14 bands -- compared array by array and element by element with the C oracle itself (not through the
+    direct kernels, not through fluxes): 1024 columns x 60 layers = two full 512-column tiles per layer, tropopause layers
+    with both regimes in one tile, both vertical orientations.  tau / lay_src / lev_src / sfc_src / sfc_src_jac (LW) and
+    tau_abs / tau_rayleigh / tau / ssa / g (SW: the two-kernel chain, and tau / ssa of the one-pass form)."""
     from rte_rrtmgp_amd import synth
 
-    kd = synth.make_kdist("lw")  # g256 shape: 16 bands of 16, 10 flavors
-    ncol, nlay = 1500, 30
-    atm = synth.make_atmosphere(ncol, nlay, seed=11, kdist=kd, top_at_1=top_at_1)
-    xp = frontend.TorchArrays("cuda:0")
+    kd = synth.make_kdist(kind)
+    ncol, nlay = 1024, 60
+    atm = synth.make_atmosphere(ncol, nlay, seed=21, kdist=kd, top_at_1=top_at_1)
+    xp, xn = frontend.TorchArrays("cuda:0"), frontend.NumpyArrays()
     A = xp.asarray
-    go = frontend.GasOptics(hip, kd, xp)
-    args = [A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tsfc", "col_gas", "tlev")]
     outs = {}
-    try:
-        for variant in (1, 2):
-            hiplib.ext_call(hip, "rte_hip_geom_variant", ["i"], variant)
-            bufs = {}
-            go.gas_optics_lw(ncol, nlay, *args, atm.top_at_1, buffers=bufs)
-            outs[variant] = {k: xp.to_numpy(bufs[k]).copy() for k in ("tau", "lay_src", "lev_src", "sfc_src")}
-    finally:
-        hiplib.ext_call(hip, "rte_hip_geom_variant", ["i"], 2)
-    for k in outs[1]:
-        assert np.array_equal(outs[1][k], outs[2][k]), k
-        assert np.isfinite(outs[2][k]).all() and outs[2][k].max() > 0, k
+    for mode, lib, arr, conv in (("hip", hip, xp, A), ("oracle", oracle_c, xn, (lambda v: v))):
+        go = frontend.GasOptics(lib, kd, arr)
+        if kind == "lw":
+            b = go.gas_optics_lw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.tsfc), conv(atm.col_gas),
+                                 conv(atm.tlev), atm.top_at_1)
+            keys = ("tau", "lay_src", "lev_src", "sfc_src", "sfc_src_jac")
+        else:
+            b = go.gas_optics_sw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.col_gas), conv(atm.col_dry))
+            keys = ("tau_abs", "tau_rayleigh", "tau", "ssa", "g")
+        outs[mode] = {k: np.array(arr.to_numpy(b[k])) for k in keys if b.get(k) is not None}
+    assert hiplib.ext_call(hip, "rte_hip_stat", ["i"], 2) in (1, 2)  # (the tile geometry of the slab kernel was derived: not rerouted)
+    for k, ref in outs["oracle"].items():
+        got = outs["hip"][k]
+        assert np.isfinite(got).all(), (kind, k)
+        assert cases.rel_err(got, ref) <= RTOL_GAS, (kind, k, cases.rel_err(got, ref))
+        assert cases.elem_err(got, ref, 1e-8) <= ETOL_GAS, (kind, k, cases.elem_err(got, ref, 1e-8))
+    if kind == "sw":  # the one-pass form (absorption + Rayleigh + combine in the slab kernel)
+        go = frontend.GasOptics(hip, kd, xp)
+        b = go.gas_optics_sw(ncol, nlay, A(atm.play), A(atm.plev), A(atm.tlay), A(atm.col_gas), A(atm.col_dry), fuse_rayleigh="all")
+        for k in ("tau", "ssa"):
+            got = np.array(xp.to_numpy(b[k]))
+            assert cases.elem_err(got, outs["oracle"][k], 1e-8) <= ETOL_GAS, (kind, k, "one-pass")
 
 
 def test_plans_follow_tables_changed_in_place(hip, oracle_c):

@@ -11,7 +11,7 @@ go = frontend.GasOptics(lib, kd, xp); A = xp.asarray
 play, plev, tlay, tlev, tsfc, col_gas = (A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas"))
 bufs = {}
 def run(tv, pv, reps=3):
-    hiplib.ext_call(lib, "rte_hip_tau_variant", ["i"], tv); hiplib.ext_call(lib, "rte_hip_planck_variant", ["i"], pv)
+    hiplib.ext_call(lib, "rte_hip_planck_variant", ["i"], pv)
     go.gas_optics_lw(ncol, 60, play, plev, tlay, tsfc, col_gas, tlev, False, buffers=bufs)
     hiplib.ext_call(lib, "rte_hip_profile_reset", []); hiplib.ext_call(lib, "rte_hip_profile_enable", ["i"], 1)
     for _ in range(reps): go.gas_optics_lw(ncol, 60, play, plev, tlay, tsfc, col_gas, tlev, False, buffers=bufs)
