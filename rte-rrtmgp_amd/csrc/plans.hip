@@ -17,10 +17,7 @@ int rte_hip_share_geometry(int on) {
   return 0;
 }
 int rte_hip_force_direct_gather(int on) { g_tau_force_direct = on; return 0; }
-// (rounds 1-4 had several generations of the tau / Planck / geometry kernels selectable at run time; one of each is left)
-int rte_hip_tau_variant(int) { return 0; }
 int rte_hip_tau_zero_check(int on) { g_tau_no_zero_check = on ? 0 : 1; return 0; }
-int rte_hip_planck_variant(int) { return 0; }
 int rte_hip_invalidate_plans(void) {
   RTE_TRY
   rte::CtxLock l;
@@ -29,7 +26,6 @@ int rte_hip_invalidate_plans(void) {
   RTE_CATCH("rte_hip_invalidate_plans")
   return 0;
 }
-int rte_hip_geom_variant(int) { return 0; }
 // diagnostics (synchronises): 0 = (column tile, layer, band) triples the last compute_tau_absorption call handed to the
 // direct-gather worklist, 1 = (column tile, band) pairs of the last compute_Planck_source call
 int rte_hip_stat(int which) {

@@ -600,6 +600,20 @@ static long mirror_find(const char* p, size_t bytes, bool declared = false /* th
       }
     }
     if (contained && guarded && hit < 0 && canaries_intact(m)) { hit = (long)i; continue; }
+    // A contained part WITHOUT a canary inside it (a slice shorter than about 1/33 of the array: one g-point plane, a column
+    // block) of a mirror whose canaries are all intact is most likely a slice of the LIVE array, whose only valid copy is on
+    // the device: it is lost with the mirror, and the kernel is staged from host memory that holds canaries and stale data.
+    // The guard above cannot tell that from reused memory, so the loss is made visible (once; counted in rte_hip_mirror_stat(4)):
+    // a host program that hands slices of a library output back to the library calls rte_hip_writeback(array) first.
+    if (contained && !guarded && canaries_intact(m)) {
+      static std::atomic<bool> warned{false};
+      if (!warned.exchange(true))
+        fprintf(stderr, "rte_rrtmgp_hip: host-mirror mode was handed %zu bytes at %p, a part of the %zu-byte host array at %p whose only "
+                        "valid copy is on the device; the part holds none of the array's canaries, so the device copy is dropped and "
+                        "the call reads the host memory as it is (stale).  Call rte_hip_writeback(array) before passing slices shorter "
+                        "than 1/33 of a library output back to the library (INTEGRATION.md); further cases are counted only "
+                        "(rte_hip_mirror_stat(4))\n", bytes, (const void*)p, m.bytes, (void*)m.host);
+    }
     ++c.mstat[contained ? 4 : 5];
     mirror_drop(i);
     if (hit > (long)i) --hit;

@@ -2648,7 +2648,13 @@ int rte_hip_sw_solver_2stream_byband(int ncol, int nlay, int ngpt, int nbnd, int
   q.ncol = ncol; q.nlay = nlay; q.ngpt = ngpt; q.S = (nlay + L - 1) / L; q.g_per_block = 0;
   q.top_at_1 = top_at_1 != 0; q.has_dif_bc = has_dif_bc != 0;
   q.band_lims = c.in(band_lims_gpt, (size_t)2 * nbnd);
-  q.tau = c.in(tau, ncl * ngpt); q.ssa = c.in(ssa, ncl * ngpt); q.g = c.in(g, ncl * ngpt); q.mu0 = c.in(mu0, ncl);
+  q.tau = c.in(tau, ncl * ngpt); q.ssa = c.in(ssa, ncl * ngpt); q.mu0 = c.in(mu0, ncl);
+  if (g) q.g = c.in(g, ncl * ngpt);
+  else {  // g == NULL: g = 0 everywhere, as in rte_sw_solver_2stream
+    Float* z = (Float*)rte::scratch(sizeof(Float) * ncl * ngpt);
+    HIP_CHECK(hipMemsetAsync(z, 0, sizeof(Float) * ncl * ngpt, rte::stream()));
+    q.g = z;
+  }
   q.sfc_alb_dir = c.in(sfc_alb_dir, ncg); q.sfc_alb_dif = c.in(sfc_alb_dif, ncg); q.inc_flux_dir = c.in(inc_flux_dir, ncg);
   q.inc_flux_dif = has_dif_bc ? c.in(inc_flux_dif, ncg) : nullptr;
   q.part_up = c.out(byband_up, nclv * nbnd); q.part_dn = c.out(byband_dn, nclv * nbnd); q.part_dir = c.out(byband_dir, nclv * nbnd);

@@ -29,10 +29,10 @@ def test_library_builds_and_exports_every_header_symbol():
         assert hasattr(dll, name), f"{name} declared in the header but not exported"
     for ext in ("rte_hip_set_stream", "rte_hip_sync", "rte_hip_profile_enable", "rte_hip_profile_get",
                 "rte_hip_combine_abs_and_rayleigh_2str", "rte_hip_broadcast_gpt", "rte_hip_release",
-                "rte_hip_defer_zero", "rte_hip_tau_variant", "rte_hip_planck_variant", "rte_hip_force_direct_gather",
+                "rte_hip_defer_zero", "rte_hip_force_direct_gather",
                 "rte_hip_force_generic_lw", "rte_hip_force_generic_sw", "rte_hip_invalidate_plans",
                 "rte_hip_set_lw2str_bugcompat", "rte_hip_device_count", "rte_hip_cloud_masks", "rte_hip_cloud_combine",
-                "rte_hip_geom_variant", "rte_hip_seg_groups", "rte_hip_get_layer_number", "rte_hip_get_layer_mass",
+                "rte_hip_seg_groups", "rte_hip_get_layer_number", "rte_hip_get_layer_mass",
                 "rte_hip_col_gas_fill", "rte_hip_tlev_interp", "rte_hip_compute_optimal_angles",
                 "rte_hip_combine_abs_and_rayleigh_1scl", "rte_hip_combine_abs_and_rayleigh_nstr",
                 "rte_hip_expand_and_transpose", "rte_hip_secants_fill", "rte_hip_rfmip_sw_toa_renorm",

@@ -27,8 +27,9 @@ NCOL = 100000
 TOL = 1e-8
 # all-sky: cloudy layers (ssa -> 1, optical depths of tens) are where two correct evaluations of the two-stream coefficients
 # differ most -- every elementwise worst case of this file sits there (7e-9 with round 3's kernels, 1.1e-8 since the SW solver
-# evaluates Rdir / Tdir in 15 instead of 32 operations, round 4); the contract is 1e-6 (BASELINE.json north_star)
-TOL_ALLSKY = 3e-8
+# evaluates Rdir / Tdir in 15 instead of 32 operations, round 4); the contract is 1e-6 (BASELINE.json north_star).  The
+# bound asserted is the measured one with a third of headroom, so that further drift is caught; LW and SW stay pinned at 1e-8.
+TOL_ALLSKY = 1.5e-8
 
 
 def _elem(a, b):
