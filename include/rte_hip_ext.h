@@ -150,6 +150,16 @@ int rte_hip_cloud_optics_fused(int ncol, int nlay, int nbnd, int twostr, int del
                                double diamice_lwr, const Float* extice, const Float* ssaice, const Float* asyice, Float* tau,
                                Float* ssa, Float* g);
 
+/* ---- the exchange step of the column-sharded path for host programs without torch (csrc/collectives.hip) ----------------
+ * Columns shard as contiguous ranges per rank, tables replicated, no data-path collective; ranks exchange only broadband
+ * flux diagnostics.  nccl_comm: the caller's ncclComm_t (RCCL; from its MPI ranks: INTEGRATION.md section 5), enqueued on
+ * the context's stream.  RCCL is resolved at run time: no link-time dependency.  Return -3: no RCCL in this process. */
+int rte_hip_rccl_available(void);
+int rte_hip_allreduce_mean_profile(void* nccl_comm /* NULL: one rank */, int ncol_local, int nlev, const Float* flux_up,
+                                   const Float* flux_dn, long long ncol_global, Float* mean_up /* (nlev) */, Float* mean_dn);
+int rte_hip_allgather_columns(void* nccl_comm, int ncol_local, int nlev, const Float* local /* (ncol_local, nlev), device */,
+                              Float* global /* (ncol_local * nranks, nlev), device */);
+
 /* ---- switches for tests and A/B timing (process-wide) ------------------------------------------------------------------ */
 int rte_hip_force_direct_gather(int on);   /* gas optics on the direct-gather kernels only */
 int rte_hip_force_generic_lw(int on);      /* LW solvers on the generic (any layer count) kernels only */

@@ -160,6 +160,70 @@ def test_two_ranks_of_bench_share_one_device_over_gloo():
     assert res["step_ms"]["n"] == 2 and res["step_ms"]["min"] <= res["step_ms"]["median"]
 
 
+def test_c_level_flux_reduction_over_rccl():
+    """The exchange step for host programs without torch (csrc/collectives.hip): rte_hip_allreduce_mean_profile and
+    rte_hip_allgather_columns on a communicator made with RCCL's own C API -- one rank (RCCL refuses two ranks on this
+    box's one device; N ranks differ in the communicator only) -- and the communicator-free single-rank form, against numpy.
+    Device and host pointers."""
+    import ctypes
+
+    import torch
+
+    hip = hiplib.load()
+    ncol, nlev = 70001, 61
+    rng = np.random.default_rng(5)
+    up, dn = rng.random((nlev, ncol)) * 400.0, rng.random((nlev, ncol)) * 300.0  # Fortran (ncol, nlev)
+    ref_up, ref_dn = up.sum(axis=1) / (3.0 * ncol), dn.sum(axis=1) / (3.0 * ncol)  # "a third of a 3-rank domain"
+    fn = hip.raw("rte_hip_allreduce_mean_profile")
+    fn.restype = ctypes.c_int
+    P, I, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
+
+    def mean(comm, a, b, on_device):
+        if on_device:
+            ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+            mu, md = torch.empty(nlev, dtype=torch.float64, device="cuda"), torch.empty(nlev, dtype=torch.float64, device="cuda")
+            rc = fn(P(comm), I(ncol), I(nlev), P(ta.data_ptr()), P(tb.data_ptr()), LL(3 * ncol), P(mu.data_ptr()), P(md.data_ptr()))
+            torch.cuda.synchronize()
+            return rc, mu.cpu().numpy(), md.cpu().numpy()
+        mu, md = np.empty(nlev), np.empty(nlev)
+        rc = fn(P(comm), I(ncol), I(nlev), P(a.ctypes.data), P(b.ctypes.data), LL(3 * ncol), P(mu.ctypes.data), P(md.ctypes.data))
+        return rc, mu, md
+
+    for on_device in (True, False):  # no communicator: one rank
+        rc, mu, md = mean(None, up, dn, on_device)
+        assert rc == 0
+        assert np.allclose(mu, ref_up, rtol=1e-13, atol=0) and np.allclose(md, ref_dn, rtol=1e-13, atol=0)
+    assert hiplib.ext_call(hip, "rte_hip_rccl_available", []) == 1
+    # a one-rank communicator from RCCL's C API (the library resolves the same librccl)
+    try:
+        rccl = ctypes.CDLL("librccl.so", mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        rccl = ctypes.CDLL("librccl.so.1", mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid, comm = UniqueId(), ctypes.c_void_p()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        rc, mu, md = mean(comm.value, up, dn, True)
+        assert rc == 0
+        assert np.allclose(mu, ref_up, rtol=1e-13, atol=0) and np.allclose(md, ref_dn, rtol=1e-13, atol=0)
+        ag = hip.raw("rte_hip_allgather_columns")
+        ag.restype = ctypes.c_int
+        loc = torch.from_numpy(up).cuda()
+        glob = torch.zeros_like(loc)
+        assert ag(P(comm.value), I(ncol), I(nlev), P(loc.data_ptr()), P(glob.data_ptr())) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(glob, loc)
+        assert ag(P(comm.value), I(ncol), I(nlev), P(up.ctypes.data), P(glob.data_ptr())) == -2  # host memory: refused
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def test_32bit_offset_guard_falls_back():
     """The segmented solver addresses a g-point plane with 32-bit byte offsets (8 * ncol * (nlay+1) < 2^32).  A call
     beyond that must take the generic kernel, not abort or wrap: 2^24 columns x 32 layers x 1 g-point (13 GB of
