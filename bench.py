@@ -675,6 +675,40 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001
             factored = f"failed: {e}"
+    # ... and the same factored step through the REFERENCE symbols only (rte_hip_defer_sources: what an unchanged device-pointer
+    # binary gets with RTE_HIP_DEFER_SOURCES=1): rrtmgp_compute_Planck_source records the factors, rte_lw_solver_noscat consumes them
+    deferred = None
+    if args.workload == "lw" and not args.no_factored:
+        try:
+            hiplib.ext_call(lib, "rte_hip_defer_sources", ["i"], 1)
+            rb_d = {}
+
+            def step_deferred():
+                go.gas_optics_lw(ncol, NLAY, play, plev, tlay, tsfc, col_gas, tlev, atm.top_at_1, buffers=bufs)
+                frontend.rte_lw(lib, xp, ncol, NLAY, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["lay_src"], bufs["lev_src"], emis, bufs["sfc_src"], buffers=rb_d)
+
+            d_ms = timed_ms(step_deferred, reps=5)
+            hiplib.ext_call(lib, "rte_hip_sync", [])  # (materialises what the last step left deferred)
+            hiplib.ext_call(lib, "rte_hip_defer_sources", ["i"], 0)
+            step()
+            fence()
+            # byte model of the deferred chain: K3 writes the Planck fraction (8N) + the bands' Planck functions instead of 8N + 8Nr;
+            # K4 reads tau + fraction (16N) + those instead of 16N + 8Nr
+            nb_ = kd.nbnd
+            d_bytes = ncol * NLAY * (1297 + 3345 + (25 + 72 * 10 + 8 * 61 / 60 + 8 * kd.ngpt + 8 * nb_ * (1 + 61 / 60)) +
+                                     (16 * kd.ngpt + 8 * nb_ * (1 + 61 / 60) + 32 * kd.ngpt / NLAY + 16 * 61 / 60))
+            deferred = {"ms_per_step": round(d_ms, 4), "columns_per_s": round(ncol * world / (d_ms * 1e-3), 1),
+                        "fluxes_bit_identical_to_abi_chain": bool(torch.equal(rb["flux_up"], rb_d["flux_up"]) and
+                                                                  torch.equal(rb["flux_dn"], rb_d["flux_dn"])),
+                        "alg_GB_per_step": round(d_bytes / 1e9, 3), "frac_of_8TBps_on_its_own_bytes": round(d_bytes / (d_ms * 1e-3) / 8e12, 4),
+                        "note": "opt-in rte_hip_defer_sources (RTE_HIP_DEFER_SOURCES=1) + the headline's opt-ins, reference symbols only: "
+                                "rrtmgp_compute_Planck_source leaves the Planck fraction in lay_source and the bands' Planck functions in a "
+                                "library buffer, rte_lw_solver_noscat on these arrays solves from them; any other use of the arrays finds "
+                                "them expanded.  Outside the timed region, never `value`"}
+            rb_d.clear()
+        except Exception as e:  # noqa: BLE001
+            deferred = f"failed: {e}"
+            hiplib.ext_call(lib, "rte_hip_defer_sources", ["i"], 0)
     if args.workload == "allsky" and not args.no_factored:
         try:
             st_f = {}
@@ -886,6 +920,8 @@ def main():
                        "plain_abi_columns_per_s": (round(ncol * world / (plain_abi_ms * 1e-3), 1) if isinstance(plain_abi_ms, float) else None),
                        "plain_abi_note": "the same step through the reference ABI only, no rte_hip_* opt-ins (3 steps outside the timed region)",
                        "factored_sources": factored,
+                       "deferred_sources": deferred,
+                       "deferred_sources_ms_per_step": (deferred["ms_per_step"] if isinstance(deferred, dict) else None),
                        "implicit_g": implicit_g,
                        "glue_ms_per_step_outside_timed_region": (round(glue_ms, 4) if glue_ms is not None else None),
                        "allgather_global_fluxes_ms_outside_timed_region": (round(allgather_ms, 4) if allgather_ms is not None else None),

@@ -127,6 +127,22 @@ void defer_zero(void* p, size_t bytes);
 bool take_pending_zero(const void* p, size_t bytes);
 void flush_pending_zeros();
 
+// deferred LW sources (runtime.hip; opt-in rte_hip_defer_sources / RTE_HIP_DEFER_SOURCES=1): compute_Planck_source on device
+// arrays leaves the FACTORED sources -- the Planck fraction in the caller's lay_source array, the bands' Planck functions
+// in library buffers, lev_source untouched -- and records that; rte_lw_solver_noscat on exactly these arrays solves from
+// the factors (planck.hip, solvers.hip).  Any other library entry that is handed lay_source or lev_source finds them
+// materialised first (Call::in), a new output into them drops the record (Call::out).
+struct PendingSources {
+  const void *lay, *lev;         // the caller's arrays
+  int ncol, nlay, nbnd, ngpt;
+  const void *plk_lay, *plk_lev; // (ncol, nlay, nbnd), (ncol, nlay+1, nbnd): library buffers
+  const int* band_lims;          // device copy of band_lims_gpt
+};
+bool defer_sources_enabled();
+void defer_sources(const PendingSources& s, void (*expand)(const PendingSources&));
+bool take_pending_sources(const void* lay, const void* lev, PendingSources* out);
+void flush_pending_sources();
+
 // kernel-level timing hooks (rte_hip_profile_*): record(name) brackets a launch with events
 void prof_begin(const char* kernel);
 void prof_end();

@@ -414,9 +414,9 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
 
 // factored -> lay_source / lev_source (one thread per (column, level, band), the band's g-points in a loop)
 __global__ void __launch_bounds__(256)
-expand_factored_sources_kernel(int ncol, int nlay, const int* __restrict__ band_lims, const Float* __restrict__ pfrac,
-                               const Float* __restrict__ plk_lay, const Float* __restrict__ plk_lev, Float* __restrict__ lay_src,
-                               Float* __restrict__ lev_src) {
+expand_factored_sources_kernel(int ncol, int nlay, const int* __restrict__ band_lims, const Float* pfrac,
+                               const Float* __restrict__ plk_lay, const Float* __restrict__ plk_lev, Float* lay_src,
+                               Float* __restrict__ lev_src, int what /* 3: both, 1: lev_src only, 2: lay_src only (in place: pfrac == lay_src, 1 then 2) */) {
   const int icol = blockIdx.x * blockDim.x + threadIdx.x, ilev = blockIdx.y, ibnd = blockIdx.z;
   if (icol >= ncol) return;
   const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
@@ -426,13 +426,29 @@ expand_factored_sources_kernel(int ncol, int nlay, const int* __restrict__ band_
   for (int g = gS; g <= gE; ++g) {
     const Float* pf = pfrac + ncl * (size_t)g + icol;
     const Float below = pf[(size_t)ncol * min(ilev, nlay - 1)];
-    if (ilev < nlay) lay_src[icol + (size_t)ncol * ilev + ncl * g] = below * pl_lay;                       // :674
-    const Float f = (ilev == 0 || ilev == nlay) ? below : sqrt(pf[(size_t)ncol * (ilev - 1)] * below);   // :695, :699, :705
-    lev_src[icol + (size_t)ncol * ilev + nclv * g] = f * pl_lev;
+    if ((what & 1) != 0) {
+      const Float f = (ilev == 0 || ilev == nlay) ? below : sqrt(pf[(size_t)ncol * (ilev - 1)] * below);   // :695, :699, :705
+      lev_src[icol + (size_t)ncol * ilev + nclv * g] = f * pl_lev;
+    }
+    if ((what & 2) != 0 && ilev < nlay) lay_src[icol + (size_t)ncol * ilev + ncl * g] = below * pl_lay;   // :674
   }
 }
 
 }  // namespace
+
+// deferred sources: lay_source / lev_source from the factors the record names, in place (runtime.hip calls this with the
+// context held, possibly from inside another entry point's Call: launches only)
+constexpr int kPlanckDeferSlot = 12;
+static void planck_expand_pending(const rte::PendingSources& s) {
+  rte::ProfScope p("expand_factored_sources_kernel");
+  const dim3 grid(cdiv(s.ncol, 256), s.nlay + 1, s.nbnd);
+  Float* lay = (Float*)const_cast<void*>(s.lay);
+  Float* lev = (Float*)const_cast<void*>(s.lev);
+  hipLaunchKernelGGL(expand_factored_sources_kernel, grid, dim3(256), 0, rte::stream(), s.ncol, s.nlay, s.band_lims, (const Float*)lay,
+                     (const Float*)s.plk_lay, (const Float*)s.plk_lev, lay, lev, 1);
+  hipLaunchKernelGGL(expand_factored_sources_kernel, grid, dim3(256), 0, rte::stream(), s.ncol, s.nlay, s.band_lims, (const Float*)lay,
+                     (const Float*)s.plk_lay, (const Float*)s.plk_lev, lay, lev, 2);
+}
 
 // the body of rrtmgp_compute_Planck_source and of its factored form (plk_lay != nullptr: see PlanckArgs)
 static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, int ngpt, int nflav, int neta, int npres, int ntemp,
@@ -440,13 +456,32 @@ static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, i
                                const Float* fmajor, const int* jeta, const Bool* tropo, const int* jtemp, const int* jpress,
                                const int* band_lims_gpt, const Float* pfracin, Float temp_ref_min_v, Float totplnk_delta_v,
                                const Float* totplnk, const int* gpoint_flavor, Float* sfc_src, Float* lay_src, Float* lev_src,
-                               Float* sfc_source_Jac, Float* plk_lay, Float* plk_lev) {
-  const bool factored = plk_lay != nullptr;
+                               Float* sfc_source_Jac, Float* plk_lay, Float* plk_lev, rte::PendingSources* deferred = nullptr) {
   const int* sfc_lay_ = &sfc_lay;
   const Float *temp_ref_min = &temp_ref_min_v, *totplnk_delta = &totplnk_delta_v;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0) return;
   rte::Call c(name);
   const size_t ncl = (size_t)ncol * nlay;
+  // Deferred sources (rte_hip_defer_sources / RTE_HIP_DEFER_SOURCES=1; runtime.hip): the factored form into the caller's own
+  // arrays -- the Planck fraction where lay_source goes, nothing to lev_source, the bands' Planck functions into a library
+  // buffer -- and a record of it; rte_lw_solver_noscat on these arrays solves from the factors, anything else the library
+  // is handed them for finds them expanded first (planck_expand_pending).
+  Float* lev_src_deferred = nullptr;
+  int* bl_dev = nullptr;
+  if (deferred) {
+    const size_t nclv = (size_t)ncol * (nlay + 1);
+    (void)c.out(lev_src, nclv * ngpt);  // (an earlier record on this array goes)
+    plk_lay = (Float*)rte::persistent(kPlanckDeferSlot, sizeof(Float) * (ncl + nclv) * nbnd + sizeof(int) * 2 * nbnd, nullptr);
+    plk_lev = plk_lay + ncl * nbnd;
+    bl_dev = (int*)(plk_lev + nclv * nbnd);
+    HIP_CHECK(hipMemcpyAsync(bl_dev, band_lims_gpt, sizeof(int) * 2 * nbnd, hipMemcpyDefault, rte::stream()));
+    if (!rte::is_device_pointer(band_lims_gpt)) HIP_CHECK(hipStreamSynchronize(rte::stream()));  // (pageable source)
+    lev_src_deferred = lev_src;
+    lev_src = nullptr;
+    // (recorded by the entry point once this call has staged its arguments: Call::out on lay_source drops records on it)
+    *deferred = rte::PendingSources{lay_src, lev_src_deferred, ncol, nlay, nbnd, ngpt, plk_lay, plk_lev, bl_dev};
+  }
+  const bool factored = plk_lay != nullptr;
   const Float* d_tlay = c.in(tlay, ncl);
   const Float* d_tlev = c.in(tlev, (size_t)ncol * (nlay + 1));
   const Float* d_tsfc = c.in(tsfc, (size_t)ncol);
@@ -612,9 +647,13 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
                                   Float* lev_src, Float* sfc_source_Jac) {
   (void)gpoint_bands;
   RTE_TRY
+  rte::PendingSources rec{};
+  const bool deferred = rte::defer_sources_enabled() && rte::is_device_memory(lay_src) && rte::is_device_memory(lev_src) && *nlay_ <= 80 &&
+                        (size_t)*ncol_ * (*nlay_ + 1) < ((size_t)1 << 29) && *nbnd_ > 0;
   planck_source_impl("rrtmgp_compute_Planck_source", *ncol_, *nlay_, *nbnd_, *ngpt_, *nflav_, *neta_, *npres_, *ntemp_, *nPlanckTemp_,
                      tlay, tlev, tsfc, *sfc_lay_, fmajor, jeta, tropo, jtemp, jpress, band_lims_gpt, pfracin, *temp_ref_min,
-                     *totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_source_Jac, nullptr, nullptr);
+                     *totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_source_Jac, nullptr, nullptr, deferred ? &rec : nullptr);
+  if (deferred && rec.lay) rte::defer_sources(rec, planck_expand_pending);
   RTE_CATCH("rrtmgp_compute_Planck_source")
 }
 
@@ -652,8 +691,13 @@ int rte_hip_expand_factored_sources(int ncol, int nlay, int nbnd, int ngpt, cons
   const Float *d_pf = c.in(pfrac, ncl * ngpt), *d_ply = c.in(planck_lay, ncl * nbnd), *d_plv = c.in(planck_lev, nclv * nbnd);
   Float *d_lay = c.out(lay_source, ncl * ngpt), *d_lev = c.out(lev_source, nclv * ngpt);
   rte::ProfScope p("expand_factored_sources_kernel");
-  hipLaunchKernelGGL(expand_factored_sources_kernel, dim3(cdiv(ncol, 256), nlay + 1, nbnd), dim3(256), 0, rte::stream(), ncol, nlay,
-                     d_bl, d_pf, d_ply, d_plv, d_lay, d_lev);
+  const dim3 grid(cdiv(ncol, 256), nlay + 1, nbnd);
+  if (d_pf == d_lay) {  // in place: every level source first (they read the neighbouring layers' fractions), then the layer sources
+    hipLaunchKernelGGL(expand_factored_sources_kernel, grid, dim3(256), 0, rte::stream(), ncol, nlay, d_bl, d_pf, d_ply, d_plv, d_lay, d_lev, 1);
+    hipLaunchKernelGGL(expand_factored_sources_kernel, grid, dim3(256), 0, rte::stream(), ncol, nlay, d_bl, d_pf, d_ply, d_plv, d_lay, d_lev, 2);
+  } else {
+    hipLaunchKernelGGL(expand_factored_sources_kernel, grid, dim3(256), 0, rte::stream(), ncol, nlay, d_bl, d_pf, d_ply, d_plv, d_lay, d_lev, 3);
+  }
   return 0;
   RTE_CATCH("rte_hip_expand_factored_sources")
   return -1;

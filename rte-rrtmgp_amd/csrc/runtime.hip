@@ -70,6 +70,10 @@ struct Context {
   std::vector<PendingZero> pending;
   // (RTE_HIP_DEFER_ZERO=1: the opt-in for an unchanged device-pointer binary that cannot call rte_hip_defer_zero)
   bool defer_zero = getenv("RTE_HIP_DEFER_ZERO") && atoi(getenv("RTE_HIP_DEFER_ZERO")) > 0;
+  // deferred LW sources (see common.h): at most a few records (one per source-function object in flight)
+  std::vector<PendingSources> pending_src;
+  void (*expand_src)(const PendingSources&) = nullptr;
+  bool defer_sources = getenv("RTE_HIP_DEFER_SOURCES") && atoi(getenv("RTE_HIP_DEFER_SOURCES")) > 0;
   long seq = 0;
   // ---- host-mirror mode
   std::vector<Mirror> mirrors;
@@ -131,7 +135,7 @@ static Context* auto_context() {
   if (!default_taken) { default_taken = true; return &default_context(); }
   auto* c = new Context();
   const Context& d = default_context();
-  c->overlap = d.overlap; c->aux_on = d.aux_on; c->defer_zero = d.defer_zero; c->sticky_errors = d.sticky_errors;
+  c->overlap = d.overlap; c->aux_on = d.aux_on; c->defer_zero = d.defer_zero; c->defer_sources = d.defer_sources; c->sticky_errors = d.sticky_errors;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess) c->own_stream = true;
   return c;
 }
@@ -359,6 +363,53 @@ void flush_pending_zeros() {
   std::lock_guard<std::recursive_mutex> l(c.mutex);
   for (auto& z : c.pending) HIP_CHECK(hipMemsetAsync(z.p, 0, z.bytes, c.stream));
   c.pending.clear();
+}
+
+// ---- deferred LW sources (opt-in, rte_hip_defer_sources; see common.h) ------------------------------------------------
+// compute_Planck_source and lw_solver_noscat are separate calls of the reference interface, with 26 GB of lay_source /
+// lev_source written by one and read by the other at 1e5 x 60 x 256; in factored form (Planck fraction per g-point, Planck
+// function per band) it is 13.7 GB.  With the option on, an UNCHANGED device-pointer binary gets the factored step: the
+// arrays are materialised (in place, bit-identical to the plain call) as soon as the library is handed one of them for
+// anything but that solve.  Same promise as the deferred zero fill: between the two calls the caller touches these arrays
+// only through this library (rte_hip_sync materialises everything).
+bool defer_sources_enabled() { return C.defer_sources; }
+void defer_sources(const PendingSources& s, void (*expand)(const PendingSources&)) {
+  Context& c = C;
+  std::lock_guard<std::recursive_mutex> l(c.mutex);
+  if (expand) c.expand_src = expand;  // (nullptr: a record goes back on the list, the expander is known)
+  c.pending_src.push_back(s);
+}
+bool take_pending_sources(const void* lay, const void* lev, PendingSources* out) {
+  Context& c = C;
+  std::lock_guard<std::recursive_mutex> l(c.mutex);
+  for (size_t i = 0; i < c.pending_src.size(); ++i)
+    if (c.pending_src[i].lay == lay && c.pending_src[i].lev == lev) {
+      *out = c.pending_src[i];
+      c.pending_src.erase(c.pending_src.begin() + i);
+      return true;
+    }
+  return false;
+}
+void flush_pending_sources() {
+  Context& c = C;
+  std::lock_guard<std::recursive_mutex> l(c.mutex);
+  while (!c.pending_src.empty()) {
+    const PendingSources s = c.pending_src.back();
+    c.pending_src.pop_back();
+    c.expand_src(s);
+  }
+}
+// a library call is handed the array at p: as an input (or in / out) it is materialised first, as a pure output the record
+// goes (the factors in it are about to be overwritten).  Ranges are compared by their start: the frontend passes whole arrays.
+static void sources_touch(const void* p, bool copy_in) {
+  Context& c = C;
+  for (size_t i = 0; i < c.pending_src.size(); ++i)
+    if (c.pending_src[i].lay == p || c.pending_src[i].lev == p) {
+      const PendingSources s = c.pending_src[i];
+      c.pending_src.erase(c.pending_src.begin() + i);
+      if (copy_in) c.expand_src(s);
+      return;
+    }
 }
 
 // ---- host-mirror mode (opt-in: rte_hip_host_mirror(1) or RTE_HIP_HOST_MIRROR=1) ---------------------------------
@@ -679,7 +730,10 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
   if (!p || bytes == 0) return p;
   void* dv;
   const int kind = classify(p, &dv);
-  if (kind == 1) return p;
+  if (kind == 1) {
+    if (!C.pending_src.empty()) sources_touch(p, copy_in);
+    return p;
+  }
   if (kind == 2) { host_visible_ = true; return dv; }  // in place, but synchronous for the caller (see ~Call)
   Context& c = C;
   if (mirror_on()) {
@@ -974,7 +1028,7 @@ void* rte_hip_ctx_create(int device, void* stream) {
   if (stream) c->stream = (hipStream_t)stream;
   else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
   if (device >= 0 && prev != device) HIP_CHECK(hipSetDevice(prev));
-  c->overlap = cur.overlap; c->aux_on = cur.aux_on; c->defer_zero = cur.defer_zero; c->mirror_mode = cur.mirror_mode;
+  c->overlap = cur.overlap; c->aux_on = cur.aux_on; c->defer_zero = cur.defer_zero; c->defer_sources = cur.defer_sources; c->mirror_mode = cur.mirror_mode;
   c->mirror_max_age = cur.mirror_max_age; c->sticky_errors = cur.sticky_errors;
   return c;
   RTE_CATCH("rte_hip_ctx_create")
@@ -1049,6 +1103,7 @@ int rte_hip_set_stream(void* s) {
   // work queued on the old stream still uses the scratch arena, the persistent slots and recorded zero fills:
   // materialise the fills there and drain it before anything is launched on the new stream
   rte::flush_pending_zeros();
+  rte::flush_pending_sources();
   HIP_CHECK(hipStreamSynchronize(c.stream));  // (forked calls have been joined into it)
   c.fork_valid = false;
   if (c.own_stream) { HIP_CHECK(hipStreamDestroy(c.stream)); c.own_stream = false; }
@@ -1060,8 +1115,18 @@ int rte_hip_sync(void) {
   RTE_TRY
   LOCK_CTX;
   rte::flush_pending_zeros();
+  rte::flush_pending_sources();
   HIP_CHECK(hipStreamSynchronize(rte::ctx().stream));
   RTE_CATCH("rte_hip_sync")
+  return 0;
+}
+// compute_Planck_source leaves factored sources for the rte_lw_solver_noscat call that follows (see above)
+int rte_hip_defer_sources(int on) {
+  RTE_TRY
+  LOCK_CTX;
+  rte::flush_pending_sources();
+  rte::ctx().defer_sources = on != 0;
+  RTE_CATCH("rte_hip_defer_sources")
   return 0;
 }
 // defer zero_array_* on device buffers until compute_tau_absorption consumes them (see above)

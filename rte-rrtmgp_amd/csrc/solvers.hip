@@ -1980,6 +1980,11 @@ int rte_hip_force_generic_sw(int on) { g_sw_force_generic = on; return 0; }
 int rte_hip_seg_groups(int n) { g_seg_groups = n; return 0; }
 int rte_hip_lw_sfc_lds(int on) { g_lw_sfc_lds = on; return 0; }
 
+int rte_hip_lw_solver_noscat_factored(int ncol, int nlay, int ngpt, int nbnd, int top_at_1, int nmus, const Float* Ds,
+                                      const Float* weights, const int* band_lims_gpt, const Float* tau, const Float* pfrac,
+                                      const Float* planck_lay, const Float* planck_lev, const Float* sfc_emis, const Float* sfc_src,
+                                      const Float* inc_flux, Float* broadband_up, Float* broadband_dn, int do_jac,
+                                      const Float* sfc_srcJac, Float* flux_upJac);
 void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, const Bool* top_at_1,
                           const int* nmus_, const Float* Ds, const Float* weights, const Float* tau,
                           const Float* lay_source, const Float* lev_source, const Float* sfc_emis,
@@ -1991,6 +1996,21 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
   const int ncol = *ncol_, nlay = *nlay_, ngpt = *ngpt_, nmus = *nmus_, nlev = nlay + 1;
   const bool do_broadband = *do_broadband_, do_jac = *do_Jacobians_, do_rescaling = *do_rescaling_;
   if (ncol <= 0 || nlay <= 0 || ngpt <= 0 || nmus <= 0) return;
+  {
+    // deferred sources (rte_hip_defer_sources; runtime.hip, planck.hip): lay_source holds the Planck fraction and a record
+    // names the bands' Planck functions -- solve from the factors (bit-identical fluxes), then leave the record in place so
+    // that a later use of these arrays still finds them expanded
+    rte::PendingSources ps;
+    if (rte::take_pending_sources(lay_source, lev_source, &ps)) {
+      int rc = -2;
+      if (do_broadband && !do_rescaling && ps.ncol == ncol && ps.nlay == nlay && ps.ngpt == ngpt)
+        rc = rte_hip_lw_solver_noscat_factored(ncol, nlay, ngpt, ps.nbnd, *top_at_1 ? 1 : 0, nmus, Ds, weights, ps.band_lims, tau,
+                                               lay_source, (const Float*)ps.plk_lay, (const Float*)ps.plk_lev, sfc_emis, sfc_src,
+                                               inc_flux, broadband_up, broadband_dn, do_jac ? 1 : 0, sfc_srcJac, flux_upJac);
+      rte::defer_sources(ps, nullptr);  // (back on the list: consumed here or expanded by Call::in below)
+      if (rc == 0) return;
+    }
+  }
   RTE_TRY
   rte::Call c("rte_lw_solver_noscat");
   const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * nlev, ncg = (size_t)ncol * ngpt;

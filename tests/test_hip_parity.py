@@ -944,3 +944,59 @@ def test_implicit_asymmetry_parameter_of_clear_sky_sw(hip, nlay, top_at_1, do_br
     for k in keys:
         assert torch.equal(out[0][k], out[1][k]), (k, float((out[0][k] - out[1][k]).abs().max()))
     assert float(out[0][keys[0]].max()) > 0
+
+
+@pytest.mark.parametrize("nlay,top_at_1,nmus,do_jac", [(60, False, 1, False), (72, True, 2, True), (33, True, 1, False)])
+def test_deferred_lw_sources_through_the_reference_symbols(hip, nlay, top_at_1, nmus, do_jac):
+    """rte_hip_defer_sources(1) (RTE_HIP_DEFER_SOURCES=1 for an unchanged binary): rrtmgp_compute_Planck_source on device arrays
+    leaves the factored sources and a record, rte_lw_solver_noscat on exactly these arrays solves from them -- fluxes identical
+    BIT FOR BIT to the plain chain.  Misuse: the arrays handed to another entry point (lw_solver_2stream), read after
+    rte_hip_sync, or a second solve on them all find lay_source / lev_source expanded, bit-identical to the plain call."""
+    import torch
+    from rte_rrtmgp_amd import synth
+
+    kd = synth.make_kdist("lw")
+    ncol = 1500
+    atm = synth.make_atmosphere(ncol, nlay, seed=31, kdist=kd, top_at_1=top_at_1)
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    go = frontend.GasOptics(hip, kd, xp)
+    args = [A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tsfc", "col_gas", "tlev")]
+    emis = xp.full((ncol, kd.ngpt), 0.98)
+
+    def chain(solve=True, second=None):
+        b = {}
+        go.gas_optics_lw(ncol, nlay, *args, atm.top_at_1, buffers=b)
+        rb = {}
+        if solve:
+            frontend.rte_lw(hip, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"], emis, b["sfc_src"], buffers=rb,
+                            n_gauss_angles=nmus, do_jacobians=do_jac, sfc_src_jac=b["sfc_src_jac"] if do_jac else None)
+        if second == "solve_again":
+            rb2 = {}
+            frontend.rte_lw(hip, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"], emis, b["sfc_src"], buffers=rb2)
+            rb["again_up"] = rb2["flux_up"]
+        if second == "two_stream":
+            ssa, g = xp.full((ncol, nlay, kd.ngpt), 0.0), xp.full((ncol, nlay, kd.ngpt), 0.0)
+            rb2 = {}
+            frontend.rte_lw(hip, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"], emis, b["sfc_src"], buffers=rb2,
+                            ssa=ssa, g=g, use_2stream=True)
+            rb["two_up"] = rb2["flux_up"]
+        hiplib.ext_call(hip, "rte_hip_sync", [])
+        torch.cuda.synchronize()
+        out = {k: xp.to_numpy(v).copy() for k, v in rb.items() if v is not None and hasattr(v, "shape")}
+        out["lay_src"], out["lev_src"] = xp.to_numpy(b["lay_src"]).copy(), xp.to_numpy(b["lev_src"]).copy()
+        return out
+
+    plain = {m: chain(True, m) for m in (None, "solve_again", "two_stream")}
+    plain_nosolve = chain(False)
+    try:
+        hiplib.ext_call(hip, "rte_hip_defer_sources", ["i"], 1)
+        for m in (None, "solve_again", "two_stream"):
+            got = chain(True, m)
+            for k, ref in plain[m].items():
+                assert np.array_equal(got[k], ref), (m, k)
+        got = chain(False)  # never solved: rte_hip_sync materialises
+        for k in ("lay_src", "lev_src"):
+            assert np.array_equal(got[k], plain_nosolve[k]), k
+    finally:
+        hiplib.ext_call(hip, "rte_hip_defer_sources", ["i"], 0)
