@@ -27,6 +27,9 @@
 #include <algorithm>
 #include <vector>
 
+#include <ctype.h>
+#include <sched.h>
+
 #include "common.h"
 
 namespace rte {
@@ -139,8 +142,47 @@ static Context* auto_context() {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess) c->own_stream = true;
   return c;
 }
+// RTE_HIP_BIND_NUMA=1 (host-array callers): a thread's first library call pins it to the CPUs of the NUMA node the GPU hangs
+// off, so that the thread, its pageable arrays (first touch) and the pinned staging buffers it allocates stay on the socket
+// whose PCIe root the device is on.  Pass times of the unchanged Fortran frontend on host arrays were bimodal (0.05 s / 0.3 s,
+// whole phases of a run) while the scheduler was free to move the eight OpenMP threads between the sockets of a 256-CPU
+// host.  Opt-in: changing a caller's thread affinity is not something a library does unasked.
+static void bind_thread_to_gpu_node() {
+  static const bool on = getenv("RTE_HIP_BIND_NUMA") && atoi(getenv("RTE_HIP_BIND_NUMA")) > 0;
+  static thread_local bool done = false;
+  if (!on || done) return;
+  done = true;
+  int dev = 0;
+  char bus[64] = {0};
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) return;
+  for (char* q = bus; *q; ++q) *q = (char)tolower(*q);
+  char path[256];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+  int node = -1;
+  if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+  if (node < 0) return;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  cpu_set_t set, allowed;
+  CPU_ZERO(&set);
+  int a = 0, b = 0;
+  char sep = 0;
+  while (fscanf(f, "%d", &a) == 1) {  // "0-63,128-191"
+    b = a;
+    int ch = fgetc(f);
+    if (ch == '-') { if (fscanf(f, "%d", &b) != 1) b = a; ch = fgetc(f); }
+    for (int k = a; k <= b && k < CPU_SETSIZE; ++k) CPU_SET(k, &set);
+    sep = (char)ch;
+    if (sep != ',') break;
+  }
+  fclose(f);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) CPU_AND(&set, &set, &allowed);  // (never beyond what the process may use)
+  if (CPU_COUNT(&set) > 0) (void)sched_setaffinity(0, sizeof(set), &set);
+}
 Context& ctx() {
   if (t_ctx) return *t_ctx;
+  bind_thread_to_gpu_node();
   if (Context* a = auto_context()) { t_ctx = a; return *a; }
   return default_context();
 }
