@@ -237,15 +237,6 @@ __global__ void __launch_bounds__(256) lw_noscat_generic_kernel(LwArgs a) {
 // formed from composites (same mathematics, different rounding: ~1e-16 relative).
 // After the block's g-points: acc * pi * weight -> partial broadband slab for this g-group.
 // ---------------------------------------------------------------------------------------------
-#ifdef LW_TIMING
-// experiment builds only (tools/fastbuild.py lwt:solvers.hip=-DLW_TIMING): s_memtime ticks the waves of lw_noscat_seg_kernel spend per
-// g-point, summed per segment number: [0] issuing the next g-point's loads, [1] pass 1 up to the LDS writes (includes the wait for
-// this g-point's inputs), [2] waiting at the barrier, [3] chains across segments, [4] pass 2
-__device__ unsigned long long lw_clk[8][5];
-#define LW_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define LW_T(k) do { } while (0)
-#endif
 
 template <int L>
 struct SegTile {  // one g-point's inputs for one thread's segment
@@ -320,11 +311,7 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, SegOffsets<L>& o, int ig
     return __builtin_nontemporal_load(reinterpret_cast<const Float*>(reinterpret_cast<const char*>(plane) + off));
 #endif
   };
-#ifdef LW_X_SAMEPLANE  // timing experiment: every g-point reads the first g-point's planes (cache hits; wrong results)
-  const int igp = 0;
-#else
   const int igp = igpt;
-#endif
   const Float* tau = tau_ + ncl * igp;
   const Float* lay = lay_source_ + ncl * igp;
   const Float* lev = lev_source_ + nclv * igp;
@@ -457,9 +444,6 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     }
   };
 
-#ifdef LW_TIMING
-  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
   // One g-point of work on tile `cur` (padded slots are neutral, see seg_load: no predication)
   // `request(i0, i1)`: the next g-point's rows of slots [i0, i1), issued BETWEEN the layer pairs of pass 1 (fenced on both sides).
   // Issued in one burst at the top of the g-point, the block's 200-264 row requests kept every wave stalled at its load
@@ -482,11 +466,7 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       // at the column's ends (and on the repeated bottom level of a partial last segment) both rows are the same row, and the
       // correctly rounded root of the rounded square is the fraction itself (:695 / :705) for every value whose square neither
       // underflows nor overflows -- no select (measured: 18 v_cndmask per g-point and wave in a kernel bound by its issue)
-#ifdef FACT_X_NOSQRT  // timing experiment: what the kernel costs without the nine roots (wrong results)
-      const Float gm = pa * pb;
-#else
       const Float gm = rte::sqrt_cr0(pa * pb);
-#endif
       Float v = gm * PLK[(L + i) * 64];
       asm volatile("" : "+v"(v));
       return v;
@@ -512,12 +492,6 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       t[i] = tr;
       Sd = tr * Sd + sd[i];
       Td = Td * tr;
-#ifdef LW_X_FINE  // experiment: one slot's rows after every layer (the in-place refresh cannot move above the slot's last use)
-      if (i >= 1) request(i - 1, i);
-      if (i == L - 1) request(L - 1, L);
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);
-    }
-#else
       if (i & 1) {
         __builtin_amdgcn_sched_barrier(0);  // bound the interleaving (register pressure) to 2 layers
         request(i - 1, i + 1 == L ? L : i + 1);
@@ -528,7 +502,6 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       request(L - 1, L);
       __builtin_amdgcn_sched_barrier(0);
     }
-#endif
     Float Su = 0;
 #pragma unroll
     for (int i = L - 1; i >= 0; --i) Su = t[i] * Su + su[i];
@@ -539,9 +512,7 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     X[(0 * MAXS + s) * 64 + lane] = Td;
     X[(1 * MAXS + s) * 64 + lane] = Sd;
     X[(2 * MAXS + s) * 64 + lane] = Su;
-    LW_T(1);
     __syncthreads();
-    LW_T(2);
     Float r = cur.inc * inv_piw;  // radiance entering segment 0 from above (:144)
     Float r_in = r;
     Float u, jv;
@@ -576,7 +547,6 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     }
     // the level below the segment's last slot (used only by a FULL last segment: the surface)
     asm volatile("" : "+v"(u), "+v"(r_in));
-    LW_T(3);
     put(acc_up, spec_up, L, u, ig);
     if (do_jac) acc_j[L] += jv;
     // ---- pass 2: down; slot i is the level at the top of layer i.  In a partial last segment the
@@ -642,20 +612,10 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
     for (; igpt < g_stop; ++igpt, buf ^= 1) {
       if (SFCLDS && gl == 0) sfc_fetch(chunk + 1);           // a chunk ahead, behind this g-point's barrier ...
       if (SFCLDS && gl == 1) sfc_publish((chunk + 1) & 1);   // ... written an iteration later, read 14 barriers later
-      LW_T(0);
-#ifdef LW_X_NOLOAD  // timing experiment: no requests after the first g-point's (compute and synchronisation alone; wrong results)
-      process(cur, buf, gl, chunk & 1, igpt, [&](int, int) {});
-#else
       process(cur, buf, gl, chunk & 1, igpt, [&](int i0, int i1) { load(cur, igpt + 1, i0, i1); });
-#endif
-      LW_T(4);
       if (++gl == CH) { gl = 0; ++chunk; }
     }
   }
-#ifdef LW_TIMING
-  if (lane == 0)
-    for (int k = 0; k < 5; ++k) atomicAdd(&lw_clk[s][k], tacc[k]);
-#endif
   // ---- partial broadband for this g-group: (ncol, nlev, ngroups)
   if (active && (!SPEC || do_jac)) {
     const size_t base = icol + nclv * blockIdx.y;
@@ -736,14 +696,8 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
 #pragma clang fp contract(fast)
   constexpr int LT = 2 * L, MAXS = 8;
   // input prefetch (see process): kept where it fits; the widest variant and the Jacobian variants spilled 39-103 registers
-  // with it and run without (-DLW2_PREF_ALL / -DLW2_PREF_NONE for the A/B)
-#if defined(LW2_PREF_ALL)
-  constexpr bool PREF2 = true;
-#elif defined(LW2_PREF_NONE)
+  // with it and run without
   constexpr bool PREF2 = false;
-#else
-  constexpr bool PREF2 = false;
-#endif
   extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][MAXS][64], then A's parked values [3][L][512]
   const int lane = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1188,15 +1142,6 @@ struct Sw2SegArgs {
 // SPEC: spectral output (rte_sw with a ty_fluxes other than ty_fluxes_broadband, rte/frontend/mo_rte_sw.F90): every wave
 // stores the three fluxes of the levels it owns per g-point instead of accumulating them
 
-#ifdef SW_TIMING
-// experiment builds only (tools/fastbuild.py swt:solvers.hip=-DSW_TIMING): s_memtime ticks the waves of sw_2stream_seg_kernel spend
-// in each phase of a g-point, summed per segment number: [wave][0] pass 1 + composite, [1] waiting at the first barrier,
-// [2] beam + adding chain, [3] own layers + downward composite, [4] waiting at the second barrier, [5] final sweep
-__device__ unsigned long long sw_clk[8][6];
-#define SW_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define SW_T(k) do { } while (0)
-#endif
 // G0: the asymmetry parameter is zero everywhere and its array does not exist (g == NULL in rte_sw_solver_2stream: clear-sky optical
 // properties as rte_hip_gas_optics_sw_2str leaves them without a g array) -- nothing is read for it and the terms it multiplies are
 // dropped as written (5 + 3 * 0, 1 - 0, 0.75 mu0 * 0): the same bits as with an array of zeros.
@@ -1234,14 +1179,8 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
   // most of each other's wait for a g-point's first inputs.  Where it does not fit it costs far more than it gives: the
   // spectral-output variants spilled (17.7 -> 15.6 ms at 60 layers, 31.1 -> 17.9 ms at 72 without it), and 10 ... 12 layers
   // per wave (73 ... 96 layers) spilled 61-112 registers and ran at 244-320 us per layer -- without the prefetch they run at
-  // the 100-108 us per layer of the others (-DSW_PREF_ALL / -DSW_PREF_NONE for the A/B).
-#if defined(SW_PREF_ALL)
-  constexpr bool PREF = true;
-#elif defined(SW_PREF_NONE)
-  constexpr bool PREF = false;
-#else
+  // the 100-108 us per layer of the others.
   constexpr bool PREF = L <= 9 && !SPEC && !WIN;
-#endif
   constexpr bool DIRLDS = (L <= 9 || L >= 11) && !SPEC;  // the direct-flux accumulators in LDS (ds_add_f64 on the thread's own slots): 2L+2 registers
   // L == 9 (72 layers) is 15 registers over: the upward-flux accumulators go to LDS as well, and to make room there
   // only ONE value per layer is parked (the reciprocal is formed again per g-point, 6 instructions per layer)
@@ -1336,9 +1275,6 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     x.inc_dif = a.has_dif_bc ? at(a.inc_flux_dif + cg, ocg) : (Float)0;  // :579-583
   };
 
-#ifdef SW_TIMING
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
   auto process = [&](In& x, int igpt_next) {
 #pragma clang fp contract(fast)
     Float R[L], T[L], su[L], sd[L];  // Rdif, Tdif, source up / down (relative to the beam entering the segment)
@@ -1432,9 +1368,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     X1[(5 * SMAX + s) * 64 + lane] = m12;
     X1[(6 * SMAX + s) * 64 + lane] = m20;
     X1[(7 * SMAX + s) * 64 + lane] = m22;
-    SW_T(0);
     __syncthreads();
-    SW_T(1);
     // comparisons with the wave's segment number stay scalar instructions inside the loop: hoisted out of it they became 64-bit
     // masks in spilled scalar registers (two v_readlane in front of every branch)
     int s_u = s, S_u = S;
@@ -1467,7 +1401,6 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     }
     Float src = sig * (dir_in * P_own);  // the beam leaving this segment
     asm volatile("" : "+v"(src), "+v"(alb));
-    SW_T(2);
     // ---- own layers, bottom -> top, the reference's expressions (:1174-1186 / :1214-1226); the beam at the
     // levels is accumulated on the way (direct flux, and the direct part of flux_dn, :603,:606)
     Float al[L + 1], sr[L + 1];  // albedo and source at the levels of the segment (slot i = top of layer i)
@@ -1495,9 +1428,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     for (int i = 0; i < L; ++i) { B = fa[i] * B + fb[i]; A = fa[i] * A; }
     X2[(0 * SMAX + s) * 64 + lane] = A;
     X2[(1 * SMAX + s) * 64 + lane] = B;
-    SW_T(3);
     __syncthreads();
-    SW_T(4);
     // ---- (3) diffuse flux entering the segment from above, final sweep (:1188-1202 / :1228-1243)
     Float fd = inc_dif;
     {
@@ -1534,12 +1465,7 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
     gcur = igpt;
     if constexpr (!PREF) load(cur, igpt);
     process(cur, igpt + 1);
-    SW_T(5);
   }
-#ifdef SW_TIMING
-  if (lane == 0)
-    for (int k = 0; k < 6; ++k) atomicAdd(&sw_clk[s][k], tacc[k]);
-#endif
   if constexpr (SPEC) return;
   if (active) {
     const size_t base = icol + nclp * blockIdx.y;
@@ -2696,21 +2622,3 @@ int rte_hip_sw_solver_2stream_byband(int ncol, int nlay, int ngpt, int nbnd, int
 }  // extern "C"
 
 
-#ifdef LW_TIMING
-extern "C" int rte_hip_lw_timing(unsigned long long* out /*[8][5]*/) {
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(lw_clk), sizeof(unsigned long long) * 40);
-  unsigned long long z[40] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(lw_clk), z, sizeof(z));
-  return 0;
-}
-#endif
-#ifdef SW_TIMING
-extern "C" int rte_hip_sw_timing(unsigned long long* out /*[8][6]*/) {
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(sw_clk), sizeof(unsigned long long) * 48);
-  unsigned long long z[48] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(sw_clk), z, sizeof(z));
-  return 0;
-}
-#endif

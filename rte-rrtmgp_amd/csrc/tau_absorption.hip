@@ -455,15 +455,6 @@ static void tau_absorption_impl(
   RTE_CATCH(api_name)
 }
 
-#ifdef TAU_TIMING  // experiment builds only (tools/time_tau_phases.py)
-extern "C" int rte_hip_tau_timing(unsigned long long* out /*[16]*/) {
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(tau_clk), sizeof(unsigned long long) * 16);
-  unsigned long long z[16] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(tau_clk), z, sizeof(z));
-  return 0;
-}
-#endif
 extern "C" {
 void rrtmgp_compute_tau_absorption(
     const int* ncol_, const int* nlay_, const int* nbnd_, const int* ngpt_, const int* ngas_,

@@ -52,14 +52,6 @@ struct SlabStage { int b, emin, nE, rowsMaj, rowsLo, rowsUp, rowsAll, g0; };  //
 struct alignas(16) SlabPeek { int idx[4], isc[4], n, bits, flav[2]; };
 constexpr int SLAB_MAXSTAGE = 32;  // ngpt / G the kernel handles (host-checked)
 
-#ifdef TAU_TIMING
-// experiment builds only (tools/time_tau_phases.py): s_memtime ticks per phase of a stage, [0..7] the waves that store at
-// the end of a stage, [8..15] the rotated ones
-__device__ unsigned long long tau_clk[16];
-#define TAU_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define TAU_T(k) do { } while (0)
-#endif
 
 // OVERWRITE: tau is known to be zero on entry (deferred zero fill, or the zero test said so); otherwise the stage's sums
 //   are added to the incoming values with fp64 atomics in L2.
@@ -384,9 +376,6 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   load_minor_w(nq, mw);
   // Nothing outstanding when the loop is entered: the wait counts inside it are then those of the steady state
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#ifdef TAU_TIMING
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
 #pragma unroll 1
   for (int s = 0; s < nstage; ++s) {
     const SlabStage cur = get_stage(s);
@@ -408,15 +397,12 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #pragma unroll
     for (int k = 0; k < MM; ++k)
       if (__builtin_amdgcn_ballot_w64(((cq_bits >> (4 * k)) & 1) != 0) != 0) nslot = k + 1;
-    TAU_T(6);
     __syncthreads();  // B(s): slab(s) is complete, and every wave is done with the other buffer
-    TAU_T(0);
     const int b_next = __builtin_amdgcn_readfirstlane(s_stage[s + 1].b);
     const int rows_next = __builtin_amdgcn_readfirstlane(s_stage[s + 1].rowsAll);
     PVec pv;
     stage_load(s + 1, rows_next, pv);  // slab(s+1), for the buffer just released
     stage_rest(s + 1, rows_next);
-    TAU_T(5);
     if constexpr (ROT) {
       if (ALLRUN ? s > 0 : have_prev) flush(g0_prev, addv_prev);
       have_prev = false;
@@ -466,7 +452,6 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     auto tau_at = [&](int j) { return reinterpret_cast<Float*>(tplane + gstride * j + toff); };
 #pragma unroll
     for (int j = 0; j < G; ++j) acc[j] = 0;
-    TAU_T(1);
     // ================= ONE rolling pipeline of LDS row reads through the stage =================
     const Float f0 = fn0.x, f1 = fn0.y, f2 = fn1.x, f3 = fn1.y;
     Float2 kb[DEPTH][4];
@@ -513,7 +498,6 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    TAU_T(2);
     // the minor intervals of this lane: scalings (:461-480), 0 for a slot that is not this lane's or not this stage's
     Float scl[MM];
 #pragma unroll
@@ -561,7 +545,6 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       }
       c1 = n1; c2 = n2;
     }
-    TAU_T(3);
     // the next slab's pieces, requested behind the barrier, have had the stage to arrive (written after the major pass --
     // 32 registers fewer through the minor pass -- the wave waits here for pieces that queue behind the previous stage's stores)
     stage_write(s + 1, rows_next, pv);
@@ -630,11 +613,6 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   if constexpr (ROT) {
     if (ALLRUN ? nstage > 0 : have_prev) flush(g0_prev, addv_prev);
   }
-#ifdef TAU_TIMING
-  TAU_T(6);
-  if ((tid & 63) == 0)
-    for (int k = 0; k < 7; ++k) atomicAdd(&tau_clk[k + (ROT ? 8 : 0)], tacc[k]);
-#endif
   };
   // the fused variants end a stage with LDS reads of their own slab and cannot rotate
   constexpr bool ROTATE = RAYL == 0;
