@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # bench.py's kernel groups <- the kernels whose traffic belongs to them (the call's helpers included)
 GROUPS = {
     "interpolation_kernel": ("interpolation_kernel",),
-    "tau_absorption_kernel": ("tau_absorption_v9_kernel", "tau_absorption_worklist_kernel", "tile_geom2_kernel",
+    "tau_absorption_kernel": ("tau_slab_kernel", "tau_absorption_worklist_kernel", "tile_geom2_kernel",
                               "tau_setup_kernel", "tau_absorption_kernel"),
     "planck_source_kernel": ("planck_source_v9_kernel", "planck_source_worklist_kernel", "planck_flags_kernel",
                              "planck_source_kernel", "relayout_gfast_kernel"),
@@ -19,7 +19,7 @@ GROUPS = {
 }
 
 
-MAIN = {"interpolation_kernel": "interpolation_kernel", "tau_absorption_kernel": "tau_absorption_v9_kernel",
+MAIN = {"interpolation_kernel": "interpolation_kernel", "tau_absorption_kernel": "tau_slab_kernel",
         "planck_source_kernel": "planck_source_v9_kernel", "lw_noscat_seg_kernel": "lw_noscat_seg_kernel"}
 
 
