@@ -890,6 +890,28 @@ def main():
                                                          "when no fused extension kernel runs, i.e. for the LW headline)"}},
                     "profile_backed": profile_backed,
                     "per_kernel": per_kernel, "other_kernels_avg_ms": others}
+            # the SW two-stream solver is bound by fp64 instruction ISSUE, not by HBM: state that roofline beside the HBM one.
+            # VALU instructions per launch from the committed SQ counters (profiles/*_sw_pmc_summary.csv, SQ_INSTS_VALU of the
+            # 60-layer kernel at 1e5 columns x 224 g-points), 4 cycles per wave64 instruction on one of 1024 SIMDs at 2.4 GHz
+            if "sw_2stream_seg_kernel" in per_kernel and args.workload == "sw":
+                try:
+                    import csv
+                    import glob as _glob
+
+                    fcsv = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_sw_pmc_summary.csv")))[-1]
+                    valu = [float(r_["SQ_INSTS_VALU"]) for r_ in csv.DictReader(open(fcsv)) if r_["kernel"].startswith("sw_2stream_seg_kernel<8")][0]
+                    scale = ncol * NLAY * kd.ngpt / (100000 * 60 * 224)
+                    issue_ms = valu * scale * 4 / (1024 * 2.4e9) * 1e3
+                    ms_ = per_kernel["sw_2stream_seg_kernel"]["avg_ms"]
+                    roof["fp64_issue"] = {"kernel": "sw_2stream_seg_kernel", "bound": "fp64 VALU issue", "valu_instructions_per_launch": valu * scale,
+                                          "valu_instructions_per_gpoint_and_wave": round(valu / (1563 * 224 * 8), 1),
+                                          "issue_ms_at_peak": round(issue_ms, 3), "measured_ms": ms_, "frac_of_issue_peak": round(issue_ms / ms_, 4),
+                                          "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (= 78.6 TFLOP/s of fp64 FMA)",
+                                          "source": os.path.relpath(fcsv, ROOT),
+                                          "note": "this kernel's HBM fraction (roofline.per_kernel) is low because it is compute-bound: "
+                                                  "every fp64 and integer vector instruction of a wave occupies its SIMD for 4 cycles"}
+                except Exception:  # noqa: BLE001
+                    pass
         res = {
             "metric": {"lw": "columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)",
                        "sw": "columns/sec (SW gas-optics + sw_solver_2stream, 224 gpt x 60 lay)",
