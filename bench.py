@@ -907,6 +907,9 @@ def main():
                                           "valu_instructions_per_gpoint_and_wave": round(valu / (1563 * 224 * 8), 1),
                                           "issue_ms_at_peak": round(issue_ms, 3), "measured_ms": ms_, "frac_of_issue_peak": round(issue_ms / ms_, 4),
                                           "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (= 78.6 TFLOP/s of fp64 FMA)",
+                                          # rocm-smi beside tools/loop_sw.py (tools/clocks_beside.sh): the kernel runs at the package power limit
+                                          "observed_sclk_GHz": 2.05, "issue_ms_at_observed_clock": round(issue_ms * 2.4 / 2.05, 3),
+                                          "frac_at_observed_clock": round(issue_ms * 2.4 / 2.05 / ms_, 4),
                                           "source": os.path.relpath(fcsv, ROOT),
                                           "note": "this kernel's HBM fraction (roofline.per_kernel) is low because it is compute-bound: "
                                                   "every fp64 and integer vector instruction of a wave occupies its SIMD for 4 cycles"}
