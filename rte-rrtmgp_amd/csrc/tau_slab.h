@@ -23,6 +23,8 @@
 //   * half of the waves keep a stage's sums in registers across the next barrier and store them then ("rotated"), so the
 //     two halves of the block are never in the store phase together; the unrotated half plans the rows while it would
 //     otherwise wait at the barrier.
+//   * a tile whose columns are all in one regime at its layer walks the bands sorted by that regime's flavor, and a stage
+//     of the previous stage's flavor keeps the flavor weights in registers: they are read once per flavor, not per band.
 // Vector-memory operations of a wave retire in order, which fixes where things are requested: see the stage loop.
 // (tile, layer, band) items whose box exceeds the slab are left to the direct-gather worklist kernel (tau_absorption.hip).
 #pragma once

@@ -436,6 +436,43 @@ def test_production_kernels_at_the_real_table_shape_against_the_oracle(hip, orac
             assert cases.elem_err(got, outs["oracle"][k], 1e-8) <= ETOL_GAS, (kind, k, "one-pass")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nflav,top_at_1", [("lw", 2, False), ("lw", 3, True), ("sw", 2, True), ("lw", 1, False)])
+def test_bands_that_share_a_flavor_keep_their_weights(hip, oracle_c, kind, nflav, top_at_1):
+    """Tables with FEW flavors: the slab kernel walks a single-regime tile's bands sorted by flavor and keeps the flavor weights
+    in registers across stages of one flavor -- with 1 ... 3 flavors over 14 / 16 bands nearly every stage does, in the table
+    order too (tiles at the tropopause, both regimes' flavors unchanged from band to band).  tau (SW: tau_abs, tau_rayleigh,
+    and tau / ssa of the one-pass form) element by element against the C oracle."""
+    from rte_rrtmgp_amd import synth
+
+    kd = synth.make_kdist(kind, nflav=nflav)
+    ncol, nlay = 1024, 60
+    atm = synth.make_atmosphere(ncol, nlay, seed=5, kdist=kd, top_at_1=top_at_1)
+    xp, xn = frontend.TorchArrays("cuda:0"), frontend.NumpyArrays()
+    A = xp.asarray
+    outs = {}
+    for mode, lib, arr, conv in (("hip", hip, xp, A), ("oracle", oracle_c, xn, (lambda v: v))):
+        go = frontend.GasOptics(lib, kd, arr)
+        if kind == "lw":
+            b = go.gas_optics_lw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.tsfc), conv(atm.col_gas),
+                                 conv(atm.tlev), atm.top_at_1)
+            keys = ("tau", "lay_src")
+        else:
+            b = go.gas_optics_sw(ncol, nlay, conv(atm.play), conv(atm.plev), conv(atm.tlay), conv(atm.col_gas), conv(atm.col_dry))
+            keys = ("tau_abs", "tau_rayleigh", "tau", "ssa")
+        outs[mode] = {k: np.array(arr.to_numpy(b[k])) for k in keys if b.get(k) is not None}
+    assert hiplib.ext_call(hip, "rte_hip_stat", ["i"], 2) in (1, 2)  # (the slab kernel ran: its tile geometry was derived)
+    for k, ref in outs["oracle"].items():
+        got = outs["hip"][k]
+        assert np.isfinite(got).all(), (kind, k)
+        assert cases.elem_err(got, ref, 1e-8) <= ETOL_GAS, (kind, nflav, k, cases.elem_err(got, ref, 1e-8))
+    if kind == "sw":
+        go = frontend.GasOptics(hip, kd, xp)
+        b = go.gas_optics_sw(ncol, nlay, A(atm.play), A(atm.plev), A(atm.tlay), A(atm.col_gas), A(atm.col_dry), fuse_rayleigh="all")
+        for k in ("tau", "ssa"):
+            assert cases.elem_err(np.array(xp.to_numpy(b[k])), outs["oracle"][k], 1e-8) <= ETOL_GAS, (kind, k, "one-pass")
+
+
 def test_plans_follow_tables_changed_in_place(hip, oracle_c):
     """The host-side plans of the production kernels are cached per table ADDRESS; the device-side plan guards must
     notice tables whose CONTENTS changed behind those addresses (no rte_hip_invalidate_plans()): the call then runs
