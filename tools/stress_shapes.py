@@ -8,8 +8,10 @@ worst = 0.0
 SHARE = "share" in sys.argv[1:]  # production runs with the opt-in driver modes: deferred zero fill + geometry sharing (masks
                                  # from the interpolation call, ragged last blocks included)
 RAGGED = "ragged" in sys.argv[1:]  # tables with 0 ... 8 minor intervals per band and regime (the tail pass of the tau kernel)
+NFLAV = 2 if "fewflav" in sys.argv[1:] else 10  # two flavors: nearly every stage keeps the previous stage's weights (tau_slab.h)
 for kind, ncol, nlay, top in itertools.product(("lw", "sw"), (512, 513, 1023, 1537), (1, 2, 7, 33, 64, 65, 100), (False, True)):
-    kd = synth.make_kdist(kind, ngpt=128, nbnd=8, minor_distribution="ragged") if RAGGED else synth.make_kdist(kind, ngpt=64, nbnd=4)
+    kd = (synth.make_kdist(kind, ngpt=128, nbnd=8, nflav=NFLAV, minor_distribution="ragged") if RAGGED
+          else synth.make_kdist(kind, ngpt=64, nbnd=4, nflav=NFLAV))
     atm = synth.make_atmosphere(ncol, nlay, seed=ncol + nlay, kdist=kd, top_at_1=top)
     outs = []
     for direct in (0, 1):
