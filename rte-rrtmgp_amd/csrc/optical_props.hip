@@ -214,55 +214,67 @@ struct CldFused {
   const Float *lext, *lssa, *lasy, *iext, *issa, *iasy;  // (nsteps, nbnd)
   Float *tau, *ssa, *g;
 };
-__device__ __forceinline__ void cld_lookup(bool on, Float wp, Float re, Float offset, Float step_size, int nsteps, int ibnd,
-                                           const Float* __restrict__ te, const Float* __restrict__ ts_, const Float* __restrict__ ta,
-                                           Float& tau, Float& taussa, Float& taussag) {
+// index and interpolation weight of one phase's table for this cell (:334-341 of the frontend's masks, compute_cld_from_table)
+struct CldIdx { bool on; Float wp, fint; int o; };
+__device__ __forceinline__ CldIdx cld_index(Float wp, Float re, Float offset, Float step_size, int nsteps) {
+  CldIdx r;
+  r.on = wp > (Float)0; r.wp = wp;
+  const Float x = (re - offset) / step_size;
+  const int index = r.on ? min((int)floor(x) + 1, nsteps - 1) : 1;  // 1-based (a cell without this phase reads row 1: never used)
+  r.fint = x - (Float)(index - 1);
+  r.o = index - 1;
+  return r;
+}
+__device__ __forceinline__ void cld_lookup(const CldIdx& q, int nsteps, int ibnd, const Float* __restrict__ te, const Float* __restrict__ ts_,
+                                           const Float* __restrict__ ta, Float& tau, Float& taussa, Float& taussag) {
   tau = 0; taussa = 0; taussag = 0;
-  if (on) {
-    const Float x = (re - offset) / step_size;
-    const int index = min((int)floor(x) + 1, nsteps - 1);  // 1-based
-    const Float fint = x - (Float)(index - 1);
-    const size_t o = (size_t)nsteps * ibnd + (index - 1);
-    const Float t = wp * (te[o] + fint * (te[o + 1] - te[o]));
-    const Float ts = t * (ts_[o] + fint * (ts_[o + 1] - ts_[o]));
-    taussag = ts * (ta[o] + fint * (ta[o + 1] - ta[o]));
+  if (q.on) {
+    const size_t o = (size_t)nsteps * ibnd + q.o;
+    const Float t = q.wp * (te[o] + q.fint * (te[o + 1] - te[o]));
+    const Float ts = t * (ts_[o] + q.fint * (ts_[o + 1] - ts_[o]));
+    taussag = ts * (ta[o] + q.fint * (ta[o + 1] - ta[o]));
     taussa = ts;
     tau = t;
   }
 }
+// thread = one (column, layer) cell, the bands walked inside it: the four cloud fields are read once (as a grid dimension the
+// bands' blocks ran far apart and re-read them per band: 784 B moved per cell for 368 B of inputs and outputs), the table row
+// and weight of a phase are formed once, and a wave without cloud in any of its cells only stores
 template <bool TWOSTR, bool DELTA>
 __global__ void __launch_bounds__(256) cloud_optics_fused_kernel(CldFused a) {
   const int cl = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ibnd = blockIdx.y;
   if (cl >= a.ncl) return;
-  const Float lwp = a.clwp[cl], iwp = a.ciwp[cl];
-  Float lt, lts, ltsg, it, its, itsg;
-  cld_lookup(lwp > (Float)0, lwp, a.reliq[cl], a.liq_off, a.liq_step, a.liq_nsteps, ibnd, a.lext, a.lssa, a.lasy, lt, lts, ltsg);
-  cld_lookup(iwp > (Float)0, iwp, a.deice[cl], a.ice_off, a.ice_step, a.ice_nsteps, ibnd, a.iext, a.issa, a.iasy, it, its, itsg);
-  const size_t i = (size_t)cl + (size_t)a.ncl * ibnd;
-  if (!TWOSTR) {
-    a.tau[i] = (lt - lts) + (it - its);
-    return;
-  }
-  const Float t = lt + it;
-  const Float ts = lts + its;
+  const CldIdx ql = cld_index(a.clwp[cl], a.reliq[cl], a.liq_off, a.liq_step, a.liq_nsteps);
+  const CldIdx qi = cld_index(a.ciwp[cl], a.deice[cl], a.ice_off, a.ice_step, a.ice_nsteps);
 #ifdef RTE_USE_SP
   const Float eps = 1.1920929e-07f;  // epsilon(tau)
 #else
   const Float eps = 2.220446049250313e-16;
 #endif
-  Float g = (ltsg + itsg) / fmax(eps, ts);
-  Float ssa = ts / fmax(eps, t);
-  Float tau = t;
-  if (DELTA) {  // delta_scale_2str_k, rte/kernels/mo_optical_props_kernels.F90:76-98
-    const Float f = g * g;
-    const Float wf = ssa * f;
-    tau = ((Float)1 - wf) * tau;
-    const Float ssa_new = (ssa - wf) / fmax(kEps, ((Float)1 - wf));
-    g = (g - f) / fmax(kEps, ((Float)1 - f));
-    ssa = ssa_new;
+  for (int ibnd = 0; ibnd < a.nbnd; ++ibnd) {
+    Float lt, lts, ltsg, it, its, itsg;
+    cld_lookup(ql, a.liq_nsteps, ibnd, a.lext, a.lssa, a.lasy, lt, lts, ltsg);
+    cld_lookup(qi, a.ice_nsteps, ibnd, a.iext, a.issa, a.iasy, it, its, itsg);
+    const size_t i = (size_t)cl + (size_t)a.ncl * ibnd;
+    if (!TWOSTR) {
+      rte::store_stream(a.tau + i, (lt - lts) + (it - its));
+      continue;
+    }
+    const Float t = lt + it;
+    const Float ts = lts + its;
+    Float g = (ltsg + itsg) / fmax(eps, ts);
+    Float ssa = ts / fmax(eps, t);
+    Float tau = t;
+    if (DELTA) {  // delta_scale_2str_k, rte/kernels/mo_optical_props_kernels.F90:76-98
+      const Float f = g * g;
+      const Float wf = ssa * f;
+      tau = ((Float)1 - wf) * tau;
+      const Float ssa_new = (ssa - wf) / fmax(kEps, ((Float)1 - wf));
+      g = (g - f) / fmax(kEps, ((Float)1 - f));
+      ssa = ssa_new;
+    }
+    rte::store_stream(a.tau + i, tau); rte::store_stream(a.ssa + i, ssa); rte::store_stream(a.g + i, g);
   }
-  a.tau[i] = tau; a.ssa[i] = ssa; a.g[i] = g;
 }
 }  // namespace
 
@@ -406,7 +418,7 @@ int rte_hip_cloud_optics_fused(int ncol, int nlay, int nbnd, int twostr, int del
   a.ssa = twostr ? c.out(ssa, ncl * nbnd) : nullptr;
   a.g = twostr ? c.out(g, ncl * nbnd) : nullptr;
   rte::ProfScope p("cloud_optics_fused_kernel");
-  const dim3 grid(cdiv(ncl, 256), nbnd), blk(256);
+  const dim3 grid(cdiv(ncl, 256)), blk(256);
   if (!twostr) hipLaunchKernelGGL((cloud_optics_fused_kernel<false, false>), grid, blk, 0, rte::stream(), a);
   else if (delta_scale) hipLaunchKernelGGL((cloud_optics_fused_kernel<true, true>), grid, blk, 0, rte::stream(), a);
   else hipLaunchKernelGGL((cloud_optics_fused_kernel<true, false>), grid, blk, 0, rte::stream(), a);
