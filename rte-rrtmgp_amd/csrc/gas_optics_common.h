@@ -131,6 +131,11 @@ relayout_gfast_kernel(int TE, int nouter, int ng, const Float* __restrict__ in, 
 // -------------------------------------------------------------------------------------------
 constexpr int MAXM = 12;   // minor intervals per (band, regime) handled by the production kernels; more -> native kernel
 constexpr int MAXB = 32;   // bands
+// calls of a few thousand columns: the tau and Planck kernels split a (tile, layer) / (tile, band) pair's work over several
+// blocks until about this many blocks are in the grid (two per CU)
+#ifndef RTE_SMALL_GRID_BLOCKS
+#define RTE_SMALL_GRID_BLOCKS 512u
+#endif
 
 struct MinorMeta {  // one minor interval
   int mS, mE, idx_minor, idx_scaling, kstart, flags /*1: scales with density, 2: by complement*/;

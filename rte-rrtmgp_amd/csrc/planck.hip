@@ -174,7 +174,11 @@ planck_flags_kernel(const TileGeom* __restrict__ geom, int tiles, int nlay, int 
 
 // FACT: factored output -- the Planck fraction goes to lay_src as it is (16 stores per stage instead of 32), the band's Planck
 // function at the layer and level temperatures to plk_lay / plk_lev (once per band), nothing to lev_src.
-template <int NCW, int NLW, int SLAB, int G, bool FACT = false>
+// LCH: the layers are dealt to gridDim.y blocks per (tile, band) -- for calls of a few thousand columns, whose (tile, band) pairs
+// do not fill the chip and whose time is then one block's walk over all layers (1 024 columns: 32 blocks, 244 us).  A block
+// whose range starts inside the column first forms the Planck fractions of the layer above it (they enter the geometric mean at
+// its first level, :699) and stores nothing for that layer; the same operations on the same values as the walk in one piece.
+template <int NCW, int NLW, int SLAB, int G, bool FACT = false, bool LCH = false>
 __global__ void __launch_bounds__((NCW + NLW) * 64, (NCW + NLW + 3) / 4)
 planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* __restrict__ geom,
                         const int* __restrict__ flags) {
@@ -190,9 +194,10 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
   // same time and share the tile's index arrays and, per flavor, its interpolation weights in the caches
   // XCD-aware: workgroups go to the 8 XCDs round-robin by linear id, so (id % 8) picks the XCD and the
   // sequence id / 8 on one XCD walks the bands of one tile before the next tile
+  // (LCH -- few tiles -- takes the blocks as they come: pinned, two tiles would use two of the eight XCDs)
   const unsigned lin = blockIdx.x, xcd = lin % 8, seq = lin / 8;
-  const int ibnd = (int)(seq % (unsigned)nbnd);
-  const unsigned tile = (seq / (unsigned)nbnd) * 8 + xcd;
+  const int ibnd = (int)((LCH ? lin : seq) % (unsigned)nbnd);
+  const unsigned tile = LCH ? lin / (unsigned)nbnd : (seq / (unsigned)nbnd) * 8 + xcd;
   if (tile >= ntiles) return;  // block-uniform (grid padded to a multiple of 8 tiles)
   if (flags[tile * nbnd + ibnd]) return;  // block-uniform: the direct kernel does this (tile, band)
   const unsigned ncol = a.ncol, nlay = a.nlay;
@@ -211,7 +216,11 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
   // fractions are still in registers -- the surface layer once more for sfc_source (keeps those stores and
   // their addresses out of the layer loop)
   const int lsfc = a.sfc_lay - 1;
-  const int spc = (int)nlay + (lsfc == (int)nlay - 1 ? 0 : 1);
+  // this block's layers [lb, le); lw0: the first layer it walks (lb - 1 for the fractions above its first level)
+  const int lb = LCH ? (int)((blockIdx.y * nlay) / gridDim.y) : 0, le = LCH ? (int)(((blockIdx.y + 1) * nlay) / gridDim.y) : (int)nlay;
+  const bool lastc = !LCH || blockIdx.y == gridDim.y - 1;  // the block with the last layer: top level, surface source
+  const int lw0 = lb > 0 ? lb - 1 : 0, nwalk = le - lw0;
+  const int spc = nwalk + ((lastc && lsfc != (int)nlay - 1) ? 1 : 0);
   const int nstage = nchunk * spc;
 
   if (tid >= TILE) {
@@ -224,7 +233,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
     constexpr int SB = 8;  // 16-byte pieces per lane requested back to back
 #pragma unroll 1
     for (int s = 0; s < nstage; ++s) {
-      const int ls = s % spc, l = ls < (int)nlay ? ls : lsfc, g0 = gptS + (s / spc) * G;
+      const int ls = s % spc, l = ls < nwalk ? lw0 + ls : lsfc, g0 = gptS + (s / spc) * G;
       const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], nP = gl[l][3], emin = gl[l][4], nE = gl[l][5];
       const float inv_nE = 1.0f / (float)nE, inv_nT = 1.0f / (float)nT;
       const int nAll = nP * nT * nE * (G / 2);
@@ -291,16 +300,17 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
   int s = 0;
 #pragma unroll 1
   for (int g0 = gptS; g0 <= gptE; g0 += G) {
-    load_idx(0, x0);
-    load_idx(min(1u, nlay - 1), x1);
-    load_wts(0, x0, w0);
+    load_idx((unsigned)lw0, x0);
+    load_idx(min((unsigned)lw0 + 1u, nlay - 1), x1);
+    load_wts((unsigned)lw0, x0, w0);
 #pragma unroll
     for (int j = 0; j < G; ++j) prev[j] = 0;
     // nothing outstanding at loop entry: the wait counts inside are then those of the steady state (requests of
     // the following layers, then this layer's 32 stores), not their merge with this prologue
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll 1
-    for (unsigned l = 0; l < nlay; ++l, ++s) {
+    for (unsigned l = (unsigned)lw0; l < (unsigned)le; ++l, ++s) {
+      const bool st_ = !LCH || (int)l >= lb;  // (block-uniform) false: the layer above this block's range, nothing is stored
       // this layer's values into locals, then request the following layers' inputs
       const Float f0 = w0.fm[0].x, f1 = w0.fm[0].y, f2 = w0.fm[1].x, f3 = w0.fm[1].y, f4 = w0.fm[2].x, f5 = w0.fm[2].y,
                   f6 = w0.fm[3].x, f7 = w0.fm[3].y;
@@ -326,7 +336,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
       char* const plev_ = reinterpret_cast<char*>(a.lev_src + (size_t)nclv * g0);
       const size_t slay = (size_t)ncl * sizeof(Float), slev = (size_t)nclv * sizeof(Float);
       if constexpr (FACT) {
-        if (g0 == gptS) {  // (block-uniform; unconditional across lanes like the other stores)
+        if (g0 == gptS && st_) {  // (block-uniform; unconditional across lanes like the other stores)
           store_stream(reinterpret_cast<Float*>(reinterpret_cast<char*>(a.plk_lay + (size_t)ncl * ibnd) + olay), pl_lay);
           store_stream(reinterpret_cast<Float*>(reinterpret_cast<char*>(a.plk_lev + (size_t)nclv * ibnd) + olay), pl_lev);
         }
@@ -353,12 +363,14 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
           // addresses: unconditional stores keep the number of outstanding memory operations static, so the
           // wait for the next layer's weights is a counted one instead of a drain of these stores
           if constexpr (FACT) {
-            store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), pf);
+            if (st_) store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), pf);
           } else {
             const Float vlay = pf * pl_lay;                                      // :674
             const Float vlev = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;      // :695,:699
-            store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), vlay);
-            store_stream(reinterpret_cast<Float*>(plev_ + slev * j + olay), vlev);  // level l of (ncol, nlay+1): same column offset
+            if (st_) {
+              store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), vlay);
+              store_stream(reinterpret_cast<Float*>(plev_ + slev * j + olay), vlev);  // level l of (ncol, nlay+1): same column offset
+            }
           }
           prev[j] = pf;
         }
@@ -366,6 +378,7 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
         __builtin_amdgcn_sched_barrier(0);   // at most 8 row reads (32 VGPRs) in flight
       }
     }
+    if (!lastc) continue;  // (block-uniform)
     if (valid) {
       const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
       if constexpr (FACT) {
@@ -601,6 +614,9 @@ static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, i
     ga.jeta = d_jeta; ga.jtemp = d_jtemp; ga.jpress = d_jpress; ga.tropo = d_tropo; ga.band_lims = d_band_lims;
     ga.gpoint_flavor = d_gpoint_flavor; ga.worklist = v.worklist; ga.flags = d_flags; ga.skip_if = guard;
     ga.skip_if2 = shared ? gs().shared.valid : nullptr;  // (set on the device by that call's geometry kernel, if it ran)
+    // few (tile, band) pairs (calls of some thousand columns): the layers of a pair go to several blocks, at least 8 each,
+    // until about two blocks per CU are in the grid (planck_source_v9_kernel, LCH)
+    const int lchunks = (int)std::max(1u, std::min((unsigned)nlay / 8u, RTE_SMALL_GRID_BLOCKS / std::max(1u, tiles * (unsigned)nbnd)));
 #define RTE_LAUNCH_PLANCK9(GW)                                                                                    \
   do {                                                                                                            \
     {                                                                                                             \
@@ -611,6 +627,15 @@ static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, i
       hipLaunchKernelGGL((tile_geom2_kernel<NCW * 64, GW>), dim3(tiles, nlay), dim3(NCW * 64), 0, st, ga, d_geom); \
     }                                                                                                             \
     rte::ProfScope p(factored ? "planck_source_factored_kernel" : "planck_source_kernel");                        \
+    if (lchunks > 1) {                                                                                            \
+      const dim3 gch(nbnd * tiles, lchunks);                                                                      \
+      if (factored)                                                                                               \
+        hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW, true, true>), gch, dim3((NCW + NLW) * 64), \
+                           sizeof(Float) * nPlanckTemp, st, v, nbnd, tiles, (const TileGeom*)d_geom, (const int*)d_flags); \
+      else                                                                                                        \
+        hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW, false, true>), gch, dim3((NCW + NLW) * 64), \
+                           sizeof(Float) * nPlanckTemp, st, v, nbnd, tiles, (const TileGeom*)d_geom, (const int*)d_flags); \
+    } else                                                                                                        \
     if (factored)                                                                                                 \
       hipLaunchKernelGGL((planck_source_v9_kernel<NCW, NLW, SLAB9, GW, true>), dim3(nbnd * 8 * cdiv(tiles, 8)),  \
                          dim3((NCW + NLW) * 64), sizeof(Float) * nPlanckTemp, st, v, nbnd, tiles,                 \

@@ -376,6 +376,10 @@ static void tau_absorption_impl(
       d_geom = (TileGeom*)rte::scratch(sizeof(TileGeom) * (size_t)tiles * nlay);
     }
     const dim3 grid(tiles, nlay), blk(NCW * 64);
+    // few (tile, layer) pairs (calls of some thousand columns): the stages of a pair go to several blocks, at least 4 each, until
+    // about two blocks per CU are in the grid
+    const unsigned nz = std::max(1u, std::min((unsigned)(ngpt / cache.gw) / 4u, RTE_SMALL_GRID_BLOCKS / std::max(1u, tiles * (unsigned)nlay)));
+    const dim3 gridk(tiles, nlay, nz);
     const size_t dyn = sizeof(BandMeta) * nbnd;
     const TileGeom* cg = d_geom;
     Geom2Args ga{};
@@ -393,7 +397,7 @@ static void tau_absorption_impl(
       ga.imask_nblk = cdiv(ncol, 256);
     }
 // <overwrite, stage width, by-band operand, fused Rayleigh form>; two steps of LDS row reads in flight per wave
-#define RTE_TAU_K(OW, GW, AB, RV) hipLaunchKernelGGL((tau_slab_kernel<NCW, SLAB, OW, GW, 4, AB, RV, TAU_DEPTH>), grid, blk, dyn, st, vk, cg)
+#define RTE_TAU_K(OW, GW, AB, RV) hipLaunchKernelGGL((tau_slab_kernel<NCW, SLAB, OW, GW, 4, AB, RV, TAU_DEPTH>), gridk, blk, dyn, st, vk, cg)
 #define RTE_LAUNCH_TAU_(GW, AB)                                                                                   \
   do {                                                                                                            \
     if (overwrite_ok) { const TauV5& vk = v; RTE_TAU_K(true, GW, AB, 0); }                                        \

@@ -99,39 +99,43 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   __syncthreads();
   const int Tmin = tg.Tmin, nT = tg.nT, Pmin = tg.Pmin, nP = tg.nP;
   const bool has_lo = tg.has_lo != 0, has_up = tg.has_up != 0;
-  const int nstage = ngpt / G;  // host guarantees whole, G-aligned chunks per band and nstage <= SLAB_MAXSTAGE
+  const int nstage_all = ngpt / G;  // host guarantees whole, G-aligned chunks per band and nstage_all <= SLAB_MAXSTAGE
   // ---- the order of the stages.  A tile whose columns are all in one regime at this layer walks the bands sorted by that
   // regime's flavor: what a lane requests per stage (fmajor, fminor, col_mix, jeta of the band's flavor) is then the previous
   // stage's for every band but the first of a flavor: the stage record says so (bit 8 of b) and the lanes keep their registers
   // (measured traffic was 1.23 x the algorithmic bytes with the bands in table order -- 16 reads of the weights per layer
   // instead of one per flavor; the kernel itself gains 1 %: it is not bound by these bytes).
   // s_order[position] = the chunk of G g-points done there.
-  if (tid < nstage) {
+  if (tid < nstage_all) {
     const int g0 = tid * G;
     int b = 0;
     while (b + 1 < nbnd && bm[b].gE < g0) ++b;
     s_key[tid] = (has_lo != has_up ? bm[b].flav[has_up ? 1 : 0] : 0) * SLAB_MAXSTAGE + tid;
   }
-  if (tid >= nstage && tid < nstage + 2) s_order[tid] = tid;
+  if (tid >= nstage_all && tid < nstage_all + 2) s_order[tid] = tid;
   __syncthreads();
-  if (tid < nstage) {
+  if (tid < nstage_all) {
     const int key = s_key[tid];
     int pos = 0;
-    for (int t = 0; t < nstage; ++t) pos += s_key[t] < key ? 1 : 0;
+    for (int t = 0; t < nstage_all; ++t) pos += s_key[t] < key ? 1 : 0;
     s_order[pos] = tid;
   }
   __syncthreads();
+  // calls of a few thousand columns (fewer (tile, layer) pairs than the chip holds blocks): gridDim.z blocks share a pair,
+  // each takes a run of positions of that order; the rest of the kernel sees its own stages 0 ... nstage - 1
+  const int sz0 = (int)((blockIdx.z * (unsigned)nstage_all) / gridDim.z);
+  const int nstage = (int)(((blockIdx.z + 1) * (unsigned)nstage_all) / gridDim.z) - sz0;
   // ---- the block's schedule: what every stage stages (rows ordered: major [t][eta][p], then one [t][eta] plane per minor
   // interval of the lower, then of the upper regime, RAYL: then the two Rayleigh planes).  Entries nstage, nstage + 1: empty.
   if (tid < nstage + 2) {
     SlabStage si{};
     if (tid < nstage) {
-      const int g0 = s_order[tid] * G;
+      const int g0 = s_order[sz0 + tid] * G;
       int b = 0;
       while (b + 1 < nbnd && bm[b].gE < g0) ++b;
       si.b = b; si.g0 = g0; si.emin = tg.eg[b].x; si.nE = tg.eg[b].y;
       if (tid > 0) {  // the lanes' weights are the previous stage's: same flavor in every regime the tile has columns in
-        const int g0p = s_order[tid - 1] * G;
+        const int g0p = s_order[sz0 + tid - 1] * G;
         int bp = 0;
         while (bp + 1 < nbnd && bm[bp].gE < g0p) ++bp;
         const bool same = (!has_lo || bm[bp].flav[0] == bm[b].flav[0]) && (!has_up || bm[bp].flav[1] == bm[b].flav[1]);
@@ -150,7 +154,7 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     s_stage[tid] = si;
   }
   if (tid < 2 * (nstage + 1)) {
-    const int st = tid >> 1, r = tid & 1, g0 = s_order[st] * G;
+    const int st = tid >> 1, r = tid & 1, g0 = s_order[sz0 + st] * G;
     int b = 0;
     while (b + 1 < nbnd && bm[b].gE < g0) ++b;
     SlabPeek pk{};
