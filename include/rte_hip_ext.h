@@ -21,6 +21,13 @@ void* rte_hip_ctx_get_current(void);
 int   rte_hip_ctx_destroy(void* ctx);
 int   rte_hip_set_stream(void* hip_stream);   /* the current context launches on this stream from now on */
 int   rte_hip_sync(void);                     /* materialise recorded fills, drain the context's stream */
+/* a sequence of library calls captured as ONE hipGraph and replayed with one submission: halves the host time per chain
+ * (0.13 -> 0.05 ms); the device time is that of the launches themselves (measured).  Device pointers only, the same arrays at every launch, one uncaptured run of the same sequence
+ * beforehand, no value returned to the host inside the region.  All return 0, -1 on a HIP error. */
+int   rte_hip_graph_begin(void);
+int   rte_hip_graph_end(void** graph_exec);
+int   rte_hip_graph_launch(void* graph_exec); /* on the context's stream, ordered with the calls around it */
+int   rte_hip_graph_destroy(void* graph_exec);
 int   rte_hip_release(void);                  /* free every device buffer the context holds */
 int   rte_hip_device_count(void);
 

@@ -124,6 +124,39 @@ def ext_call(lib: cabi.KernelLib, name: str, kinds: Sequence[str], *args):
     return fn(*cargs)
 
 
+class CallGraph:
+    """A sequence of library calls captured as one hipGraph (``rte_hip_graph_begin`` / ``_end``) and replayed with one
+    submission: ``g = CallGraph(lib, fn)`` runs ``fn()`` once uncaptured (sizes the scratch arena) and once captured;
+    ``g.launch()`` replays it on the library's stream.  ``fn`` must use device arrays that stay where they are (pass the
+    ``buffers=`` dictionaries of the frontend functions) and must not read values back."""
+
+    def __init__(self, lib: cabi.KernelLib, fn, warm: bool = True):
+        self.lib = lib
+        if warm:
+            fn()
+        if ext_call(lib, "rte_hip_graph_begin", []) != 0:
+            raise RuntimeError("rte_hip_graph_begin failed")
+        try:
+            fn()
+        finally:
+            handle = ctypes.c_void_p(0)
+            rc = lib.raw("rte_hip_graph_end")(ctypes.byref(handle))
+        if rc != 0 or not handle.value:
+            raise RuntimeError("rte_hip_graph_end failed")
+        self.handle = handle
+
+    def launch(self) -> None:
+        fn = self.lib.raw("rte_hip_graph_launch")
+        fn.restype = ctypes.c_int
+        if fn(self.handle) != 0:
+            raise RuntimeError("rte_hip_graph_launch failed")
+
+    def close(self) -> None:
+        if self.handle is not None and self.handle.value:
+            self.lib.raw("rte_hip_graph_destroy")(self.handle)
+            self.handle = None
+
+
 def set_stream(lib: cabi.KernelLib, stream_handle: Optional[int]) -> None:
     """Make the library launch on the given hipStream_t (0/None = the null stream, which is also
     torch's default stream on ROCm)."""

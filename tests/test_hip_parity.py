@@ -473,6 +473,66 @@ def test_bands_that_share_a_flavor_keep_their_weights(hip, oracle_c, kind, nflav
             assert cases.elem_err(np.array(xp.to_numpy(b[k])), outs["oracle"][k], 1e-8) <= ETOL_GAS, (kind, k, "one-pass")
 
 
+@pytest.mark.gpu
+def test_call_graph_replays_the_chain(hip):
+    """rte_hip_graph_begin / _end / _launch: the LW chain (gas optics + rte_lw_solver_noscat, deferred zero fill and shared
+    geometry as the bench runs it) captured once as a hipGraph and replayed on CHANGED inputs in the same arrays gives, bit
+    for bit, what the calls themselves give on those inputs."""
+    import torch
+    from rte_rrtmgp_amd import synth
+
+    kd = synth.make_kdist("lw")
+    ncol, nlay = 1024, 60
+    atm = synth.make_atmosphere(ncol, nlay, seed=3, kdist=kd)
+    atm2 = synth.make_atmosphere(ncol, nlay, seed=4, kdist=kd)
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    names = ("play", "plev", "tlay", "tlev", "tsfc", "col_gas")
+    dev = {k: A(getattr(atm, k)) for k in names}
+    alt = {k: A(getattr(atm2, k)) for k in names}
+    first = {k: v.clone() for k, v in dev.items()}
+    emis = xp.full((ncol, kd.ngpt), 0.98)
+    go = frontend.GasOptics(hip, kd, xp)
+    bufs, rb = {}, {}
+    for name in ("rte_hip_defer_zero", "rte_hip_share_geometry"):
+        hiplib.ext_call(hip, name, ["i"], 1)
+    try:
+        def chain():
+            go.gas_optics_lw(ncol, nlay, dev["play"], dev["plev"], dev["tlay"], dev["tsfc"], dev["col_gas"], dev["tlev"], atm.top_at_1,
+                             buffers=bufs)
+            frontend.rte_lw(hip, xp, ncol, nlay, kd.ngpt, atm.top_at_1, bufs["tau"], bufs["lay_src"], bufs["lev_src"], emis,
+                            bufs["sfc_src"], buffers=rb)
+
+        def result():
+            hiplib.ext_call(hip, "rte_hip_sync", [])
+            return {k: np.array(xp.to_numpy(rb[k])) for k in ("flux_up", "flux_dn")} | {"tau": np.array(xp.to_numpy(bufs["tau"]))}
+
+        chain()
+        want1 = result()
+        for k in names:
+            dev[k].copy_(alt[k])
+        chain()
+        want2 = result()
+        assert np.abs(want1["flux_up"] - want2["flux_up"]).max() > 0
+        g = hiplib.CallGraph(hip, chain)
+        try:
+            for inputs, want in ((first, want1), (alt, want2), (first, want1)):
+                for k in names:
+                    dev[k].copy_(inputs[k])
+                for t in (bufs["tau"], rb["flux_up"], rb["flux_dn"]):
+                    t.fill_(-1.0)
+                torch.cuda.synchronize()
+                g.launch()
+                got = result()
+                for k in want:
+                    assert np.array_equal(got[k], want[k]), k
+        finally:
+            g.close()
+    finally:
+        for name in ("rte_hip_defer_zero", "rte_hip_share_geometry"):
+            hiplib.ext_call(hip, name, ["i"], 0)
+
+
 def test_plans_follow_tables_changed_in_place(hip, oracle_c):
     """The host-side plans of the production kernels are cached per table ADDRESS; the device-side plan guards must
     notice tables whose CONTENTS changed behind those addresses (no rte_hip_invalidate_plans()): the call then runs
