@@ -643,12 +643,13 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 // instead of a register per row (the two-sub-segment kernel below has no registers to spare for 4 L + 2 offsets)
 template <int L, bool do_jac, bool SFC>
 __device__ __forceinline__ void seg_load2(SegTile<L>& t, unsigned lay0, unsigned lev0, unsigned step, unsigned cg, int np_off, int np,
-                                          int igpt, int ncol, int nlay, const Float* __restrict__ Dsec,
+                                          int igpt, int ncol, size_t ncl, size_t nclv, const Float* __restrict__ Dsec,
                                           const Float* __restrict__ tau_, const Float* __restrict__ lay_source_,
                                           const Float* __restrict__ lev_source_, const Float* __restrict__ sfc_emis,
                                           const Float* __restrict__ sfc_src, const Float* __restrict__ inc_flux,
                                           const Float* __restrict__ sfc_srcJac) {
-  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1), ncg = (size_t)ncol * igpt;
+  // ncl, nclv: elements between the g-point planes of the layer / level arrays (a WINDOW of layers keeps the column's)
+  const size_t ncg = (size_t)ncol * igpt;
   auto at = [](const Float* plane, unsigned off) {  // plane is wave-uniform
     asm volatile("" : "+v"(off));
     return __builtin_nontemporal_load(reinterpret_cast<const Float*>(reinterpret_cast<const char*>(plane) + off));
@@ -684,7 +685,16 @@ __device__ __forceinline__ void seg_load2(SegTile<L>& t, unsigned lay0, unsigned
 // registers A just left, and publishes the composite of A followed by B; after the exchange pass 2 sweeps A from LDS
 // and B from registers.  Same arithmetic per layer as the one-segment kernel, same composites across waves.
 // ---------------------------------------------------------------------------------------------
-template <int L, bool do_jac, bool SPEC>
+// WIN (columns of 177 ... 352 layers, solved as an upper and a lower window of at most 176 layers; host: lw_noscat_windows):
+// the kernel works on a window of nlay layers of arrays whose g-point planes are the whole column's (pointers offset to the
+// window's first row), takes the radiance entering at its top as it is, and leaves the downward radiance at its bottom and
+// the upward radiance (and its Jacobian) at its top per (column, g-point).
+struct LwWin {
+  size_t plane_lay, plane_lev;  // elements between g-point planes of the layer / level arrays
+  bool inc_is_radiance;         // inc_flux holds a radiance (the upper window's out_dn_bot), not a flux
+  Float *out_dn_bot, *out_up_top, *out_jv_top;  // (ncol, ngpt), each optional
+};
+template <int L, bool do_jac, bool SPEC, bool WIN = false>
 __global__ void __launch_bounds__(64 * 8)
 lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
                       const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
@@ -692,7 +702,7 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
                       const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
                       const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
                       Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac,
-                      Float* __restrict__ spec_up, Float* __restrict__ spec_dn, bool spec_add) {
+                      Float* __restrict__ spec_up, Float* __restrict__ spec_dn, bool spec_add, LwWin win) {
 #pragma clang fp contract(fast)
   constexpr int LT = 2 * L, MAXS = 8;
   // input prefetch (see process): kept where it fits; the widest variant and the Jacobian variants spilled 39-103 registers
@@ -705,7 +715,8 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
   const bool active = icol < ncol;
   const int c = active ? icol : ncol - 1;
   const int nlev = nlay + 1;
-  const size_t nclv = (size_t)ncol * nlev;
+  const size_t nclv = (size_t)ncol * nlev;  // one partial slab (the window's levels)
+  const size_t pl_lay = WIN ? win.plane_lay : (size_t)ncol * nlay, pl_lev = WIN ? win.plane_lev : nclv;
   const int p0 = s * LT;
   const int np = min(LT, nlay - p0);  // layers of this wave (>= 1 by construction)
   const bool last = (s == S - 1);
@@ -755,11 +766,11 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
     }
   };
   auto loadA = [&](SegTile<L>& tile, int igpt) {
-    seg_load2<L, do_jac, true>(tile, layA, olev0, dlev, ocg, npA, npA, min(igpt, g_end - 1), ncol, nlay, Dsec, tau_, lay_source_,
+    seg_load2<L, do_jac, true>(tile, layA, olev0, dlev, ocg, npA, npA, min(igpt, g_end - 1), ncol, pl_lay, pl_lev, Dsec, tau_, lay_source_,
                                lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac);
   };
   auto loadB = [&](SegTile<L>& tile, int igpt) {
-    seg_load2<L, do_jac, false>(tile, layB, levB, dlev, ocg, max(npB, 1), npB, min(igpt, g_end - 1), ncol, nlay, Dsec, tau_,
+    seg_load2<L, do_jac, false>(tile, layB, levB, dlev, ocg, max(npB, 1), npB, min(igpt, g_end - 1), ncol, pl_lay, pl_lev, Dsec, tau_,
                                 lay_source_, lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac);
   };
   // One g-point.  The inputs of a sub-segment are dead after its pass 1: the next g-point's are requested into the same
@@ -803,11 +814,14 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
     X[(1 * MAXS + s) * 64 + lane] = TdB * SdA + SdB;
     X[(2 * MAXS + s) * 64 + lane] = TdA * SuB + SuA;
     __syncthreads();
-    Float r = inc * inv_piw;  // radiance entering segment 0 from above (:144)
+    Float r = (WIN && win.inc_is_radiance) ? inc : inc * inv_piw;  // radiance entering segment 0 from above (:144)
     Float r_in = r;
     for (int q = 0; q < S; ++q) {
       if (q == s) r_in = r;
       r = X[(0 * MAXS + q) * 64 + lane] * r + X[(1 * MAXS + q) * 64 + lane];
+    }
+    if constexpr (WIN) {  // (r: the downward radiance below the last wave's last layer)
+      if (win.out_dn_bot && s == 0 && active) win.out_dn_bot[icol + (size_t)ncol * ig] = r;
     }
     Float u = r * ((Float)1 - emis) + emis * ssrc;  // :198-200
     Float jv = do_jac ? emis * sjac : (Float)0;
@@ -844,6 +858,12 @@ lw_noscat_seg2_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool
       u = ta_ * u + PARK[(2 * L + i) * 512];
       put(acc_up, spec_up, i, u, ig);
       if (do_jac) { jv = ta_ * jv; acc_j[i] += jv; }
+    }
+    if constexpr (WIN) {  // (wave 0: u, jv are at the window's top level)
+      if (s == 0 && active) {
+        if (win.out_up_top) win.out_up_top[icol + (size_t)ncol * ig] = u;
+        if (do_jac && win.out_jv_top) win.out_jv_top[icol + (size_t)ncol * ig] = jv;
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PREF2) loadB(tb, ig + 1);
@@ -1860,6 +1880,22 @@ reduce_parts_kernel(size_t n2, int ngroups, const Float* __restrict__ parts, Flo
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// the same for a run of rows of the slabs: out(i) = sum_q parts[first + i + stride q], i < n
+__global__ void __launch_bounds__(256)
+reduce_parts_rows_kernel(size_t n, size_t first, size_t stride, int ngroups, const Float* __restrict__ parts, Float* __restrict__ out,
+                         Float scale, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Float s = 0;
+  for (int q = 0; q < ngroups; ++q) s = s + parts[first + i + stride * (size_t)q];
+  s = scale * s;
+  out[i] = accumulate ? out[i] + s : s;
+}
+__global__ void __launch_bounds__(256) fill_kernel(Float* __restrict__ p, size_t n, Float v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 size_t pick_gchunk(size_t bytes_per_g, int ngpt) {
   const size_t budget = (size_t)3 << 30;  // scratch budget for the generic solvers
   size_t c = budget / (bytes_per_g ? bytes_per_g : 1);
@@ -2099,7 +2135,7 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
                                   (int)lds_bytes));                                                                       \
     hipLaunchKernelGGL((lw_noscat_seg2_kernel<LL, JJ, SS>), dim3(col_tiles, ngroups), dim3(64 * S2), lds_bytes, st, ncol, \
                        nlay, ngpt, S2, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev,     \
-                       d_emis, d_sfc, d_inc, d_srcJac, part_up, part_dn, part_jac, d_flux_up, d_flux_dn, imu > 0);        \
+                       d_emis, d_sfc, d_inc, d_srcJac, part_up, part_dn, part_jac, d_flux_up, d_flux_dn, imu > 0, LwWin{}); \
   } while (0)
 #define RTE_LAUNCH_SEG2_(LL)                                                                     \
   do {                                                                                           \
@@ -2118,6 +2154,79 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
       }
       if (do_jac)
         hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st, nclv, ngroups, part_jac, d_jac, piw, imu > 0);
+    }
+    return;
+  }
+
+  if (!do_rescaling && do_broadband && nlay > 176 && nlay <= 352 && !g_lw_force_generic && nclv < ((size_t)1 << 29)) {
+    // ---------------------------------------------------------------- 177 ... 352 layers: the column as an upper and a lower
+    // WINDOW of 89 ... 176 layers on the two-sub-segment kernel.  Per angle: (A) the upper window for the downward radiance
+    // at its bottom; (B) the lower window with that radiance entering at its top and the real surface: its fluxes, and the
+    // upward radiance (and Jacobian) at its top; (C) the upper window once more over a "surface" of emissivity 1 that emits
+    // B's radiance: its fluxes.  The upper window's inputs are read twice (1.25 x the traffic of one pass; the generic kernel
+    // reads everything twice and runs at a third of the speed).
+    const int nU = nlay / 2, nLo = nlay - nU;
+    const int layU0 = *top_at_1 ? 0 : nLo, layL0 = *top_at_1 ? nU : 0;   // first array row of the windows' layers ...
+    const int levU0 = layU0, levL0 = layL0;                               // ... and of their levels
+    const int col_tiles = cdiv(ncol, 64);
+    const int g_per_block = seg_g_per_block(col_tiles, ngpt);
+    const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
+    const int nwmax = std::max(nU, nLo);
+    const size_t nclv_w = (size_t)ncol * (nwmax + 1);
+    const int nparts = 2 + (do_jac ? 1 : 0);
+    Float* parts = (Float*)rte::scratch(sizeof(Float) * nclv_w * ngroups * nparts);
+    Float* edge = (Float*)rte::scratch(sizeof(Float) * ncg * 4);  // dn at the interface, up there, its Jacobian, ones
+    Float *e_dn = edge, *e_up = edge + ncg, *e_jv = edge + 2 * ncg, *e_one = edge + 3 * ncg;
+    hipLaunchKernelGGL(fill_kernel, dim3(cdiv(ncg, 256)), dim3(256), 0, st, e_one, ncg, (Float)1);
+    // store: 0 nothing, 1 all of the window's levels, 2 all but the interface level (the upper window owns it)
+    auto run_window = [&](int nw, int lay0, int lev0, Float weight, const Float* Dsec, const Float* emis_, const Float* sfc_, const Float* inc_,
+                          const Float* jac_, LwWin win, int store, bool accumulate) {
+      const int L2 = nw <= 128 ? 8 : nw <= 144 ? 9 : nw <= 160 ? 10 : 11;
+      const int S2 = (nw + 2 * L2 - 1) / (2 * L2);
+      const size_t nclv_k = (size_t)ncol * (nw + 1);
+      Float* part_up = parts;
+      Float* part_dn = parts + nclv_k * ngroups;
+      Float* part_jac = do_jac ? parts + nclv_k * ngroups * 2 : nullptr;
+      const size_t lds_bytes = sizeof(Float) * (2 * 3 * 8 * 64 + 3 * L2 * 512 + (L2 == 9 ? 6 : L2 == 10 ? 3 : 0) * 512);
+      win.plane_lay = ncl; win.plane_lev = nclv;
+      const Float* t_ = d_tau + (size_t)ncol * lay0;
+      const Float* l_ = d_lay + (size_t)ncol * lay0;
+      const Float* v_ = d_lev + (size_t)ncol * lev0;
+      {
+        rte::ProfScope p("lw_noscat_seg2_kernel");
+#define RTE_LAUNCH_WIN(LL, JJ)                                                                                            \
+  do {                                                                                                                    \
+    HIP_CHECK(hipFuncSetAttribute((const void*)lw_noscat_seg2_kernel<LL, JJ, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds_bytes));                                                                       \
+    hipLaunchKernelGGL((lw_noscat_seg2_kernel<LL, JJ, false, true>), dim3(col_tiles, ngroups), dim3(64 * S2), lds_bytes, st, ncol, \
+                       nw, ngpt, S2, g_per_block, (bool)*top_at_1, weight, Dsec, t_, l_, v_, emis_, sfc_, inc_, jac_, part_up,     \
+                       part_dn, part_jac, (Float*)nullptr, (Float*)nullptr, false, win);                                  \
+  } while (0)
+#define RTE_LAUNCH_WIN_(LL) do { if (do_jac) RTE_LAUNCH_WIN(LL, true); else RTE_LAUNCH_WIN(LL, false); } while (0)
+        if (L2 == 8) RTE_LAUNCH_WIN_(8); else if (L2 == 9) RTE_LAUNCH_WIN_(9); else if (L2 == 10) RTE_LAUNCH_WIN_(10); else RTE_LAUNCH_WIN_(11);
+#undef RTE_LAUNCH_WIN_
+#undef RTE_LAUNCH_WIN
+      }
+      if (!store) return;
+      rte::ProfScope p("lw_reduce_parts");
+      const Float piw = (Float)3.14159265358979323846264338327950288 * weight;
+      // the window's levels are a contiguous run of rows of the (ncol, nlev) outputs; the interface level is the lower window's
+      // first row (top_at_1) or last row
+      const size_t first = (store == 2 && *top_at_1) ? (size_t)ncol : 0, n = nclv_k - (store == 2 ? (size_t)ncol : 0);
+      const size_t o = (size_t)ncol * lev0 + first;
+      const int acc = accumulate ? 1 : 0;
+      hipLaunchKernelGGL(reduce_parts_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, n, first, nclv_k, ngroups, (const Float*)part_up, d_bb_up + o, piw, acc);
+      hipLaunchKernelGGL(reduce_parts_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, n, first, nclv_k, ngroups, (const Float*)part_dn, d_bb_dn + o, piw, acc);
+      if (do_jac)
+        hipLaunchKernelGGL(reduce_parts_rows_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, n, first, nclv_k, ngroups, (const Float*)part_jac, d_jac + o, piw, acc);
+    };
+    for (int imu = 0; imu < nmus; ++imu) {
+      const Float* Dsec = d_Ds + ncg * imu;
+      LwWin wa{}; wa.out_dn_bot = e_dn;
+      run_window(nU, layU0, levU0, w_h[imu], Dsec, e_one, d_sfc, d_inc, do_jac ? d_srcJac : nullptr, wa, 0, false);
+      LwWin wb{}; wb.inc_is_radiance = true; wb.out_up_top = e_up; wb.out_jv_top = do_jac ? e_jv : nullptr;
+      run_window(nLo, layL0, levL0, w_h[imu], Dsec, d_emis, d_sfc, e_dn, do_jac ? d_srcJac : nullptr, wb, 2, imu > 0);
+      run_window(nU, layU0, levU0, w_h[imu], Dsec, e_one, e_up, d_inc, do_jac ? e_jv : nullptr, LwWin{}, 1, imu > 0);
     }
     return;
   }

@@ -197,6 +197,46 @@ def test_lw_noscat_with_more_than_80_layers(hip, oracle_c, nlay, top_at_1):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1, kw)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlay,top_at_1", [(177, True), (200, False), (256, True), (289, False), (300, True), (352, False)])
+def test_lw_noscat_with_177_to_352_layers(hip, oracle_c, nlay, top_at_1):
+    """Columns of 177 ... 352 layers: an upper and a lower window of 89 ... 176 layers on the two-sub-segment kernel (the upper
+    window twice: for the downward radiance at the interface, and again over the lower window's upward radiance).  Broadband
+    with three angles, incident flux and Jacobian, and with one angle, against the oracle; odd and even splits, both
+    orientations; rte_hip_stat is not consulted: the generic kernel would pass too, so the kernel that ran is checked by name."""
+    import numpy as np
+
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    rng = np.random.default_rng(nlay)
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    ncol, ngpt = 70, 16
+    tau = F(ncol, nlay, ngpt) * 0.2
+    lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
+    emis, sfc, inc, sj = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10, F(ncol, ngpt), F(ncol, ngpt)
+    hiplib.ext_call(hip, "rte_hip_profile_reset", [])
+    hiplib.ext_call(hip, "rte_hip_profile_enable", ["i"], 1)
+    try:
+        for kw, keys in ((dict(n_gauss_angles=3, do_jacobians=True), ("flux_up", "flux_dn", "flux_up_jac")),
+                         (dict(), ("flux_up", "flux_dn"))):
+            ref = frontend.rte_lw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, lay, lev, emis, sfc, inc_flux=inc,
+                                  sfc_src_jac=sj, **kw)
+            out = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(lay), A(lev), A(emis), A(sfc), inc_flux=A(inc),
+                                  sfc_src_jac=A(sj), **kw)
+            for k in keys:
+                assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1, kw)
+    finally:
+        hiplib.ext_call(hip, "rte_hip_profile_enable", ["i"], 0)
+    import ctypes
+    names = []
+    for i in range(hiplib.ext_call(hip, "rte_hip_profile_count", [])):
+        buf = ctypes.create_string_buffer(128); cnt, ms = ctypes.c_longlong(0), ctypes.c_double(0)
+        hip.raw("rte_hip_profile_get")(ctypes.c_int(i), buf, ctypes.c_int(128), ctypes.byref(cnt), ctypes.byref(ms))
+        if cnt.value:
+            names.append(buf.value.decode())
+    assert "lw_noscat_seg2_kernel" in names, names
+
+
 @pytest.mark.parametrize("nlay,top_at_1", [(100, False), (112, True), (128, False), (137, True), (144, False)])
 def test_lw_rescaling_with_up_to_144_layers(hip, oracle_c, nlay, top_at_1):
     """rte_lw's default for two-stream (cloudy) optical properties -- lw_solver_noscat with Tang rescaling -- on the segmented
