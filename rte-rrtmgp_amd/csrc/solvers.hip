@@ -2158,27 +2158,33 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     return;
   }
 
-  if (!do_rescaling && do_broadband && nlay > 176 && nlay <= 352 && !g_lw_force_generic && nclv < ((size_t)1 << 29)) {
-    // ---------------------------------------------------------------- 177 ... 352 layers: the column as an upper and a lower
-    // WINDOW of 89 ... 176 layers on the two-sub-segment kernel.  Per angle: (A) the upper window for the downward radiance
-    // at its bottom; (B) the lower window with that radiance entering at its top and the real surface: its fluxes, and the
-    // upward radiance (and Jacobian) at its top; (C) the upper window once more over a "surface" of emissivity 1 that emits
-    // B's radiance: its fluxes.  The upper window's inputs are read twice (1.25 x the traffic of one pass; the generic kernel
-    // reads everything twice and runs at a third of the speed).
-    const int nU = nlay / 2, nLo = nlay - nU;
-    const int layU0 = *top_at_1 ? 0 : nLo, layL0 = *top_at_1 ? nU : 0;   // first array row of the windows' layers ...
-    const int levU0 = layU0, levL0 = layL0;                               // ... and of their levels
+  constexpr int kWinLay = 128, kWinMax = 8;  // layers per window (8 per sub-segment: no spills), windows per column
+  if (!do_rescaling && do_broadband && nlay > 176 && nlay <= kWinLay * kWinMax && !g_lw_force_generic && nclv < ((size_t)1 << 29)) {
+    // ---------------------------------------------------------------- 177 ... 1024 layers: the column as K = ceil(nlay / 128)
+    // WINDOWS of layers on the two-sub-segment kernel.  Per angle, top to bottom: (A) every window but the last for the
+    // downward radiance at its bottom, which enters the next one; (B) the last window with the real surface: its fluxes, and the
+    // upward radiance (and Jacobian) at its top; then bottom to top (C) every other window once more over a "surface" of
+    // emissivity 1 that emits the radiance of the window below: its fluxes.  All windows but the last are read twice
+    // ((2 K - 1) / K of the traffic of one pass; the generic kernel reads everything twice at a third of the speed).
+    const int K = (nlay + kWinLay - 1) / kWinLay;
+    int wn[kWinMax], wrow[kWinMax];  // layers of window w (from the top), first array row of its layers and levels
+    for (int w = 0, pos = 0; w < K; ++w) {
+      wn[w] = nlay / K + (w < nlay % K ? 1 : 0);
+      wrow[w] = *top_at_1 ? pos : nlay - pos - wn[w];
+      pos += wn[w];
+    }
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
     const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
-    const int nwmax = std::max(nU, nLo);
-    const size_t nclv_w = (size_t)ncol * (nwmax + 1);
+    const size_t nclv_w = (size_t)ncol * (wn[0] + 1);  // (the first window is the largest)
     const int nparts = 2 + (do_jac ? 1 : 0);
     Float* parts = (Float*)rte::scratch(sizeof(Float) * nclv_w * ngroups * nparts);
-    Float* edge = (Float*)rte::scratch(sizeof(Float) * ncg * 4);  // dn at the interface, up there, its Jacobian, ones
-    Float *e_dn = edge, *e_up = edge + ncg, *e_jv = edge + 2 * ncg, *e_one = edge + 3 * ncg;
+    // (column, g-point) arrays: the downward radiance entering windows 1 ... K - 1, the upward radiance and its Jacobian at an
+    // interface (two each: a window reads the one below it and writes the one above it), ones
+    Float* edge = (Float*)rte::scratch(sizeof(Float) * ncg * (K + 4));
+    Float *e_dn = edge, *e_up = edge + ncg * (K - 1), *e_jv = e_up + 2 * ncg, *e_one = e_jv + 2 * ncg;
     hipLaunchKernelGGL(fill_kernel, dim3(cdiv(ncg, 256)), dim3(256), 0, st, e_one, ncg, (Float)1);
-    // store: 0 nothing, 1 all of the window's levels, 2 all but the interface level (the upper window owns it)
+    // store: 0 nothing, 1 all of the window's levels, 2 all but its top level (the window above owns an interface)
     auto run_window = [&](int nw, int lay0, int lev0, Float weight, const Float* Dsec, const Float* emis_, const Float* sfc_, const Float* inc_,
                           const Float* jac_, LwWin win, int store, bool accumulate) {
       const int L2 = nw <= 128 ? 8 : nw <= 144 ? 9 : nw <= 160 ? 10 : 11;
@@ -2222,11 +2228,22 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
     };
     for (int imu = 0; imu < nmus; ++imu) {
       const Float* Dsec = d_Ds + ncg * imu;
-      LwWin wa{}; wa.out_dn_bot = e_dn;
-      run_window(nU, layU0, levU0, w_h[imu], Dsec, e_one, d_sfc, d_inc, do_jac ? d_srcJac : nullptr, wa, 0, false);
-      LwWin wb{}; wb.inc_is_radiance = true; wb.out_up_top = e_up; wb.out_jv_top = do_jac ? e_jv : nullptr;
-      run_window(nLo, layL0, levL0, w_h[imu], Dsec, d_emis, d_sfc, e_dn, do_jac ? d_srcJac : nullptr, wb, 2, imu > 0);
-      run_window(nU, layU0, levU0, w_h[imu], Dsec, e_one, e_up, d_inc, do_jac ? e_jv : nullptr, LwWin{}, 1, imu > 0);
+      auto inc_of = [&](int w) { return w == 0 ? d_inc : (const Float*)(e_dn + ncg * (w - 1)); };
+      for (int w = 0; w + 1 < K; ++w) {  // (A)
+        LwWin wa{}; wa.inc_is_radiance = w > 0; wa.out_dn_bot = e_dn + ncg * w;
+        run_window(wn[w], wrow[w], wrow[w], w_h[imu], Dsec, e_one, d_sfc, inc_of(w), do_jac ? d_srcJac : nullptr, wa, 0, false);
+      }
+      int cur = 0;  // which of the two (e_up, e_jv) pairs holds the radiance below the window being solved
+      {             // (B)
+        LwWin wb{}; wb.inc_is_radiance = true; wb.out_up_top = e_up + ncg * cur; wb.out_jv_top = do_jac ? e_jv + ncg * cur : nullptr;
+        run_window(wn[K - 1], wrow[K - 1], wrow[K - 1], w_h[imu], Dsec, d_emis, d_sfc, inc_of(K - 1), do_jac ? d_srcJac : nullptr, wb, 2, imu > 0);
+      }
+      for (int w = K - 2; w >= 0; --w, cur ^= 1) {  // (C)
+        LwWin wc{}; wc.inc_is_radiance = w > 0;
+        if (w > 0) { wc.out_up_top = e_up + ncg * (cur ^ 1); wc.out_jv_top = do_jac ? e_jv + ncg * (cur ^ 1) : nullptr; }
+        run_window(wn[w], wrow[w], wrow[w], w_h[imu], Dsec, e_one, e_up + ncg * cur, inc_of(w), do_jac ? e_jv + ncg * cur : nullptr, wc,
+                   w > 0 ? 2 : 1, imu > 0);
+      }
     }
     return;
   }

@@ -198,12 +198,13 @@ def test_lw_noscat_with_more_than_80_layers(hip, oracle_c, nlay, top_at_1):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nlay,top_at_1", [(177, True), (200, False), (256, True), (289, False), (300, True), (352, False)])
-def test_lw_noscat_with_177_to_352_layers(hip, oracle_c, nlay, top_at_1):
-    """Columns of 177 ... 352 layers: an upper and a lower window of 89 ... 176 layers on the two-sub-segment kernel (the upper
-    window twice: for the downward radiance at the interface, and again over the lower window's upward radiance).  Broadband
-    with three angles, incident flux and Jacobian, and with one angle, against the oracle; odd and even splits, both
-    orientations; rte_hip_stat is not consulted: the generic kernel would pass too, so the kernel that ran is checked by name."""
+@pytest.mark.parametrize("nlay,top_at_1", [(177, True), (200, False), (256, True), (257, False), (300, True), (352, False), (400, True),
+                                           (513, False), (1024, True)])
+def test_lw_noscat_with_177_to_1024_layers(hip, oracle_c, nlay, top_at_1):
+    """Columns of 177 ... 1024 layers: ceil(nlay / 128) windows of layers on the two-sub-segment kernel (top to bottom for the
+    downward radiance at the interfaces, the last window with the surface, then bottom to top over the upward radiance of the
+    window below).  Broadband with three angles, incident flux and Jacobian, and with one angle, against the oracle; 2 ... 8
+    windows, uneven splits, both orientations.  The generic kernel would pass too: the kernel that ran is checked by name."""
     import numpy as np
 
     xp = frontend.TorchArrays("cuda:0")
@@ -211,7 +212,7 @@ def test_lw_noscat_with_177_to_352_layers(hip, oracle_c, nlay, top_at_1):
     rng = np.random.default_rng(nlay)
     F = lambda *sh: np.asfortranarray(rng.random(sh))
     ncol, ngpt = 70, 16
-    tau = F(ncol, nlay, ngpt) * 0.2
+    tau = F(ncol, nlay, ngpt) * (20.0 / nlay)
     lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
     emis, sfc, inc, sj = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10, F(ncol, ngpt), F(ncol, ngpt)
     hiplib.ext_call(hip, "rte_hip_profile_reset", [])
