@@ -45,7 +45,7 @@ int rte_hip_clear_error(void);
 int       rte_hip_host_mirror(int on);
 int       rte_hip_writeback(const void* host_ptr);  /* 1: array copied back, 0: not held on the device */
 int       rte_hip_mirror_drop_all(void);
-long long rte_hip_mirror_stat(int which);           /* counters, see csrc/runtime.hip */
+long long rte_hip_mirror_stat(int which);           /* counters, see csrc/runtime.hip (10, 11: unchanged host inputs served from the device, bytes not uploaded) */
 
 /* ---- opt-in modes for drivers that touch the arrays only through this library between two calls -------------------- */
 int rte_hip_defer_zero(int on);        /* zero_array_* recorded, folded into compute_tau_absorption (tau write-only) */

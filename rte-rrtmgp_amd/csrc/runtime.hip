@@ -107,6 +107,16 @@ struct Context {
   std::chrono::steady_clock::time_point call_t0;
   bool report_on = false;        // RTE_HIP_STAGING_REPORT: also keep the wall-clock per entry point
   std::vector<std::pair<const char*, std::pair<double, long>>> t_entry;
+  // ---- host-mirror mode: device copies of INPUT arrays the host produced, each with a host-side shadow of what was uploaded
+  // (see Call::stage): the frontend hands the same play / tlay / col_gas to three kernel calls in a row and the same constant
+  // emissivity / incident-flux / secant fields to every solver call
+  struct InputCopy { const char* host; size_t bytes; char* shadow; char* dev; long last_use; };
+  std::vector<InputCopy> inputs;
+  size_t inputs_total = 0;
+  int input_cache = -1;  // RTE_HIP_INPUT_CACHE (default on in host-mirror mode)
+  long long input_hits = 0, input_saved = 0;
+  std::vector<std::pair<long long, long long>> b_entry;  // per entry point: bytes copied host-to-device / device-to-host
+  long long call_h2d0 = 0, call_d2h0 = 0;
   // ---- timing
   bool prof_on = false;
   std::string prof_only;  // non-empty: only this scope is timed
@@ -479,6 +489,7 @@ static void sources_touch(const void* p, bool copy_in) {
 // writes both back (writeback_produced_by).  Mirrors belong to a context: arrays produced on one context are consumed on it.
 constexpr int kCanaries = 34;
 constexpr size_t kLazyMinBytes = 4096;
+constexpr size_t kInputCacheMin = size_t(64) << 10;  // host-produced inputs from this size on keep a device copy + shadow
 static int g_procmem_fd = -2;
 // device bytes held by the mirrors (and their free lists) of ALL contexts, and the limit they share: with one context per
 // host thread, per-context limits of "60 % of what is free" would add up to several times the device
@@ -496,13 +507,18 @@ static void staging_report() {
   for (Context* c : g_report_contexts) {
     fprintf(stderr, "rte_rrtmgp_hip staging report (context %d): %ld calls, %.3f s inside the library (host-to-device copies %.3f s for %.3f GB, "
             "waits + device-to-host %.3f s for %.3f GB, mirror look-ups %.3f s); mirrors made %lld, hits %lld, dropped %lld + %lld, aged %lld, "
-            "zero fills elided %lld, device bytes held %.2f GB; host tables uploaded %lld, reused %lld\n", i++, c->n_calls, c->t_call, c->t_h2d, c->mstat[2] * 1e-9, c->t_wait,
+            "zero fills elided %lld, device bytes held %.2f GB; host tables uploaded %lld, reused %lld; unchanged inputs served from the device %lld "
+            "(%.3f GB not copied)\n", i++, c->n_calls, c->t_call, c->t_h2d, c->mstat[2] * 1e-9, c->t_wait,
             c->mstat[3] * 1e-9, c->t_find, c->mstat[1], c->mstat[0], c->mstat[4], c->mstat[5], c->mstat[6], c->mstat[7], c->mirror_total * 1e-9,
-            c->table_uploads, c->table_hits);
-    auto v = c->t_entry;
-    std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.first > b.second.first; });
-    for (size_t k = 0; k < v.size() && k < 12; ++k)
-      fprintf(stderr, "    %-44s %6ld calls %9.4f s\n", v[k].first, v[k].second.second, v[k].second.first);
+            c->table_uploads, c->table_hits, c->input_hits, c->input_saved * 1e-9);
+    std::vector<size_t> order(c->t_entry.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return c->t_entry[a].second.first > c->t_entry[b].second.first; });
+    for (size_t k = 0; k < order.size() && k < 16; ++k) {
+      const auto& e = c->t_entry[order[k]];
+      fprintf(stderr, "    %-44s %6ld calls %9.4f s  to device %9.3f MB  to host %9.3f MB\n", e.first, e.second.second, e.second.first,
+              c->b_entry[order[k]].first * 1e-6, c->b_entry[order[k]].second * 1e-6);
+    }
   }
 }
 static bool mirror_on() {
@@ -734,6 +750,7 @@ Call::Call(const char* n) : name(n) {
     ++c.seq;
     ++c.n_calls;
     c.call_t0 = std::chrono::steady_clock::now();
+    c.call_h2d0 = c.mstat[2]; c.call_d2h0 = c.mstat[3];
     fork_candidate_ = c.fork_valid;  // the previous call left a fork point (it is consumed or dropped by this call)
     c.fork_valid = false;
     if (!c.pending.empty()) {
@@ -823,6 +840,65 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
       return d;
     }
   }
+  if (c.mirror_mode == 1 && copy_in && !copy_out && bytes >= kInputCacheMin && bytes <= (size_t(256) << 20)) {
+    // An input the host produced.  The library keeps the device copy AND a host-side shadow of what it uploaded; when the
+    // same range comes again with the same bytes (compared in full: memcmp costs the thread what the copy into the pinned
+    // staging ring would, and saves the transfer) the device copy is served.  The unchanged frontend passes play, tlay and
+    // col_gas to interpolation, compute_tau_absorption and compute_Planck_source in a row, and an emissivity, a zero incident
+    // flux and a secant field that do not change from block to block to every solver call: 19.6 KB per column crossed PCIe
+    // where 6.3 KB were new.
+    if (c.input_cache < 0) { const char* e = getenv("RTE_HIP_INPUT_CACHE"); c.input_cache = (e && atoi(e) == 0) ? 0 : 1; }
+    if (c.input_cache) {
+      const auto t0 = std::chrono::steady_clock::now();
+      Context::InputCopy* hit = nullptr;  // the entry of this very range, if there is one (it is refilled on a mismatch)
+      Context::InputCopy* same = nullptr;  // an entry that holds these bytes
+      for (auto& e : c.inputs)
+        if (e.host == (const char*)p && e.bytes == bytes) { hit = &e; break; }
+      if (hit && memcmp(hit->shadow, p, bytes) == 0) same = hit;
+      if (!same) {
+        // the same bytes under another address: the frontend's emissivity / incident-flux / secant fields are temporaries that
+        // land where the allocator puts them, with the same contents every time (a memcmp of different fields ends at the
+        // first word)
+        for (auto& e : c.inputs)
+          if (&e != hit && e.bytes == bytes && memcmp(e.shadow, p, bytes) == 0) { same = &e; break; }
+      }
+      if (same) {
+        same->last_use = c.seq;
+        ++c.input_hits; c.input_saved += (long long)bytes;
+        c.t_h2d += secs_since(t0);
+        return same->dev;
+      }
+      if (!hit) {
+        // (bounded: 48 arrays, 1 GB of shadows per context; the least recently used goes first)
+        while (!c.inputs.empty() && (c.inputs.size() >= 48 || c.inputs_total + bytes > (size_t(1) << 30))) {
+          size_t v = 0;
+          for (size_t k = 1; k < c.inputs.size(); ++k) if (c.inputs[k].last_use < c.inputs[v].last_use) v = k;
+          HIP_CHECK(hipStreamSynchronize(c.stream));  // kernels of earlier calls may still read the device copy
+          HIP_CHECK(hipFree(c.inputs[v].dev)); free(c.inputs[v].shadow);
+          c.inputs_total -= c.inputs[v].bytes;
+          c.inputs.erase(c.inputs.begin() + v);
+        }
+        Context::InputCopy e{(const char*)p, bytes, (char*)malloc(bytes), nullptr, c.seq};
+        if (!e.shadow) throw Error{-1, "out of host memory for an input shadow"};
+        const hipError_t rc = hipMalloc((void**)&e.dev, bytes);
+        if (rc != hipSuccess) { free(e.shadow); HIP_CHECK(rc); }
+        c.inputs.push_back(e);
+        c.inputs_total += bytes;
+        hit = &c.inputs.back();
+      }
+      hit->last_use = c.seq;
+      // (through the pinned ring, stream-ordered behind the kernels that read the device copy's previous contents.  A pinned
+      //  shadow that the transfer would start from -- one memcpy instead of two -- was measured: slower, the unpipelined copy
+      //  and the pinning of every new shadow cost more than the second memcpy)
+      if (!h2d(c, hit->dev, p, bytes)) staged_plain_ = true;
+      memcpy(hit->shadow, p, bytes);
+      c.t_h2d += secs_since(t0);
+      staged_in_ = true;
+      c.mstat[2] += (long long)bytes;
+      mark_h2d();
+      return hit->dev;
+    }
+  }
   void* d = scratch(bytes);
   if (copy_in) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -881,10 +957,13 @@ static unsigned long long table_fingerprint(const char* p, size_t bytes) {
 }
 void drop_table_copies() {
   Context& c = C;
-  if (c.tables.empty()) return;
+  if (c.tables.empty() && c.inputs.empty()) return;
   HIP_CHECK(hipStreamSynchronize(c.stream));
   for (auto& t : c.tables) HIP_CHECK(hipFree(t.dev));
   c.tables.clear();
+  for (auto& e : c.inputs) { HIP_CHECK(hipFree(e.dev)); free(e.shadow); }
+  c.inputs.clear();
+  c.inputs_total = 0;
 }
 const void* Call::stage_table(const void* p, size_t bytes) {
   void* dv;
@@ -987,9 +1066,11 @@ Call::~Call() noexcept(false) {
   if (c.report_on) {
     size_t i = 0;
     while (i < c.t_entry.size() && c.t_entry[i].first != name) ++i;  // (entry names are string literals: one address each)
-    if (i == c.t_entry.size()) c.t_entry.push_back({name, {0.0, 0L}});
+    if (i == c.t_entry.size()) { c.t_entry.push_back({name, {0.0, 0L}}); c.b_entry.push_back({0, 0}); }
     c.t_entry[i].second.first += dt_call;
     c.t_entry[i].second.second += 1;
+    c.b_entry[i].first += c.mstat[2] - c.call_h2d0;
+    c.b_entry[i].second += c.mstat[3] - c.call_d2h0;
   }
   c.mutex.unlock();
 }
@@ -1303,10 +1384,12 @@ int rte_hip_mirror_drop_all(void) {
 long long rte_hip_mirror_stat(int which) {
   LOCK_CTX;
   rte::Context& c = rte::ctx();
-  if (which < 0) { for (auto& v : c.mstat) v = 0; return 0; }
+  if (which < 0) { for (auto& v : c.mstat) v = 0; c.input_hits = 0; c.input_saved = 0; return 0; }
   if (which < 8) return c.mstat[which];
   if (which == 8) return (long long)c.mirrors.size();
   if (which == 9) return (long long)c.mirror_total;
+  if (which == 10) return c.input_hits;    // host-produced inputs served from their device copy (Call::stage)
+  if (which == 11) return c.input_saved;   // bytes not uploaded for them
   return -1;
 }
 int rte_hip_device_count(void) {

@@ -174,3 +174,42 @@ def test_host_mirror_mode_with_numpy_arrays_and_table_copies():
         hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 0)
         setc(None)
         destroy(ctx)
+
+
+@pytest.mark.gpu
+def test_host_mirror_mode_serves_unchanged_inputs_from_the_device_and_sees_changed_ones():
+    """Host-mirror mode keeps a device copy and a host-side shadow of inputs the host produced: the same bytes coming again
+    (the same range, or another array with the same contents) are not uploaded; ONE changed element in the same range is."""
+    hip = hiplib.load()
+    create, setc, destroy = _ctx_api(hip)
+    stat = hip.raw("rte_hip_mirror_stat")
+    stat.restype = ctypes.c_longlong
+    ncol, nlev, ngpt = 512, 61, 64  # 16 MB of spectral fluxes
+    rng = np.random.default_rng(7)
+    x = np.asfortranarray(rng.random((ncol, nlev, ngpt)))
+    out = np.zeros((ncol, nlev), order="F")
+    ctx = create(-1, None)
+    setc(ctx)
+    try:
+        hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 1)
+        stat(ctypes.c_int(-1))
+        hip.rte_sum_broadband(ncol, nlev, ngpt, x, out)
+        want = x.sum(axis=2)
+        assert np.allclose(out, want, rtol=1e-13) and stat(ctypes.c_int(10)) == 0
+        up0 = stat(ctypes.c_int(2))
+        out[:] = 0
+        hip.rte_sum_broadband(ncol, nlev, ngpt, x, out)              # same range, same bytes
+        assert np.allclose(out, want, rtol=1e-13)
+        assert stat(ctypes.c_int(10)) == 1 and stat(ctypes.c_int(2)) == up0 and stat(ctypes.c_int(11)) == x.nbytes
+        y = x.copy(order="F")                                        # another range, same bytes
+        hip.rte_sum_broadband(ncol, nlev, ngpt, y, out)
+        assert np.allclose(out, want, rtol=1e-13) and stat(ctypes.c_int(10)) == 2
+        x[ncol // 2, nlev // 2, ngpt // 2] += 1.0                    # one element changed in place
+        hip.rte_sum_broadband(ncol, nlev, ngpt, x, out)
+        assert stat(ctypes.c_int(10)) == 2 and stat(ctypes.c_int(2)) == up0 + x.nbytes
+        assert abs(out[ncol // 2, nlev // 2] - want[ncol // 2, nlev // 2] - 1.0) < 1e-12
+        assert np.allclose(out, x.sum(axis=2), rtol=1e-13)
+    finally:
+        hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 0)
+        setc(None)
+        destroy(ctx)
