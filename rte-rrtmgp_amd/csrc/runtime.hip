@@ -864,6 +864,7 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
       }
       if (same) {
         same->last_use = c.seq;
+        staged_in_ = true;  // (a call with host inputs stays on the library stream: the next upload into this copy is ordered behind it)
         ++c.input_hits; c.input_saved += (long long)bytes;
         c.t_h2d += secs_since(t0);
         return same->dev;
