@@ -2350,17 +2350,23 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     else hipLaunchKernelGGL((lw_2stream_seg_kernel<12>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, rte::stream(), q);
     return;
   }
-  if (nlay > 96 && nlay <= 192 && !g_lw_force_generic) {
-    // ------------------------------------------------------------------ 97 ... 192 layers: an upper part T and a lower part
-    // B on the segmented kernel, coupled through the adding method as in rte_sw_solver_2stream (B alone -> its albedo and
-    // source at its top; T with those as its surface -> the flux leaving its bottom; B again with that flux entering)
-    const int nT = nlay <= 88 + 96 ? 88 : 96, nB = nlay - nT;
+  constexpr int kLw2WinLay = 88, kLw2WinMax = 8;  // layers per window (11 per wave), windows
+  if (nlay > 96 && nlay <= kLw2WinLay * kLw2WinMax && !g_lw_force_generic) {
+    // ------------------------------------------------------------------ 97 ... 704 layers: K windows of layers on the segmented
+    // kernel, coupled through the adding method as in rte_sw_solver_2stream: bottom to top every window but the first, alone
+    // over the albedo and source of the windows below it, gives its albedo and source at its top; top to bottom every window is
+    // solved with the flux the window above leaves at its bottom entering and the window below as its surface
+    const int K = (nlay + kLw2WinLay - 1) / kLw2WinLay;
+    int wn[kLw2WinMax], wpos[kLw2WinMax];
+    for (int w = 0, pos = 0; w < K; ++w) { wn[w] = nlay / K + (w < nlay % K ? 1 : 0); wpos[w] = pos; pos += wn[w]; }
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
     const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
-    Float* side = (Float*)rte::scratch(sizeof(Float) * ncg * 3);
+    Float* side = (Float*)rte::scratch(sizeof(Float) * ncg * (2 * (K - 1) + 2));  // albedo / source at the top of windows 1 ... K - 1, two flux arrays
+    Float* const fd_pair = side + ncg * 2 * (K - 1);
     const bool top = *top_at_1;
-    auto run = [&](int lay0, int nl, int phase) {
+    auto run = [&](int w, int phase) {  // phase 1: alone (-> albedo, source at its top); 2: the final solve
+      const int lay0 = wpos[w], nl = wn[w];
       Lw2SegArgs q{};
       const int L = nl <= 64 ? 8 : (nl <= 72 ? 9 : nl <= 80 ? 10 : nl <= 88 ? 11 : 12);
       q.ncol = ncol; q.nlay = nl; q.ngpt = ngpt; q.S = (nl + L - 1) / L; q.g_per_block = g_per_block; q.top_at_1 = top;
@@ -2370,9 +2376,12 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
       q.flux_up = a.flux_up + off; q.flux_dn = a.flux_dn + off;
       q.plane_lay = ncl; q.plane_lev = nclv;
       q.sfc_emis = a.sfc_emis; q.sfc_src = a.sfc_src; q.inc_flux = a.inc_flux;
-      if (phase == 1) { q.out_alb = side; q.out_src = side + ncg; }
-      if (phase == 2) { q.sfc_emis = side; q.sfc_src = side + ncg; q.sfc_given = true; q.out_fd = side + 2 * ncg; }
-      if (phase == 3) { q.inc_flux = side + 2 * ncg; q.skip_first_level = true; }
+      if (w + 1 < K) { q.sfc_emis = side + ncg * 2 * w; q.sfc_src = side + ncg * (2 * w + 1); q.sfc_given = true; }  // the window below
+      if (phase == 1) { q.out_alb = side + ncg * 2 * (w - 1); q.out_src = side + ncg * (2 * (w - 1) + 1); }
+      else {
+        if (w > 0) { q.inc_flux = fd_pair + ncg * ((w - 1) & 1); q.skip_first_level = true; }
+        if (w + 1 < K) q.out_fd = fd_pair + ncg * (w & 1);
+      }
       const size_t lds_bytes = sizeof(Float) * 64 * 8 * (7 + 2);
       rte::ProfScope p("lw_2stream_seg_kernel");
       const dim3 grid(col_tiles, ngroups), blk(64 * q.S);
@@ -2382,9 +2391,8 @@ void rte_lw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
       else if (L == 11) hipLaunchKernelGGL((lw_2stream_seg_kernel<11, true>), grid, blk, lds_bytes, rte::stream(), q);
       else hipLaunchKernelGGL((lw_2stream_seg_kernel<12, true>), grid, blk, lds_bytes, rte::stream(), q);
     };
-    run(nT, nB, 1);
-    run(0, nT, 2);
-    run(nT, nB, 3);
+    for (int w = K - 1; w >= 1; --w) run(w, 1);
+    for (int w = 0; w < K; ++w) run(w, 2);
     return;
   }
   const size_t gchunk = pick_gchunk(sizeof(Float) * ncl * 4, ngpt);
@@ -2490,20 +2498,30 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, q.part_dir, d_bdir, (Float)1, false);
     return;
   }
-  if (nlay > kSwMaxLay && nlay <= 2 * kSwMaxLay && !g_sw_force_generic && nclv < ((size_t)1 << 29)) {
-    // ------------------------------------------------------------------ 97 ... 192 layers: the column as an upper part T and a
-    // lower part B, each on the segmented kernel (WIN).  The adding method composes: (1) B alone gives the albedo and the source
-    // (per unit of beam) it presents at its top; (2) T is solved with those as its "surface" and leaves the diffuse and the
-    // direct flux at its bottom; (3) B is solved again with these as its top boundary.  B is made as short as T's limit
-    // allows (it is evaluated twice).
-    const int nT = nlay <= 88 + kSwMaxLay ? 88 : kSwMaxLay, nB = nlay - nT;  // (11 layers per wave: the widest variant without spills)
+  constexpr int kSwWinLay = 88, kSwWinMax = 8;  // layers per window (11 per wave: the widest variant without spills), windows
+  if (nlay > kSwMaxLay && nlay <= kSwWinLay * kSwWinMax && !g_sw_force_generic && nclv < ((size_t)1 << 29)) {
+    // ------------------------------------------------------------------ 97 ... 704 layers: the column as K windows of layers,
+    // each on the segmented kernel (WIN).  The adding method composes: bottom to top (phase 1) every window but the first,
+    // alone under a unit beam, over the albedo and source of the windows below it (the last: the surface), gives the albedo
+    // and the source per unit of beam it presents at its top; top to bottom every window is then solved with the diffuse and
+    // direct flux the window above leaves at its bottom as its top boundary (the first: the column's) and the window below as
+    // its "surface".  Every window but the first is evaluated twice.
+    const int K = (nlay + kSwWinLay - 1) / kSwWinLay;
+    int wn[kSwWinMax], wpos[kSwWinMax];  // layers of window w, its first layer's position from the top
+    for (int w = 0, pos = 0; w < K; ++w) { wn[w] = nlay / K + (w < nlay % K ? 1 : 0); wpos[w] = pos; pos += wn[w]; }
     const int col_tiles = cdiv(ncol, 64);
     const int g_per_block = seg_g_per_block(col_tiles, ngpt);
     const int ngroups = (ngpt + g_per_block - 1) / g_per_block;
     Float* parts = do_broadband ? (Float*)rte::scratch(sizeof(Float) * nclv * ngroups * 3) : nullptr;
-    Float* side = (Float*)rte::scratch(sizeof(Float) * ncg * 4);  // albedo / source at B's top, diffuse / direct flux at T's bottom
+    // (column, g-point) arrays: albedo / source at the top of windows 1 ... K - 1, diffuse / direct flux at a window's bottom (two
+    // pairs: a window reads the pair of the window above and writes its own)
+    Float* side = (Float*)rte::scratch(sizeof(Float) * ncg * (2 * (K - 1) + 4));
+    Float* const flux_pair = side + ncg * 2 * (K - 1);
     const bool top = *top_at_1;
-    auto run = [&](int lay0, int nl, int phase) {
+    // phase 1: alone under a unit beam (-> albedo, source at its top); phase 2: the final solve.  Window w's "surface" is window
+    // w + 1 (the last: the surface), its top boundary what window w - 1 left (the first: the column's)
+    auto run = [&](int w, int phase) {
+      const int lay0 = wpos[w], nl = wn[w];
       Sw2SegArgs q{};
       // (a short lower part gets 4 layers per wave: all eight waves -- all four SIMDs -- work instead of two or three)
       const int L = nl <= 32 ? 4 : nl <= 64 ? 8 : (nl <= 72 ? 9 : nl <= 80 ? 10 : nl <= 88 ? 11 : 12);
@@ -2516,9 +2534,18 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
       else { q.spec_up = d_up + off; q.spec_dn = d_dn + off; q.spec_dir = d_dir + off; }  // (spectral: phase 1 writes B's levels too, phases 2 and 3 overwrite them)
       q.sfc_alb_dir = a.sfc_alb_dir; q.sfc_alb_dif = a.sfc_alb_dif; q.inc_flux_dir = a.inc_flux_dir; q.inc_flux_dif = a.inc_flux_dif;
       q.has_dif_bc = *has_dif_bc;
-      if (phase == 1) { q.beam_mode = 1; q.has_dif_bc = false; q.out_alb = side; q.out_src = side + ncg; }
-      if (phase == 2) { q.sfc_alb_dif = side; q.sfc_alb_dir = side + ncg; q.sfc_src_given = true; q.out_fd = side + 2 * ncg; q.out_dir = side + 3 * ncg; }
-      if (phase == 3) { q.beam_mode = 2; q.inc_flux_dir = side + 3 * ncg; q.inc_flux_dif = side + 2 * ncg; q.has_dif_bc = true; q.skip_first_level = true; }
+      if (w + 1 < K) {  // the window below as the surface
+        q.sfc_alb_dif = side + ncg * 2 * w; q.sfc_alb_dir = side + ncg * (2 * w + 1); q.sfc_src_given = true;
+      }
+      if (phase == 1) {
+        q.beam_mode = 1; q.has_dif_bc = false; q.out_alb = side + ncg * 2 * (w - 1); q.out_src = side + ncg * (2 * (w - 1) + 1);
+      } else {
+        if (w > 0) {  // what the window above left at its bottom
+          Float* in = flux_pair + ncg * 2 * ((w - 1) & 1);
+          q.beam_mode = 2; q.inc_flux_dif = in; q.inc_flux_dir = in + ncg; q.has_dif_bc = true; q.skip_first_level = true;
+        }
+        if (w + 1 < K) { Float* out = flux_pair + ncg * 2 * (w & 1); q.out_fd = out; q.out_dir = out + ncg; }
+      }
       const size_t lds_bytes = do_broadband
           ? sizeof(Float) * 64 * (8 * 8 + 2 * 8 + ((L == 9 || L >= 11) ? 1 : 2) * 8 * L + ((L <= 9 || L >= 11) ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0))
           : sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 2 * 8 * L);
@@ -2540,9 +2567,8 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
       else if (L == 11) hipLaunchKernelGGL((sw_2stream_seg_kernel<11, false, true>), grid, blk, lds_bytes, st0, q);
       else hipLaunchKernelGGL((sw_2stream_seg_kernel<12, false, true>), grid, blk, lds_bytes, st0, q);
     };
-    run(nT, nB, 1);
-    run(0, nT, 2);
-    run(nT, nB, 3);
+    for (int w = K - 1; w >= 1; --w) run(w, 1);
+    for (int w = 0; w < K; ++w) run(w, 2);
     if (!do_broadband) return;
     rte::ProfScope p("sw_reduce_parts");
     hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(nclv, 256)), dim3(256), 0, st0, nclv, ngroups, parts, d_bu, (Float)1, false);

@@ -122,9 +122,9 @@ def test_segmented_and_generic_sw_solvers_agree(hip, oracle_c, name):
     F = lambda *sh: np.asfortranarray(rng.random(sh))
     A = xp.asarray
     # 72 / 75 / 88 / 91 / 96: nine ... twelve layers per wave (91 and 137 levels are what host models bring)
-    # 100 ... 192: sw_solver_2stream as an upper and a lower part on the segmented kernel (three launches)
+    # 97 ... 704: sw_solver_2stream as 2 ... 8 windows of layers on the segmented kernel (every window but the first twice)
     for nlay, top_at_1 in ((27, False), (27, True), (72, False), (75, True), (81, True), (88, False), (91, True), (96, False), (100, False),
-                           (137, True), (185, False), (192, True)):
+                           (137, True), (185, False), (192, True), (200, False), (300, True), (445, False), (704, True)):
         ncol, ngpt = 70, 16
         tau, ssa, g = F(ncol, nlay, ngpt) * 3.0, F(ncol, nlay, ngpt) * 0.999, F(ncol, nlay, ngpt) * 0.9 - 0.1
         mu0 = np.asfortranarray(np.repeat((rng.random(ncol) * 1.2 - 0.2)[:, None], nlay, axis=1))  # some <= 0
