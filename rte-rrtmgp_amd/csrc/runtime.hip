@@ -495,6 +495,7 @@ static int g_procmem_fd = -2;
 // host thread, per-context limits of "60 % of what is free" would add up to several times the device
 static std::atomic<size_t> g_mirror_all{0};
 static std::atomic<size_t> g_mirror_limit_all{0};
+static std::atomic<int> g_staging_contexts{0};  // contexts that have staged a host-produced input in host-mirror mode
 static std::mutex g_report_mutex;
 static std::vector<Context*> g_report_contexts;
 
@@ -847,8 +848,15 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
     // col_gas to interpolation, compute_tau_absorption and compute_Planck_source in a row, and an emissivity, a zero incident
     // flux and a secant field that do not change from block to block to every solver call: 19.6 KB per column crossed PCIe
     // where 6.3 KB were new.
-    if (c.input_cache < 0) { const char* e = getenv("RTE_HIP_INPUT_CACHE"); c.input_cache = (e && atoi(e) == 0) ? 0 : 1; }
-    if (c.input_cache) {
+    // Default: on as soon as a second context stages host arrays (several host threads share the PCIe link, and the link is what
+    // binds them: 1.6-1.7 -> 2.2-2.75 M columns/s on eight threads); a single thread is bound by its own passes over the
+    // arrays, and compare + shadow cost it 10 % (0.50 -> 0.45 M).  RTE_HIP_INPUT_CACHE=1 / 0 forces it on / off.
+    if (c.input_cache < 0) {
+      const char* e = getenv("RTE_HIP_INPUT_CACHE");
+      c.input_cache = (!e || !*e) ? 2 : (atoi(e) == 0 ? 0 : 1);
+      ++g_staging_contexts;
+    }
+    if (c.input_cache == 1 || (c.input_cache == 2 && g_staging_contexts.load(std::memory_order_relaxed) >= 2)) {
       const auto t0 = std::chrono::steady_clock::now();
       Context::InputCopy* hit = nullptr;  // the entry of this very range, if there is one (it is refilled on a mismatch)
       Context::InputCopy* same = nullptr;  // an entry that holds these bytes

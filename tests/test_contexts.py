@@ -190,6 +190,7 @@ def test_host_mirror_mode_serves_unchanged_inputs_from_the_device_and_sees_chang
     out = np.zeros((ncol, nlev), order="F")
     ctx = create(-1, None)
     setc(ctx)
+    os.environ["RTE_HIP_INPUT_CACHE"] = "1"  # (read at the context's first staged input; by default on from the second staging context on)
     try:
         hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 1)
         stat(ctypes.c_int(-1))
@@ -210,6 +211,7 @@ def test_host_mirror_mode_serves_unchanged_inputs_from_the_device_and_sees_chang
         assert abs(out[ncol // 2, nlev // 2] - want[ncol // 2, nlev // 2] - 1.0) < 1e-12
         assert np.allclose(out, x.sum(axis=2), rtol=1e-13)
     finally:
+        os.environ.pop("RTE_HIP_INPUT_CACHE", None)
         hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 0)
         setc(None)
         destroy(ctx)
