@@ -114,7 +114,7 @@ struct Context {
   std::vector<InputCopy> inputs;
   size_t inputs_total = 0;
   int input_cache = -1;  // RTE_HIP_INPUT_CACHE (default on in host-mirror mode)
-  long long input_hits = 0, input_saved = 0;
+  long long input_hits = 0, input_saved = 0, input_made = 0, input_evicted = 0;
   std::vector<std::pair<long long, long long>> b_entry;  // per entry point: bytes copied host-to-device / device-to-host
   long long call_h2d0 = 0, call_d2h0 = 0;
   // ---- timing
@@ -509,9 +509,9 @@ static void staging_report() {
     fprintf(stderr, "rte_rrtmgp_hip staging report (context %d): %ld calls, %.3f s inside the library (host-to-device copies %.3f s for %.3f GB, "
             "waits + device-to-host %.3f s for %.3f GB, mirror look-ups %.3f s); mirrors made %lld, hits %lld, dropped %lld + %lld, aged %lld, "
             "zero fills elided %lld, device bytes held %.2f GB; host tables uploaded %lld, reused %lld; unchanged inputs served from the device %lld "
-            "(%.3f GB not copied)\n", i++, c->n_calls, c->t_call, c->t_h2d, c->mstat[2] * 1e-9, c->t_wait,
+            "(%.3f GB not copied; %lld input copies made, %lld evicted)\n", i++, c->n_calls, c->t_call, c->t_h2d, c->mstat[2] * 1e-9, c->t_wait,
             c->mstat[3] * 1e-9, c->t_find, c->mstat[1], c->mstat[0], c->mstat[4], c->mstat[5], c->mstat[6], c->mstat[7], c->mirror_total * 1e-9,
-            c->table_uploads, c->table_hits, c->input_hits, c->input_saved * 1e-9);
+            c->table_uploads, c->table_hits, c->input_hits, c->input_saved * 1e-9, c->input_made, c->input_evicted);
     std::vector<size_t> order(c->t_entry.size());
     for (size_t k = 0; k < order.size(); ++k) order[k] = k;
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return c->t_entry[a].second.first > c->t_entry[b].second.first; });
@@ -886,6 +886,7 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
           HIP_CHECK(hipFree(c.inputs[v].dev)); free(c.inputs[v].shadow);
           c.inputs_total -= c.inputs[v].bytes;
           c.inputs.erase(c.inputs.begin() + v);
+          ++c.input_evicted;
         }
         Context::InputCopy e{(const char*)p, bytes, (char*)malloc(bytes), nullptr, c.seq};
         if (!e.shadow) throw Error{-1, "out of host memory for an input shadow"};
@@ -893,6 +894,7 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
         if (rc != hipSuccess) { free(e.shadow); HIP_CHECK(rc); }
         c.inputs.push_back(e);
         c.inputs_total += bytes;
+        ++c.input_made;
         hit = &c.inputs.back();
       }
       hit->last_use = c.seq;
