@@ -123,23 +123,28 @@ interpolation_kernel(int ncol, int nlay, int ngas, int nflav, int neta, int npre
     s_je[t * 3] = je[0]; s_je[t * 3 + 1] = je[1];
     __syncthreads();
     const size_t rec0 = (size_t)c0 + (size_t)ncol * ilay + ncl * iflav;  // record index of the block's first column
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int e = t + 256 * k;
-      if (e < 8 * nc) fmajor[8 * rec0 + e] = s_fmj[(e >> 3) * 9 + (e & 7)];
-    }
+    // 16 bytes per lane and store, 4 KB contiguous per instruction (8 bytes per lane: 1.37-1.51 against 1.27-1.35 ms)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int e = t + 256 * k;
-      if (e < 4 * nc) fminor[4 * rec0 + e] = s_fmn[(e >> 2) * 5 + (e & 3)];
+      const int e = 2 * t + 512 * k;
+      if (e < 8 * nc) {
+        Float2 v; v.x = s_fmj[(e >> 3) * 9 + (e & 7)]; v.y = s_fmj[(e >> 3) * 9 + (e & 7) + 1];
+        *reinterpret_cast<Float2*>(fmajor + 8 * rec0 + e) = v;
+      }
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int e = t + 256 * k;
-      if (e < 2 * nc) {
-        col_mix[2 * rec0 + e] = s_cm[(e >> 1) * 3 + (e & 1)];
-        jeta[2 * rec0 + e] = s_je[(e >> 1) * 3 + (e & 1)];
+      const int e = 2 * t + 512 * k;
+      if (e < 4 * nc) {
+        Float2 v; v.x = s_fmn[(e >> 2) * 5 + (e & 3)]; v.y = s_fmn[(e >> 2) * 5 + (e & 3) + 1];
+        *reinterpret_cast<Float2*>(fminor + 4 * rec0 + e) = v;
       }
+    }
+    if (t < nc) {
+      Float2 v; v.x = s_cm[t * 3]; v.y = s_cm[t * 3 + 1];
+      *reinterpret_cast<Float2*>(col_mix + 2 * rec0 + 2 * t) = v;
+      int2 w; w.x = s_je[t * 3]; w.y = s_je[t * 3 + 1];
+      *reinterpret_cast<int2*>(jeta + 2 * rec0 + 2 * t) = w;
     }
   }
   if (masks) {

@@ -48,6 +48,24 @@ __global__ void __launch_bounds__(512) kE(double* b, int L) {  // grid: tile fas
   if (c >= nch) return;
   for (int l = c * L; l < (c + 1) * L; ++l) put(b, tile, band, l, 1.0);
 }
+// A with 16 bytes per lane: the same 512 threads, lane pairs store two columns of one plane (even lanes the even g-points, odd lanes
+// the odd ones): half as many store instructions for the same bytes, pieces and planes
+__global__ void __launch_bounds__(512) kA16(double* b) {
+  const int id = blockIdx.x, tile = id % NT, band = id / NT;
+  const size_t plane = (size_t)NCOL * NLAY, planev = (size_t)NCOL * (NLAY + 1);
+  double* lev = b + plane * NBND * GPB;
+  const int par = threadIdx.x & 1, c0 = threadIdx.x & ~1;
+  for (int l = 0; l < NLAY; ++l) {
+    const size_t o = (size_t)l * NCOL + (size_t)tile * 512 + c0;
+#pragma unroll
+    for (int g = 0; g < GPB; g += 2) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const d2 v = {1.0, 1.0};
+      __builtin_nontemporal_store(v, reinterpret_cast<d2*>(b + plane * (band * GPB + g + par) + o));
+      __builtin_nontemporal_store(v, reinterpret_cast<d2*>(lev + planev * (band * GPB + g + par) + o));
+    }
+  }
+}
 int main() {
   const size_t n = (size_t)NCOL * (2 * NLAY + 1) * NBND * GPB;
   double* buf; CK(hipMalloc(&buf, n * 8));
@@ -60,6 +78,7 @@ int main() {
     printf("%-84s %7.3f ms  %6.0f GB/s\n", name, best, gb / (best * 1e-3));
   };
   timeit("A  (tile, band) walking layers, tile fastest", [&] { hipLaunchKernelGGL(kA, dim3(NT * NBND), dim3(512), 0, 0, buf, 0); });
+  timeit("A16 as A with 16-byte stores of lane pairs", [&] { hipLaunchKernelGGL(kA16, dim3(NT * NBND), dim3(512), 0, 0, buf); });
   timeit("A' (tile, band) walking layers, XCD-aware order (bands of a tile on one XCD)", [&] { hipLaunchKernelGGL(kA, dim3(((NT + 7) / 8) * 8 * NBND), dim3(512), 0, 0, buf, 1); });
   timeit("B  (band, layer) walking the column tiles, band fastest", [&] { hipLaunchKernelGGL(kB, dim3(NBND * NLAY), dim3(512), 0, 0, buf, 0); });
   timeit("B' (band, layer) walking the column tiles, layer fastest", [&] { hipLaunchKernelGGL(kB, dim3(NBND * NLAY), dim3(512), 0, 0, buf, 1); });
