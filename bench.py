@@ -362,6 +362,155 @@ def _device_uuid(torch, idx):
             return None
 
 
+# fp64 operations sw_dif_and_source + adding need per (column, layer, g-point), counted on the reference's expressions
+# (rte/kernels/mo_rte_solver_kernels.F90:1029-1110 and :1174-1202 / :1221-1243), one operation = one fp64 vector instruction
+# (an FMA counts once; exp / sqrt / reciprocal at the length of a correctly rounded-to-1-ulp software sequence on a machine
+# without fp64 transcendentals beyond v_rcp_f64 / v_rsq_f64):
+SW_FP64_OPS = {
+    "gamma1, gamma2 (:1036-1037)": 6, "k: two sums, product, max (:1045)": 4, "-tau k, exp^2 (:1046-1047)": 2,
+    "RT_term denominator (:1050-1051)": 4, "Rdif, Tdif (:1053, :1056)": 5, "mu0_s, k_mu, 1 - k_mu^2, guard, w0 RT / . (:1063-1073)": 8,
+    "gamma3, gamma4, alpha1, alpha2, k gamma3, k gamma4 (:1078-1088)": 10, "-tau / mu0_s (:1089)": 1, "Rdir (:1090-1093)": 12,
+    "Tdir (:1100-1103)": 13, "the two clamps (:1108-1109)": 6, "source_up, source_dn, dir_flux_trans (:1111-1113)": 3,
+    "adding, upward: denom, albedo, src (:1176-1186)": 8, "adding, downward: flux_dn, flux_up (:1198-1202)": 5,
+    "broadband sums of flux_up, flux_dn, flux_dir over g (mo_fluxes_broadband_kernels.F90:31-46, r = 61/60)": 3,
+    "2 x exp (range reduction 5, degree-11 polynomial 11, scaling 2)": 36, "sqrt (v_rsq_f64 + 2 Newton steps)": 8,
+    "3 x reciprocal (v_rcp_f64 + 2 Newton steps)": 15,
+}
+
+
+def sw_fp64_bound(ncol, nlay, ngpt, measured_ms, sclk):
+    """The fp64-issue bound of sw_solver_2stream: operations the algorithm needs (SW_FP64_OPS) x cells, on 1024 SIMDs issuing one
+    wave64 fp64 instruction per 4 cycles (= the 78.6 TFLOP/s of fp64 FMA of the guide), at the nominal 2.4 GHz and at the shader
+    clock sampled in THIS run while the step loops (`sclk`, see sample_sclk)."""
+    ops = sum(SW_FP64_OPS.values())
+    cells = ncol * nlay * ngpt
+    ms_nominal = cells / 64.0 * ops * 4 / (1024 * 2.4e9) * 1e3
+    out = {"kernel": "sw_2stream_seg_kernel", "bound": "fp64 VALU issue, algorithmic operation count",
+           "fp64_ops_per_cell": ops, "ops_breakdown": SW_FP64_OPS, "cells_per_launch": cells,
+           "ms_at_peak": round(ms_nominal, 3), "measured_ms": measured_ms, "frac_of_peak": round(ms_nominal / measured_ms, 4),
+           "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 instruction (= 78.6 TFLOP/s of fp64 FMA)",
+           "sclk": sclk}
+    if sclk and sclk.get("median_GHz"):
+        ghz = sclk["median_GHz"]
+        out["ms_at_sampled_clock"] = round(ms_nominal * 2.4 / ghz, 3)
+        out["frac_at_sampled_clock"] = round(ms_nominal * 2.4 / ghz / measured_ms, 4)
+    return out
+
+
+def sample_sclk(run_for, seconds=2.0):
+    """Shader clock while `run_for(seconds)` keeps the GPU busy: a thread reads the hwmon frequency of the first amdgpu device
+    every 10 ms (sysfs), else polls `rocm-smi --showclocks`.  Returns {"median_GHz", "min_GHz", "max_GHz", "samples", "source"}
+    or None."""
+    import glob as _glob
+    import re
+    import subprocess
+    import threading
+
+    paths = sorted(_glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                if paths:
+                    samples.append(int(open(paths[0]).read()) / 1e9)  # Hz
+                    time.sleep(0.01)
+                else:
+                    o = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                    m = re.search(r"sclk clock level.*?\((\d+)Mhz\)", o)
+                    if m:
+                        samples.append(int(m.group(1)) / 1e3)
+            except Exception:  # noqa: BLE001
+                time.sleep(0.05)
+
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    try:
+        run_for(seconds)
+    finally:
+        stop.set()
+        th.join(timeout=10)
+    samples = sorted(x for x in samples if x > 0.05)
+    if not samples:
+        return None
+    # (the first and last samples may fall outside the busy loop: the median does not care)
+    return {"median_GHz": round(samples[len(samples) // 2], 3), "min_GHz": round(samples[0], 3), "max_GHz": round(samples[-1], 3),
+            "samples": len(samples), "source": (paths[0] if paths else "rocm-smi --showclocks") + f", while the step loops for {seconds} s"}
+
+
+def run_secondary(steps=5, warmup=2, timeout=300):
+    """config.secondary of the default line: the SW chain (BASELINE configs[2]), the all-sky chain (configs[3]) and the LW
+    chain on 100 distinct RFMIP-like sites, in contiguous runs and in random column order (the direct-gather worklist's worst
+    case), each as a child run of this script: `steps` timed steps, no CPU baseline, no extras.  What is kept of a child's
+    line: step time, columns/s, the chain's fraction of 8 TB/s on the bytes its kernels must move, kernel times, worklist."""
+    import subprocess
+
+    runs = {"sw": ["--workload", "sw"], "allsky": ["--workload", "allsky"],
+            "lw_sites": ["--atmosphere", "sites"], "lw_sites_shuffled": ["--atmosphere", "sites-shuffled"]}
+    out = {"what": f"child runs of bench.py after the timed region ({steps} steps, {warmup} warm-up each, same device, the parent's "
+                   "buffers released): BASELINE configs[2], configs[3], and the headline chain on 100 distinct sites in runs / shuffled"}
+    for name, extra in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+               "--no-cpu-baseline", "--no-plain-abi", "--no-factored", "--no-secondary"] + extra
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+            r = json.loads(line)
+            roof = r.get("roofline") or {}
+            pk = roof.get("per_kernel") or {}
+            ent = {"ms_per_step": round(r["ms_per_step"], 4), "columns_per_s": round(r["value"], 1),
+                   "chain_frac": (roof.get("chain") or {}).get("frac"),
+                   "chain_alg_GB": (roof.get("chain") or {}).get("alg_GB_per_step"),
+                   "kernel_ms": {k: v["avg_ms"] for k, v in pk.items()},
+                   "kernel_frac": {k: v["frac"] for k, v in pk.items()},
+                   "worklist_items": (r["config"].get("direct_gather_worklist") or {}).get("tau_tile_layer_bands"),
+                   "worklist_of": (r["config"].get("direct_gather_worklist") or {}).get("of"),
+                   "workload": r["config"]["workload"][:120]}
+            if "sw_2stream_seg_kernel" in pk:
+                ent["solver_ms"] = pk["sw_2stream_seg_kernel"]["avg_ms"]
+            if roof.get("fp64_issue"):
+                ent["fp64"] = roof["fp64_issue"]
+            out[name] = ent
+        except Exception as e:  # noqa: BLE001
+            out[name] = f"failed: {type(e).__name__}: {e}"[:300]
+    return out
+
+
+def _skipped_line(args, reason):
+    """The JSON line of a run that cannot start (fewer devices than ranks): same keys, no value, exit status 0."""
+    return json.dumps({"metric": "columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)", "value": None, "unit": "columns/s",
+                       "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                       "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "skipped": reason,
+                       "config": {"workload": "not run", "rccl_world_size": 0}})
+
+
+def self_launch(args, torch):
+    """`python bench.py --gpus N` (N > 1) started without torch.distributed.run: re-execute this script under it, one rank
+    per GPU on this node (RCCL; 127.0.0.1 rendezvous on a free port).  Returns the exit status.  With fewer visible devices
+    than ranks nothing is started: one JSON line with "skipped", status 0 (ranks may share cuda:0 only with --single-device
+    --dist-backend gloo, the plumbing test)."""
+    import socket
+    import subprocess
+
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev == 0:
+        print(_skipped_line(args, "no GPU visible (the product path has no CPU fallback)"))
+        return 0
+    if args.gpus > ndev and not args.single_device:
+        print(_skipped_line(args, f"--gpus {args.gpus} but only {ndev} device(s) visible on this node"))
+        return 0
+    if args.single_device and args.dist_backend == "nccl":
+        print(_skipped_line(args, "--single-device needs --dist-backend gloo (RCCL refuses ranks that share a device)"))
+        return 0
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-worker":  # internal: one process of cpu_baseline()
         cpu_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else None)
@@ -405,10 +554,16 @@ def main():
                          "(rte_hip_overlap_planck; measured -0.12 ms per LW step: together the two kernels sit at the "
                          "HBM ceiling).  Off by default: the per-kernel event and rocprof durations of the pair then "
                          "overlap and no longer describe the kernels themselves")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip config.secondary of the default LW run (the SW, all-sky and site-ordered LW steps, each a short "
+                         "child run of this script after the timed region)")
     args = ap.parse_args()
 
     import torch
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU
+        raise SystemExit(self_launch(args, torch))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -416,6 +571,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.single_device:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():  # a launcher started more ranks than this node has devices
+        if rank == 0:
+            print(_skipped_line(args, f"WORLD_SIZE={world} ranks but only {torch.cuda.device_count()} device(s) visible on this node"))
+        return
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run: one process per GPU over RCCL
@@ -425,7 +584,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
         else:
             dist.init_process_group("gloo")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.ncol is None:
         # BASELINE configs[1] on one GPU; on several, the per-rank shard of configs[4] (1e6 columns on 8 GPUs = 125000 per rank;
         # the same 125000 per rank at 2 and 4 GPUs: weak scaling)
@@ -595,6 +755,20 @@ def main():
         per_rank = mine.cpu().numpy()
         dt = float(per_rank[:, 0].max()) * args.steps / 1e3  # the job's step time is its slowest rank's
     assert torch.isfinite(rb["flux_up"]).all() and float(rb["flux_up"].max()) > 0
+    sclk = None
+    if args.workload in ("sw", "allsky") and rank == 0:
+        def busy(seconds):
+            t_end = time.perf_counter() + seconds
+            while time.perf_counter() < t_end:
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+
+        try:
+            sclk = sample_sclk(busy)
+        except Exception:  # noqa: BLE001
+            sclk = None
+        torch.cuda.synchronize()
     # work the production gas-optics kernels handed to the direct-gather worklists in the last step
     wl_tau = hiplib.ext_call(lib, "rte_hip_stat", ["i"], 0)
     wl_planck = hiplib.ext_call(lib, "rte_hip_stat", ["i"], 1)
@@ -797,6 +971,16 @@ def main():
         kern_serial = read_profile(3)
         hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1)
 
+    # BASELINE configs[2], configs[3] and the headline's sensitivity to the order of the columns, in the ONE line the driver
+    # records: short child runs of this script (5 steps each) after the LW buffers are released; never `value`
+    secondary = None
+    if (rank == 0 and world == 1 and args.workload == "lw" and args.atmosphere == "rce" and not args.no_secondary
+            and args.ncol == 100000 and args.minor_distribution == "even"):
+        bufs.clear(); rb.clear()
+        torch.cuda.empty_cache()
+        hiplib.ext_call(lib, "rte_hip_release", [])
+        secondary = run_secondary()
+
     if rank == 0:
         # Fused extension kernels get their OWN byte model (the bytes that kernel must move): the one-pass SW gas optics runs
         # under the scope name of compute_tau_absorption; `abi_equivalent_GB` is what the chain of reference-ABI calls it
@@ -890,31 +1074,15 @@ def main():
                                                          "when no fused extension kernel runs, i.e. for the LW headline)"}},
                     "profile_backed": profile_backed,
                     "per_kernel": per_kernel, "other_kernels_avg_ms": others}
-            # the SW two-stream solver is bound by fp64 instruction ISSUE, not by HBM: state that roofline beside the HBM one.
-            # VALU instructions per launch from the committed SQ counters (profiles/*_sw_pmc_summary.csv, SQ_INSTS_VALU of the
-            # 60-layer kernel at 1e5 columns x 224 g-points), 4 cycles per wave64 instruction on one of 1024 SIMDs at 2.4 GHz
-            if "sw_2stream_seg_kernel" in per_kernel and args.workload == "sw":
+            # the SW two-stream solver is bound by fp64 instruction ISSUE, not by HBM: state that roofline beside the HBM one,
+            # from the ALGORITHM's operation count (SW_FP64_OPS: what sw_dif_and_source + adding need per cell whoever writes
+            # the kernel), not from this kernel's own instruction counter
+            if "sw_2stream_seg_kernel" in per_kernel and args.workload in ("sw", "allsky"):
                 try:
-                    import csv
-                    import glob as _glob
-
-                    fcsv = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_sw_pmc_summary.csv")))[-1]
-                    valu = [float(r_["SQ_INSTS_VALU"]) for r_ in csv.DictReader(open(fcsv)) if r_["kernel"].startswith("sw_2stream_seg_kernel<8")][0]
-                    scale = ncol * NLAY * kd.ngpt / (100000 * 60 * 224)
-                    issue_ms = valu * scale * 4 / (1024 * 2.4e9) * 1e3
-                    ms_ = per_kernel["sw_2stream_seg_kernel"]["avg_ms"]
-                    roof["fp64_issue"] = {"kernel": "sw_2stream_seg_kernel", "bound": "fp64 VALU issue", "valu_instructions_per_launch": valu * scale,
-                                          "valu_instructions_per_gpoint_and_wave": round(valu / (1563 * 224 * 8), 1),
-                                          "issue_ms_at_peak": round(issue_ms, 3), "measured_ms": ms_, "frac_of_issue_peak": round(issue_ms / ms_, 4),
-                                          "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (= 78.6 TFLOP/s of fp64 FMA)",
-                                          # rocm-smi beside tools/loop_sw.py (tools/clocks_beside.sh): the kernel runs at the package power limit
-                                          "observed_sclk_GHz": 2.05, "issue_ms_at_observed_clock": round(issue_ms * 2.4 / 2.05, 3),
-                                          "frac_at_observed_clock": round(issue_ms * 2.4 / 2.05 / ms_, 4),
-                                          "source": os.path.relpath(fcsv, ROOT),
-                                          "note": "this kernel's HBM fraction (roofline.per_kernel) is low because it is compute-bound: "
-                                                  "every fp64 and integer vector instruction of a wave occupies its SIMD for 4 cycles"}
-                except Exception:  # noqa: BLE001
-                    pass
+                    roof["fp64_issue"] = sw_fp64_bound(ncol, nlay_w, kds.ngpt if args.workload == "allsky" else kd.ngpt,
+                                                       per_kernel["sw_2stream_seg_kernel"]["avg_ms"], sclk)
+                except Exception as e:  # noqa: BLE001
+                    roof["fp64_issue"] = f"failed: {e}"
         res = {
             "metric": {"lw": "columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)",
                        "sw": "columns/sec (SW gas-optics + sw_solver_2stream, 224 gpt x 60 lay)",
@@ -962,6 +1130,7 @@ def main():
                        "deferred_sources": deferred,
                        "deferred_sources_ms_per_step": (deferred["ms_per_step"] if isinstance(deferred, dict) else None),
                        "implicit_g": implicit_g,
+                       "secondary": secondary,
                        "glue_ms_per_step_outside_timed_region": (round(glue_ms, 4) if glue_ms is not None else None),
                        "allgather_global_fluxes_ms_outside_timed_region": (round(allgather_ms, 4) if allgather_ms is not None else None),
                        "dist_backend": (args.dist_backend if dist is not None else None),

@@ -26,7 +26,10 @@ int   rte_hip_sync(void);                     /* materialise recorded fills, dra
  * beforehand, no value returned to the host inside the region.  All return 0, -1 on a HIP error. */
 int   rte_hip_graph_begin(void);
 int   rte_hip_graph_end(void** graph_exec);
-int   rte_hip_graph_launch(void* graph_exec); /* on the context's stream, ordered with the calls around it */
+int   rte_hip_graph_launch(void* graph_exec); /* on the context's stream, ordered with the calls around it.  -4: the graph is
+                                                  stale -- it addresses library buffers (scratch arena, persistent slots) that
+                                                  were freed or reallocated since the capture (a LARGER call on the context,
+                                                  rte_hip_release, dropped host tables): capture again.  -1: HIP error */
 int   rte_hip_graph_destroy(void* graph_exec);
 int   rte_hip_release(void);                  /* free every device buffer the context holds */
 int   rte_hip_device_count(void);

@@ -110,22 +110,27 @@ int rte_hip_rccl_available(void) { return rccl().ok ? 1 : 0; }
 // error (error channel as for every entry point), -3 if nccl_comm is given but no RCCL can be resolved.
 int rte_hip_allreduce_mean_profile(void* nccl_comm, int ncol_local, int nlev, const Float* flux_up, const Float* flux_dn,
                                    long long ncol_global, Float* mean_up, Float* mean_dn) {
-  if (ncol_local <= 0 || nlev <= 0 || ncol_global <= 0) return 0;
+  // (arguments every rank of the job shares decide the early return; a rank whose OWN column range is empty still joins the
+  //  collective -- with zeros -- or the other ranks would wait for it forever)
+  if (nlev <= 0 || ncol_global <= 0) return 0;
+  if (ncol_local <= 0 && !nccl_comm) return 0;
   if (nccl_comm && !rccl().ok) return -3;
   RTE_TRY
   rte::Call c("rte_hip_allreduce_mean_profile");
-  const size_t n = (size_t)ncol_local * nlev;
-  const Float* d_up = c.in(flux_up, n);
-  const Float* d_dn = c.in(flux_dn, n);
   hipStream_t st = rte::stream();
-  const int nchunk = (ncol_local + kSumChunk - 1) / kSumChunk;
-  Float* part = (Float*)rte::scratch(sizeof(Float) * (size_t)2 * nlev * nchunk);
   Float* prof = (Float*)rte::scratch(sizeof(Float) * (size_t)2 * nlev);
-  {
+  if (ncol_local > 0) {
+    const size_t n = (size_t)ncol_local * nlev;
+    const Float* d_up = c.in(flux_up, n);
+    const Float* d_dn = c.in(flux_dn, n);
+    const int nchunk = (ncol_local + kSumChunk - 1) / kSumChunk;
+    Float* part = (Float*)rte::scratch(sizeof(Float) * (size_t)2 * nlev * nchunk);
     rte::ProfScope p("mean_profile_sums");
     hipLaunchKernelGGL(column_sum_stage1, dim3(nchunk, 2 * nlev), dim3(256), 0, st, ncol_local, nlev, d_up, d_dn, part, nchunk);
     hipLaunchKernelGGL(column_sum_stage2, dim3(rte::cdiv(2 * nlev, 64)), dim3(64), 0, st, 2 * nlev, nchunk, (const Float*)part,
                        (Float)1 / (Float)ncol_global, prof);
+  } else {
+    HIP_CHECK(hipMemsetAsync(prof, 0, sizeof(Float) * (size_t)2 * nlev, st));
   }
   if (nccl_comm) {
     rte::ProfScope p("rccl_allreduce");
@@ -144,7 +149,8 @@ int rte_hip_allreduce_mean_profile(void* nccl_comm, int ncol_local, int nlev, co
 
 // The assembled field on every rank: global(ncol_local * nranks, nlev) from the ranks' local(ncol_local, nlev) slabs, rank r's
 // columns at r * ncol_local (equal widths: pad the last rank's block to ncol_local columns).  `local` and `global` must be
-// DEVICE pointers (RCCL moves device memory; 61 MB per field and rank at 125 000 columns x 61 levels).
+// DEVICE pointers (RCCL moves device memory; 61 MB per field and rank at 125 000 columns x 61 levels).  ncol_local is the
+// SAME on every rank (the slab width), so `ncol_local <= 0` returns on all ranks together: no rank waits for another.
 int rte_hip_allgather_columns(void* nccl_comm, int ncol_local, int nlev, const Float* local, Float* global) {
   if (ncol_local <= 0 || nlev <= 0) return 0;
   if (!nccl_comm || !rccl().ok) return -3;

@@ -132,16 +132,32 @@ void flush_pending_zeros();
 // in library buffers, lev_source untouched -- and records that; rte_lw_solver_noscat on exactly these arrays solves from
 // the factors (planck.hip, solvers.hip).  Any other library entry that is handed lay_source or lev_source finds them
 // materialised first (Call::in), a new output into them drops the record (Call::out).
+// Lifetime of a record: the caller's promise covers the time between compute_Planck_source and the solve.  Until the first
+// solve has consumed it the record is trusted.  Afterwards it stays -- a second solve on the same sources (clear-sky and all-sky
+// fluxes) and any other use must still find them right -- but it is no longer trusted: when the solve is done a fingerprint of
+// the fraction (64 values spread over lay_source) is kept, and every later use compares it first; if the memory has other
+// contents by then (the caller wrote or freed and reused it) the record is dropped and the arrays are taken as they are.
+// At most one record lives per context: a deferred compute_Planck_source on other arrays first expands what is pending
+// (the factors share one library buffer).
 struct PendingSources {
   const void *lay, *lev;         // the caller's arrays
   int ncol, nlay, nbnd, ngpt;
   const void *plk_lay, *plk_lev; // (ncol, nlay, nbnd), (ncol, nlay+1, nbnd): library buffers
   const int* band_lims;          // device copy of band_lims_gpt
+  void* sample;                  // 64 Floats + one int behind them: the fingerprint and the compare kernel's flag
+  bool consumed;                 // a solve has used the record: validate before any further use
+};
+struct PendingSourcesOps {
+  void (*expand)(const PendingSources&);       // lay_source / lev_source from the factors, in place
+  void (*take_sample)(const PendingSources&);  // keep the fingerprint of lay_source (asynchronous)
+  bool (*still_factored)(const PendingSources&);  // does lay_source still hold it? (synchronises)
 };
 bool defer_sources_enabled();
-void defer_sources(const PendingSources& s, void (*expand)(const PendingSources&));
+void defer_sources(const PendingSources& s, const PendingSourcesOps* ops);
 bool take_pending_sources(const void* lay, const void* lev, PendingSources* out);
+void sources_consumed(PendingSources s);  // back on the list after a solve from the factors
 void flush_pending_sources();
+void flush_pending_sources_except(const void* lay, const void* lev);
 
 // kernel-level timing hooks (rte_hip_profile_*): record(name) brackets a launch with events
 void prof_begin(const char* kernel);

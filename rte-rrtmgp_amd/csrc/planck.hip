@@ -463,6 +463,35 @@ static void planck_expand_pending(const rte::PendingSources& s) {
                      (const Float*)s.plk_lay, (const Float*)s.plk_lev, lay, lev, 2);
 }
 
+// the fingerprint of a consumed record (common.h): 64 values spread over the fraction array; mode 0 keeps them, mode 1
+// compares bit for bit and raises the flag behind them
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+__device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_int(a) == __float_as_int(b); }
+__global__ void __launch_bounds__(64) sources_fingerprint_kernel(const Float* __restrict__ lay, size_t n, Float* sample, int mode) {
+  const size_t idx = (size_t)((double)(n - 1) * (double)threadIdx.x / 63.0);
+  const Float v = lay[idx];
+  if (mode == 0) {
+    sample[threadIdx.x] = v;
+  } else if (!same_bits(v, sample[threadIdx.x])) {
+    atomicOr(reinterpret_cast<int*>(sample + 64), 1);
+  }
+}
+static void planck_take_sample(const rte::PendingSources& s) {
+  hipLaunchKernelGGL(sources_fingerprint_kernel, dim3(1), dim3(64), 0, rte::stream(), (const Float*)s.lay,
+                     (size_t)s.ncol * s.nlay * s.ngpt, (Float*)s.sample, 0);
+}
+static bool planck_still_factored(const rte::PendingSources& s) {
+  int* flag = reinterpret_cast<int*>((Float*)s.sample + 64);
+  HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), rte::stream()));
+  hipLaunchKernelGGL(sources_fingerprint_kernel, dim3(1), dim3(64), 0, rte::stream(), (const Float*)s.lay,
+                     (size_t)s.ncol * s.nlay * s.ngpt, (Float*)s.sample, 1);
+  int h = 1;
+  HIP_CHECK(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, rte::stream()));
+  HIP_CHECK(hipStreamSynchronize(rte::stream()));
+  return h == 0;
+}
+static const rte::PendingSourcesOps kPlanckSourcesOps{planck_expand_pending, planck_take_sample, planck_still_factored};
+
 // the body of rrtmgp_compute_Planck_source and of its factored form (plk_lay != nullptr: see PlanckArgs)
 static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, int ngpt, int nflav, int neta, int npres, int ntemp,
                                int nPlanckTemp, const Float* tlay, const Float* tlev, const Float* tsfc, int sfc_lay,
@@ -484,15 +513,18 @@ static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, i
   if (deferred) {
     const size_t nclv = (size_t)ncol * (nlay + 1);
     (void)c.out(lev_src, nclv * ngpt);  // (an earlier record on this array goes)
-    plk_lay = (Float*)rte::persistent(kPlanckDeferSlot, sizeof(Float) * (ncl + nclv) * nbnd + sizeof(int) * 2 * nbnd, nullptr);
+    // (one buffer for every record's factors: records on OTHER arrays were expanded by the entry point before this call,
+    //  rte::flush_pending_sources_except, so growing or overwriting it takes nothing from a record that is still alive)
+    plk_lay = (Float*)rte::persistent(kPlanckDeferSlot, sizeof(Float) * ((ncl + nclv) * nbnd + 64 + 2) + sizeof(int) * 2 * nbnd, nullptr);
     plk_lev = plk_lay + ncl * nbnd;
-    bl_dev = (int*)(plk_lev + nclv * nbnd);
+    Float* sample = plk_lev + nclv * nbnd;  // 64 values + the compare flag
+    bl_dev = (int*)(sample + 64 + 2);
     HIP_CHECK(hipMemcpyAsync(bl_dev, band_lims_gpt, sizeof(int) * 2 * nbnd, hipMemcpyDefault, rte::stream()));
     if (!rte::is_device_pointer(band_lims_gpt)) HIP_CHECK(hipStreamSynchronize(rte::stream()));  // (pageable source)
     lev_src_deferred = lev_src;
     lev_src = nullptr;
     // (recorded by the entry point once this call has staged its arguments: Call::out on lay_source drops records on it)
-    *deferred = rte::PendingSources{lay_src, lev_src_deferred, ncol, nlay, nbnd, ngpt, plk_lay, plk_lev, bl_dev};
+    *deferred = rte::PendingSources{lay_src, lev_src_deferred, ncol, nlay, nbnd, ngpt, plk_lay, plk_lev, bl_dev, sample, false};
   }
   const bool factored = plk_lay != nullptr;
   const Float* d_tlay = c.in(tlay, ncl);
@@ -675,10 +707,11 @@ void rrtmgp_compute_Planck_source(const int* ncol_, const int* nlay_, const int*
   rte::PendingSources rec{};
   const bool deferred = rte::defer_sources_enabled() && rte::is_device_memory(lay_src) && rte::is_device_memory(lev_src) && *nlay_ <= 80 &&
                         (size_t)*ncol_ * (*nlay_ + 1) < ((size_t)1 << 29) && *nbnd_ > 0;
+  if (deferred) rte::flush_pending_sources_except(lay_src, lev_src);  // (the factors of every record share one buffer)
   planck_source_impl("rrtmgp_compute_Planck_source", *ncol_, *nlay_, *nbnd_, *ngpt_, *nflav_, *neta_, *npres_, *ntemp_, *nPlanckTemp_,
                      tlay, tlev, tsfc, *sfc_lay_, fmajor, jeta, tropo, jtemp, jpress, band_lims_gpt, pfracin, *temp_ref_min,
                      *totplnk_delta, totplnk, gpoint_flavor, sfc_src, lay_src, lev_src, sfc_source_Jac, nullptr, nullptr, deferred ? &rec : nullptr);
-  if (deferred && rec.lay) rte::defer_sources(rec, planck_expand_pending);
+  if (deferred && rec.lay) rte::defer_sources(rec, &kPlanckSourcesOps);
   RTE_CATCH("rrtmgp_compute_Planck_source")
 }
 

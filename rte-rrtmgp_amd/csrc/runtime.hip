@@ -59,6 +59,9 @@ struct Context {
   // ---- rte_hip_graph_begin / _end: the stream a region is captured from, and the context's stream meanwhile
   hipStream_t graph_stream = nullptr, graph_saved = nullptr;
   bool graph_saved_valid = false, graph_saved_aux = true;
+  // a captured graph bakes in addresses of the scratch arena and of the persistent slots: every time one of those buffers is
+  // freed or reallocated the epoch moves, and a graph of an earlier epoch refuses to launch (rte_hip_graph_launch: -4)
+  long addr_epoch = 0;
   // ---- side stream (opt-in, rte_hip_overlap_planck)
   bool overlap = false;
   hipStream_t side = nullptr;
@@ -80,7 +83,7 @@ struct Context {
   bool defer_zero = getenv("RTE_HIP_DEFER_ZERO") && atoi(getenv("RTE_HIP_DEFER_ZERO")) > 0;
   // deferred LW sources (see common.h): at most a few records (one per source-function object in flight)
   std::vector<PendingSources> pending_src;
-  void (*expand_src)(const PendingSources&) = nullptr;
+  PendingSourcesOps src_ops{nullptr, nullptr, nullptr};
   bool defer_sources = getenv("RTE_HIP_DEFER_SOURCES") && atoi(getenv("RTE_HIP_DEFER_SOURCES")) > 0;
   long seq = 0;
   // ---- host-mirror mode
@@ -263,6 +266,7 @@ static void scratch_reset() {
   // keep one block big enough for the largest call seen so far; drop fragmentation
   if (bl.size() > 1) {
     HIP_CHECK(hipStreamSynchronize(stream()));
+    ++C.addr_epoch;
     size_t total = 0;
     for (auto& b : bl) { total += b.size; HIP_CHECK(hipFree(b.base)); }
     bl.clear();
@@ -331,7 +335,7 @@ void* persistent(int slot, size_t bytes, bool* fresh) {
   Slot& s = c.slots[slot];
   if (fresh) *fresh = false;
   if (s.bytes < bytes) {
-    if (s.p) { HIP_CHECK(hipStreamSynchronize(c.stream)); HIP_CHECK(hipFree(s.p)); }
+    if (s.p) { HIP_CHECK(hipStreamSynchronize(c.stream)); HIP_CHECK(hipFree(s.p)); ++c.addr_epoch; }
     HIP_CHECK(hipMalloc(&s.p, bytes));
     s.bytes = bytes;
     if (fresh) *fresh = true;
@@ -430,12 +434,15 @@ void flush_pending_zeros() {
 // anything but that solve.  Same promise as the deferred zero fill: between the two calls the caller touches these arrays
 // only through this library (rte_hip_sync materialises everything).
 bool defer_sources_enabled() { return C.defer_sources; }
-void defer_sources(const PendingSources& s, void (*expand)(const PendingSources&)) {
+void defer_sources(const PendingSources& s, const PendingSourcesOps* ops) {
   Context& c = C;
   std::lock_guard<std::recursive_mutex> l(c.mutex);
-  if (expand) c.expand_src = expand;  // (nullptr: a record goes back on the list, the expander is known)
+  if (ops) c.src_ops = *ops;
   c.pending_src.push_back(s);
 }
+// may the record still be used?  Unconsumed: the caller's promise holds.  Consumed: only if lay_source still holds the fraction.
+// (inside a graph capture the region's contract holds -- library calls only -- and the check, which synchronises, cannot run)
+static bool sources_usable(const PendingSources& s) { return !s.consumed || C.graph_saved_valid || C.src_ops.still_factored(s); }
 bool take_pending_sources(const void* lay, const void* lev, PendingSources* out) {
   Context& c = C;
   std::lock_guard<std::recursive_mutex> l(c.mutex);
@@ -443,28 +450,40 @@ bool take_pending_sources(const void* lay, const void* lev, PendingSources* out)
     if (c.pending_src[i].lay == lay && c.pending_src[i].lev == lev) {
       *out = c.pending_src[i];
       c.pending_src.erase(c.pending_src.begin() + i);
-      return true;
+      return sources_usable(*out);  // (a stale record is gone now: the arrays are taken as they are)
     }
   return false;
 }
-void flush_pending_sources() {
+void sources_consumed(PendingSources s) {
   Context& c = C;
   std::lock_guard<std::recursive_mutex> l(c.mutex);
-  while (!c.pending_src.empty()) {
-    const PendingSources s = c.pending_src.back();
-    c.pending_src.pop_back();
-    c.expand_src(s);
+  if (!s.consumed) {
+    s.consumed = true;
+    c.src_ops.take_sample(s);
+  }
+  c.pending_src.push_back(s);
+}
+void flush_pending_sources_except(const void* lay, const void* lev) {
+  Context& c = C;
+  std::lock_guard<std::recursive_mutex> l(c.mutex);
+  for (size_t i = c.pending_src.size(); i-- > 0;) {
+    const PendingSources s = c.pending_src[i];
+    if (s.lay == lay && s.lev == lev) continue;
+    c.pending_src.erase(c.pending_src.begin() + i);
+    if (sources_usable(s)) c.src_ops.expand(s);
   }
 }
-// a library call is handed the array at p: as an input (or in / out) it is materialised first, as a pure output the record
-// goes (the factors in it are about to be overwritten).  Ranges are compared by their start: the frontend passes whole arrays.
+void flush_pending_sources() { flush_pending_sources_except(nullptr, nullptr); }
+// a library call is handed `bytes` at p: as an input (or in / out) the array is materialised first, as a pure output the record
+// goes (the factors in it are about to be overwritten).  Ranges are matched by their start: the frontend passes whole arrays;
+// a consumed record is used only if its fingerprint still matches (see common.h).
 static void sources_touch(const void* p, bool copy_in) {
   Context& c = C;
   for (size_t i = 0; i < c.pending_src.size(); ++i)
     if (c.pending_src[i].lay == p || c.pending_src[i].lev == p) {
       const PendingSources s = c.pending_src[i];
       c.pending_src.erase(c.pending_src.begin() + i);
-      if (copy_in) c.expand_src(s);
+      if (copy_in && sources_usable(s)) c.src_ops.expand(s);
       return;
     }
 }
@@ -901,17 +920,26 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
         c.t_h2d += secs_since(t0);
         return same->dev;
       }
-      if (!hit) {
+      // An entry that an EARLIER argument of this very call was served from (last_use == c.seq) is neither refilled nor
+      // evicted: its device copy is about to be read by this call's kernel (Fortran temporaries swap addresses between
+      // calls, so argument X may have matched entry E by content while argument Y now arrives at E's address with other
+      // bytes).  Such an argument is staged through scratch like any uncached input.
+      bool cacheable = !(hit && hit->last_use == c.seq);
+      if (cacheable && !hit) {
         // (bounded: 48 arrays, 1 GB of shadows per context; the least recently used goes first)
         while (!c.inputs.empty() && (c.inputs.size() >= 48 || c.inputs_total + bytes > (size_t(1) << 30))) {
-          size_t v = 0;
-          for (size_t k = 1; k < c.inputs.size(); ++k) if (c.inputs[k].last_use < c.inputs[v].last_use) v = k;
+          size_t v = c.inputs.size();
+          for (size_t k = 0; k < c.inputs.size(); ++k)
+            if (c.inputs[k].last_use != c.seq && (v == c.inputs.size() || c.inputs[k].last_use < c.inputs[v].last_use)) v = k;
+          if (v == c.inputs.size()) { cacheable = false; break; }  // everything held belongs to this call
           HIP_CHECK(hipStreamSynchronize(c.stream));  // kernels of earlier calls may still read the device copy
           HIP_CHECK(hipFree(c.inputs[v].dev)); free(c.inputs[v].shadow);
           c.inputs_total -= c.inputs[v].bytes;
           c.inputs.erase(c.inputs.begin() + v);
           ++c.input_evicted;
         }
+      }
+      if (cacheable && !hit) {
         Context::InputCopy e{(const char*)p, bytes, (char*)malloc(bytes), nullptr, c.seq};
         if (!e.shadow) throw Error{-1, "out of host memory for an input shadow"};
         const hipError_t rc = hipMalloc((void**)&e.dev, bytes);
@@ -921,17 +949,20 @@ void* Call::stage(void* p, size_t bytes, bool copy_in, bool copy_out, bool lazy,
         ++c.input_made;
         hit = &c.inputs.back();
       }
-      hit->last_use = c.seq;
-      // (through the pinned ring, stream-ordered behind the kernels that read the device copy's previous contents.  A pinned
-      //  shadow that the transfer would start from -- one memcpy instead of two -- was measured: slower, the unpipelined copy
-      //  and the pinning of every new shadow cost more than the second memcpy)
-      if (!h2d(c, hit->dev, p, bytes)) staged_plain_ = true;
-      memcpy(hit->shadow, p, bytes);
+      if (cacheable) {
+        hit->last_use = c.seq;
+        // (through the pinned ring, stream-ordered behind the kernels that read the device copy's previous contents.  A pinned
+        //  shadow that the transfer would start from -- one memcpy instead of two -- was measured: slower, the unpipelined copy
+        //  and the pinning of every new shadow cost more than the second memcpy)
+        if (!h2d(c, hit->dev, p, bytes)) staged_plain_ = true;
+        memcpy(hit->shadow, p, bytes);
+        c.t_h2d += secs_since(t0);
+        staged_in_ = true;
+        c.mstat[2] += (long long)bytes;
+        mark_h2d();
+        return hit->dev;
+      }
       c.t_h2d += secs_since(t0);
-      staged_in_ = true;
-      c.mstat[2] += (long long)bytes;
-      mark_h2d();
-      return hit->dev;
     }
   }
   void* d = scratch(bytes);
@@ -994,6 +1025,7 @@ void drop_table_copies() {
   Context& c = C;
   if (c.tables.empty() && c.inputs.empty()) return;
   HIP_CHECK(hipStreamSynchronize(c.stream));
+  ++c.addr_epoch;
   for (auto& t : c.tables) HIP_CHECK(hipFree(t.dev));
   c.tables.clear();
   for (auto& e : c.inputs) { HIP_CHECK(hipFree(e.dev)); free(e.shadow); }
@@ -1153,6 +1185,9 @@ static void prof_resolve() {
 static void release_context_buffers() {
   Context& c = C;
   flush_pending_zeros();
+  if (c.src_ops.expand) flush_pending_sources();  // (a record names factors in a slot that is about to go)
+  c.pending_src.clear();
+  ++c.addr_epoch;  // graphs captured on this context address buffers that are freed here
   HIP_CHECK(hipStreamSynchronize(c.stream));
   if (c.side) HIP_CHECK(hipStreamSynchronize(c.side));
   if (c.aux) HIP_CHECK(hipStreamSynchronize(c.aux));
@@ -1289,6 +1324,7 @@ int rte_hip_sync(void) {
 // stream is forked from it and joined into it, so it is captured with it); nothing runs until the graph is launched.  The
 // caller's contract: device pointers only, the same arrays at every launch, one chain run uncaptured beforehand (it sizes the
 // scratch arena: an allocation cannot be captured), no call inside the region that returns values to the host.
+struct GraphHandle { hipGraphExec_t exec; rte::Context* ctx; long epoch; };
 int rte_hip_graph_begin(void) {
   RTE_TRY
   LOCK_CTX;
@@ -1326,23 +1362,34 @@ int rte_hip_graph_end(void** graph_exec) {
   const hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
   HIP_CHECK(rc);
-  *graph_exec = (void*)e;
+  // (a capture during which the arena grew or a slot moved has baked in addresses that are gone already)
+  *graph_exec = (void*)new GraphHandle{e, &c, c.addr_epoch};
   return 0;
   RTE_CATCH("rte_hip_graph_end")
   return -1;
 }
+// 0; -4 if library buffers the graph addresses were freed or reallocated since the capture (a larger call on this context,
+// rte_hip_release, host tables dropped): the graph is stale, capture it again; -1 on a HIP error
 int rte_hip_graph_launch(void* graph_exec) {
   RTE_TRY
   LOCK_CTX;
+  GraphHandle* h = (GraphHandle*)graph_exec;
+  if (!h || !h->exec) return -1;
+  rte::Context& c = rte::ctx();
+  if (h->ctx != &c || h->epoch != c.addr_epoch) return -4;
   rte::flush_pending_zeros();
   rte::flush_pending_sources();
-  HIP_CHECK(hipGraphLaunch((hipGraphExec_t)graph_exec, rte::ctx().stream));
+  HIP_CHECK(hipGraphLaunch(h->exec, c.stream));
   return 0;
   RTE_CATCH("rte_hip_graph_launch")
   return -1;
 }
 int rte_hip_graph_destroy(void* graph_exec) {
-  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  GraphHandle* h = (GraphHandle*)graph_exec;
+  if (h) {
+    if (h->exec) (void)hipGraphExecDestroy(h->exec);
+    delete h;
+  }
   return 0;
 }
 // compute_Planck_source leaves factored sources for the rte_lw_solver_noscat call that follows (see above)

@@ -1969,8 +1969,10 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
         rc = rte_hip_lw_solver_noscat_factored(ncol, nlay, ngpt, ps.nbnd, *top_at_1 ? 1 : 0, nmus, Ds, weights, ps.band_lims, tau,
                                                lay_source, (const Float*)ps.plk_lay, (const Float*)ps.plk_lev, sfc_emis, sfc_src,
                                                inc_flux, broadband_up, broadband_dn, do_jac ? 1 : 0, sfc_srcJac, flux_upJac);
-      rte::defer_sources(ps, nullptr);  // (back on the list: consumed here or expanded by Call::in below)
-      if (rc == 0) return;
+      // back on the list: consumed here (from now on the record is used only while lay_source still holds the fraction:
+      // common.h) or expanded by Call::in below
+      if (rc == 0) { rte::sources_consumed(ps); return; }
+      rte::defer_sources(ps, nullptr);
     }
   }
   RTE_TRY

@@ -148,7 +148,11 @@ class CallGraph:
     def launch(self) -> None:
         fn = self.lib.raw("rte_hip_graph_launch")
         fn.restype = ctypes.c_int
-        if fn(self.handle) != 0:
+        rc = fn(self.handle)
+        if rc == -4:
+            raise RuntimeError("rte_hip_graph_launch: the graph is stale -- library buffers it addresses were freed or reallocated "
+                               "since the capture (a larger call on this context, rte_hip_release): capture it again")
+        if rc != 0:
             raise RuntimeError("rte_hip_graph_launch failed")
 
     def close(self) -> None:

@@ -1,0 +1,117 @@
+"""Edge shapes and the worst-case column order of the PRODUCTION path against the C oracle (run with -m gpu).
+
+The suite's other oracle comparisons start at 5 columns x 10 layers and use climatologically similar neighbours.  Here:
+  * ncol in {1, 63, 65, 513, 1537} x nlay in {1, 2, 3, 7, 65}, both vertical orientations, LW and SW: single columns, one
+    lane short of / past a wavefront, one column past a 512-column tile, three tiles + 1; one-, two-, three-layer columns,
+    one layer past a wave's 8 x 8 layer segments -- whole chains (gas optics + solver), as the benchmark drives them
+    (deferred zero fill, shared geometry), gas-optics arrays element by element and fluxes against the oracle;
+  * 2 048 columns drawn from 100 distinct RFMIP-like sites in RANDOM order at the g256 table shape: every 512-column tile
+    spans polar to tropical profiles, so many (tile, layer, band) boxes exceed the slab and go to the direct-gather worklist
+    (rte_hip_stat(0) > 0 is asserted): slab kernel + worklist kernel together against the oracle.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+import cases
+from rte_rrtmgp_amd import frontend, hiplib, synth
+
+pytestmark = pytest.mark.gpu
+
+ETOL_GAS, ETOL_FLUX = 1e-11, 1e-8
+_REF = {}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return hiplib.load()
+
+
+@pytest.fixture(scope="module")
+def oracle_c():
+    from oracle import oracle as O
+
+    return O.load_c()
+
+
+def _chain(lib, xp, kd, atm, kind, conv):
+    ncol, nlay = atm.ncol, atm.nlay
+    go = frontend.GasOptics(lib, kd, xp)
+    a = {k: conv(getattr(atm, k)) for k in ("play", "plev", "tlay", "tlev", "tsfc", "col_gas", "col_dry")}
+    out = {}
+    if kind == "lw":
+        b = go.gas_optics_lw(ncol, nlay, a["play"], a["plev"], a["tlay"], a["tsfc"], a["col_gas"], a["tlev"], atm.top_at_1)
+        r = frontend.rte_lw(lib, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"],
+                            xp.full((ncol, kd.ngpt), 0.97), b["sfc_src"])
+        gas = ("tau", "lay_src", "lev_src", "sfc_src")
+        flux = ("flux_up", "flux_dn")
+    else:
+        b = go.gas_optics_sw(ncol, nlay, a["play"], a["plev"], a["tlay"], a["col_gas"], a["col_dry"])
+        mu0 = conv(np.asfortranarray(np.full((ncol, nlay), 0.7)))
+        alb = xp.full((ncol, kd.ngpt), 0.1)
+        r = frontend.rte_sw(lib, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["ssa"], b["g"], mu0, b["toa_src"], alb, alb)
+        gas = ("tau", "ssa")
+        flux = ("flux_up", "flux_dn", "flux_dir")
+    for k in gas:
+        out["gas." + k] = np.array(xp.to_numpy(b[k]))
+    for k in flux:
+        out["flux." + k] = np.array(xp.to_numpy(r[k]))
+    return out
+
+
+def _compare(got, ref, label):
+    for k, rv in ref.items():
+        gv = got[k]
+        assert gv.shape == rv.shape and np.isfinite(gv).all(), (label, k)
+        if k.startswith("gas."):
+            e = cases.elem_err(gv, rv, 1e-8)
+            assert e <= ETOL_GAS, (label, k, e)
+        else:
+            e = cases.elem_err(gv, rv, 1e-4)
+            assert e <= ETOL_FLUX, (label, k, e)
+
+
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+@pytest.mark.parametrize("opt_ins", [False, True])
+def test_edge_shapes_against_the_oracle(hip, oracle_c, kind, opt_ins):
+    kd = synth.make_kdist(kind, ngpt=64, nbnd=4)
+    xp, xn = frontend.TorchArrays("cuda:0"), frontend.NumpyArrays()
+    hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 1 if opt_ins else 0)
+    hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 1 if opt_ins else 0)
+    try:
+        for ncol, nlay, top in itertools.product((1, 63, 65, 513, 1537), (1, 2, 3, 7, 65), (False, True)):
+            atm = synth.make_atmosphere(ncol, nlay, seed=7 * ncol + nlay, kdist=kd, top_at_1=top)
+            key = (kind, ncol, nlay, top)
+            if key not in _REF:  # (the oracle's answer does not depend on the library's modes: once per shape)
+                _REF[key] = _chain(oracle_c, xn, kd, atm, kind, lambda v: v)
+            got = _chain(hip, xp, kd, atm, kind, xp.asarray)
+            _compare(got, _REF[key], (kind, ncol, nlay, top, opt_ins))
+    finally:
+        hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 0)
+        hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 0)
+
+
+@pytest.mark.parametrize("kind", ["lw", "sw"])
+def test_shuffled_sites_populate_the_worklist_and_match_the_oracle(hip, oracle_c, kind):
+    kd = synth.make_kdist(kind)  # g256 / g224 shapes
+    ncol, nlay = 2048, 60
+    sites = synth.make_atmosphere(100, nlay, seed=42, kdist=kd, climate="sites")
+    idx = np.random.default_rng(7).permutation(np.repeat(np.arange(100), -(-ncol // 100))[:ncol])
+    atm = synth.Atmosphere(ncol, nlay, sites.top_at_1, *(np.asfortranarray(getattr(sites, k)[idx]) for k in
+                           ("play", "plev", "tlay", "tlev", "tsfc", "vmr", "col_dry", "col_gas")))
+    xp, xn = frontend.TorchArrays("cuda:0"), frontend.NumpyArrays()
+    hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 1)
+    hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 1)
+    try:
+        got = _chain(hip, xp, kd, atm, kind, xp.asarray)
+        items = hiplib.ext_call(hip, "rte_hip_stat", ["i"], 0)
+        assert hiplib.ext_call(hip, "rte_hip_stat", ["i"], 2) in (1, 2)  # the slab kernel ran (its tile geometry was derived)
+    finally:
+        hiplib.ext_call(hip, "rte_hip_share_geometry", ["i"], 0)
+        hiplib.ext_call(hip, "rte_hip_defer_zero", ["i"], 0)
+    total = (ncol // 512) * nlay * kd.nbnd
+    print(f"{kind}: {items} of {total} (tile, layer, band) items on the direct-gather worklist")
+    assert items > total // 20, f"worklist hardly populated ({items} of {total}): not the case this test is for"
+    ref = _chain(oracle_c, xn, kd, atm, kind, lambda v: v)
+    _compare(got, ref, (kind, "shuffled sites"))

@@ -567,6 +567,15 @@ def test_call_graph_replays_the_chain(hip):
                 got = result()
                 for k in want:
                     assert np.array_equal(got[k], want[k]), k
+            # a graph addresses the library's scratch arena and persistent buffers: once those are freed (here: rte_hip_release;
+            # the same after a larger call that makes the arena grow) the graph must refuse to launch, not run on freed memory
+            hiplib.ext_call(hip, "rte_hip_release", [])
+            with pytest.raises(RuntimeError, match="stale"):
+                g.launch()
+            chain()  # (and the context works on: the calls themselves re-allocate)
+            got = result()
+            for k in want1:
+                assert np.array_equal(got[k], want1[k]), k
         finally:
             g.close()
     finally:
@@ -1136,5 +1145,76 @@ def test_deferred_lw_sources_through_the_reference_symbols(hip, nlay, top_at_1, 
         got = chain(False)  # never solved: rte_hip_sync materialises
         for k in ("lay_src", "lev_src"):
             assert np.array_equal(got[k], plain_nosolve[k]), k
+    finally:
+        hiplib.ext_call(hip, "rte_hip_defer_sources", ["i"], 0)
+
+
+def test_deferred_lw_sources_two_source_objects_and_reuse_after_the_solve(hip):
+    """(1) Planck(A), Planck(B) on other, LARGER arrays, solve(A), solve(B): B's call must not take A's factors away
+    (A is expanded first; both solves bit-identical to the plain chain).  (2) After the solve the record is no longer trusted:
+    the caller overwrites lay_source with its own data (a torch kernel, not the library) and solves again -- the library must
+    take the arrays as they are, and nothing may be expanded into the caller's data."""
+    import torch
+    from rte_rrtmgp_amd import synth
+
+    kd = synth.make_kdist("lw")
+    nlay = 60
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    go = frontend.GasOptics(hip, kd, xp)
+
+    def inputs(ncol, seed):
+        atm = synth.make_atmosphere(ncol, nlay, seed=seed, kdist=kd)
+        return atm, [A(getattr(atm, k)) for k in ("play", "plev", "tlay", "tsfc", "col_gas", "tlev")], xp.full((ncol, kd.ngpt), 0.98)
+
+    def solve(ncol, atm, b, emis):
+        rb = {}
+        frontend.rte_lw(hip, xp, ncol, nlay, kd.ngpt, atm.top_at_1, b["tau"], b["lay_src"], b["lev_src"], emis, b["sfc_src"], buffers=rb)
+        return rb
+
+    def run(interleaved):
+        (na, nb) = (700, 1900)
+        atm_a, args_a, em_a = inputs(na, 5)
+        atm_b, args_b, em_b = inputs(nb, 6)
+        ba, bb = {}, {}
+        go.gas_optics_lw(na, nlay, *args_a, atm_a.top_at_1, buffers=ba)
+        if interleaved:
+            go.gas_optics_lw(nb, nlay, *args_b, atm_b.top_at_1, buffers=bb)
+            ra = solve(na, atm_a, ba, em_a)
+            rbb = solve(nb, atm_b, bb, em_b)
+        else:
+            ra = solve(na, atm_a, ba, em_a)
+            go.gas_optics_lw(nb, nlay, *args_b, atm_b.top_at_1, buffers=bb)
+            rbb = solve(nb, atm_b, bb, em_b)
+        hiplib.ext_call(hip, "rte_hip_sync", [])
+        torch.cuda.synchronize()
+        return {k: xp.to_numpy(v).copy() for k, v in (("a_up", ra["flux_up"]), ("a_dn", ra["flux_dn"]), ("b_up", rbb["flux_up"]),
+                                                       ("b_dn", rbb["flux_dn"]), ("a_lay", ba["lay_src"]), ("a_lev", ba["lev_src"]),
+                                                       ("b_lay", bb["lay_src"]), ("b_lev", bb["lev_src"]))}
+
+    plain = run(True)
+    try:
+        hiplib.ext_call(hip, "rte_hip_defer_sources", ["i"], 1)
+        for interleaved in (True, False):
+            got = run(interleaved)
+            for k, ref in plain.items():
+                assert np.array_equal(got[k], ref), (interleaved, k)
+        # (2) the caller's own data in lay_source after the solve
+        ncol = 900
+        atm, args, emis = inputs(ncol, 8)
+        b = {}
+        go.gas_optics_lw(ncol, nlay, *args, atm.top_at_1, buffers=b)
+        solve(ncol, atm, b, emis)
+        torch.cuda.synchronize()
+        mine = torch.full_like(b["lay_src"], 3.25)
+        b["lay_src"].copy_(mine)        # not through the library
+        b["lev_src"].fill_(3.25)
+        r2 = solve(ncol, atm, b, emis)  # must solve from 3.25 everywhere, not from "fractions"
+        torch.cuda.synchronize()
+        hiplib.ext_call(hip, "rte_hip_defer_sources", ["i"], 0)
+        r_plain = solve(ncol, atm, b, emis)
+        torch.cuda.synchronize()
+        assert torch.equal(r2["flux_up"], r_plain["flux_up"]) and torch.equal(r2["flux_dn"], r_plain["flux_dn"])
+        assert torch.equal(b["lay_src"], mine)  # and nothing expanded into the caller's data
     finally:
         hiplib.ext_call(hip, "rte_hip_defer_sources", ["i"], 0)

@@ -160,6 +160,34 @@ def test_two_ranks_of_bench_share_one_device_over_gloo():
     assert res["step_ms"]["n"] == 2 and res["step_ms"]["min"] <= res["step_ms"]["median"]
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the N > 1 analogue of the driver's 1-GPU command): bench.py starts
+    its ranks under torch.distributed.run itself; here both ranks on this box's one GPU over gloo.  And without
+    --single-device, two ranks on a one-GPU box: a "skipped" line and status 0, never an assertion."""
+    import json
+    import subprocess
+
+    import torch
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--dist-backend", "gloo", "--ncol", "4096",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-plain-abi", "--no-factored"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["rccl_world_size"] == 2 and res["config"]["columns_per_gpu"] == 4096
+    assert len(res["per_rank_ms_per_step"]["ranks"]) == 2 and res["allreduce_ms_per_step"]["max_over_ranks"] > 0
+    assert res["value"] > 0
+    want = torch.cuda.device_count() + 1  # one rank more than the box has devices
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == want and res["value"] is None and "visible" in res["skipped"]
+
+
 def test_c_level_flux_reduction_over_rccl():
     """The exchange step for host programs without torch (csrc/collectives.hip): rte_hip_allreduce_mean_profile and
     rte_hip_allgather_columns on a communicator made with RCCL's own C API -- one rank (RCCL refuses two ranks on this

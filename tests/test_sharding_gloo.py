@@ -79,3 +79,54 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert np.allclose(mean[0], up.mean(axis=0), rtol=1e-13)
     assert np.allclose(mean[1], dn.mean(axis=0), rtol=1e-13)
     assert np.array_equal(full_up, up)  # per-column results do not depend on the sharding
+
+
+def _worker_uneven(rank, world, port, out, ncol):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from rte_rrtmgp_amd import sharding
+
+    nlev = 5
+    whole = torch.arange(nlev * ncol, dtype=torch.float64).reshape(nlev, ncol) * 0.25 + 1.0  # torch shape of Fortran (ncol, nlev)
+    first, count = sharding.shard_columns(ncol, rank, world)
+    mine = whole[:, first:first + count].contiguous()
+    mean = sharding.allreduce_mean_profile(mine, 2.0 * mine, ncol)
+    full = sharding.allgather_fluxes(mine, ncol)
+    ok = bool(torch.equal(full, whole)) and bool(torch.allclose(mean[0], whole.mean(dim=1), rtol=1e-14, atol=0)) \
+        and bool(torch.allclose(mean[1], 2.0 * whole.mean(dim=1), rtol=1e-14, atol=0))
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag)  # every rank must have assembled the same field
+    if rank == 0:
+        np.save(out + f"_{ncol}.npy", np.array([int(flag), count]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_gloo_uneven_widths(tmp_path):
+    """The 8-GPU job's exchange step on CPU: 8 gloo ranks, column counts that do not divide by 8 (shards of different
+    widths, incl. fewer columns than ranks: empty shards), all-gather of the slabs and all-reduce of the mean profile."""
+    out = str(tmp_path / "r")
+    for ncol in (1003, 13, 5):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_worker_uneven, args=(8, port, out, ncol), nprocs=8, join=True)
+        got = np.load(out + f"_{ncol}.npy")
+        assert got[0] == 8, f"ncol={ncol}: {8 - got[0]} rank(s) assembled a different field"
+
+
+def test_bench_without_a_gpu_or_with_too_few_prints_a_skipped_line():
+    """`python bench.py --gpus 8` on a box with fewer devices (here: none) must print one "skipped" JSON line and exit 0."""
+    import json
+    import subprocess
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 8 and res["value"] is None and res["skipped"]
