@@ -80,6 +80,12 @@ if [ -f "$OUT/librefkernels.so" ]; then
   $FC -o "$OUT/bin/ref_frontend_driver_glue" ref_frontend_driver.o mo_raw_stream.o $FRONT_OBJS shim.o glue_recorder.o \
       -L"$OUT" -lrefkernels -L"$HERE" -loracle -ldl -Wl,-rpath,'$ORIGIN/..' -Wl,-rpath,'$ORIGIN/../..'
 fi
+# ---- 4. INTEGRATION.md section 4a: the Fortran binding of the factored LW sources (shim/mo_rte_hip_factored.F90) beside the
+#         reference's own kernel interface modules, and a data-free program that checks it (oracle/factored_binding_driver.F90)
+$FC $FFLAGS -c "$ROOT/shim/mo_rte_hip_factored.F90" 2> err.log || { echo "build_extern: mo_rte_hip_factored.F90 failed:" >&2; cat err.log >&2; exit 1; }
+$FC $FFLAGS -c "$HERE/factored_binding_driver.F90" 2> err.log || { echo "build_extern: factored_binding_driver.F90 failed:" >&2; cat err.log >&2; exit 1; }
+$FC -o "$OUT/bin/factored_binding_driver" factored_binding_driver.o mo_rte_hip_factored.o \
+    -L"$LIBDIR" -lrte_rrtmgp_hip -Wl,-rpath,'$ORIGIN/../../../rte-rrtmgp_amd' -Wl,-rpath,/opt/rocm/lib
 # the invariances of the reference's tests/check_equivalence.F90 on the synthetic streams (oracle/ref_equivalence_driver.F90, ours)
 $FC $FFLAGS -c "$HERE/ref_equivalence_driver.F90" 2> err.log || { cat err.log >&2; exit 1; }
 $FC -o "$OUT/bin/ref_equivalence_driver" ref_equivalence_driver.o mo_raw_stream.o $FRONT_OBJS shim.o \

@@ -273,8 +273,9 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
     const Float t0 = tpl[index - 1], t1 = tpl[index];
     return t0 + frac * (t1 - t0);
   };
-  const Float pl_sfc = planck(a.tsfc[ic]);
-  const Float pl_sfc1 = planck(a.tsfc[ic] + (Float)1);
+  // (the surface values are formed where they are used, after the layer walk: held across it they were spilled -- 60 bytes of
+  //  scratch per lane in the headline instantiation, none of it touched inside the layer loop, but a kernel with scratch
+  //  costs 14 us more to launch)
 
   struct Idx { Bool tropo; int jT, jpress; Float tlay, tlev; };  // raw loaded values: nothing is derived at load
   struct Wts { Float2 fm[4]; int je1, je2; };                     // time, so no request waits for another
@@ -379,19 +380,31 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
       }
     }
     if (!lastc) continue;  // (block-uniform)
+    // (the column index of this epilogue is made opaque: its 64-bit addresses -- top level, surface layer -- are formed here,
+    //  once per chunk, instead of being hoisted out of the chunk loop and spilled across the layer walk)
+    unsigned ice = ic;
+    asm volatile("" : "+v"(ice));
     if (valid) {
-      const Float pl_top = planck(a.tlev[ic + ncol * nlay]);
+      const Float pl_top = planck(a.tlev[ice + ncol * nlay]);
       if constexpr (FACT) {
-        if (g0 == gptS) a.plk_lev[ic + ncol * nlay + (size_t)nclv * ibnd] = pl_top;
+        if (g0 == gptS) a.plk_lev[ice + ncol * nlay + (size_t)nclv * ibnd] = pl_top;
       } else {
 #pragma unroll
-        for (int j = 0; j < G; ++j) a.lev_src[ic + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
+        for (int j = 0; j < G; ++j) a.lev_src[ice + ncol * nlay + (size_t)nclv * (g0 + j)] = prev[j] * pl_top;  // :705
       }
     }
     // ---- surface source (:651-653) from the Planck fractions of the surface layer
     if (lsfc != (int)nlay - 1) {
-      load_idx(lsfc, x0);
-      load_wts(lsfc, x0, w0);
+      {  // (load_idx / load_wts on the opaque column index)
+        const unsigned cl = ice + ncol * (unsigned)lsfc;
+        x0.tropo = a.tropo[cl]; x0.jT = a.jtemp[cl]; x0.jpress = a.jpress[cl]; x0.tlay = a.tlay[cl]; x0.tlev = a.tlev[cl];
+        const size_t clf = cl + (size_t)ncl * (x0.tropo ? flav0 : flav1);
+        const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w0.fm[i] = fmp[i];
+        const int2 je = *reinterpret_cast<const int2*>(a.jeta + 2 * clf);
+        w0.je1 = je.x; w0.je2 = je.y;
+      }
       const int Tmin = gl[lsfc][0], nT = gl[lsfc][1], Pmin = gl[lsfc][2], emin = gl[lsfc][4], nE = gl[lsfc][5];
       __syncthreads();  // B(s): the surface layer's slab is complete
       const Float* sl = slab[s & 1];
@@ -414,10 +427,13 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
       }
     }
     if (valid) {
+      const Float tsfc = a.tsfc[ice];
+      const Float pl_sfc = planck(tsfc);
+      const Float pl_sfc1 = planck(tsfc + (Float)1);
 #pragma unroll
       for (int j = 0; j < G; ++j) {
-        a.sfc_src[ic + (size_t)ncol * (g0 + j)] = prev[j] * pl_sfc;
-        a.sfc_jac[ic + (size_t)ncol * (g0 + j)] = prev[j] * (pl_sfc1 - pl_sfc);
+        a.sfc_src[ice + (size_t)ncol * (g0 + j)] = prev[j] * pl_sfc;
+        a.sfc_jac[ice + (size_t)ncol * (g0 + j)] = prev[j] * (pl_sfc1 - pl_sfc);
       }
     }
   }

@@ -106,6 +106,20 @@ def _have(binary):
     return os.path.exists(os.path.join(BIN, binary))
 
 
+@pytest.mark.gpu
+def test_fortran_binding_of_the_factored_sources():
+    """INTEGRATION.md section 4a is compiled, not only printed: shim/mo_rte_hip_factored.F90 (the interface block a maintainer
+    would add) beside the reference's own kernel interface modules, and oracle/factored_binding_driver.F90 calling the
+    factored pair and the reference pair on the same host arrays -- fluxes and expanded sources bit-identical."""
+    path = os.path.join(BIN, "factored_binding_driver")
+    assert os.path.exists(path), f"{path} missing: run oracle/build_extern.sh where /root/reference exists"
+    for env in ({}, {"RTE_HIP_HOST_MIRROR": "1"}):
+        r = subprocess.run(f"ulimit -s unlimited 2>/dev/null; exec '{path}'", shell=True, capture_output=True, text=True, timeout=600,
+                           cwd=ROOT, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "factored binding: PASS" in r.stdout, r.stdout
+
+
 @pytest.mark.parametrize("kind,top_at_1", [("lw", False), ("lw", True), ("sw", False), ("sw", True)])
 def test_python_mirror_of_the_frontend_matches_the_reference_frontend(kind, top_at_1, tmp_path):
     """rte-rrtmgp_amd/frontend.py (the call sequence bench.py and the GPU tests drive) on the C oracle against the
