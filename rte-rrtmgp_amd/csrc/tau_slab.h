@@ -559,12 +559,22 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     // everything the next stage needs of this column: its registers are free now, and the requests are a minor pass
     // ahead of their use (requested at the end of the stage their latency is exposed at the barrier; behind the
     // stage's stores they arrive a store drain late)
+    // the requests go out at a raised issue priority: a wave that has reached this point is served ahead of the block's other
+    // waves, still in their major pass, so its requests have the whole minor pass to arrive (A/B in one process, three rounds:
+    // 4.83-4.87 against 4.94-5.01 ms; the same around the slab requests behind the barrier or around the stage's stores: slower
+    // or no different -- docs/lab-notebook.md, round 6).  -DTAU_NO_REQ_PRIO for A/B.
+#if !defined(TAU_NO_REQ_PRIO)
+    __builtin_amdgcn_s_setprio(2);
+#endif
     if (fresh_next) {
       load_major(nq.flav_major, mj);
       load_minor_w(nq, mw);
     }
     load_minor(b_next, nq, mn);
     __builtin_amdgcn_sched_barrier(0);
+#if !defined(TAU_NO_REQ_PRIO)
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll 1
     for (int q = 0; q < nslot; ++q) {
       Float scaling = scl[0];
