@@ -210,6 +210,50 @@ def test_hip_glue_matches_the_reference_frontend():
     _check_against_frontend(_glue_on_fixture(hiplib.load(), frontend.TorchArrays("cuda:0"), fx), fx, "csrc/glue.hip vs the reference frontend")
 
 
+# ---- the RFMIP-SW driver's boundary conditions, pinned against the reference's own statements (tests/golden/rfmip_sw_glue.npz:
+# examples/rfmip-clear-sky/rrtmgp_rfmip_sw.F90:269-318, :331-337 cut out of the reference file where it lies and compiled in a
+# C-callable frame by oracle/build_rfmip_sw_glue.sh; generator beside the fixture)
+def _rfmip_sw_on_fixture(lib, xp):
+    f = np.load(os.path.join(ROOT, "tests", "golden", "rfmip_sw_glue.npz"))
+    fx = {k: np.asfortranarray(f[k]) for k in f.files}
+    b = int(np.asarray(fx["block"]).reshape(-1)[0]) - 1
+    A = xp.asarray
+    E = lambda *a, **k: hiplib.ext_call(lib, *a, **k)  # noqa: E731
+    ncol, ngpt = fx["in_toa_flux"].shape
+    nbnd, nlev = fx["out_sfc_alb_spec"].shape[0], fx["in_flux_up"].shape[1]
+    usecol = np.asfortranarray(fx["in_usecol"][:, b] != 0)
+    toa = A(fx["in_toa_flux"].copy(order="F")); E("rte_hip_rfmip_sw_toa_renorm", "iiaa", ncol, ngpt, A(np.asfortranarray(fx["in_tsi"][:, b])), toa)
+    mu0 = xp.empty((ncol,)); E("rte_hip_rfmip_sw_mu0", "iaaa", ncol, A(np.asfortranarray(fx["in_sza"][:, b])), A(usecol), mu0)
+    albs = xp.empty((nbnd, ncol)); E("rte_hip_broadcast_cols", "iiaa", nbnd, ncol, A(np.asfortranarray(fx["in_albedo"][:, b])), albs)
+    fu, fd = A(np.asfortranarray(fx["in_flux_up"][:, :, b])), A(np.asfortranarray(fx["in_flux_dn"][:, :, b]))
+    E("rte_hip_mask_columns", "iiaaa", ncol, nlev, A(usecol), fu, fd)
+    xp.sync()
+    got = {k: np.array(xp.to_numpy(v)) for k, v in (("toa", toa), ("mu0", mu0), ("alb", albs), ("fu", fu), ("fd", fd))}
+    return got, fx, b
+
+
+def _check_rfmip_sw(got, fx, b, label):
+    # the renormalisation sums 24 terms and divides: the reference's  sum(toa_flux, dim=2)  may associate differently (<= 2 ulp)
+    assert float(np.max(np.abs(got["toa"] - fx["out_toa_flux"]) / fx["out_toa_flux"])) <= 5e-16, label
+    assert np.allclose(got["toa"].sum(axis=1), fx["in_tsi"][:, b], rtol=1e-14, atol=0), label  # what the block is for
+    assert float(np.max(np.abs(got["mu0"] - fx["out_mu0"]))) <= 2e-16, label                       # libm / device cos
+    assert np.array_equal(got["mu0"][fx["in_usecol"][:, b] == 0], np.ones(int((fx["in_usecol"][:, b] == 0).sum()))), label
+    assert np.array_equal(got["alb"], fx["out_sfc_alb_spec"]), label
+    assert np.array_equal(got["fu"], fx["out_flux_up"][:, :, b]) and np.array_equal(got["fd"], fx["out_flux_dn"][:, :, b]), label
+    assert (fx["out_flux_up"][fx["in_usecol"][:, b] == 0, :, b] == 0).all() and (fx["in_usecol"][:, b] == 0).sum() >= 3  # a real test
+
+
+def test_c_restatement_matches_the_reference_rfmip_sw_boundary_block():
+    got, fx, b = _rfmip_sw_on_fixture(O.load_c(), frontend.NumpyArrays())
+    _check_rfmip_sw(got, fx, b, "glue_oracle.c vs rrtmgp_rfmip_sw.F90")
+
+
+@pytest.mark.gpu
+def test_hip_glue_matches_the_reference_rfmip_sw_boundary_block():
+    got, fx, b = _rfmip_sw_on_fixture(hiplib.load(), frontend.TorchArrays("cuda:0"))
+    _check_rfmip_sw(got, fx, b, "csrc/glue.hip vs rrtmgp_rfmip_sw.F90")
+
+
 @pytest.mark.gpu
 def test_hip_glue_matches_oracle():
     import torch
