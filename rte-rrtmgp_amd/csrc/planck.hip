@@ -279,16 +279,16 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
 
   struct Idx { Bool tropo; int jT, jpress; Float tlay, tlev; };  // raw loaded values: nothing is derived at load
   struct Wts { Float2 fm[4]; int je1, je2; };                     // time, so no request waits for another
-  auto load_idx = [&](unsigned l, Idx& x) {
-    const unsigned cl = ic + ncol * l;
+  auto load_idx = [&](unsigned c0, unsigned l, Idx& x) {  // c0: the lane's column (ic, or an opaque copy of it)
+    const unsigned cl = c0 + ncol * l;
     x.tropo = a.tropo[cl];
     x.jT = a.jtemp[cl];
     x.jpress = a.jpress[cl];
     x.tlay = a.tlay[cl];
     x.tlev = a.tlev[cl];
   };
-  auto load_wts = [&](unsigned l, const Idx& x, Wts& w) {
-    const size_t clf = (ic + ncol * l) + (size_t)ncl * (x.tropo ? flav0 : flav1);
+  auto load_wts = [&](unsigned c0, unsigned l, const Idx& x, Wts& w) {
+    const size_t clf = (c0 + ncol * l) + (size_t)ncl * (x.tropo ? flav0 : flav1);
     const Float2* fmp = reinterpret_cast<const Float2*>(a.fmajor + 8 * clf);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w.fm[i] = fmp[i];
@@ -301,9 +301,15 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
   int s = 0;
 #pragma unroll 1
   for (int g0 = gptS; g0 <= gptE; g0 += G) {
-    load_idx((unsigned)lw0, x0);
-    load_idx(min((unsigned)lw0 + 1u, nlay - 1), x1);
-    load_wts((unsigned)lw0, x0, w0);
+    {
+      // (an opaque copy of the column index: the prologue's 64-bit addresses are formed here, once per chunk, not hoisted out
+      //  of the chunk loop and held -- one of them spilled -- across the layer walk)
+      unsigned icp = ic;
+      asm volatile("" : "+v"(icp));
+      load_idx(icp, (unsigned)lw0, x0);
+      load_idx(icp, min((unsigned)lw0 + 1u, nlay - 1), x1);
+      load_wts(icp, (unsigned)lw0, x0, w0);
+    }
 #pragma unroll
     for (int j = 0; j < G; ++j) prev[j] = 0;
     // nothing outstanding at loop entry: the wait counts inside are then those of the steady state (requests of
@@ -321,8 +327,8 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
       // unconditional (the last layers repeat the last one): a request made on some paths only makes the number of
       // outstanding memory operations path-dependent, and the compiler then drains them all -- this layer's requests
       // and the previous layer's 32 stores -- in front of every barrier
-      load_wts(min(l + 1, nlay - 1), x0, w0);
-      load_idx(min(l + 2, nlay - 1), x1);
+      load_wts(ic, min(l + 1, nlay - 1), x0, w0);
+      load_idx(ic, min(l + 2, nlay - 1), x1);
       const int Tmin = gl[l][0], nT = gl[l][1], Pmin = gl[l][2], emin = gl[l][4], nE = gl[l][5];
       const Float pl_lay = planck(tl), pl_lev = planck(tv);
       __syncthreads();  // B(s): slab(s) is complete
