@@ -115,7 +115,9 @@ def run_frontend_driver(binary, kfile, afile, ofile, gases, ncol, nlay, is_lw, e
     if "_omp" in binary:  # ... and OpenMP worker threads have stacks of their own (virtual reservation only)
         env.setdefault("OMP_STACKSIZE", "24G")
     # flang keeps automatic arrays on the stack
-    r = subprocess.run(f"ulimit -s unlimited 2>/dev/null; exec '{path}' '{kfile}' '{afile}' '{ofile}' '{','.join(gases)}'"
+    # REF_DRIVER_PREFIX: a command to run the program under (e.g. "rocprofv3 --hip-trace --stats -d gpurun_out/x --": experiments)
+    prefix = os.environ.get("REF_DRIVER_PREFIX", "")
+    r = subprocess.run(f"ulimit -s unlimited 2>/dev/null; exec {prefix} '{path}' '{kfile}' '{afile}' '{ofile}' '{','.join(gases)}'"
                        + (f" '{cloud_file}'" if cloud_file else ""),
                        shell=True, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
     global last_stderr
