@@ -1,5 +1,6 @@
 #!/bin/bash
-# The scaling curve of the headline metric on one node: bench.py at 1, 2, 4 and 8 GPUs, one rank per GPU over RCCL
+# The scaling curve of the headline metric on one node: bench.py at 1, 2, 4 and 8 GPUs, one rank per GPU over RCCL (bench.py --gpus N
+# starts its own ranks since round 6; this script loops over N and keeps the launcher form the driver uses)
 # (weak scaling: 100000 columns on one GPU = BASELINE configs[1], 125000 per rank on several = the shard of configs[4];
 # 8 GPUs = configs[4] itself, 1e6 columns).  One JSON line per run into $OUT (default gpurun_out/scale).
 #   usage: bash tools/run_scale.sh [steps] [warmup]        (GPUS="1 2 4 8" overrides the list)
