@@ -200,7 +200,17 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   Float wray = 0;  // Rayleigh: column amount of moist air (:553)
   if (RAYL) wray = a.col_gas[cl + (size_t)ncl * a.idx_h2o] + a.rf.col_dry[cl];
 
-  __syncthreads();  // the schedule is in LDS
+  // uni_reg: EVERY lane of the block is in the same regime at this layer (all lower or all upper, tropo flag in step): what a
+  // lane looks up per stage -- the band table's record of its regime: gas indices, slot bits, flavors -- is then one value per
+  // wave, kept in scalar registers, and the requests that depend on it are (scalar base) + (the lane's 32-bit offset).  The
+  // block-wide AND doubles as the barrier behind the schedule.
+  const int all_lo = __syncthreads_and(regime == 1 && itropo == 0);
+  const int all_up = __syncthreads_and(regime == 2 && itropo == 1);
+#if defined(TAU_NO_UNI)
+  const bool uni_reg = false;
+#else
+  const bool uni_reg = (all_lo | all_up) != 0;
+#endif
   auto get_stage = [&](int s) -> SlabStage {  // (wave-uniform: into scalar registers)
     const int4* p = reinterpret_cast<const int4*>(&s_stage[s]);
     const int4 u = p[0], v = p[1];
@@ -320,29 +330,48 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   // flavors to request, and the slots' bits.  Looked up in the band table where they are used, every request waited for
   // its own LDS round trip.
   struct MinorIdx { int idx[MM], isc[MM], flav, flav_major, n, bits; };
-  auto peek_minor = [&](int st, MinorIdx& q) {
+  auto peek_minor = [&](auto uni_tag, int st, MinorIdx& q) {
+    constexpr bool UNI = decltype(uni_tag)::value;  // (the record is the same for every lane: into scalar registers)
+    auto U = [](int v) { return UNI ? __builtin_amdgcn_readfirstlane(v) : v; };
     const int4* p = reinterpret_cast<const int4*>(&s_peek[st][rsel]);
     const int4 u = p[0], v = p[1], w = p[2];
-    q.idx[0] = u.x; q.idx[1] = u.y; q.idx[2] = u.z; q.idx[3] = u.w;
-    q.isc[0] = v.x; q.isc[1] = v.y; q.isc[2] = v.z; q.isc[3] = v.w;
-    q.n = regime > 0 ? w.x : 0;
-    q.bits = regime > 0 ? w.y : (w.y & ~0x1111);
-    q.flav = rsel ? w.w : w.z;           // minor absorbers use THEIR regime's flavor (:487)
-    q.flav_major = itropo ? w.w : w.z;
+    q.idx[0] = U(u.x); q.idx[1] = U(u.y); q.idx[2] = U(u.z); q.idx[3] = U(u.w);
+    q.isc[0] = U(v.x); q.isc[1] = U(v.y); q.isc[2] = U(v.z); q.isc[3] = U(v.w);
+    q.n = U(regime > 0 ? w.x : 0);
+    q.bits = U(regime > 0 ? w.y : (w.y & ~0x1111));
+    q.flav = U(rsel ? w.w : w.z);           // minor absorbers use THEIR regime's flavor (:487)
+    q.flav_major = U(itropo ? w.w : w.z);
+    // looked up here, not where they are used
+    if constexpr (UNI) {
 #pragma unroll
-    for (int k = 0; k < MM; ++k) asm volatile("" : "+v"(q.idx[k]), "+v"(q.isc[k]));  // looked up here, not where they are used
-    asm volatile("" : "+v"(q.flav), "+v"(q.flav_major), "+v"(q.bits), "+v"(q.n));
+      for (int k = 0; k < MM; ++k) asm volatile("" : "+s"(q.idx[k]), "+s"(q.isc[k]));
+      asm volatile("" : "+s"(q.flav), "+s"(q.flav_major), "+s"(q.bits), "+s"(q.n));
+    } else {
+#pragma unroll
+      for (int k = 0; k < MM; ++k) asm volatile("" : "+v"(q.idx[k]), "+v"(q.isc[k]));
+      asm volatile("" : "+v"(q.flav), "+v"(q.flav_major), "+v"(q.bits), "+v"(q.n));
+    }
   };
   // (requested only where the lane has the slot: always 2 MM requests -- a static count of outstanding operations, counted
   //  waits behind them -- was measured: 5.13 against 5.01 ms; every vector-memory instruction costs more than its wait)
-  auto load_minor = [&](int b, const MinorIdx& q, Minor& x) {
-    x.addv = ADDB ? a.add_bybnd[cl + (size_t)ncl * b] : (Float)0;
+  auto load_minor = [&](auto uni_tag, int b, const MinorIdx& q, Minor& x) {
+    constexpr bool UNI = decltype(uni_tag)::value;
+    // a (ncol, nlay) plane of a 3-D array: wave-uniform plane base + this column's 32-bit byte offset (8 ncol nlay < 2^32)
+    auto plane_at = [&](const Float* base, size_t plane) {
+      return *reinterpret_cast<const Float*>(reinterpret_cast<const char*>(base + (size_t)ncl * plane) + cl8);
+    };
+    x.addv = ADDB ? plane_at(a.add_bybnd, (size_t)b) : (Float)0;
 #pragma unroll
     for (int k = 0; k < MM; ++k) {
       x.sc[k] = 0; x.cgs[k] = 0;
       if (k < q.n) {
-        x.sc[k] = a.col_gas[cl + (size_t)ncl * q.idx[k]];
-        if (q.isc[k] >= 0) x.cgs[k] = a.col_gas[cl + (size_t)ncl * q.isc[k]];
+        if constexpr (UNI) {
+          x.sc[k] = plane_at(a.col_gas, (size_t)q.idx[k]);
+          if (q.isc[k] >= 0) x.cgs[k] = plane_at(a.col_gas, (size_t)q.isc[k]);
+        } else {
+          x.sc[k] = a.col_gas[cl + (size_t)ncl * q.idx[k]];
+          if (q.isc[k] >= 0) x.cgs[k] = a.col_gas[cl + (size_t)ncl * q.isc[k]];
+        }
       }
     }
   };
@@ -353,8 +382,10 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     x.em = *reinterpret_cast<const int2*>(a.jeta + 2 * clm);
   };
 
-  auto run_stages = [&](auto allrun_tag, auto rot_tag, auto rotate_tag) {
+  auto run_stages = [&](auto allrun_tag, auto rot_tag, auto rotate_tag, auto uni_tag) {
   constexpr bool ALLRUN = decltype(allrun_tag)::value;
+  constexpr bool UNI = decltype(uni_tag)::value;  // one regime in the whole block: see uni_reg
+  const int regime_u = UNI ? __builtin_amdgcn_readfirstlane(regime) : regime;
   // ROT: this wave issues a stage's tau stores AFTER the next stage's barrier, while the other half of the block gathers
   constexpr bool ROT = decltype(rot_tag)::value;
   constexpr bool ROTATE = decltype(rotate_tag)::value;  // the block has rotated waves (its upper half)
@@ -410,9 +441,9 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     stage_rest(0, rows0);
     stage_write(0, rows0, v0);
   }
-  peek_minor(0, nq);
+  peek_minor(uni_tag, 0, nq);
   load_major(nq.flav_major, mj);
-  load_minor(get_stage(0).b, nq, mn);
+  load_minor(uni_tag, get_stage(0).b, nq, mn);
   load_minor_w(nq, mw);
   // Nothing outstanding when the loop is entered: the wait counts inside it are then those of the steady state
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -437,8 +468,10 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     // slots the wave walks: up to the last one any of its lanes uses (wave-uniform; a lane without that slot adds 0 x a row it may read)
     int nslot = 0;
 #pragma unroll
-    for (int k = 0; k < MM; ++k)
-      if (__builtin_amdgcn_ballot_w64(((cq_bits >> (4 * k)) & 1) != 0) != 0) nslot = k + 1;
+    for (int k = 0; k < MM; ++k) {
+      if constexpr (UNI) { if ((cq_bits >> (4 * k)) & 1) nslot = k + 1; }
+      else if (__builtin_amdgcn_ballot_w64(((cq_bits >> (4 * k)) & 1) != 0) != 0) nslot = k + 1;
+    }
     __syncthreads();  // B(s): slab(s) is complete, and every wave is done with the other buffer
     const int bw_next = __builtin_amdgcn_readfirstlane(s_stage[s + 1].b), b_next = bw_next & 255;
     const bool fresh_next = (bw_next & 256) == 0;  // (block-uniform) the next stage's flavor weights are not this stage's
@@ -463,12 +496,12 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       cld_g = a.rf.cld_g[cl + (size_t)ncl * ibnd];
     }
     if (!ALLRUN && !run) {
-      peek_minor(s + 1, nq);
+      peek_minor(uni_tag, s + 1, nq);
       if (fresh_next) {
         load_major(nq.flav_major, mj);
         load_minor_w(nq, mw);
       }
-      load_minor(b_next, nq, mn);
+      load_minor(uni_tag, b_next, nq, mn);
       stage_write(s + 1, rows_next, pv);
       if constexpr (PLANNER) plan_rows(get_stage(s + 2), s + 2, tid, NPLAN);
       fresh_cur = fresh_next;
@@ -481,7 +514,7 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     const int sE = nP * RS;  // to the row of the next eta
     const Float* A1 = A0 + sE;
     const Float* B1 = B0 + sE;
-    const Float* M0 = sl + (cur.rowsMaj + (regime == 2 ? cur.rowsLo : 0)) * RS;
+    const Float* M0 = sl + (cur.rowsMaj + (regime_u == 2 ? cur.rowsLo : 0)) * RS;
     const Float* r1_0 = M0 + ((jT - Tmin) * nE + (em.x - emin)) * RS;
     const Float* r2_0 = M0 + ((jT + 1 - Tmin) * nE + (em.y - emin)) * RS;
     const int plane = nT * nE * RS;
@@ -496,8 +529,10 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     unsigned toff = cl8;
     if (RAYL) asm volatile("" : "+v"(toff));  // keep the 64-bit address out of the loop-invariant registers
     auto tau_at = [&](int j) { return reinterpret_cast<Float*>(tplane + gstride * j + toff); };
+#if defined(TAU_NO_FOLD)
 #pragma unroll
     for (int j = 0; j < G; ++j) acc[j] = 0;
+#endif
     // ================= ONE rolling pipeline of LDS row reads through the stage =================
     const Float f0 = fn0.x, f1 = fn0.y, f2 = fn1.x, f3 = fn1.y;
     Float2 kb[DEPTH][4];
@@ -531,14 +566,20 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
           m = fma(w6, k[2].x, m); n = fma(w6, k[2].y, n);
           m = fma(w7, k[3].x, m); n = fma(w7, k[3].y, n);
           const int j = h & ~1;
+#if defined(TAU_NO_FOLD)
           acc[j] = acc[j] + m;
           acc[j + 1] = acc[j + 1] + n;
+#else
+          // (the stage's sums START as the major species' term: 0 + m is m, but the compiler may not drop the addition)
+          acc[j] = m;
+          acc[j + 1] = n;
+#endif
           // pin the accumulation here: otherwise the FMA chains are sunk below the whole loop and every read stays live
           asm volatile("" : "+v"(acc[j]), "+v"(acc[j + 1]));
         }
         // the next stage's record is read AHEAD of the minor rows in the LDS queue (reads return in order: behind them its
         // use -- the requests below -- would drain the pipeline)
-        if (h == G - DEPTH - 1) peek_minor(s + 1, nq);
+        if (h == G - DEPTH - 1) peek_minor(uni_tag, s + 1, nq);
         if (h + DEPTH < G) rd_major(k, h + DEPTH);
         else if (nslot > 0) rd_minor(k, c1, c2, h + DEPTH - G);
         __builtin_amdgcn_sched_barrier(0);
@@ -570,7 +611,7 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       load_major(nq.flav_major, mj);
       load_minor_w(nq, mw);
     }
-    load_minor(b_next, nq, mn);
+    load_minor(uni_tag, b_next, nq, mn);
     __builtin_amdgcn_sched_barrier(0);
 #if !defined(TAU_NO_REQ_PRIO)
     __builtin_amdgcn_s_setprio(0);
@@ -584,15 +625,27 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       const Float* n1;
       const Float* n2;
       slot_rows(q + 1, n1, n2);
+#if !defined(TAU_NO_FOLD)
+      // the interval's scaling folded into the four interpolation weights (4 products per interval and stage): 4 operations per
+      // g-point instead of 5; the association differs from the reference's scaling x (interpolated k) by an ulp of the term
+      const Float g0_ = scaling * f0, g1_ = scaling * f1, g2_ = scaling * f2, g3_ = scaling * f3;
+#endif
 #pragma unroll
       for (int j = 0; j < G / 2; ++j) {
         Float2 (&k)[4] = kb[j % DEPTH];
+#if defined(TAU_NO_FOLD)
         Float s_ = f0 * k[0].x, t_ = f0 * k[0].y;
         s_ = fma(f1, k[1].x, s_); t_ = fma(f1, k[1].y, t_);
         s_ = fma(f2, k[2].x, s_); t_ = fma(f2, k[2].y, t_);
         s_ = fma(f3, k[3].x, s_); t_ = fma(f3, k[3].y, t_);
         acc[2 * j] = fma(scaling, s_, acc[2 * j]);  // :493
         acc[2 * j + 1] = fma(scaling, t_, acc[2 * j + 1]);
+#else
+        acc[2 * j] = fma(g0_, k[0].x, acc[2 * j]); acc[2 * j + 1] = fma(g0_, k[0].y, acc[2 * j + 1]);  // :493
+        acc[2 * j] = fma(g1_, k[1].x, acc[2 * j]); acc[2 * j + 1] = fma(g1_, k[1].y, acc[2 * j + 1]);
+        acc[2 * j] = fma(g2_, k[2].x, acc[2 * j]); acc[2 * j + 1] = fma(g2_, k[2].y, acc[2 * j + 1]);
+        acc[2 * j] = fma(g3_, k[3].x, acc[2 * j]); acc[2 * j + 1] = fma(g3_, k[3].y, acc[2 * j + 1]);
+#endif
         asm volatile("" : "+v"(acc[2 * j]), "+v"(acc[2 * j + 1]));
         if (j + DEPTH < G / 2) rd_minor(k, c1, c2, j + DEPTH);
         else if (more) rd_minor(k, n1, n2, j + DEPTH - G / 2);
@@ -672,17 +725,23 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
   };
   // the fused variants end a stage with LDS reads of their own slab and cannot rotate
   constexpr bool ROTATE = RAYL == 0;
+  // (the rare combination -- a tile with direct-gather items AND one regime -- runs the per-lane instance)
+  using T_ = std::true_type;
+  using F_ = std::false_type;
   if constexpr (ROTATE) {
     if (wv >= NCW / 2) {
-      if (all_run) run_stages(std::true_type{}, std::true_type{}, std::true_type{});
-      else run_stages(std::false_type{}, std::true_type{}, std::true_type{});
+      if (all_run && uni_reg) run_stages(T_{}, T_{}, T_{}, T_{});
+      else if (all_run) run_stages(T_{}, T_{}, T_{}, F_{});
+      else run_stages(F_{}, T_{}, T_{}, F_{});
       return;
     }
-    if (all_run) run_stages(std::true_type{}, std::false_type{}, std::true_type{});
-    else run_stages(std::false_type{}, std::false_type{}, std::true_type{});
+    if (all_run && uni_reg) run_stages(T_{}, F_{}, T_{}, T_{});
+    else if (all_run) run_stages(T_{}, F_{}, T_{}, F_{});
+    else run_stages(F_{}, F_{}, T_{}, F_{});
   } else {
-    if (all_run) run_stages(std::true_type{}, std::false_type{}, std::false_type{});
-    else run_stages(std::false_type{}, std::false_type{}, std::false_type{});
+    if (all_run && uni_reg) run_stages(T_{}, F_{}, F_{}, T_{});
+    else if (all_run) run_stages(T_{}, F_{}, F_{}, F_{});
+    else run_stages(F_{}, F_{}, F_{}, F_{});
   }
 }
 
