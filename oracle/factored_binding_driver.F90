@@ -24,7 +24,9 @@ program factored_binding_driver
   real(wp) :: weights(nmus), fe, fp, ft, r
   integer  :: icol, ilay, igpt, ibnd, iflav, i, j, k
   integer(c_int) :: rc
-  logical  :: ok
+  integer  :: rc_env
+  character(len=8) :: mirror_env
+  logical  :: ok, fluxes_only
 
   allocate(tlay(ncol,nlay), tlev(ncol,nlay+1), tsfc(ncol), fmajor(2,2,2,ncol,nlay,nflav), pfracin(ntemp,neta,npres+1,ngpt), &
            totplnk(nPlanckTemp,nbnd), jeta(2,ncol,nlay,nflav), jtemp(ncol,nlay), jpress(ncol,nlay), gpoint_bands(ngpt), &
@@ -96,10 +98,17 @@ program factored_binding_driver
   rc = rte_hip_expand_factored_sources(ncol, nlay, nbnd, ngpt, band_lims_gpt, pfrac, plk_lay, plk_lev, lay3, lev3)
   if (rc /= 0) stop "rte_hip_expand_factored_sources failed"
 
-  ok = all(bb_up == bb_up2) .and. all(bb_dn == bb_dn2) .and. all(sfc_src == sfc_src2) .and. all(sfc_jac == sfc_jac2) &
+  ! host-mirror mode (RTE_HIP_HOST_MIRROR=1) keeps the arrays a frontend only hands from kernel to kernel -- the sources -- on the
+  ! device and does NOT write the host copies: there only the fluxes can be compared on the host
+  call get_environment_variable("RTE_HIP_HOST_MIRROR", mirror_env, status=rc_env)
+  fluxes_only = rc_env == 0 .and. mirror_env(1:1) == "1"
+  ok = all(bb_up == bb_up2) .and. all(bb_dn == bb_dn2)
+  if (.not. fluxes_only) ok = ok .and. all(sfc_src == sfc_src2) .and. all(sfc_jac == sfc_jac2) &
        .and. all(lay3 == lay_src) .and. all(lev3 == lev_src)
-  print '(a,es12.4,a,es12.4)', "factored binding: max flux_up ", maxval(bb_up), "  max |difference| ", &
-        max(maxval(abs(bb_up - bb_up2)), maxval(abs(bb_dn - bb_dn2)), maxval(abs(lay3 - lay_src)), maxval(abs(lev3 - lev_src)))
+  print '(a,es12.4,a,2es11.3)', "factored binding: max flux_up ", maxval(bb_up), "  max |difference| of flux_up, flux_dn ", &
+        maxval(abs(bb_up - bb_up2)), maxval(abs(bb_dn - bb_dn2))
+  if (.not. fluxes_only) print '(a,4es11.3)', "factored binding: max |difference| of sfc_src, sfc_jac, lay_source, lev_source ", &
+        maxval(abs(sfc_src - sfc_src2)), maxval(abs(sfc_jac - sfc_jac2)), maxval(abs(lay3 - lay_src)), maxval(abs(lev3 - lev_src))
   if (ok .and. maxval(bb_up) > 0._wp .and. minval(bb_dn(:,1)) > 0._wp) then
     print '(a)', "factored binding: PASS"
   else
