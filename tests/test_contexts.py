@@ -215,3 +215,46 @@ def test_host_mirror_mode_serves_unchanged_inputs_from_the_device_and_sees_chang
         hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 0)
         setc(None)
         destroy(ctx)
+
+
+@pytest.mark.gpu
+def test_input_cache_does_not_refill_an_entry_already_handed_out_in_the_same_call():
+    """Fortran temporaries swap addresses between calls.  Call 1 passes (play = P at address A, tlay = T at address
+    B).  Call 2 passes play = a NEW array at address C whose bytes equal T (served from the entry of B by content) and tlay = NEW
+    bytes at address B: refilling B's entry for tlay would overwrite the device copy play is about to be read from.  Checked with
+    rte_hip_tlev_interp (two same-sized inputs) against the C oracle."""
+    from oracle import oracle as O
+
+    hip = hiplib.load()
+    create, setc, destroy = _ctx_api(hip)
+    ncol, nlay = 4096, 40  # 1.3 MB per array: above the cache's 64 KB floor
+    rng = np.random.default_rng(11)
+    F = np.asfortranarray
+    plev = F(np.sort(rng.uniform(100.0, 101000.0, (ncol, nlay + 1)), axis=1)[:, ::-1])
+    a_buf = F(0.5 * (plev[:, 1:] + plev[:, :-1]))          # address A: pressures
+    b_buf = F(rng.uniform(180.0, 320.0, (ncol, nlay)))       # address B: temperatures T
+    oracle = O.load_c()
+
+    def tlev_of(lib, play, tlay):
+        out = np.zeros((ncol, nlay + 1), order="F")
+        assert hiplib.ext_call(lib, "rte_hip_tlev_interp", "iiaaaa", ncol, nlay, play, plev, tlay, out) == 0
+        return out
+
+    ctx = create(-1, None)
+    setc(ctx)
+    os.environ["RTE_HIP_INPUT_CACHE"] = "1"
+    try:
+        hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 1)
+        first = tlev_of(hip, a_buf, b_buf)
+        assert np.array_equal(first, tlev_of(oracle, a_buf, b_buf))
+        c_buf = b_buf.copy(order="F")                        # address C: the bytes of T, handed in as "play"
+        b_buf[:] = F(rng.uniform(200.0, 300.0, (ncol, nlay)))  # address B: new contents, handed in as "tlay"
+        want = tlev_of(oracle, c_buf, b_buf)
+        got = tlev_of(hip, c_buf, b_buf)
+        assert np.array_equal(got, want), float(np.max(np.abs(got - want)))
+        assert np.array_equal(tlev_of(hip, c_buf, b_buf), want)  # and again, from whatever the cache holds now
+    finally:
+        os.environ.pop("RTE_HIP_INPUT_CACHE", None)
+        hiplib.ext_call(hip, "rte_hip_host_mirror", ["i"], 0)
+        setc(None)
+        destroy(ctx)
