@@ -7,9 +7,12 @@ Only the file I/O lives here: the variables are read under the names the referen
 (rrtmgp/data-loading-examples/mo_optics_utils_rrtmgp.F90:102-182), turned to the Fortran orientation of its reader
 (netCDF's C order reversed), and handed to rte-rrtmgp_amd/kdist_load.init_from_raw, which performs the load-time
 reductions (validated against the reference's own load: tests/test_kdist_load.py).
-The real files are netCDF-4 (HDF5): that needs netCDF4, which the build image lacks, and the data, which are not offline either.
-What IS tested here (tests/test_netcdf_converter.py): the same code path on a synthetic file in the netCDF-3 classic format,
-written with the reference's variable names and dimension order and read through scipy's reader.
+The real files are netCDF-4 (HDF5).  They are read with netCDF4 where it is installed, otherwise through the HDF5 C library
+itself (rte-rrtmgp_amd/hdf5_reader.py: a ctypes binding, no Python package needed -- any libhdf5 >= 1.8 on the machine);
+netCDF-3 classic / 64-bit-offset files go through scipy's reader.  The data are not offline, so what IS tested
+(tests/test_netcdf_converter.py) is this code path on synthetic files with the reference's variable names and dimension order:
+one in the classic format, and netCDF-4-style HDF5 files written by the HDF5 library the way netCDF-C lays them out (chunked,
+shuffled, deflated, dimension-scale datasets; old and latest file-format generation).
 """
 import argparse
 import os
@@ -18,13 +21,12 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rte_rrtmgp_amd import kdist_io, kdist_load  # noqa: E402
+from rte_rrtmgp_amd import hdf5_reader, kdist_io, kdist_load  # noqa: E402
 
 
 def open_dataset(path):
-    """netCDF4 where it is installed (the rrtmgp-data files are netCDF-4 / HDF5); otherwise scipy's reader, which handles the
-    netCDF-3 classic and 64-bit-offset formats only (`nccopy -k classic` converts a file where the netCDF tools exist).
-    Returns (variables mapping, close function)."""
+    """netCDF4 where it is installed; otherwise an HDF5 file (netCDF-4: what rrtmgp-data ships) goes through the HDF5 C library
+    (hdf5_reader) and a netCDF-3 classic / 64-bit-offset file through scipy's reader.  Returns (variables mapping, close function)."""
     try:
         import netCDF4  # noqa: PLC0415  (not installed in the build image)
 
@@ -32,10 +34,14 @@ def open_dataset(path):
         nc.set_auto_mask(False)
         return nc.variables, nc.close
     except ImportError:
-        from scipy.io import netcdf_file  # noqa: PLC0415
+        pass
+    if hdf5_reader.is_hdf5(path):
+        variables, _, close = hdf5_reader.open_netcdf4(path)  # raises HDF5Unavailable with the places it looked in
+        return variables, close
+    from scipy.io import netcdf_file  # noqa: PLC0415
 
-        nc = netcdf_file(path, "r", mmap=False)
-        return nc.variables, nc.close
+    nc = netcdf_file(path, "r", mmap=False)
+    return nc.variables, nc.close
 
 
 def read_raw(path):
