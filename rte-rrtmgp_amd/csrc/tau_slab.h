@@ -411,8 +411,15 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     if (OVERWRITE) {
       // lanes past the last column repeat it (ic is clamped): same values to the same addresses.  Unconditional
       // stores keep the count of outstanding memory operations static (counted waits instead of drains).
+#if defined(TAUX_NOSTORE)
+      Float t_ = 0;
+#pragma unroll
+      for (int j = 0; j < G; ++j) t_ += acc[j];
+      if (t_ == (Float)1.2345e-300) store_stream(tau_at(0), t_);
+#else
 #pragma unroll
       for (int j = 0; j < G; ++j) store_stream(tau_at(j), acc[j]);
+#endif
     } else if (valid) {
       // tau is inout (the reference accumulates onto it, :637,:679): the stage's sum is added to the incoming value as a
       // hardware floating-point atomic add performed in L2 (no return value) -- the same single addition tau_in + sum,
@@ -472,13 +479,19 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
       if constexpr (UNI) { if ((cq_bits >> (4 * k)) & 1) nslot = k + 1; }
       else if (__builtin_amdgcn_ballot_w64(((cq_bits >> (4 * k)) & 1) != 0) != 0) nslot = k + 1;
     }
+#if !defined(TAUX_NOBARRIER)
     __syncthreads();  // B(s): slab(s) is complete, and every wave is done with the other buffer
+#endif
     const int bw_next = __builtin_amdgcn_readfirstlane(s_stage[s + 1].b), b_next = bw_next & 255;
     const bool fresh_next = (bw_next & 256) == 0;  // (block-uniform) the next stage's flavor weights are not this stage's
     const int rows_next = __builtin_amdgcn_readfirstlane(s_stage[s + 1].rowsAll);
     PVec pv;
+#if defined(TAUX_NOSTAGE)
+    pv = PVec{};
+#else
     stage_load(s + 1, rows_next, pv);  // slab(s+1), for the buffer just released
     stage_rest(s + 1, rows_next);
+#endif
     if constexpr (ROT) {
       if (ALLRUN ? s > 0 : have_prev) flush(g0_prev, addv_prev);
       have_prev = false;
@@ -536,6 +549,10 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     // ================= ONE rolling pipeline of LDS row reads through the stage =================
     const Float f0 = fn0.x, f1 = fn0.y, f2 = fn1.x, f3 = fn1.y;
     Float2 kb[DEPTH][4];
+#if defined(TAUX_NOGATHER)  // (attribution builds, results wrong: the stage without its LDS row reads)
+    auto rd_major = [&](Float2 (&k)[4], int h) { k[0] = fn0; k[1] = fn1; k[2] = fn0; k[3] = fn1; };
+    auto rd_minor = [&](Float2 (&k)[4], const Float* p1, const Float* p2, int j) { k[0] = fn0; k[1] = fn1; k[2] = fn0; k[3] = fn1; };
+#else
     auto rd_major = [&](Float2 (&k)[4], int h) {  // h: (g-point pair, lower / upper temperature); :791-801
       const Float* b0 = ((h & 1) ? B0 : A0) + 2 * (h >> 1);
       const Float* b1 = ((h & 1) ? B1 : A1) + 2 * (h >> 1);
@@ -544,6 +561,7 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
     auto rd_minor = [&](Float2 (&k)[4], const Float* p1, const Float* p2, int j) {  // j: g-point pair; :757-760
       k[0] = ld2(p1 + 2 * j); k[1] = ld2(p1 + RS + 2 * j); k[2] = ld2(p2 + 2 * j); k[3] = ld2(p2 + RS + 2 * j);
     };
+#endif
     const Float* c1;
     const Float* c2;
     slot_rows(0, c1, c2);
@@ -607,11 +625,15 @@ tau_slab_kernel(TauV5 a, const TileGeom* __restrict__ geom) {
 #if !defined(TAU_NO_REQ_PRIO)
     __builtin_amdgcn_s_setprio(2);
 #endif
+#if !defined(TAUX_NOWEIGHTS)
     if (fresh_next) {
       load_major(nq.flav_major, mj);
       load_minor_w(nq, mw);
     }
+#if !defined(TAUX_NOAMOUNTS)
     load_minor(uni_tag, b_next, nq, mn);
+#endif
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #if !defined(TAU_NO_REQ_PRIO)
     __builtin_amdgcn_s_setprio(0);
