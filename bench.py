@@ -588,6 +588,11 @@ def main():
         # BASELINE configs[1] on one GPU; on several, the per-rank shard of configs[4] (1e6 columns on 8 GPUs = 125000 per rank;
         # the same 125000 per rank at 2 and 4 GPUs: weak scaling)
         args.ncol = 100000 if world == 1 else 125000
+    # args.ncol is the NOMINAL count per rank; a job of several ranks shards args.ncol * world columns with sharding.shard_columns,
+    # whose boundaries fall on multiples of 64 columns: 1e6 columns on 8 ranks are 125 056 + 7 x 124 992, not 8 x 125 000 --
+    # a (125 000, nlay, ...) array has rows 1 000 000 bytes apart, 64-byte but not 128-byte aligned, and the whole chain runs 5 %
+    # slower on it (5.28 against 5.54-5.56 M columns/s on one MI355X, docs/lab-notebook.md round 6)
+    ncol_global = args.ncol * world
 
     from rte_rrtmgp_amd import frontend, hiplib, sharding, synth
 
@@ -606,7 +611,7 @@ def main():
     hiplib.ext_call(lib, "rte_hip_overlap_planck", ["i"], 1 if overlap else 0)
     dev = f"cuda:{local_rank}"
     xp = frontend.TorchArrays(dev)
-    ncol = args.ncol
+    ncol = sharding.shard_columns(ncol_global, rank, world)[1] if world > 1 else args.ncol
     nlay_w = 72 if args.workload == "allsky" else NLAY
     kd = synth.make_kdist("lw" if args.workload == "allsky" else args.workload, minor_distribution=args.minor_distribution)
     if args.atmosphere == "rce":
@@ -633,7 +638,7 @@ def main():
         if timing:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        mean_profile.copy_(sharding.allreduce_mean_profile(rb["flux_up"], rb["flux_dn"], ncol * world))
+        mean_profile.copy_(sharding.allreduce_mean_profile(rb["flux_up"], rb["flux_dn"], ncol_global))
         if timing:
             e1.record()
             ar_events.append((e0, e1))
@@ -848,7 +853,7 @@ def main():
             fk = read_profile(3)
             step()  # the ABI chain again: its fluxes for the comparison (and its buffers as the timed region left them)
             fence()
-            factored = {"ms_per_step": round(f_ms, 4), "columns_per_s": round(ncol * world / (f_ms * 1e-3), 1),
+            factored = {"ms_per_step": round(f_ms, 4), "columns_per_s": round(ncol_global / (f_ms * 1e-3), 1),
                         "fluxes_bit_identical_to_abi_chain": bool(torch.equal(rb["flux_up"], rb_f["flux_up"]) and
                                                                   torch.equal(rb["flux_dn"], rb_f["flux_dn"])),
                         "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(fk.items(), key=lambda kv: -kv[1]["avg_ms"]) if v["avg_ms"] >= 0.02},
@@ -883,7 +888,7 @@ def main():
             nb_ = kd.nbnd
             d_bytes = ncol * NLAY * (1297 + 3345 + (25 + 72 * 10 + 8 * 61 / 60 + 8 * kd.ngpt + 8 * nb_ * (1 + 61 / 60)) +
                                      (16 * kd.ngpt + 8 * nb_ * (1 + 61 / 60) + 32 * kd.ngpt / NLAY + 16 * 61 / 60))
-            deferred = {"ms_per_step": round(d_ms, 4), "columns_per_s": round(ncol * world / (d_ms * 1e-3), 1),
+            deferred = {"ms_per_step": round(d_ms, 4), "columns_per_s": round(ncol_global / (d_ms * 1e-3), 1),
                         "fluxes_bit_identical_to_abi_chain": bool(torch.equal(rb["flux_up"], rb_d["flux_up"]) and
                                                                   torch.equal(rb["flux_dn"], rb_d["flux_dn"])),
                         "alg_GB_per_step": round(d_bytes / 1e9, 3), "frac_of_8TBps_on_its_own_bytes": round(d_bytes / (d_ms * 1e-3) / 8e12, 4),
@@ -907,7 +912,7 @@ def main():
 
             f_ms = timed_ms(step_allsky_f, reps=3)
             same = bool(torch.equal(st_f["rb"]["flux_up"], st_as["l"][2]["flux_up"]) and torch.equal(st_f["rb"]["flux_dn"], st_as["l"][2]["flux_dn"]))
-            factored = {"ms_per_step": round(f_ms, 4), "columns_per_s": round(ncol * world / (f_ms * 1e-3), 1),
+            factored = {"ms_per_step": round(f_ms, 4), "columns_per_s": round(ncol_global / (f_ms * 1e-3), 1),
                         "lw_fluxes_bit_identical": same,
                         "note": "the LW half with factored sources (see the LW workload); outside the timed region, never `value`"}
             st_f.clear()
@@ -937,7 +942,7 @@ def main():
             gk = read_profile(3)
             step()
             fence()
-            implicit_g = {"ms_per_step": round(g_ms, 4), "columns_per_s": round(ncol * world / (g_ms * 1e-3), 1),
+            implicit_g = {"ms_per_step": round(g_ms, 4), "columns_per_s": round(ncol_global / (g_ms * 1e-3), 1),
                           "fluxes_bit_identical": bool(all(torch.equal(rb[k], rb_g[k]) for k in ("flux_up", "flux_dn", "flux_dir"))),
                           "kernel_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(gk.items(), key=lambda kv: -kv[1]["avg_ms"]) if v["avg_ms"] >= 0.02},
                           "note": "clear-sky g = 0 neither stored by rte_hip_gas_optics_sw_2str nor read by rte_sw_solver_2stream (g == NULL); "
@@ -949,8 +954,8 @@ def main():
     # assembling the global broadband field on every rank (all-gather of the per-rank slabs), outside the timed region
     allgather_ms = None
     if dist is not None:
-        allgather_ms = timed_ms(lambda: (sharding.allgather_fluxes(rb["flux_up"], ncol * world),
-                                         sharding.allgather_fluxes(rb["flux_dn"], ncol * world)))
+        allgather_ms = timed_ms(lambda: (sharding.allgather_fluxes(rb["flux_up"], ncol_global),
+                                         sharding.allgather_fluxes(rb["flux_dn"], ncol_global)))
 
     # With the overlap on, compute_tau_absorption and compute_Planck_source run at the same time: their event
     # durations in the timed region overlap (each is stretched by the other).  A short pass outside the timed region
@@ -1085,7 +1090,7 @@ def main():
             "metric": {"lw": "columns/sec (LW gas-optics + lw_solver_noscat, 256 gpt x 60 lay)",
                        "sw": "columns/sec (SW gas-optics + sw_solver_2stream, 224 gpt x 60 lay)",
                        "allsky": "columns/sec (all-sky LW + SW with cloud optics, 256 + 224 gpt x 72 lay)"}[args.workload],
-            "value": ncol * world * args.steps / dt, "unit": "columns/s", "n_gpus": world, "steps": args.steps,
+            "value": ncol_global * args.steps / dt, "unit": "columns/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             # median and minimum over the timed steps (rank 0's per-step durations, one event per step boundary)
             "step_ms": {"median": round(step_ms[len(step_ms) // 2], 4), "min": round(step_ms[0], 4), "max": round(step_ms[-1], 4),
@@ -1102,9 +1107,9 @@ def main():
             "config": {"workload": (f"RFMIP-like clear-sky LW, {ncol} synthetic columns per GPU x {NLAY} layers x "
                                     f"{kd.ngpt} g-points ("
                                     + ("BASELINE configs[1]" if world == 1 and ncol == 100000 else
-                                       f"BASELINE configs[4]: {ncol * world} columns sharded across {world} GPUs, RCCL flux reduce"
-                                       if ncol * world == 1000000 else
-                                       f"the {ncol}-column shard of BASELINE configs[4] on {world} GPUs, {ncol * world} columns in all")
+                                       f"BASELINE configs[4]: {ncol_global} columns sharded across {world} GPUs, RCCL flux reduce"
+                                       if ncol_global == 1000000 else
+                                       f"a {args.ncol}-column (nominal) shard of BASELINE configs[4] per GPU on {world} GPUs, {ncol_global} columns in all")
                                     + "), synthetic g256-shaped k-distribution"
                                     if args.workload == "lw" else
                                     f"clear-sky SW gas optics + two-stream solver, {ncol} synthetic columns per GPU x {NLAY} "
@@ -1113,7 +1118,10 @@ def main():
                                     f"all-sky LW (clouds as absorbers) + SW (two-stream clouds, delta-scaled), {ncol} synthetic "
                                     f"columns per GPU x {nlay_w} layers, 256 + 224 g-points (BASELINE configs[3] shape), "
                                     f"synthetic k-distributions and cloud tables, cloud field of examples/all-sky"),
-                       "columns_per_gpu": ncol, "nlay": nlay_w, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero,
+                       "columns_per_gpu": args.ncol, "columns_this_rank": ncol,
+                       "shard_boundaries": ("multiples of 64 columns (sharding.shard_columns): " + ", ".join(str(sharding.shard_columns(ncol_global, r, world)[1]) for r in range(world))
+                                            if world > 1 else None),
+                       "nlay": nlay_w, "ngpt": kd.ngpt, "sharding": f"columns x{world}", "defer_zero": not args.no_defer_zero,
                        "overlap_tau_planck": overlap, "share_geometry": share_geom, "worklist_beside_slab_kernel": not args.no_aux_stream,
                        "atmosphere": args.atmosphere, "minor_distribution": args.minor_distribution,
                        "direct_gather_worklist": {"tau_tile_layer_bands": wl_tau, "of": tiles * nlay_w * kd.nbnd,
@@ -1122,7 +1130,7 @@ def main():
                        "device": torch.cuda.get_device_name(local_rank), "device_uuid": _device_uuid(torch, local_rank),
                        "opt_in_modes": "rte_hip_defer_zero + rte_hip_share_geometry" + (" + one-pass SW gas optics / fused cloud kernels" if args.workload != "lw" else ""),
                        "plain_abi_ms_per_step": (round(plain_abi_ms, 4) if isinstance(plain_abi_ms, float) else plain_abi_ms),
-                       "plain_abi_columns_per_s": (round(ncol * world / (plain_abi_ms * 1e-3), 1) if isinstance(plain_abi_ms, float) else None),
+                       "plain_abi_columns_per_s": (round(ncol_global / (plain_abi_ms * 1e-3), 1) if isinstance(plain_abi_ms, float) else None),
                        "plain_abi_note": "the same step through the reference ABI only, no rte_hip_* opt-ins (3 steps outside the timed region)",
                        "factored_sources": factored,
                        "deferred_sources": deferred,

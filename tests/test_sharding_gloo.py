@@ -57,13 +57,18 @@ def test_shard_columns_partition():
     sys.path.insert(0, ROOT)
     from rte_rrtmgp_amd import sharding
 
-    for n in (1, 7, 100000, 1000003):
+    for n in (1, 7, 100000, 1000000, 1000003):
         for w in (1, 2, 4, 8):
-            parts = [sharding.shard_columns(n, r, w) for r in range(w)]
-            assert parts[0][0] == 0 and sum(c for _, c in parts) == n
-            for (s0, c0), (s1, _) in zip(parts, parts[1:]):
-                assert s0 + c0 == s1
-            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+            for align in (None, 1, 64):
+                parts = [sharding.shard_columns(n, r, w, align) for r in range(w)]
+                assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+                for (s0, c0), (s1, _) in zip(parts, parts[1:]):
+                    assert s0 + c0 == s1
+                a = align if align else (64 if n >= 1024 * w else 1)  # the default: 64-column boundaries for shards of >= 1024 columns
+                assert max(c for _, c in parts) - min(c for _, c in parts) < max(2, 2 * a)  # (one block, and the last block may be short)
+                assert all(s0 % a == 0 or (s0 == n and c0 == 0) for s0, c0 in parts)  # (ranks past the end: empty)
+    # BASELINE configs[4]: 1e6 columns on 8 ranks -- no rank gets the 125 000 columns whose rows are 64-byte aligned only
+    assert [sharding.shard_columns(1000000, r, 8)[1] for r in range(8)] == [125056] + [124992] * 7
 
 
 def test_two_rank_gloo_matches_single_process(tmp_path):
