@@ -171,6 +171,10 @@ int rte_hip_allreduce_mean_profile(void* nccl_comm /* NULL: one rank */, int nco
                                    const Float* flux_dn, long long ncol_global, Float* mean_up /* (nlev) */, Float* mean_dn);
 int rte_hip_allgather_columns(void* nccl_comm, int ncol_local, int nlev, const Float* local /* (ncol_local, nlev), device */,
                               Float* global /* (ncol_local * nranks, nlev), device */);
+/* slabs of unequal width (shard boundaries on multiples of 64 columns): ncol_slab >= every rank's ncol_local and ncol_global = their
+ * sum are the same on every rank; rank r's columns lie behind those of the ranks before it */
+int rte_hip_allgatherv_columns(void* nccl_comm, int ncol_local, int nlev, const Float* local /* (ncol_local, nlev), device */,
+                               int ncol_slab, long long ncol_global, Float* global /* (ncol_global, nlev), device */);
 
 /* ---- switches for tests and A/B timing (process-wide) ------------------------------------------------------------------ */
 int rte_hip_force_direct_gather(int on);   /* gas optics on the direct-gather kernels only */

@@ -22,7 +22,7 @@ namespace {
 // the few declarations of rccl.h this file needs (ABI of NCCL 2.x / RCCL)
 typedef void* NcclComm;
 enum { kNcclSum = 0 };
-enum { kNcclFloat32 = 7, kNcclFloat64 = 8 };
+enum { kNcclInt32 = 2, kNcclFloat32 = 7, kNcclFloat64 = 8 };
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, NcclComm, hipStream_t);
 typedef int (*AllGatherFn)(const void*, void*, size_t, int, NcclComm, hipStream_t);
 typedef int (*CommCountFn)(NcclComm, int*);
@@ -94,6 +94,32 @@ __global__ void __launch_bounds__(256) interleave_slabs(int nranks, int ncol_loc
     const size_t c = i % ncol_local, rest = i / ncol_local;
     const size_t lev = rest % nlev, r = rest / nlev;
     out[(r * ncol_local + c) + (size_t)nranks * ncol_local * lev] = in[i];
+  }
+}
+
+// slabs of unequal width: (ncol_local, nlev) -> (ncol_slab, nlev), zero beyond the rank's own columns
+__global__ void __launch_bounds__(256) pad_slab(int ncol_local, int ncol_slab, int nlev, const Float* __restrict__ in, Float* __restrict__ out) {
+  const size_t n = (size_t)ncol_slab * nlev;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t c = i % ncol_slab, lev = i / ncol_slab;
+    out[i] = c < (size_t)ncol_local ? in[c + (size_t)ncol_local * lev] : (Float)0;
+  }
+}
+// (nranks, ncol_slab, nlev) with cnt[r] valid columns each -> (ncol_global, nlev): rank r's columns behind those of the ranks before it
+__global__ void __launch_bounds__(256) compact_slabs(int nranks, int ncol_slab, int nlev, long long ncol_global, const int* __restrict__ cnt,
+                                                      const Float* __restrict__ in, Float* __restrict__ out) {
+  extern __shared__ long long off[];  // [nranks]: exclusive prefix sums of the counts
+  if (threadIdx.x == 0) {
+    long long o = 0;
+    for (int r = 0; r < nranks; ++r) { off[r] = o; o += max(0, min(cnt[r], ncol_slab)); }
+  }
+  __syncthreads();
+  const size_t n = (size_t)nranks * ncol_slab * nlev;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t c = i % ncol_slab, rest = i / ncol_slab;
+    const size_t lev = rest % nlev, r = rest / nlev;
+    const long long g = off[r] + (long long)c;
+    if ((long long)c < (long long)cnt[r] && g < ncol_global) out[(size_t)g + (size_t)ncol_global * lev] = in[i];
   }
 }
 
@@ -171,6 +197,47 @@ int rte_hip_allgather_columns(void* nccl_comm, int ncol_local, int nlev, const F
   hipLaunchKernelGGL(interleave_slabs, dim3(2048), dim3(256), 0, st, nranks, ncol_local, nlev, (const Float*)staged, global);
   return 0;
   RTE_CATCH("rte_hip_allgather_columns")
+  return -1;
+}
+
+// The same for slabs of UNEQUAL width (shard boundaries on multiples of 64 columns: 1e6 columns on 8 ranks are 125 056 + 7 x
+// 124 992): global(ncol_global, nlev) with rank r's ncol_local columns behind those of the ranks before
+// it.  ncol_slab: a width every rank agrees on, >= every rank's ncol_local (the widest shard); ncol_global: the sum of the
+// ranks' ncol_local.  The counts travel by a second, 4-byte-per-rank all-gather and stay on the device: no host synchronisation.
+// ncol_slab, nlev and ncol_global are the same on every rank, so the early returns are taken by all ranks together; a rank
+// whose own range is empty (ncol_local == 0) still takes part.
+int rte_hip_allgatherv_columns(void* nccl_comm, int ncol_local, int nlev, const Float* local, int ncol_slab, long long ncol_global,
+                               Float* global) {
+  if (ncol_slab <= 0 || nlev <= 0 || ncol_global <= 0) return 0;
+  if (ncol_local < 0 || ncol_local > ncol_slab) return -2;
+  if (!nccl_comm || !rccl().ok) return -3;
+  if ((ncol_local > 0 && !rte::is_device_memory(local)) || !rte::is_device_memory(global)) return -2;
+  RTE_TRY
+  rte::Call c("rte_hip_allgatherv_columns");
+  int nranks = 1;
+  nccl_check(rccl().count((NcclComm)nccl_comm, &nranks), "ncclCommCount");
+  hipStream_t st = rte::stream();
+  const size_t n = (size_t)ncol_slab * nlev;
+  int* cnt = (int*)rte::scratch(sizeof(int) * (size_t)(nranks + 1));
+  Float* staged = (Float*)rte::scratch(sizeof(Float) * n * nranks);
+  const Float* mine = local;
+  if (ncol_local != ncol_slab) {
+    Float* padded = (Float*)rte::scratch(sizeof(Float) * n);
+    hipLaunchKernelGGL(pad_slab, dim3(1024), dim3(256), 0, st, ncol_local, ncol_slab, nlev, local, padded);
+    mine = padded;
+  }
+  HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(cnt + nranks), ncol_local, 1, st));
+  {
+    rte::ProfScope p("rccl_allgather");
+    nccl_check(rccl().all_gather(cnt + nranks, cnt, 1, kNcclInt32, (NcclComm)nccl_comm, st), "ncclAllGather (counts)");
+    nccl_check(rccl().all_gather(mine, staged, n, sizeof(Float) == 8 ? kNcclFloat64 : kNcclFloat32, (NcclComm)nccl_comm, st),
+               "ncclAllGather");
+  }
+  rte::ProfScope p("compact_slabs");
+  hipLaunchKernelGGL(compact_slabs, dim3(2048), dim3(256), sizeof(long long) * nranks, st, nranks, ncol_slab, nlev, ncol_global,
+                     (const int*)cnt, (const Float*)staged, global);
+  return 0;
+  RTE_CATCH("rte_hip_allgatherv_columns")
   return -1;
 }
 

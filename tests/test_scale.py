@@ -247,6 +247,18 @@ def test_c_level_flux_reduction_over_rccl():
         torch.cuda.synchronize()
         assert torch.equal(glob, loc)
         assert ag(P(comm.value), I(ncol), I(nlev), P(up.ctypes.data), P(glob.data_ptr())) == -2  # host memory: refused
+        # slabs of unequal width (shard boundaries on multiples of 64 columns): this rank's columns in a wider, agreed slab
+        agv = hip.raw("rte_hip_allgatherv_columns")
+        agv.restype = ctypes.c_int
+        glob.zero_()
+        assert agv(P(comm.value), I(ncol), I(nlev), P(loc.data_ptr()), I(ncol + 59), LL(ncol), P(glob.data_ptr())) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(glob, loc)
+        part = torch.full((nlev, ncol + 7), -1.0, dtype=torch.float64, device="cuda")  # "global" field with 7 columns of another rank behind
+        assert agv(P(comm.value), I(ncol), I(nlev), P(loc.data_ptr()), I(ncol), LL(ncol + 7), P(part.data_ptr())) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(part[:, :ncol], loc) and bool((part[:, ncol:] == -1.0).all())
+        assert agv(P(comm.value), I(ncol), I(nlev), P(loc.data_ptr()), I(ncol - 1), LL(ncol), P(glob.data_ptr())) == -2  # wider than the slab
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
