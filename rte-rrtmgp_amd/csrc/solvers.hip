@@ -1506,6 +1506,278 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------
+// sw_2stream_seg_kernel with segments of TWO lengths (broadband output, whole column, 57 ... 60 layers): waves 0-3 own LA
+// layers each, waves 4-7 LB -- 4 x 7 + 4 x 8 = 60.  With 8 layers per wave the eighth wave owns four layers and computes four
+// neutral slots: 16 slots per SIMD (waves s and s + 4 share one) for 15 layers.  Measured at 1e5 x 60 x 224, two rounds in one
+// process each: 8 + 8 10.66-10.70 ms, 9 + 6 10.57-10.58, 8 + 7 10.26-10.29, 7 + 8 10.23-10.26, 6 + 9 10.20-10.24 (256 registers).
+// (The idea it started from -- the wave a SIMD serves first, s < 4, should own MORE layers so that both reach the barrier
+//  together instead of the younger one finishing alone at a single wave's issue rate -- is refuted by 9 + 6: what pays is the
+//  sixteenth slot not computed, and the split that gives the later wave the longer segment is, if anything, the better one.)
+// sw_seg_wave is the body of sw_2stream_seg_kernel for ONE wave with its segment's length as the template parameter (same
+// expressions in the same order: see the comments there); a wave's private LDS slots (64 lanes each) are, from `priv`:
+// NMU x L values of mu0, L + 1 direct-flux accumulators, and with UPLDS L + 1 upward-flux accumulators.
+// ---------------------------------------------------------------------------------------------
+template <int L, bool G0, bool UPLDS, bool ONEMU>
+__device__ __forceinline__ void sw_seg_wave(const Sw2SegArgs& a, Float* __restrict__ const X1, Float* __restrict__ const X2,
+                                            Float* __restrict__ const priv, const int s, const int p0, const int np, const bool last) {
+#pragma clang fp contract(fast)
+  constexpr int SMAX = 8, NMU = ONEMU ? 1 : 2;
+  const int lane = threadIdx.x & 63;
+  const int S = a.S, ncol = a.ncol, nlay = a.nlay;
+  const int icol = blockIdx.x * 64 + lane;
+  const bool active = icol < ncol;
+  const int c = active ? icol : ncol - 1;
+  const size_t ncl = (size_t)ncol * nlay, nclv = (size_t)ncol * (nlay + 1);
+  const int g_begin = blockIdx.y * a.g_per_block;
+  const int g_end = min(a.ngpt, g_begin + a.g_per_block);
+  const Float min_k = (Float)1.e4 * (Float)RTE_EPS;
+  const Float min_mu0 = sqrt((Float)RTE_EPS);
+  auto layer_of = [&](int i) {
+    const int p = p0 + min(i, np - 1);
+    return a.top_at_1 ? p : nlay - 1 - p;
+  };
+  Float* const mu0s = priv + lane;
+  Float* const mu0i = mu0s + L * 64;
+  Float* const dirs = priv + NMU * L * 64 + lane;
+  Float* const ups = dirs + (L + 1) * 64;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    const Float m = a.mu0[c + (size_t)ncol * layer_of(i)];
+    const Float ms = fmax(min_mu0, m);
+    if constexpr (ONEMU) {
+      mu0s[i * 64] = m > (Float)0 ? ms : -ms;
+    } else {
+      mu0s[i * 64] = ms;
+      mu0i[i * 64] = m > (Float)0 ? rte::rcp_nr(ms) : -rte::rcp_nr(ms);
+    }
+  }
+  const Float mu0_top = a.mu0[c + (size_t)ncol * (a.top_at_1 ? 0 : nlay - 1)];
+  const Float mu0_sfc = a.mu0[c + (size_t)ncol * (a.top_at_1 ? nlay - 1 : 0)];
+  Float acc_up[UPLDS ? 1 : L + 1], acc_dn[L + 1];
+#pragma unroll
+  for (int i = 0; i <= L; ++i) {
+    acc_dn[i] = 0;
+    if constexpr (UPLDS) ups[i * 64] = 0; else acc_up[i] = 0;
+    dirs[i * 64] = 0;
+  }
+  auto add_dir = [&](int i, Float v) { atomicAdd(&dirs[i * 64], v); };
+  auto add_up = [&](int i, Float v) {
+    if constexpr (UPLDS) atomicAdd(&ups[i * 64], v);
+    else acc_up[i] += v;
+  };
+  auto add_dn = [&](int i, Float v) { acc_dn[i] += v; };
+
+  struct In { Float tau[L], ssa[L], g[L], inc_dir, alb_dir, alb_dif, inc_dif; };
+  unsigned orow[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    orow[i] = ((unsigned)c + (unsigned)ncol * (unsigned)layer_of(i)) * (unsigned)sizeof(Float);
+    asm volatile("" : "+v"(orow[i]));
+  }
+  unsigned ocg = (unsigned)c * (unsigned)sizeof(Float);
+  asm volatile("" : "+v"(ocg));
+  auto at = [](const Float* plane, unsigned off) {
+    return *reinterpret_cast<const Float*>(reinterpret_cast<const char*>(plane) + off);
+  };
+  auto load = [&](In& x, int igpt_) {
+    const int igpt = min(igpt_, g_end - 1);
+    const Float *ptau = a.tau + ncl * igpt, *pssa = a.ssa + ncl * igpt, *pg = G0 ? nullptr : a.g + ncl * igpt;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      asm volatile("" : "+v"(orow[i]));
+      x.tau[i] = at(ptau, orow[i]); x.ssa[i] = at(pssa, orow[i]);
+      if constexpr (!G0) x.g[i] = at(pg, orow[i]);
+    }
+    asm volatile("" : "+v"(ocg));
+    const size_t cg = (size_t)ncol * igpt;
+    x.inc_dir = at(a.inc_flux_dir + cg, ocg); x.alb_dir = at(a.sfc_alb_dir + cg, ocg); x.alb_dif = at(a.sfc_alb_dif + cg, ocg);
+    x.inc_dif = a.has_dif_bc ? at(a.inc_flux_dif + cg, ocg) : (Float)0;
+  };
+
+  auto process = [&](In& x, int igpt_next) {
+#pragma clang fp contract(fast)
+    Float R[L], T[L], su[L], sd[L];
+    Float Tn[L];
+    Float P = 1;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      {
+        const Float tau_s = i < np ? x.tau[i] : (Float)0, w0_s = x.ssa[i], g_s = G0 ? (Float)0 : x.g[i];
+        const Float gamma1 = G0 ? ((Float)8 - w0_s * (Float)5) * (Float).25 : ((Float)8 - w0_s * ((Float)5 + (Float)3 * g_s)) * (Float).25;
+        const Float gamma2 = G0 ? (Float)3 * w0_s * (Float).25 : (Float)3 * (w0_s * ((Float)1 - g_s)) * (Float).25;
+        const Float kk = rte::sqrt_pos(fmax((gamma1 - gamma2) * (gamma1 + gamma2), min_k));
+        const Float e1 = rte::exp_nonpos(-tau_s * kk);
+        const Float e2 = e1 * e1;
+        const Float xden = kk * ((Float)1 + e2) + gamma1 * ((Float)1 - e2);
+        const Float mu0_s = ONEMU ? fabs(mu0s[i * 64]) : mu0s[i * 64];
+        const Float k_mu = kk * mu0_s;
+        const Float om = (Float)1 - k_mu * k_mu;
+        const Float om_s = fabs(om) >= (Float)RTE_EPS ? om : (Float)RTE_EPS;
+        const Float inv = rte::rcp_nr(xden * om_s);
+        Float RT = om_s * inv;
+        R[i] = RT * gamma2 * ((Float)1 - e2);
+        T[i] = i < np ? RT * (Float)2 * kk * e1 : (Float)1;
+        RT = w0_s * inv;
+        const Float gamma3 = G0 ? (Float).5 : (Float).5 - ((Float).75 * mu0_s) * g_s;
+        const Float dgam = gamma1 - gamma2;
+        const Float alpha1 = gamma1 - gamma3 * dgam;
+        const Float alpha2 = gamma2 + gamma3 * dgam;
+        const Float k_gamma3 = kk * gamma3, k_gamma4 = kk - k_gamma3;
+        Float imu;
+        if constexpr (ONEMU) { const Float r_ = rte::rcp_nr(mu0_s); imu = mu0s[i * 64] > (Float)0 ? r_ : -r_; }
+        else imu = mu0i[i * 64];
+        const Float Tnoscat = rte::exp_nonpos(-tau_s * fabs(imu));
+        const Float om2 = (Float)1 - e2, op2 = (Float)1 + e2;
+        const Float u_ = alpha2 - k_mu * k_gamma3, v_ = k_gamma3 - k_mu * alpha2;
+        const Float p_ = alpha1 + k_mu * k_gamma4, q_ = k_gamma4 + k_mu * alpha1;
+        Float Rdir = RT * (u_ * om2 + v_ * (op2 - (Float)2 * (e1 * Tnoscat)));
+        Float Tdir = -RT * (Tnoscat * (p_ * om2 + q_ * op2) - (Float)2 * (e1 * q_));
+        Rdir = fmax((Float)0, fmin(Rdir, ((Float)1 - Tnoscat)));
+        Tdir = fmax((Float)0, fmin(Tdir, ((Float)1 - Tnoscat - Rdir)));
+        const bool sun = imu > (Float)0;
+        const Float Ps = sun ? P : (Float)0;
+        su[i] = Rdir * Ps;
+        sd[i] = Tdir * Ps;
+        Tn[i] = Tnoscat;
+        P = Tnoscat * P;
+      }
+    }
+    const Float inc_dir = x.inc_dir, alb_dir = x.alb_dir, alb_dif = x.alb_dif, inc_dif = x.inc_dif;
+    load(x, igpt_next);
+    X1[(0 * SMAX + s) * 64 + lane] = P;
+    Float m00 = T[L - 1] * T[L - 1] - R[L - 1] * R[L - 1], m02 = R[L - 1], m10 = T[L - 1] * sd[L - 1] - su[L - 1] * R[L - 1],
+          m11 = T[L - 1], m12 = su[L - 1], m20 = -R[L - 1], m22 = 1;
+#pragma unroll
+    for (int i = L - 2; i >= 0; --i) {
+      const Float q00 = T[i] * T[i] - R[i] * R[i], q02 = R[i], q10 = T[i] * sd[i] - su[i] * R[i], q11 = T[i], q12 = su[i],
+                  q20 = -R[i];
+      const Float n00 = q00 * m00 + q02 * m20, n02 = q00 * m02 + q02 * m22;
+      const Float n10 = q10 * m00 + q11 * m10 + q12 * m20, n11 = q11 * m11, n12 = q10 * m02 + q11 * m12 + q12 * m22;
+      const Float n20 = q20 * m00 + m20, n22 = q20 * m02 + m22;
+      m00 = n00; m02 = n02; m10 = n10; m11 = n11; m12 = n12; m20 = n20; m22 = n22;
+    }
+    X1[(1 * SMAX + s) * 64 + lane] = m00;
+    X1[(2 * SMAX + s) * 64 + lane] = m02;
+    X1[(3 * SMAX + s) * 64 + lane] = m10;
+    X1[(4 * SMAX + s) * 64 + lane] = m11 * P;
+    X1[(5 * SMAX + s) * 64 + lane] = m12;
+    X1[(6 * SMAX + s) * 64 + lane] = m20;
+    X1[(7 * SMAX + s) * 64 + lane] = m22;
+    __syncthreads();
+    int s_u = s, S_u = S;
+    asm volatile("" : "+s"(s_u), "+s"(S_u));
+    const Float dir_toa = inc_dir * mu0_top;
+    Float pq[SMAX - 1];
+#pragma unroll
+    for (int q = 0; q < SMAX - 1; ++q) pq[q] = X1[(0 * SMAX + q) * 64 + lane];
+    const Float P_own = X1[(0 * SMAX + s) * 64 + lane];
+    Float dir_in = dir_toa;
+#pragma unroll
+    for (int q = 0; q < SMAX - 1; ++q)
+      if (q < s_u) dir_in = dir_in * pq[q];
+    Float alb = alb_dif;
+    Float sig = mu0_sfc > (Float)0 ? alb_dir : (Float)0;
+#pragma unroll
+    for (int q = SMAX - 1; q > 0; --q) {
+      if (q < S_u && q > s_u) {
+        const Float c00 = X1[(1 * SMAX + q) * 64 + lane], c02 = X1[(2 * SMAX + q) * 64 + lane];
+        const Float c10 = X1[(3 * SMAX + q) * 64 + lane], c11 = X1[(4 * SMAX + q) * 64 + lane];
+        const Float c12 = X1[(5 * SMAX + q) * 64 + lane];
+        const Float c20 = X1[(6 * SMAX + q) * 64 + lane], c22 = X1[(7 * SMAX + q) * 64 + lane];
+        const Float w = rte::rcp_nr(c20 * alb + c22);
+        const Float a_new = (c00 * alb + c02) * w;
+        sig = (c10 * alb + c11 * sig + c12) * w;
+        alb = a_new;
+      }
+    }
+    Float src = sig * (dir_in * P_own);
+    asm volatile("" : "+v"(src), "+v"(alb));
+    Float al[L + 1], sr[L + 1];
+    al[L] = alb; sr[L] = src;
+    Float fa[L], fb[L];
+#pragma unroll
+    for (int i = L - 1; i >= 0; --i) {
+      const Float sui = su[i] * dir_in, sdi = sd[i] * dir_in;
+      const Float denom = rte::rcp_nr((Float)1 - R[i] * alb);
+      const Float src_new = sui + T[i] * denom * (src + alb * sdi);
+      const Float alb_new = R[i] + T[i] * T[i] * alb * denom;
+      fa[i] = T[i] * denom;
+      fb[i] = (R[i] * src + sdi) * denom;
+      alb = alb_new; src = src_new;
+      al[i] = alb; sr[i] = src;
+    }
+    Float A = 1, B = 0;
+#pragma unroll
+    for (int i = 0; i < L; ++i) { B = fa[i] * B + fb[i]; A = fa[i] * A; }
+    X2[(0 * SMAX + s) * 64 + lane] = A;
+    X2[(1 * SMAX + s) * 64 + lane] = B;
+    __syncthreads();
+    Float fd = inc_dif;
+    {
+      Float qa[SMAX - 1], qb[SMAX - 1];
+#pragma unroll
+      for (int q = 0; q < SMAX - 1; ++q) { qa[q] = X2[(0 * SMAX + q) * 64 + lane]; qb[q] = X2[(1 * SMAX + q) * 64 + lane]; }
+#pragma unroll
+      for (int q = 0; q < SMAX - 1; ++q)
+        if (q < s_u) fd = qa[q] * fd + qb[q];
+    }
+    Float dirl = dir_in;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      add_up(i, fd * al[i] + sr[i]);
+      add_dn(i, fd + dirl);
+      add_dir(i, dirl);
+      fd = fa[i] * fd + fb[i];
+      dirl = Tn[i] * dirl;
+    }
+    add_up(L, fd * al[L] + sr[L]);
+    add_dn(L, fd + dirl);
+    add_dir(L, dirl);
+  };
+
+  In cur;
+  load(cur, g_begin);
+  for (int igpt = g_begin; igpt < g_end; ++igpt) process(cur, igpt + 1);
+  if (active) {
+    const size_t base = icol + nclv * blockIdx.y;
+#pragma unroll
+    for (int i = 0; i <= L; ++i) {
+      if (i < np || (last && i == np)) {
+        const int p = p0 + i;
+        const int ilev = a.top_at_1 ? p : nlay - p;
+        if constexpr (UPLDS) a.part_up[base + (size_t)ncol * ilev] = ups[i * 64];
+        else a.part_up[base + (size_t)ncol * ilev] = acc_up[i];
+        a.part_dn[base + (size_t)ncol * ilev] = acc_dn[i];
+        a.part_dir[base + (size_t)ncol * ilev] = dirs[i * 64];
+      }
+    }
+  }
+}
+
+// LDS: X1[8][8][64], X2[2][8][64], then the waves' private slots: 2 L values of mu0 (clamped, reciprocal), L + 1 direct-flux
+// accumulators and, from 9 layers on, L + 1 upward-flux accumulators
+constexpr int sw_mixed_slots(int L) { return 2 * L + (L + 1) + (L >= 9 ? L + 1 : 0); }
+template <int LA, int LB>
+constexpr size_t sw_mixed_lds_bytes() { return sizeof(Float) * 64 * (8 * 8 + 2 * 8 + 4 * sw_mixed_slots(LA) + 4 * sw_mixed_slots(LB)); }
+
+template <int LA, int LB, bool G0>
+__global__ void __launch_bounds__(64 * 8) sw_2stream_seg_mixed_kernel(Sw2SegArgs a) {
+  extern __shared__ Float lds[];
+  Float* const X1 = lds;
+  Float* const X2 = lds + 8 * 8 * 64;
+  Float* const PV = X2 + 2 * 8 * 64;
+  constexpr int SLOTS_A = sw_mixed_slots(LA), SLOTS_B = sw_mixed_slots(LB);
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (s < 4) {
+    const int p0 = s * LA;
+    sw_seg_wave<LA, G0, (LA >= 9), false>(a, X1, X2, PV + (size_t)s * SLOTS_A * 64, s, p0, min(LA, a.nlay - p0), false);
+  } else {
+    const int p0 = 4 * LA + (s - 4) * LB;
+    sw_seg_wave<LB, G0, (LB >= 9), false>(a, X1, X2, PV + ((size_t)4 * SLOTS_A + (size_t)(s - 4) * SLOTS_B) * 64, s, p0, min(LB, a.nlay - p0), s == 7);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LW two-stream, segmented (spectral output as the interface defines it, nlay <= 64): the scheme of
 // sw_2stream_seg_kernel without the direct beam (reference :377-440, lw_two_stream :854-909,
 // lw_source_2str :917-967, adding :1135-1245).  The layer sources are absolute here, so one exchange
@@ -1913,6 +2185,7 @@ size_t pick_gchunk(size_t bytes_per_g, int ngpt) {
 static std::atomic<int> g_lw2str_gpt1_levsource{0};
 static std::atomic<int> g_lw_force_generic{0};
 static std::atomic<int> g_sw_force_generic{0};
+static std::atomic<int> g_sw_mixed{1};  // 57 ... 60 layers on sw_2stream_seg_mixed_kernel (rte_hip_sw_mixed_segments)
 static std::atomic<int> g_lw_sfc_lds{1};  // surface arrays of the LW segmented solver through LDS chunks (rte_hip_lw_sfc_lds)
 static std::atomic<int> g_seg_groups{0};  // > 0: g-point groups per column tile of the segmented solvers (rte_hip_seg_groups; 0 = automatic;
                               // < 0: g-points per block given directly)
@@ -1939,6 +2212,7 @@ extern "C" {
 int rte_hip_set_lw2str_bugcompat(int on) { g_lw2str_gpt1_levsource = on; return 0; }
 int rte_hip_force_generic_lw(int on) { g_lw_force_generic = on; return 0; }
 int rte_hip_force_generic_sw(int on) { g_sw_force_generic = on; return 0; }
+int rte_hip_sw_mixed_segments(int on) { g_sw_mixed = on; return 0; }
 int rte_hip_seg_groups(int n) { g_seg_groups = n; return 0; }
 int rte_hip_lw_sfc_lds(int on) { g_lw_sfc_lds = on; return 0; }
 
@@ -2486,6 +2760,12 @@ void rte_sw_solver_2stream(const int* ncol_, const int* nlay_, const int* ngpt_,
     const size_t lds_bytes = sizeof(Float) * 64 * (8 * 8 + 2 * 8 + ((L == 9 || L >= 11) ? 1 : 2) * 8 * L + ((L <= 9 || L >= 11) ? 8 * (L + 1) : 0) + (L == 9 ? 8 * (L + 1) : 0));
     {
       rte::ProfScope p("sw_2stream_seg_kernel");
+      // 57 ... 60 layers: segments of 7 and 8 layers, no neutral slots (sw_2stream_seg_mixed_kernel); rte_hip_sw_mixed_segments(0) for A/B
+      if (g_sw_mixed && S == 8 && nlay >= 57 && nlay <= 60) {
+        const size_t lds_mixed = sw_mixed_lds_bytes<7, 8>();
+        if (g0_kernel) hipLaunchKernelGGL((sw_2stream_seg_mixed_kernel<7, 8, true>), dim3(col_tiles, ngroups), dim3(64 * 8), lds_mixed, st0, q);
+        else hipLaunchKernelGGL((sw_2stream_seg_mixed_kernel<7, 8, false>), dim3(col_tiles, ngroups), dim3(64 * 8), lds_mixed, st0, q);
+      } else
       if (g0_kernel && L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8, false, false, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
       else if (g0_kernel) hipLaunchKernelGGL((sw_2stream_seg_kernel<9, false, false, true>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);
       else if (L == 8) hipLaunchKernelGGL((sw_2stream_seg_kernel<8>), dim3(col_tiles, ngroups), dim3(64 * S), lds_bytes, st0, q);

@@ -1218,3 +1218,42 @@ def test_deferred_lw_sources_two_source_objects_and_reuse_after_the_solve(hip):
         assert torch.equal(b["lay_src"], mine)  # and nothing expanded into the caller's data
     finally:
         hiplib.ext_call(hip, "rte_hip_defer_sources", ["i"], 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlay,top_at_1", [(60, False), (60, True), (55, True), (57, False), (59, True)])
+def test_sw_two_stream_on_segments_of_two_lengths(hip, oracle_c, nlay, top_at_1):
+    """rte_sw_solver_2stream at 57 ... 60 layers runs on segments of seven and eight layers (sw_2stream_seg_mixed_kernel: no wave
+    computes neutral slots; 55 layers: the 8 x 8 kernel): against the C oracle -- night columns, a diffuse boundary condition, ncol not a
+    multiple of 64, several g-point groups -- against the 8 + 8 kernel (rte_hip_sw_mixed_segments(0)), and with g == NULL
+    against an array of zeros (bit-identical)."""
+    import torch
+
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    rng = np.random.default_rng(100 + nlay)
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    ncol, ngpt = 331, 48
+    tau, ssa, g = F(ncol, nlay, ngpt) * 3.0, F(ncol, nlay, ngpt) * 0.999, F(ncol, nlay, ngpt) * 0.9 - 0.1
+    tau[:, ::7, :] *= 1e-4  # optically thin layers among them
+    mu0 = np.asfortranarray(np.repeat((rng.random(ncol) * 1.2 - 0.2)[:, None], nlay, axis=1))  # some <= 0
+    adir, adif, idir, idif = F(ncol, ngpt), F(ncol, ngpt), F(ncol, ngpt) * 100, F(ncol, ngpt) * 10
+    ref = frontend.rte_sw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, idir, adir, adif, inc_flux_dif=idif)
+    dev = [A(x) for x in (tau, ssa, g, mu0, idir, adir, adif)]
+    out = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, *dev, inc_flux_dif=A(idif), buffers={})
+    for k in ("flux_up", "flux_dn", "flux_dir"):
+        assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
+    hiplib.ext_call(hip, "rte_hip_sw_mixed_segments", ["i"], 0)
+    try:
+        old = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, *dev, inc_flux_dif=A(idif), buffers={})
+    finally:
+        hiplib.ext_call(hip, "rte_hip_sw_mixed_segments", ["i"], 1)
+    for k in ("flux_up", "flux_dn", "flux_dir"):
+        assert cases.rel_err(xp.to_numpy(out[k]), xp.to_numpy(old[k])) <= 1e-12, (k, nlay, top_at_1)
+    # g == NULL (clear-sky SW): the instance that reads nothing for g, against an array of zeros
+    zeros = torch.zeros_like(dev[2])
+    z = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, dev[0], dev[1], zeros, *dev[3:], buffers={})
+    n = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, dev[0], dev[1], None, *dev[3:], buffers={})
+    for k in ("flux_up", "flux_dn", "flux_dir"):
+        assert torch.equal(z[k], n[k]), k
+    assert float(n["flux_dn"].max()) > 0

@@ -3,7 +3,10 @@ import ctypes, sys, time
 import torch
 sys.path.insert(0, ".")
 from rte_rrtmgp_amd import frontend, hiplib, synth
-lib = hiplib.load(); hiplib.ext_call(lib, "rte_hip_defer_zero", ["i"], 1); xp = frontend.TorchArrays("cuda:0")
+import os
+lib = hiplib.load(); hiplib.ext_call(lib, "rte_hip_defer_zero", ["i"], 1)
+if os.environ.get("RTE_SW_MIXED"): hiplib.ext_call(lib, "rte_hip_sw_mixed_segments", ["i"], int(os.environ["RTE_SW_MIXED"]))  # A/B: 0 = segments of 8 + 8 layers
+xp = frontend.TorchArrays("cuda:0")
 ncol = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100000
 nlay = 60
 kd = synth.make_kdist("sw"); atm = synth.make_atmosphere(ncol, nlay, seed=42, kdist=kd)
