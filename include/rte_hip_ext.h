@@ -180,6 +180,7 @@ int rte_hip_allgatherv_columns(void* nccl_comm, int ncol_local, int nlev, const 
 int rte_hip_force_direct_gather(int on);   /* gas optics on the direct-gather kernels only */
 int rte_hip_force_generic_lw(int on);      /* LW solvers on the generic (any layer count) kernels only */
 int rte_hip_force_generic_sw(int on);
+int rte_hip_lw_mixed_segments(int on);     /* the same for rte_lw_solver_noscat (broadband, no rescaling) */
 int rte_hip_sw_mixed_segments(int on);     /* 1 (default): rte_sw_solver_2stream at 57-60 layers on segments of 7 and 8 layers (no neutral slots); 0: 8 x 8 (A/B) */
 int rte_hip_tau_zero_check(int on);        /* plain-ABI compute_tau_absorption looks whether tau is zero (default on) */
 int rte_hip_set_lw2str_bugcompat(int on);  /* lw_solver_2stream: g-point 1's lev_source for every g-point, as the reference does */

@@ -360,16 +360,18 @@ __device__ __forceinline__ void seg_load(SegTile<L>& t, SegOffsets<L>& o, int ig
 // lay_source = pfrac * planck_lay (:674) and lev_source = sqrt(pfrac(above) * pfrac(below)) * planck_lev (:695-705, the fraction
 // itself at the column's two ends) with the operations of compute_Planck_source: the same bits, a third less to read
 // (8 + 10 instead of 8 + 8 + 9 rows per g-point and wave) and 26 GB the gas optics no longer write at 1e5 x 60 x 256.
-template <int L, bool do_jac, bool SFCLDS, bool SPEC = false, bool BYBAND = false, bool FACT = false>
-__global__ void __launch_bounds__(64 * 8)
-lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
-                     const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
-                     const Float* __restrict__ lay_source_, const Float* __restrict__ lev_source_,
-                     const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
-                     const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
-                     Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac,
-                     Float* __restrict__ spec_up = nullptr, Float* __restrict__ spec_dn = nullptr, bool spec_add = false,
-                     const int* __restrict__ band_lims = nullptr, const Float* __restrict__ plk_lay = nullptr) {
+// The body of lw_noscat_seg_kernel for ONE wave, whose segment -- up to L layers -- starts p0 layers below the top: the kernel
+// proper (every wave L layers, p0 = s L) and lw_noscat_seg_mixed_kernel (segments of two lengths) are thin wrappers.
+template <int L, bool do_jac, bool SFCLDS, bool SPEC, bool BYBAND, bool FACT>
+__device__ __forceinline__ void
+lw_noscat_seg_wave(const int p0, int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
+                   const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
+                   const Float* __restrict__ lay_source_, const Float* __restrict__ lev_source_,
+                   const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
+                   const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
+                   Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac,
+                   Float* __restrict__ spec_up, Float* __restrict__ spec_dn, bool spec_add,
+                   const int* __restrict__ band_lims, const Float* __restrict__ plk_lay) {
 #pragma clang fp contract(fast)  // this kernel is fp64-issue bound: fuse the recurrences' a*b+c
   extern __shared__ Float lds[];  // [2 buffers][3 (Td,Sd,Su)][MAXS][64]
   const int lane = threadIdx.x & 63;
@@ -381,7 +383,6 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
   const int c = active ? icol : ncol - 1;  // clamp: inactive lanes compute on a valid column, never store
   const int nlev = nlay + 1;
   const size_t nclv = (size_t)ncol * nlev;
-  const int p0 = s * L;
   const int np = min(L, nlay - p0);  // layers in this segment (>= 1 by construction)
   const bool last = (s == S - 1);
   const Float piw = kPi * weight;
@@ -637,6 +638,45 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
       }
     }
   }
+}
+
+template <int L, bool do_jac, bool SFCLDS, bool SPEC = false, bool BYBAND = false, bool FACT = false>
+__global__ void __launch_bounds__(64 * 8)
+lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
+                     const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
+                     const Float* __restrict__ lay_source_, const Float* __restrict__ lev_source_,
+                     const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
+                     const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
+                     Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac,
+                     Float* __restrict__ spec_up = nullptr, Float* __restrict__ spec_dn = nullptr, bool spec_add = false,
+                     const int* __restrict__ band_lims = nullptr, const Float* __restrict__ plk_lay = nullptr) {
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  lw_noscat_seg_wave<L, do_jac, SFCLDS, SPEC, BYBAND, FACT>(s * L, ncol, nlay, ngpt, S, g_per_block, top_at_1, weight, Dsec, tau_, lay_source_,
+                                                           lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac, part_up, part_dn, part_jac,
+                                                           spec_up, spec_dn, spec_add, band_lims, plk_lay);
+}
+
+// Segments of TWO lengths (broadband, 8 waves): waves 0-3 own LA layers each, waves 4-7 LB -- 4 x 7 + 4 x 8 = 60, where eight
+// layers per wave leave the eighth wave four layers and four neutral slots whose rows it requests all the same (clamped: 200
+// row requests per g-point and block for 188 rows; the kernel is bound by its row requests, see process).  As in
+// sw_2stream_seg_mixed_kernel.
+template <int LA, int LB, bool do_jac, bool SFCLDS>
+__global__ void __launch_bounds__(64 * 8)
+lw_noscat_seg_mixed_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
+                           const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
+                           const Float* __restrict__ lay_source_, const Float* __restrict__ lev_source_,
+                           const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
+                           const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
+                           Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac) {
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (s < 4)
+    lw_noscat_seg_wave<LA, do_jac, SFCLDS, false, false, false>(s * LA, ncol, nlay, ngpt, S, g_per_block, top_at_1, weight, Dsec, tau_, lay_source_,
+                                                                lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac, part_up, part_dn, part_jac,
+                                                                nullptr, nullptr, false, nullptr, nullptr);
+  else
+    lw_noscat_seg_wave<LB, do_jac, SFCLDS, false, false, false>(4 * LA + (s - 4) * LB, ncol, nlay, ngpt, S, g_per_block, top_at_1, weight, Dsec, tau_,
+                                                                lay_source_, lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac, part_up, part_dn,
+                                                                part_jac, nullptr, nullptr, false, nullptr, nullptr);
 }
 
 // seg_load with the row offsets formed where they are used: base + (clamped slot) * step, two integer operations per load
@@ -2185,7 +2225,9 @@ size_t pick_gchunk(size_t bytes_per_g, int ngpt) {
 static std::atomic<int> g_lw2str_gpt1_levsource{0};
 static std::atomic<int> g_lw_force_generic{0};
 static std::atomic<int> g_sw_force_generic{0};
-static std::atomic<int> g_sw_mixed{1};  // 57 ... 60 layers on sw_2stream_seg_mixed_kernel (rte_hip_sw_mixed_segments)
+static int env_switch(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static std::atomic<int> g_lw_mixed{env_switch("RTE_LW_MIXED", 1)};  // lw_solver_noscat, 57 ... 60 layers, broadband: lw_noscat_seg_mixed_kernel (rte_hip_lw_mixed_segments)
+static std::atomic<int> g_sw_mixed{env_switch("RTE_SW_MIXED", 1)};  // 57 ... 60 layers on sw_2stream_seg_mixed_kernel (rte_hip_sw_mixed_segments)
 static std::atomic<int> g_lw_sfc_lds{1};  // surface arrays of the LW segmented solver through LDS chunks (rte_hip_lw_sfc_lds)
 static std::atomic<int> g_seg_groups{0};  // > 0: g-point groups per column tile of the segmented solvers (rte_hip_seg_groups; 0 = automatic;
                               // < 0: g-points per block given directly)
@@ -2213,6 +2255,7 @@ int rte_hip_set_lw2str_bugcompat(int on) { g_lw2str_gpt1_levsource = on; return 
 int rte_hip_force_generic_lw(int on) { g_lw_force_generic = on; return 0; }
 int rte_hip_force_generic_sw(int on) { g_sw_force_generic = on; return 0; }
 int rte_hip_sw_mixed_segments(int on) { g_sw_mixed = on; return 0; }
+int rte_hip_lw_mixed_segments(int on) { g_lw_mixed = on; return 0; }
 int rte_hip_seg_groups(int n) { g_seg_groups = n; return 0; }
 int rte_hip_lw_sfc_lds(int on) { g_lw_sfc_lds = on; return 0; }
 
@@ -2340,6 +2383,17 @@ void rte_lw_solver_noscat(const int* ncol_, const int* nlay_, const int* ngpt_, 
                          nlay, ngpt, S, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev, \
                          d_emis, d_sfc, d_inc, d_srcJac, part_up, part_dn, part_jac);                           \
   } while (0)
+        // 57 ... 60 layers: segments of 7 and 8 layers (lw_noscat_seg_mixed_kernel); rte_hip_lw_mixed_segments(0) for A/B
+        if (g_lw_mixed && sfclds && S == 8 && nlay >= 57 && nlay <= 60) {
+          if (do_jac)
+            hipLaunchKernelGGL((lw_noscat_seg_mixed_kernel<7, 8, true, true>), dim3(col_tiles, ngroups), dim3(64 * 8), lds_bytes, st, ncol, nlay,
+                               ngpt, S, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev, d_emis, d_sfc, d_inc,
+                               d_srcJac, part_up, part_dn, part_jac);
+          else
+            hipLaunchKernelGGL((lw_noscat_seg_mixed_kernel<7, 8, false, true>), dim3(col_tiles, ngroups), dim3(64 * 8), lds_bytes, st, ncol, nlay,
+                               ngpt, S, g_per_block, (bool)*top_at_1, w_h[imu], d_Ds + ncg * imu, d_tau, d_lay, d_lev, d_emis, d_sfc, d_inc,
+                               d_srcJac, part_up, part_dn, part_jac);
+        } else
         if (L == 8) { if (do_jac) RTE_LAUNCH_SEG(8, true); else RTE_LAUNCH_SEG(8, false); }
         else if (L == 9) { if (do_jac) RTE_LAUNCH_SEG(9, true); else RTE_LAUNCH_SEG(9, false); }
         else { if (do_jac) RTE_LAUNCH_SEG(10, true); else RTE_LAUNCH_SEG(10, false); }

@@ -1257,3 +1257,38 @@ def test_sw_two_stream_on_segments_of_two_lengths(hip, oracle_c, nlay, top_at_1)
     for k in ("flux_up", "flux_dn", "flux_dir"):
         assert torch.equal(z[k], n[k]), k
     assert float(n["flux_dn"].max()) > 0
+
+
+@pytest.mark.parametrize("nlay,top_at_1,nang,jac", [(60, False, 1, False), (60, True, 2, True), (57, True, 1, True), (58, False, 3, False), (59, True, 1, False)])
+def test_lw_noscat_on_segments_of_two_lengths(hip, oracle_c, nlay, top_at_1, nang, jac):
+    """rte_lw_solver_noscat (broadband, no rescaling) at 57 ... 60 layers runs on segments of seven and eight layers
+    (lw_noscat_seg_mixed_kernel: no wave requests rows for neutral slots): against the C oracle -- several angles, Jacobian, an
+    incident flux, ncol not a multiple of 64 -- and against the 8 x 8 kernel (rte_hip_lw_mixed_segments(0))."""
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    rng = np.random.default_rng(200 + nlay)
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    ncol, ngpt = 331, 48
+    tau = F(ncol, nlay, ngpt) * 2.0
+    tau[:, ::5, :] *= 1e-5  # optically thin layers among them (the Clough source's series branch)
+    lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
+    emis, sfc, inc, sj = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10, F(ncol, ngpt), F(ncol, ngpt)
+    kw = dict(inc_flux=inc, n_gauss_angles=nang)
+    if jac:
+        kw.update(sfc_src_jac=sj, do_jacobians=True)
+    ref = frontend.rte_lw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, lay, lev, emis, sfc, **kw)
+    kwd = dict(inc_flux=A(inc), n_gauss_angles=nang)
+    if jac:
+        kwd.update(sfc_src_jac=A(sj), do_jacobians=True)
+    dev = [A(x) for x in (tau, lay, lev, emis, sfc)]
+    out = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, *dev, buffers={}, **kwd)
+    keys = ("flux_up", "flux_dn") + (("flux_up_jac",) if jac else ())
+    for k in keys:
+        assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
+    hiplib.ext_call(hip, "rte_hip_lw_mixed_segments", ["i"], 0)
+    try:
+        old = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, *dev, buffers={}, **kwd)
+    finally:
+        hiplib.ext_call(hip, "rte_hip_lw_mixed_segments", ["i"], 1)
+    for k in keys:
+        assert cases.rel_err(xp.to_numpy(out[k]), xp.to_numpy(old[k])) <= 1e-12, (k, nlay, top_at_1)
