@@ -660,23 +660,27 @@ lw_noscat_seg_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool 
 // layers per wave leave the eighth wave four layers and four neutral slots whose rows it requests all the same (clamped: 200
 // row requests per g-point and block for 188 rows; the kernel is bound by its row requests, see process).  As in
 // sw_2stream_seg_mixed_kernel.
-template <int LA, int LB, bool do_jac, bool SFCLDS>
+// (FACT: the factored-source instance, so that the deferred / factored step keeps the segments -- and with them the bits -- of
+//  the plain one; at 7 and 8 layers per wave the band's Planck functions are in registers, no per-wave LDS slots to lay out)
+template <int LA, int LB, bool do_jac, bool SFCLDS, bool FACT = false>
 __global__ void __launch_bounds__(64 * 8)
 lw_noscat_seg_mixed_kernel(int ncol, int nlay, int ngpt, int S, int g_per_block, bool top_at_1, Float weight,
                            const Float* __restrict__ Dsec, const Float* __restrict__ tau_,
                            const Float* __restrict__ lay_source_, const Float* __restrict__ lev_source_,
                            const Float* __restrict__ sfc_emis, const Float* __restrict__ sfc_src,
                            const Float* __restrict__ inc_flux, const Float* __restrict__ sfc_srcJac,
-                           Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac) {
+                           Float* __restrict__ part_up, Float* __restrict__ part_dn, Float* __restrict__ part_jac,
+                           const int* __restrict__ band_lims = nullptr, const Float* __restrict__ plk_lay = nullptr) {
+  static_assert(LA <= 9 && LB <= 9, "PLKREG: the band's Planck functions in registers");
   const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (s < 4)
-    lw_noscat_seg_wave<LA, do_jac, SFCLDS, false, false, false>(s * LA, ncol, nlay, ngpt, S, g_per_block, top_at_1, weight, Dsec, tau_, lay_source_,
-                                                                lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac, part_up, part_dn, part_jac,
-                                                                nullptr, nullptr, false, nullptr, nullptr);
+    lw_noscat_seg_wave<LA, do_jac, SFCLDS, false, false, FACT>(s * LA, ncol, nlay, ngpt, S, g_per_block, top_at_1, weight, Dsec, tau_, lay_source_,
+                                                               lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac, part_up, part_dn, part_jac,
+                                                               nullptr, nullptr, false, band_lims, plk_lay);
   else
-    lw_noscat_seg_wave<LB, do_jac, SFCLDS, false, false, false>(4 * LA + (s - 4) * LB, ncol, nlay, ngpt, S, g_per_block, top_at_1, weight, Dsec, tau_,
-                                                                lay_source_, lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac, part_up, part_dn,
-                                                                part_jac, nullptr, nullptr, false, nullptr, nullptr);
+    lw_noscat_seg_wave<LB, do_jac, SFCLDS, false, false, FACT>(4 * LA + (s - 4) * LB, ncol, nlay, ngpt, S, g_per_block, top_at_1, weight, Dsec, tau_,
+                                                               lay_source_, lev_source_, sfc_emis, sfc_src, inc_flux, sfc_srcJac, part_up, part_dn,
+                                                               part_jac, nullptr, nullptr, false, band_lims, plk_lay);
 }
 
 // seg_load with the row offsets formed where they are used: base + (clamped slot) * step, two integer operations per load
@@ -3051,6 +3055,17 @@ int rte_hip_lw_solver_noscat_factored(int ncol, int nlay, int ngpt, int nbnd, in
     if (sfclds) { if (do_jac) RTE_LAUNCH_SEGF(LL, true, true); else RTE_LAUNCH_SEGF(LL, false, true); } \
     else        { if (do_jac) RTE_LAUNCH_SEGF(LL, true, false); else RTE_LAUNCH_SEGF(LL, false, false); } \
   } while (0)
+      // (the same segments as rte_lw_solver_noscat on the same shape: the fluxes stay bit-identical to the plain chain's)
+      if (g_lw_mixed && sfclds && S == 8 && nlay >= 57 && nlay <= 60) {
+        if (do_jac)
+          hipLaunchKernelGGL((lw_noscat_seg_mixed_kernel<7, 8, true, true, true>), dim3(col_tiles, ngroups), dim3(64 * 8), lds_bytes, st, ncol, nlay,
+                             ngpt, S, g_per_block, top_at_1 != 0, w_h[imu], d_Ds + ncg * imu, d_tau, d_pf, d_plv, d_emis, d_sfc, d_inc, d_srcJac,
+                             part_up, part_dn, part_jac, d_bl, d_ply);
+        else
+          hipLaunchKernelGGL((lw_noscat_seg_mixed_kernel<7, 8, false, true, true>), dim3(col_tiles, ngroups), dim3(64 * 8), lds_bytes, st, ncol, nlay,
+                             ngpt, S, g_per_block, top_at_1 != 0, w_h[imu], d_Ds + ncg * imu, d_tau, d_pf, d_plv, d_emis, d_sfc, d_inc, d_srcJac,
+                             part_up, part_dn, part_jac, d_bl, d_ply);
+      } else
       if (L == 8) RTE_LAUNCH_SEGF_(8); else if (L == 9) RTE_LAUNCH_SEGF_(9); else RTE_LAUNCH_SEGF_(10);
 #undef RTE_LAUNCH_SEGF_
 #undef RTE_LAUNCH_SEGF
