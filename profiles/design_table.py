@@ -14,7 +14,7 @@ pk = r["roofline"]["per_kernel"]
 rows = [("interpolation_kernel", "`interpolation_kernel` (interpolation.hip)", "`rrtmgp_interpolation`", 1297),
         ("tau_absorption_kernel", "`tau_slab_kernel` (tau_slab.h) + set-up, worklist", "`rrtmgp_compute_tau_absorption`", 3345),
         ("planck_source_kernel", "`planck_source_v9_kernel` (planck.hip)", "`rrtmgp_compute_Planck_source`", 4883),
-        ("lw_noscat_seg_kernel", "`lw_noscat_seg_kernel<8>` (solvers.hip) + reduction", "`rte_lw_solver_noscat`", 6331)]
+        ("lw_noscat_seg_kernel", "`lw_noscat_seg_mixed_kernel<7, 8>` (solvers.hip) + reduction", "`rte_lw_solver_noscat`", 6331)]
 print("| kernel (file) | API symbol | B/(col,lay) | alg GB | PMC GB | ms events (rocprofv3) | frac events (rocprofv3) |")
 print("|---|---|---:|---:|---:|---:|---:|")
 tot_alg = tot_pmc = 0.0
