@@ -196,9 +196,17 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
   // sequence id / 8 on one XCD walks the bands of one tile before the next tile
   // (LCH -- few tiles -- takes the blocks as they come: pinned, two tiles would use two of the eight XCDs)
   const unsigned lin = blockIdx.x, xcd = lin % 8, seq = lin / 8;
-  const int ibnd = (int)((LCH ? lin : seq) % (unsigned)nbnd);
-  const unsigned tile = LCH ? lin / (unsigned)nbnd : (seq / (unsigned)nbnd) * 8 + xcd;
+#if defined(PLANCKX_LINEAR)  // (experiment builds: the blocks as they come, a tile's bands spread over the XCDs)
+  constexpr bool LINEAR = true;
+#else
+  constexpr bool LINEAR = LCH;
+#endif
+  const int ibnd = (int)((LINEAR ? lin : seq) % (unsigned)nbnd);
+  const unsigned tile = LINEAR ? lin / (unsigned)nbnd : (seq / (unsigned)nbnd) * 8 + xcd;
   if (tile >= ntiles) return;  // block-uniform (grid padded to a multiple of 8 tiles)
+#if defined(PLANCKX_STAGGER)  // (experiment builds: the bands of a tile start PLANCKX_STAGGER x 64 clocks apart)
+  for (int i = 0; i < ibnd * PLANCKX_STAGGER; ++i) __builtin_amdgcn_s_sleep(1);
+#endif
   if (flags[tile * nbnd + ibnd]) return;  // block-uniform: the direct kernel does this (tile, band)
   const unsigned ncol = a.ncol, nlay = a.nlay;
   const unsigned ncl = ncol * nlay, nclv = ncol * (nlay + 1);  // host guarantees 8 * nclv < 2^32
@@ -375,8 +383,12 @@ planck_source_v9_kernel(PlanckV7 a, int nbnd, unsigned ntiles, const TileGeom* _
             const Float vlay = pf * pl_lay;                                      // :674
             const Float vlev = (l == 0 ? pf : sqrt(prev[j] * pf)) * pl_lev;      // :695,:699
             if (st_) {
+#if !defined(PLANCKX_NOLAY)
               store_stream(reinterpret_cast<Float*>(play_ + slay * j + olay), vlay);
+#endif
+#if !defined(PLANCKX_NOLEV)
               store_stream(reinterpret_cast<Float*>(plev_ + slev * j + olay), vlev);  // level l of (ncol, nlay+1): same column offset
+#endif
             }
           }
           prev[j] = pf;
@@ -595,7 +607,11 @@ static void planck_source_impl(const char* name, int ncol, int nlay, int nbnd, i
       for (int b = 0; b < nbnd; ++b) al_ = al_ && (bl[2 * b] - 1) % w == 0 && bl[2 * b + 1] % w == 0;
       return al_;
     };
+#if defined(PLANCKX_GW8)  // (experiment builds: stages of 8 g-points whatever the bands allow)
+    bl_gw = aligned(8) ? 8 : 0;
+#else
     bl_gw = aligned(16) ? 16 : (aligned(8) ? 8 : 0);  // g-points per stage of the production kernel
+#endif
     bl_ok = bl_gw > 0;
     bl_key = band_lims_gpt; bl_n = nbnd; bl_epoch = gs().plan_epoch;
   }
