@@ -1126,6 +1126,8 @@ def main():
                        "atmosphere": args.atmosphere, "minor_distribution": args.minor_distribution,
                        "direct_gather_worklist": {"tau_tile_layer_bands": wl_tau, "of": tiles * nlay_w * kd.nbnd,
                                                   "planck_tile_bands": wl_planck, "of_planck": tiles * kd.nbnd},
+                       "solver_segments": ("4 x 7 + 4 x 8 layers per block (lw_noscat_seg_mixed_kernel / sw_2stream_seg_mixed_kernel: no neutral slots at 57-60 layers)"
+                                           if 57 <= nlay_w <= 60 else "8 waves x ceil(nlay / 8) layers"),
                        "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
                        "device": torch.cuda.get_device_name(local_rank), "device_uuid": _device_uuid(torch, local_rank),
                        "opt_in_modes": "rte_hip_defer_zero + rte_hip_share_geometry" + (" + one-pass SW gas optics / fused cloud kernels" if args.workload != "lw" else ""),
