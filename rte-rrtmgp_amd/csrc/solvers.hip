@@ -1209,6 +1209,7 @@ struct Sw2SegArgs {
 // G0: the asymmetry parameter is zero everywhere and its array does not exist (g == NULL in rte_sw_solver_2stream: clear-sky optical
 // properties as rte_hip_gas_optics_sw_2str leaves them without a g array) -- nothing is read for it and the terms it multiplies are
 // dropped as written (5 + 3 * 0, 1 - 0, 0.75 mu0 * 0): the same bits as with an array of zeros.
+// (sw_seg_wave below restates this body per wave for segments of two lengths: changes to the arithmetic go to both)
 template <int L, bool SPEC = false, bool WIN = false, bool G0 = false>
 __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 #pragma clang fp contract(fast)  // VALU-bound: fuse a*b+c (the segment composites already differ from the reference's rounding)
@@ -1558,7 +1559,8 @@ __global__ void __launch_bounds__(64 * 8) sw_2stream_seg_kernel(Sw2SegArgs a) {
 //  together instead of the younger one finishing alone at a single wave's issue rate -- is refuted by 9 + 6: what pays is the
 //  sixteenth slot not computed, and the split that gives the later wave the longer segment is, if anything, the better one.)
 // sw_seg_wave is the body of sw_2stream_seg_kernel for ONE wave with its segment's length as the template parameter (same
-// expressions in the same order: see the comments there); a wave's private LDS slots (64 lanes each) are, from `priv`:
+// expressions in the same order: see the comments there -- the two must be kept in step; the broadband whole-column case only,
+// always with the input prefetch and the direct-flux accumulators in LDS, i.e. what that kernel does for L <= 9); a wave's private LDS slots (64 lanes each) are, from `priv`:
 // NMU x L values of mu0, L + 1 direct-flux accumulators, and with UPLDS L + 1 upward-flux accumulators.
 // ---------------------------------------------------------------------------------------------
 template <int L, bool G0, bool UPLDS, bool ONEMU>
