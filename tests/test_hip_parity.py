@@ -1292,3 +1292,28 @@ def test_lw_noscat_on_segments_of_two_lengths(hip, oracle_c, nlay, top_at_1, nan
         hiplib.ext_call(hip, "rte_hip_lw_mixed_segments", ["i"], 1)
     for k in keys:
         assert cases.rel_err(xp.to_numpy(out[k]), xp.to_numpy(old[k])) <= 1e-12, (k, nlay, top_at_1)
+
+
+@pytest.mark.parametrize("ncol", [1, 63, 65, 129])
+def test_segments_of_two_lengths_with_few_columns(hip, oracle_c, ncol):
+    """The 60-layer solvers (segments of seven and eight layers) on calls of one column, of one short of a wave, one more than a
+    wave, and of two waves and one: the lanes past the last column compute on a clamped column and store nothing."""
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    rng = np.random.default_rng(300 + ncol)
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    nlay, ngpt = 60, 32
+    tau, ssa, g = F(ncol, nlay, ngpt) * 3.0, F(ncol, nlay, ngpt) * 0.999, F(ncol, nlay, ngpt) * 0.9 - 0.1
+    mu0 = np.asfortranarray(np.repeat((rng.random(ncol) * 1.2 - 0.2)[:, None], nlay, axis=1))
+    adir, adif, idir = F(ncol, ngpt), F(ncol, ngpt), F(ncol, ngpt) * 100
+    for top_at_1 in (False, True):
+        ref = frontend.rte_sw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, idir, adir, adif)
+        out = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(ssa), A(g), A(mu0), A(idir), A(adir), A(adif), buffers={})
+        for k in ("flux_up", "flux_dn", "flux_dir"):
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, ncol, top_at_1)
+        lay, lev = F(ncol, nlay, ngpt) * 10 + 1, F(ncol, nlay + 1, ngpt) * 10 + 1
+        emis, sfc = F(ncol, ngpt) * 0.2 + 0.8, F(ncol, ngpt) * 10
+        ref = frontend.rte_lw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, lay, lev, emis, sfc)
+        out = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(lay), A(lev), A(emis), A(sfc), buffers={})
+        for k in ("flux_up", "flux_dn"):
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, ncol, top_at_1)
