@@ -1317,3 +1317,33 @@ def test_segments_of_two_lengths_with_few_columns(hip, oracle_c, ncol):
         out = frontend.rte_lw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(lay), A(lev), A(emis), A(sfc), buffers={})
         for k in ("flux_up", "flux_dn"):
             assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, ncol, top_at_1)
+
+
+@pytest.mark.parametrize("nlay,top_at_1", [(72, False), (67, True)])
+def test_sw_two_stream_cosine_that_varies_with_the_layer(hip, oracle_c, nlay, top_at_1):
+    """mu0 is an (ncol, nlay) array of the interface: at 65 ... 72 layers (nine per wave: one parked value per layer, the reciprocal
+    formed per g-point) against the C oracle with mu0 per column, with mu0 that changes from layer to layer (spherical geometry)
+    and with a single deviating element, night columns included; with and without the g array.  (Round 6 measured an instance
+    for a layer-independent cosine picked by a device flag: 13.9 against 12.9 ms at 1e5 x 72 x 224 -- dropped, the test stays.)"""
+    import torch
+
+    xp = frontend.TorchArrays("cuda:0")
+    A = xp.asarray
+    rng = np.random.default_rng(400 + nlay)
+    F = lambda *sh: np.asfortranarray(rng.random(sh))
+    ncol, ngpt = 203, 40
+    tau, ssa, g = F(ncol, nlay, ngpt) * 3.0, F(ncol, nlay, ngpt) * 0.999, F(ncol, nlay, ngpt) * 0.9 - 0.1
+    adir, adif, idir, idif = F(ncol, ngpt), F(ncol, ngpt), F(ncol, ngpt) * 100, F(ncol, ngpt) * 10
+    per_col = np.asfortranarray(np.repeat((rng.random(ncol) * 1.2 - 0.2)[:, None], nlay, axis=1))
+    varying = np.asfortranarray(np.clip(per_col + (rng.random((ncol, nlay)) - 0.5) * 0.05, -0.3, 1.0))
+    one_off = per_col.copy(order="F"); one_off[ncol // 2, nlay // 3] += 0.01  # a single element decides the flag
+    for mu0 in (per_col, varying, one_off):
+        ref = frontend.rte_sw(oracle_c, frontend.NumpyArrays(), ncol, nlay, ngpt, top_at_1, tau, ssa, g, mu0, idir, adir, adif, inc_flux_dif=idif)
+        out = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(ssa), A(g), A(mu0), A(idir), A(adir), A(adif), inc_flux_dif=A(idif), buffers={})
+        for k in ("flux_up", "flux_dn", "flux_dir"):
+            assert cases.rel_err(xp.to_numpy(out[k]), ref[k]) <= 1e-12, (k, nlay, top_at_1)
+        zeros = torch.zeros((ngpt, nlay, ncol), dtype=torch.float64, device="cuda")
+        z = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(ssa), zeros, A(mu0), A(idir), A(adir), A(adif), buffers={})
+        n = frontend.rte_sw(hip, xp, ncol, nlay, ngpt, top_at_1, A(tau), A(ssa), None, A(mu0), A(idir), A(adir), A(adif), buffers={})
+        for k in ("flux_up", "flux_dn", "flux_dir"):
+            assert torch.equal(z[k], n[k]), k
